@@ -1,0 +1,137 @@
+/* sqd_hip.h -- C ABI of libsqd_hip.so: the MI355X (gfx950) implementation of the
+ * fermionic subspace projection + diagonalization hot path of qiskit-addon-sqd.
+ *
+ * The reference reaches this arithmetic through pyscf's ctypes boundary into
+ * libfci.so (reference qiskit_addon_sqd/fermion.py:721-729, :810-830, :117-133).
+ * Each entry point below names the reference call (file:line) and the pyscf
+ * routine it replaces.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions:
+ *   - CI string: uint64, bit p = occupation of spatial orbital p (LSB = orbital 0).
+ *   - basis = {|a>|b>}: a in strs_a (sorted, unique), b in strs_b (sorted, unique);
+ *     amplitudes C[ia*nb + ib] (row = alpha string), float64.
+ *   - h1[p*norb+q], eri[((p*norb+q)*norb+r)*norb+s] = (pq|rs) chemist order, 8-fold symmetric.
+ *   - every function returns 0 on success, <0 on error; sqd_last_error() gives the text
+ *     (thread-local).  Host buffers are caller-owned and never written unless documented
+ *     as outputs.  One context = one device + one HIP stream; contexts are independent,
+ *     so one host thread per context/device is safe.  A single context is not re-entrant.
+ */
+#ifndef SQD_HIP_H
+#define SQD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sqd_ctx sqd_ctx;
+
+#define SQD_OK 0
+#define SQD_ERR_INVALID (-1)  /* bad argument / inconsistent Hamming weight / unsorted strings */
+#define SQD_ERR_HIP (-2)      /* HIP runtime failure */
+#define SQD_ERR_STATE (-3)    /* call sequence error (e.g. no subspace set) */
+#define SQD_ERR_LIMIT (-4)    /* size beyond what this build supports */
+
+#define SQD_MAX_NORB 64
+#define SQD_MAX_SPACE 30
+
+/* ABI version of this header (bumped on any signature change). */
+int sqd_abi_version(void);
+const char* sqd_last_error(void);
+int sqd_device_count(int* count);
+
+/* Create a solver context on `device` holding the Hamiltonian integrals.
+ * Replaces: pyscf SelectedCI() construction + direct_spin1.absorb_h1e + ao2mo.restore
+ * done inside kernel_fixed_space (reference fermion.py:713,721 / :803,810). */
+int sqd_ctx_create(int device, int norb, const double* h1, const double* eri, sqd_ctx** out);
+int sqd_ctx_destroy(sqd_ctx* ctx);
+
+/* Define the subspace.  strs_a / strs_b must be strictly ascending with a constant
+ * popcount per spin (the post-condition of reference _check_ci_strs, fermion.py:1075-1097);
+ * violations return SQD_ERR_INVALID.  Builds on the device: the single-/double-excitation
+ * link tables with bit-exact addresses and signs (pyscf _all_linkstr_index: SCIcre_des_linkstr,
+ * SCIdes_des_linkstr), the diagonal (pyscf make_hdiag / FCImake_hdiag_uhf) and the per-string
+ * mean-field tables used by the sigma kernel.  nelec is taken from the popcounts. */
+int sqd_set_subspace(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb);
+
+/* Sizes of the current subspace. */
+int sqd_get_dims(sqd_ctx* ctx, int64_t* na, int64_t* nb, int* nelec_a, int* nelec_b);
+
+/* Link tables, for bit-exact addressing tests.  spin: 0 = alpha, 1 = beta.
+ * Singles: |strs[tgt]> = sign * a+_cre a_des |strs[src]>, sorted by (tgt, src);
+ *          pair = tril index max(max+1)/2+min of (cre,des) (pyscf cre_des_linkstr_tril column 0).
+ * Doubles: |strs[tgt]> = sign * a+_p a+_r a_s a_q |strs[src]>, p>r, q>s, sorted by (tgt, src);
+ *          orbs[4*i..] = p, r, q, s.
+ * Pass NULL output pointers to query counts only. */
+int sqd_link_counts(sqd_ctx* ctx, int spin, int64_t* n_single, int64_t* n_double);
+int sqd_single_links(sqd_ctx* ctx, int spin, int32_t* tgt, int32_t* src, int32_t* cre, int32_t* des,
+                     int32_t* pair, int32_t* sign, double* value);
+int sqd_double_links(sqd_ctx* ctx, int spin, int32_t* tgt, int32_t* src, int32_t* orbs, int32_t* sign,
+                     double* value);
+
+/* hdiag[ia*nb+ib] = <ab|H|ab>.  Replaces pyscf SelectedCI.make_hdiag (kernel_fixed_space). */
+int sqd_hdiag(sqd_ctx* ctx, double* out);
+
+/* sigma = P H P c  (+ penalty).  Replaces pyscf selected_ci.contract_2e
+ * (SCIcontract_2e_aaaa x2, SCIcontract_2e_bbaa) and, when use_spin != 0, the fix_spin_ wrapper:
+ *   use_spin = 0 : sigma = H c
+ *   use_spin = 1 : sigma = H c + shift * (S^2 - ss) c            (pyscf form for ss < sz(sz+1)+0.1)
+ *   use_spin = 2 : sigma = H c + shift * (S^2 - ss)^2 c          (pyscf form otherwise)
+ *   use_spin = 3 : let the library choose 1 or 2 by pyscf's rule. */
+int sqd_sigma(sqd_ctx* ctx, const double* c, double* sigma, int use_spin, double ss, double shift);
+
+/* out = P S^2 P c.  Replaces pyscf selected_ci.contract_ss. */
+int sqd_contract_ss(sqd_ctx* ctx, const double* c, double* out);
+
+typedef struct sqd_davidson_opts {
+  double tol;        /* pyscf conv_tol, default 1e-9 (SelectedCI) */
+  double lindep;     /* 1e-14 */
+  int max_cycle;     /* 100 */
+  int max_space;     /* 12 */
+  int use_spin;      /* 0 none, 3 = pyscf fix_spin_ rule */
+  double ss;         /* target S^2 value */
+  double shift;      /* penalty strength (0.1 solve_fermion, 0.2 solve_sci) */
+  int verbose;
+} sqd_davidson_opts;
+
+typedef struct sqd_davidson_stats {
+  int converged;
+  int iterations;
+  int n_sigma;         /* number of sigma builds */
+  double e_davidson;   /* eigenvalue of H + penalty (pyscf's discarded return value, without ecore) */
+  double residual;     /* final |r| */
+  double ms_total;     /* device time of the Davidson loop (HIP events on the context stream) */
+  double ms_sigma;     /* device time summed over the sigma launches */
+  double ms_setup;     /* device time of the last sqd_set_subspace */
+} sqd_davidson_stats;
+
+void sqd_davidson_default_opts(sqd_davidson_opts* o);
+
+/* Ground state of P (H + penalty) P by Davidson, resident on the device.
+ * Replaces pyscf kernel_fixed_space -> FCISolver.eig -> lib.davidson1 (reference
+ * fermion.py:721-723, :810-818).  ci0 (na*nb doubles) may be NULL: pyscf get_init_guess is used.
+ * The normalised solution stays resident in the context (used by the observables below) and is
+ * also copied to `amps` when it is not NULL. */
+int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, double* amps,
+                 sqd_davidson_stats* stats);
+
+/* Observables of a state.  amps == NULL means "the resident Davidson solution".
+ * sqd_energy: <c|H|c> without penalty (what the reference recomputes from RDMs, fermion.py:730-732,:827).
+ * sqd_spin_square: <c|S^2|c> (pyscf spin_square, fermion.py:830,:133).
+ * sqd_rdm1s: dm1a/dm1b[p*norb+q] = <a+_p a_q> per spin (pyscf make_rdm1s, fermion.py:725,:821,:121).
+ * sqd_rdm2: spin-summed dm2[p,q,r,s] = sum_{st} <p+_s r+_t s_t q_s> (pyscf make_rdm2, fermion.py:729,:826). */
+int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
+int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
+int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);
+int sqd_rdm2(sqd_ctx* ctx, const double* amps, double* dm2);
+
+/* Benchmark hooks: run `reps` sigma builds on the resident solution buffer and report the
+ * average device time per launch of the dominant sigma kernel (HIP events on the context stream). */
+int sqd_time_sigma(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift, double* ms_per_sigma);
+/* Populated-link count and algorithmic bytes of one sigma (SURVEY 8d formula) for the current subspace. */
+int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+"""MI355X-native drop-in for the fermionic subspace-diagonalization path of qiskit-addon-sqd.
+
+Public surface mirrors ``qiskit_addon_sqd.fermion`` for that path (reference
+``qiskit_addon_sqd/fermion.py``): ``solve_fermion``, ``solve_sci``, ``solve_sci_batch``,
+``SCIState``, ``SCIResult``, ``bitstring_matrix_to_ci_strs``.  All arithmetic runs in
+``libsqd_hip.so`` (hand-written HIP for gfx950) behind the C ABI of ``include/sqd_hip.h``.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,332 @@
+"""ctypes binding of ``libsqd_hip.so`` (C ABI in ``include/sqd_hip.h``).
+
+This is the only place the package crosses into native code.  There is no CPU
+fallback: if the HIP library is missing or fails to load, importing the solver
+entry points raises ``SQDNativeError`` with build instructions.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_NAME = "libsqd_hip.so"
+LIB_PATH = _HERE / "csrc" / LIB_NAME
+
+EXPORTED_SYMBOLS = (
+    "sqd_abi_version",
+    "sqd_last_error",
+    "sqd_device_count",
+    "sqd_ctx_create",
+    "sqd_ctx_destroy",
+    "sqd_set_subspace",
+    "sqd_get_dims",
+    "sqd_link_counts",
+    "sqd_single_links",
+    "sqd_double_links",
+    "sqd_hdiag",
+    "sqd_sigma",
+    "sqd_contract_ss",
+    "sqd_davidson_default_opts",
+    "sqd_davidson",
+    "sqd_energy",
+    "sqd_spin_square",
+    "sqd_rdm1s",
+    "sqd_rdm2",
+    "sqd_time_sigma",
+    "sqd_sigma_bytes",
+)
+
+
+class SQDNativeError(RuntimeError):
+    """Raised when libsqd_hip.so is unavailable or a native call fails."""
+
+
+class DavidsonOpts(C.Structure):
+    _fields_ = [
+        ("tol", C.c_double),
+        ("lindep", C.c_double),
+        ("max_cycle", C.c_int),
+        ("max_space", C.c_int),
+        ("use_spin", C.c_int),
+        ("ss", C.c_double),
+        ("shift", C.c_double),
+        ("verbose", C.c_int),
+    ]
+
+
+class DavidsonStats(C.Structure):
+    _fields_ = [
+        ("converged", C.c_int),
+        ("iterations", C.c_int),
+        ("n_sigma", C.c_int),
+        ("e_davidson", C.c_double),
+        ("residual", C.c_double),
+        ("ms_total", C.c_double),
+        ("ms_sigma", C.c_double),
+        ("ms_setup", C.c_double),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_ctxp = C.c_void_p
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Attach prototypes for every symbol declared in include/sqd_hip.h."""
+    lib.sqd_abi_version.restype = C.c_int
+    lib.sqd_last_error.restype = C.c_char_p
+    lib.sqd_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.sqd_ctx_create.argtypes = [C.c_int, C.c_int, _dp, _dp, C.POINTER(_ctxp)]
+    lib.sqd_ctx_destroy.argtypes = [_ctxp]
+    lib.sqd_set_subspace.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64]
+    lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
+    lib.sqd_single_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp]
+    lib.sqd_double_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _dp]
+    lib.sqd_hdiag.argtypes = [_ctxp, _dp]
+    lib.sqd_sigma.argtypes = [_ctxp, _dp, _dp, C.c_int, C.c_double, C.c_double]
+    lib.sqd_contract_ss.argtypes = [_ctxp, _dp, _dp]
+    lib.sqd_davidson_default_opts.argtypes = [C.POINTER(DavidsonOpts)]
+    lib.sqd_davidson_default_opts.restype = None
+    lib.sqd_davidson.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats)]
+    lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
+    lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
+    lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
+    lib.sqd_rdm2.argtypes = [_ctxp, _dp, _dp]
+    lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+    lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("sqd_last_error", "sqd_davidson_default_opts"):
+            fn.restype = C.c_int
+    return lib
+
+
+_LIB: C.CDLL | None = None
+
+
+def load_library() -> C.CDLL:
+    """Load the hipcc-built library that lives in-tree.  No fallback of any kind."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise SQDNativeError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). qiskit_addon_sqd_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(str(LIB_PATH), mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    except OSError as exc:  # pragma: no cover - depends on the box
+        raise SQDNativeError(f"failed to load {LIB_PATH}: {exc}") from exc
+    _LIB = bind(lib)
+    return _LIB
+
+
+def _as_f64(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and out.shape != shape:
+        raise ValueError(f"expected array of shape {shape}, got {out.shape}")
+    return out
+
+
+def _ptr(a: np.ndarray, typ=_dp):
+    return a.ctypes.data_as(typ)
+
+
+def strings_to_u64(strs) -> np.ndarray:
+    """CI strings (int64 / uint64 / python ints) -> contiguous uint64 array (bit pattern preserved)."""
+    arr = np.asarray(strs)
+    if arr.dtype == object:
+        arr = np.array([int(x) for x in arr], dtype=np.uint64)
+    elif arr.dtype != np.uint64:
+        if arr.size and np.issubdtype(arr.dtype, np.signedinteger) and (arr < 0).any():
+            raise ValueError("CI strings must be non-negative integers")
+        arr = arr.astype(np.uint64)
+    return np.ascontiguousarray(arr)
+
+
+class Context:
+    """RAII wrapper of one ``sqd_ctx`` (one device, one stream, one Hamiltonian)."""
+
+    def __init__(self, hcore, eri, device: int = 0, lib: C.CDLL | None = None):
+        self._lib = lib if lib is not None else load_library()
+        self._h = _ctxp()
+        hcore = _as_f64(hcore)
+        if hcore.ndim != 2 or hcore.shape[0] != hcore.shape[1]:
+            raise ValueError("hcore must be a square matrix")
+        self.norb = int(hcore.shape[0])
+        eri = _as_f64(eri)
+        if eri.size != self.norb**4:
+            raise ValueError(f"eri must have norb**4 = {self.norb**4} elements (chemist order, no symmetry packing)")
+        self.device = int(device)
+        self.na = self.nb = 0
+        self.nelec = (0, 0)
+        self._check(self._lib.sqd_ctx_create(self.device, self.norb, _ptr(hcore), _ptr(eri), C.byref(self._h)))
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.sqd_last_error()
+            msg = msg.decode() if msg else "unknown error"
+            if rc == -1:
+                raise ValueError(msg)
+            raise SQDNativeError(f"libsqd_hip error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sqd_ctx_destroy(self._h)
+            self._h = _ctxp()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- subspace
+    def set_subspace(self, strs_a, strs_b):
+        a = strings_to_u64(strs_a)
+        b = strings_to_u64(strs_b)
+        self._check(self._lib.sqd_set_subspace(self._h, _ptr(a, _u64p), a.size, _ptr(b, _u64p), b.size))
+        na, nb = C.c_int64(), C.c_int64()
+        ea, eb = C.c_int(), C.c_int()
+        self._check(self._lib.sqd_get_dims(self._h, C.byref(na), C.byref(nb), C.byref(ea), C.byref(eb)))
+        self.na, self.nb = int(na.value), int(nb.value)
+        self.nelec = (int(ea.value), int(eb.value))
+
+    def link_counts(self, spin: int):
+        ns, nd = C.c_int64(), C.c_int64()
+        self._check(self._lib.sqd_link_counts(self._h, spin, C.byref(ns), C.byref(nd)))
+        return int(ns.value), int(nd.value)
+
+    def single_links(self, spin: int) -> dict:
+        ns, _ = self.link_counts(spin)
+        out = {k: np.zeros(ns, dtype=np.int32) for k in ("tgt", "src", "cre", "des", "pair", "sign")}
+        val = np.zeros(ns)
+        self._check(
+            self._lib.sqd_single_links(
+                self._h, spin, *[_ptr(out[k], _i32p) for k in ("tgt", "src", "cre", "des", "pair", "sign")], _ptr(val)
+            )
+        )
+        out["value"] = val
+        return out
+
+    def double_links(self, spin: int) -> dict:
+        _, nd = self.link_counts(spin)
+        tgt = np.zeros(nd, dtype=np.int32)
+        src = np.zeros(nd, dtype=np.int32)
+        orbs = np.zeros((nd, 4), dtype=np.int32)
+        sign = np.zeros(nd, dtype=np.int32)
+        val = np.zeros(nd)
+        self._check(
+            self._lib.sqd_double_links(
+                self._h, spin, _ptr(tgt, _i32p), _ptr(src, _i32p), _ptr(orbs, _i32p), _ptr(sign, _i32p), _ptr(val)
+            )
+        )
+        return dict(tgt=tgt, src=src, orbs=orbs, sign=sign, value=val)
+
+    def hdiag(self) -> np.ndarray:
+        out = np.empty((self.na, self.nb))
+        self._check(self._lib.sqd_hdiag(self._h, _ptr(out)))
+        return out
+
+    # -- operators
+    def sigma(self, c, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0) -> np.ndarray:
+        c = _as_f64(c).reshape(self.na, self.nb)
+        out = np.empty_like(c)
+        self._check(self._lib.sqd_sigma(self._h, _ptr(c), _ptr(out), use_spin, ss, shift))
+        return out
+
+    def contract_ss(self, c) -> np.ndarray:
+        c = _as_f64(c).reshape(self.na, self.nb)
+        out = np.empty_like(c)
+        self._check(self._lib.sqd_contract_ss(self._h, _ptr(c), _ptr(out)))
+        return out
+
+    def davidson(
+        self,
+        ci0=None,
+        *,
+        tol: float = 1e-9,
+        lindep: float = 1e-14,
+        max_cycle: int = 100,
+        max_space: int = 12,
+        spin_sq: float | None = None,
+        shift: float = 0.2,
+        verbose: int = 0,
+        fetch: bool = True,
+    ):
+        opts = DavidsonOpts()
+        self._lib.sqd_davidson_default_opts(C.byref(opts))
+        opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
+        opts.verbose = int(verbose)
+        if spin_sq is not None:
+            opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
+        stats = DavidsonStats()
+        amps = np.empty((self.na, self.nb)) if fetch else None
+        ci0p = None
+        if ci0 is not None:
+            ci0 = _as_f64(ci0).reshape(self.na, self.nb)
+            ci0p = _ptr(ci0)
+        self._check(
+            self._lib.sqd_davidson(self._h, C.byref(opts), ci0p, _ptr(amps) if fetch else None, C.byref(stats))
+        )
+        return amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_}
+
+    # -- observables (amps=None -> resident Davidson solution)
+    def _state(self, amps):
+        if amps is None:
+            return None, None
+        a = _as_f64(amps).reshape(self.na, self.nb)
+        return a, _ptr(a)
+
+    def energy(self, amps=None) -> float:
+        keep, p = self._state(amps)
+        out = C.c_double()
+        self._check(self._lib.sqd_energy(self._h, p, C.byref(out)))
+        return float(out.value)
+
+    def spin_square(self, amps=None) -> float:
+        keep, p = self._state(amps)
+        out = C.c_double()
+        self._check(self._lib.sqd_spin_square(self._h, p, C.byref(out)))
+        return float(out.value)
+
+    def rdm1s(self, amps=None):
+        keep, p = self._state(amps)
+        a = np.empty((self.norb, self.norb))
+        b = np.empty((self.norb, self.norb))
+        self._check(self._lib.sqd_rdm1s(self._h, p, _ptr(a), _ptr(b)))
+        return a, b
+
+    def rdm2(self, amps=None) -> np.ndarray:
+        keep, p = self._state(amps)
+        out = np.empty((self.norb,) * 4)
+        self._check(self._lib.sqd_rdm2(self._h, p, _ptr(out)))
+        return out
+
+    # -- benchmark hooks
+    def time_sigma(self, reps: int = 10, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0) -> float:
+        out = C.c_double()
+        self._check(self._lib.sqd_time_sigma(self._h, reps, use_spin, ss, shift, C.byref(out)))
+        return float(out.value)
+
+    def sigma_bytes(self) -> float:
+        out = C.c_double()
+        self._check(self._lib.sqd_sigma_bytes(self._h, C.byref(out)))
+        return float(out.value)

@@ -1,0 +1,347 @@
+// extern "C" boundary of libsqd_hip.so (declared in include/sqd_hip.h).
+#include <cmath>
+#include <cstring>
+
+#include "sqd_common.h"
+
+namespace sqd {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace sqd
+
+using namespace sqd;
+
+#define SQD_API extern "C" __attribute__((visibility("default")))
+
+SQD_API int sqd_abi_version(void) { return 1; }
+SQD_API const char* sqd_last_error(void) { return g_err.c_str(); }
+
+SQD_API int sqd_device_count(int* count) {
+  if (!count) return SQD_ERR_INVALID;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return SQD_ERR_HIP;
+  }
+  return SQD_OK;
+}
+
+SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double* eri, sqd_ctx** out) {
+  if (!out || !h1 || !eri) {
+    set_error("null argument");
+    return SQD_ERR_INVALID;
+  }
+  if (norb < 1 || norb > SQD_MAX_NORB) {
+    set_error("norb must be in [1, 64]");
+    return SQD_ERR_INVALID;
+  }
+  SQD_HIP_CHECK(hipSetDevice(device));
+  sqd_ctx* c = new sqd_ctx();
+  c->device = device;
+  c->norb = norb;
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cu = v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
+    c->lds_bytes = v;
+  hipError_t e = hipStreamCreate(&c->stream);
+  if (e != hipSuccess) {
+    set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    delete c;
+    return SQD_ERR_HIP;
+  }
+  for (int i = 0; i < 4; ++i) {
+    e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+      set_error(std::string("hipEventCreate: ") + hipGetErrorString(e));
+      delete c;
+      return SQD_ERR_HIP;
+    }
+  }
+  e = hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    delete c;
+    return SQD_ERR_HIP;
+  }
+  int rc = build_integral_tables(c, h1, eri);
+  if (rc != SQD_OK) {
+    sqd_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return SQD_OK;
+}
+
+SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
+  if (!c) return SQD_OK;
+  hipError_t e = hipSetDevice(c->device);
+  (void)e;
+  if (c->stream) e = hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
+                    &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out};
+  for (DevBuf* b : bufs) b->release();
+  c->sp[0].release();
+  c->sp[1].release();
+  for (int i = 0; i < 4; ++i)
+    if (c->ev[i]) e = hipEventDestroy(c->ev[i]);
+  if (c->h_pinned) e = hipHostFree(c->h_pinned);
+  if (c->stream) e = hipStreamDestroy(c->stream);
+  delete c;
+  return SQD_OK;
+}
+
+#define CTX_ENTER(c)                           \
+  if (!(c)) {                                  \
+    set_error("null context");                 \
+    return SQD_ERR_INVALID;                    \
+  }                                            \
+  SQD_HIP_CHECK(hipSetDevice((c)->device));
+
+#define NEED_SUBSPACE(c)              \
+  if (!(c)->have_subspace) {          \
+    set_error("no subspace set");     \
+    return SQD_ERR_STATE;             \
+  }
+
+SQD_API int sqd_set_subspace(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb) {
+  CTX_ENTER(c);
+  return build_subspace(c, strs_a, na, strs_b, nb);
+}
+
+SQD_API int sqd_get_dims(sqd_ctx* c, int64_t* na, int64_t* nb, int* nelec_a, int* nelec_b) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (na) *na = c->na;
+  if (nb) *nb = c->nb;
+  if (nelec_a) *nelec_a = c->nelec[0];
+  if (nelec_b) *nelec_b = c->nelec[1];
+  return SQD_OK;
+}
+
+SQD_API int sqd_link_counts(sqd_ctx* c, int spin, int64_t* n_single, int64_t* n_double) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (spin < 0 || spin > 1) return SQD_ERR_INVALID;
+  if (n_single) *n_single = c->sp[spin].n_s;
+  if (n_double) *n_double = c->sp[spin].n_d;
+  return SQD_OK;
+}
+
+SQD_API int sqd_single_links(sqd_ctx* c, int spin, int32_t* tgt, int32_t* src, int32_t* cre, int32_t* des,
+                             int32_t* pair, int32_t* sign, double* value) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (spin < 0 || spin > 1) return SQD_ERR_INVALID;
+  const SpinTables& t = c->sp[spin];
+  const int64_t n = t.n_s;
+  if (n == 0) return SQD_OK;
+  std::vector<SRec> rec(n);
+  std::vector<uint32_t> row(n);
+  SQD_HIP_CHECK(hipMemcpy(rec.data(), t.s_rec.p, n * sizeof(SRec), hipMemcpyDeviceToHost));
+  SQD_HIP_CHECK(hipMemcpy(row.data(), t.s_row.p, n * 4, hipMemcpyDeviceToHost));
+  if (value) SQD_HIP_CHECK(hipMemcpy(value, t.s_val.p, n * 8, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t m = rec[i].meta;
+    if (tgt) tgt[i] = (int32_t)row[i];
+    if (src) src[i] = (int32_t)rec[i].src;
+    if (cre) cre[i] = (int32_t)srec_cre(m);
+    if (des) des[i] = (int32_t)srec_des(m);
+    if (pair) pair[i] = (int32_t)(srec_widx(m) >> 1);
+    if (sign) sign[i] = (m >> 31) ? -1 : 1;
+  }
+  return SQD_OK;
+}
+
+SQD_API int sqd_double_links(sqd_ctx* c, int spin, int32_t* tgt, int32_t* src, int32_t* orbs, int32_t* sign,
+                             double* value) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (spin < 0 || spin > 1) return SQD_ERR_INVALID;
+  const SpinTables& t = c->sp[spin];
+  const int64_t n = t.n_d;
+  if (n == 0) return SQD_OK;
+  std::vector<uint32_t> row(n), sr(n), ob(n);
+  SQD_HIP_CHECK(hipMemcpy(row.data(), t.d_row.p, n * 4, hipMemcpyDeviceToHost));
+  SQD_HIP_CHECK(hipMemcpy(sr.data(), t.d_src.p, n * 4, hipMemcpyDeviceToHost));
+  SQD_HIP_CHECK(hipMemcpy(ob.data(), t.d_orb.p, n * 4, hipMemcpyDeviceToHost));
+  if (value) SQD_HIP_CHECK(hipMemcpy(value, t.d_val.p, n * 8, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) {
+    if (tgt) tgt[i] = (int32_t)row[i];
+    if (src) src[i] = (int32_t)sr[i];
+    if (orbs) {
+      orbs[4 * i + 0] = ob[i] & 63;
+      orbs[4 * i + 1] = (ob[i] >> 6) & 63;
+      orbs[4 * i + 2] = (ob[i] >> 12) & 63;
+      orbs[4 * i + 3] = (ob[i] >> 18) & 63;
+    }
+    if (sign) sign[i] = (ob[i] >> 31) ? -1 : 1;
+  }
+  return SQD_OK;
+}
+
+SQD_API int sqd_hdiag(sqd_ctx* c, double* out) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  SQD_HIP_CHECK(hipMemcpy(out, c->hdiag.p, c->D * 8, hipMemcpyDeviceToHost));
+  return SQD_OK;
+}
+
+// stage a host vector into tmp slot (X buffer is not used so a Davidson state is not disturbed)
+static int upload_vec(sqd_ctx* c, const double* host, DevBuf& buf) {
+  SQD_TRY(buf.reserve((size_t)c->D * 8));
+  SQD_HIP_CHECK(hipMemcpyAsync(buf.p, host, c->D * 8, hipMemcpyHostToDevice, c->stream));
+  return SQD_OK;
+}
+
+SQD_API int sqd_sigma(sqd_ctx* c, const double* cvec, double* sigma, int use_spin, double ss, double shift) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!cvec || !sigma) return SQD_ERR_INVALID;
+  DevBuf& in = c->io_in;
+  DevBuf& out = c->io_out;
+  SQD_TRY(upload_vec(c, cvec, in));
+  SQD_TRY(out.reserve((size_t)c->D * 8));
+  SQD_TRY(apply_h(c, in.as<double>(), out.as<double>(), use_spin, ss, shift));
+  SQD_HIP_CHECK(hipMemcpyAsync(sigma, out.p, c->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return SQD_OK;
+}
+
+SQD_API int sqd_contract_ss(sqd_ctx* c, const double* cvec, double* outv) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!cvec || !outv) return SQD_ERR_INVALID;
+  DevBuf& in = c->io_in;
+  DevBuf& out = c->io_out;
+  SQD_TRY(upload_vec(c, cvec, in));
+  SQD_TRY(out.reserve((size_t)c->D * 8));
+  SQD_TRY(launch_sigma(c, in.as<double>(), out.as<double>(), 1, false, 0.0, 0.0));
+  SQD_HIP_CHECK(hipMemcpyAsync(outv, out.p, c->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return SQD_OK;
+}
+
+SQD_API void sqd_davidson_default_opts(sqd_davidson_opts* o) {
+  if (!o) return;
+  o->tol = 1e-9;
+  o->lindep = 1e-14;
+  o->max_cycle = 100;
+  o->max_space = 12;
+  o->use_spin = 0;
+  o->ss = 0.0;
+  o->shift = 0.2;
+  o->verbose = 0;
+}
+
+SQD_API int sqd_davidson(sqd_ctx* c, const sqd_davidson_opts* opts, const double* ci0, double* amps,
+                         sqd_davidson_stats* stats) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  sqd_davidson_opts o;
+  if (opts) o = *opts; else sqd_davidson_default_opts(&o);
+  if (o.tol <= 0 || o.max_cycle < 1) {
+    set_error("bad Davidson options");
+    return SQD_ERR_INVALID;
+  }
+  SQD_TRY(run_davidson(c, &o, ci0, stats));
+  if (amps) {
+    SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  return SQD_OK;
+}
+
+// resolve the state argument: host amps (uploaded to tmp2) or the resident solution
+static int state_ptr(sqd_ctx* c, const double* amps, const double** d) {
+  if (amps) {
+    SQD_TRY(upload_vec(c, amps, c->io_in));
+    *d = c->io_in.as<double>();
+    return SQD_OK;
+  }
+  if (!c->have_solution) {
+    set_error("no resident solution: run sqd_davidson or pass amplitudes");
+    return SQD_ERR_STATE;
+  }
+  *d = c->sol.as<double>();
+  return SQD_OK;
+}
+
+static int expectation(sqd_ctx* c, const double* amps, int mode, double* outv) {
+  const double* d = nullptr;
+  SQD_TRY(state_ptr(c, amps, &d));
+  SQD_TRY(c->tmp1.reserve((size_t)c->D * 8));
+  SQD_TRY(launch_sigma(c, d, c->tmp1.as<double>(), mode, false, 0.0, 0.0));
+  double num = 0.0, den = 0.0;
+  SQD_TRY(dev_dot(c, d, c->tmp1.as<double>(), &num));
+  SQD_TRY(dev_dot(c, d, d, &den));
+  if (!(den > 0.0)) {
+    set_error("state has zero norm");
+    return SQD_ERR_INVALID;
+  }
+  *outv = num / den;
+  return SQD_OK;
+}
+
+SQD_API int sqd_energy(sqd_ctx* c, const double* amps, double* e) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  return expectation(c, amps, 0, e);
+}
+SQD_API int sqd_spin_square(sqd_ctx* c, const double* amps, double* s2) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  return expectation(c, amps, 1, s2);
+}
+SQD_API int sqd_rdm1s(sqd_ctx* c, const double* amps, double* dm1a, double* dm1b) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  const double* d = nullptr;
+  SQD_TRY(state_ptr(c, amps, &d));
+  return dev_rdm1s(c, d, dm1a, dm1b);
+}
+SQD_API int sqd_rdm2(sqd_ctx* c, const double* amps, double* dm2) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  const double* d = nullptr;
+  SQD_TRY(state_ptr(c, amps, &d));
+  return dev_rdm2(c, d, dm2);
+}
+
+SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double shift, double* ms_per_sigma) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (reps < 1 || !ms_per_sigma) return SQD_ERR_INVALID;
+  const double* d = nullptr;
+  if (c->have_solution) {
+    d = c->sol.as<double>();
+  } else {
+    SQD_TRY(c->sol.reserve((size_t)c->D * 8));
+    SQD_HIP_CHECK(hipMemsetAsync(c->sol.p, 0, c->D * 8, c->stream));
+    d = c->sol.as<double>();
+  }
+  SQD_TRY(c->tmp1.reserve((size_t)c->D * 8));
+  if (use_spin == 2 || use_spin == 3) SQD_TRY(c->tmp2.reserve((size_t)c->D * 8));
+  SQD_TRY(apply_h(c, d, c->tmp1.as<double>(), use_spin == 2 ? 0 : use_spin, ss, shift));  // warm-up
+  SQD_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+  for (int i = 0; i < reps; ++i) SQD_TRY(apply_h(c, d, c->tmp1.as<double>(), use_spin == 2 ? 0 : use_spin, ss, shift));
+  SQD_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  *ms_per_sigma = (double)ms / reps;
+  return SQD_OK;
+}
+
+SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!bytes) return SQD_ERR_INVALID;
+  // B_sigma = 8 D (read c) + 8 D (write sigma) + 8 * populated links + 8 (nnorb_s^2 + nnorb_a^2)
+  const double D = (double)c->D;
+  const double links = (double)(c->sp[0].n_s + c->sp[0].n_d + c->sp[1].n_s + c->sp[1].n_d) +
+                       (double)c->na * c->nelec[0] + (double)c->nb * c->nelec[1];
+  const double ns = (double)c->nnorb, nas = (double)c->norb * (c->norb - 1) / 2.0;
+  *bytes = 16.0 * D + 8.0 * links + 8.0 * (ns * ns + nas * nas);
+  return SQD_OK;
+}

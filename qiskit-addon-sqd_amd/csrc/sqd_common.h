@@ -1,0 +1,133 @@
+// Internal declarations shared by the HIP translation units of libsqd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "sqd_hip.h"
+
+namespace sqd {
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const std::string& msg);
+#define SQD_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      sqd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + \
+                     ":" + std::to_string(__LINE__));                                    \
+      return SQD_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+#define SQD_TRY(expr)          \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != SQD_OK) return _rc; \
+  } while (0)
+
+// ---- grow-only device buffer (arena semantics: reused across set_subspace calls) ----
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);  // contents are NOT preserved on growth
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- link record encodings ----------------------------------------------------
+// single-excitation record: {src address, meta}
+//   meta bits  0..12 : widx = 2*pair + dir   (pair = tril index of (cre,des); dir = cre > des)
+//              13..18 : cre (created orbital), 19..24 : des (annihilated orbital), 31 : sign (1 = -1)
+struct SRec {
+  uint32_t src;
+  uint32_t meta;
+};
+__host__ __device__ inline uint32_t srec_widx(uint32_t m) { return m & 0x1fffu; }
+__host__ __device__ inline uint32_t srec_cre(uint32_t m) { return (m >> 13) & 63u; }
+__host__ __device__ inline uint32_t srec_des(uint32_t m) { return (m >> 19) & 63u; }
+__host__ __device__ inline double srec_sign(uint32_t m) { return (m >> 31) ? -1.0 : 1.0; }
+// double-excitation orbital word: p | r<<6 | q<<12 | s<<18 | sign<<31
+__host__ __device__ inline uint32_t tril(uint32_t p, uint32_t q) {
+  return p >= q ? p * (p + 1) / 2 + q : q * (q + 1) / 2 + p;
+}
+
+// Per-spin tables.  "row" role = alpha (rows of C), "col" role = beta (columns of C); both
+// spins carry the CSR form, the sliced-ELL copies are what the column role reads coalesced.
+struct SpinTables {
+  int64_t n = 0;
+  int nocc = 0;
+  int64_t n_s = 0, n_d = 0;      // populated single / double links
+  int64_t n_slices = 0;          // ceil(n/64)
+  DevBuf strs;                   // u64[n]
+  DevBuf e_str;                  // f64[n]   same-spin diagonal energy of each string
+  DevBuf s_ptr, d_ptr;           // i64[n+1] CSR row pointers
+  DevBuf s_row, d_row;           // u32      COO row (tgt) of each link
+  DevBuf s_rec;                  // SRec[n_s]
+  DevBuf s_val;                  // f64[n_s] sign*(h_ab + sum_k in src (ab|kk)-(ak|kb))
+  DevBuf d_src;                  // u32[n_d]
+  DevBuf d_orb;                  // u32[n_d]
+  DevBuf d_val;                  // f64[n_d] sign*((pq|rs)-(ps|rq))
+  DevBuf jrow;                   // f64[n][nnorb]   J[I][pair] = sum_{k in I} (pair|kk)   (row role)
+  DevBuf jT;                     // f64[nnorb][n]   transposed copy                        (col role)
+  // sliced ELL (slice = 64 consecutive strings), records of slice b start at *_sl[b], entry
+  // (k, lane) lives at *_sl[b] + k*64 + lane
+  DevBuf es_sl, ed_sl;           // i64[n_slices+1]
+  DevBuf es_rec;                 // SRec
+  DevBuf es_val;                 // f64
+  DevBuf ed_src;                 // u32
+  DevBuf ed_val;                 // f64
+  void release();
+};
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace sqd
+
+struct sqd_ctx {
+  int device = 0;
+  int norb = 0, nnorb = 0;
+  int num_cu = 256;
+  int lds_bytes = 160 * 1024;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // integrals
+  sqd::DevBuf h1, eri4, eri_pp, jm, km;  // eri_pp[nnorb][nnorb]; jm/km[norb][norb]
+  // subspace
+  bool have_subspace = false;
+  int64_t na = 0, nb = 0, D = 0;
+  int nelec[2] = {0, 0};
+  sqd::SpinTables sp[2];
+  sqd::DevBuf hdiag;        // f64[D]
+  // Davidson workspace
+  sqd::DevBuf X, AX;        // (max_space+1) * D each
+  sqd::DevBuf sol;          // f64[D] resident solution
+  bool have_solution = false;
+  sqd::DevBuf tmp1, tmp2;   // f64[D] scratch vectors
+  sqd::DevBuf io_in, io_out;  // staging of host vectors crossing the C ABI
+  sqd::DevBuf partial;      // reduction partials
+  sqd::DevBuf scal;         // small device scalars
+  sqd::DevBuf scratch;      // misc (counts, scans)
+  double* h_pinned = nullptr;  // pinned host scratch (>= 4096 doubles)
+  double ms_setup = 0.0;
+  std::vector<double> host_tmp;
+};
+
+namespace sqd {
+// tables (sqd_tables.hip)
+int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri);
+int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb);
+// sigma (sqd_sigma.hip).  mode 0: H (+ shift*(S^2-ss) if spin) ; mode 1: pure S^2
+int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift);
+int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift);
+// blas-1 (sqd_davidson.hip)
+int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
+int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st);
+// observables (sqd_rdm.hip)
+int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
+int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
+}  // namespace sqd

@@ -1,0 +1,432 @@
+// Device-resident single-root Davidson for P (H + penalty) P.
+//
+// Replaces pyscf kernel_fixed_space -> FCISolver.eig -> lib.davidson1 (numpy BLAS-1 on the host)
+// as called from qiskit_addon_sqd/fermion.py:721-723 and :810-818.  Control flow and constants
+// follow SURVEY.md Appendix A.6: tol on |dE| and sqrt(tol) on |r|, preconditioner
+// r/(hdiag - e + 1e-4), Gram-Schmidt against the whole basis, lindep drop, restart when the basis
+// reaches max_space.  One deliberate difference: at a restart pyscf throws the fresh correction
+// vector away and spends a sigma build on the Ritz vector; here the basis collapses to
+// {Ritz vector, correction} and A*Ritz is formed by linear combination, saving that sigma build.
+//
+// All vectors (basis X, A X, hdiag) stay in HBM; only the (m x m) projected matrix and a handful of
+// norms cross to the host per iteration.  BLAS-1 work is fused: one pass builds residual +
+// preconditioned correction + its overlaps with the basis; reductions are fixed-order (bitwise
+// reproducible run to run).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "sqd_common.h"
+
+namespace sqd {
+
+constexpr int NV = 16;        // vectors per fused reduction launch
+constexpr int RED_BLOCKS = 512;
+constexpr int RED_T = 256;
+
+__device__ inline double block_sum(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+  }
+  return s;  // valid on thread 0
+}
+
+// partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
+__global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
+                       const double* __restrict__ y, double* __restrict__ partial) {
+  __shared__ double red[16];
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double yv = y[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (v < nvec) acc[v] += X[(int64_t)v * stride + i] * yv;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const double s = block_sum(acc[v], red);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * NV + v] = s;
+  }
+}
+
+// out[v] = sum_b partial[b*width + v]
+__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, int nv,
+                                  double* __restrict__ out) {
+  const int v = threadIdx.x;
+  if (v >= nv) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + v];
+  out[v] = s;
+}
+
+struct Coef {
+  double v[SQD_MAX_SPACE + 2];
+};
+
+// out = sum_{v<nvec} coef[v] * X[v]
+__global__ void k_lincomb(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef coef,
+                          double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int v = 0; v < nvec; ++v) s += coef.v[v] * X[(int64_t)v * stride + i];
+    out[i] = s;
+  }
+}
+
+// r = sum_v coef[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to `out`.
+// partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]
+__global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
+                                   int64_t stride, int nvec, const Coef coef, double e,
+                                   const double* __restrict__ hdiag, double* __restrict__ out,
+                                   double* __restrict__ partial, int width) {
+  __shared__ double red[16];
+  double rr = 0.0, tt = 0.0;
+  double acc[SQD_MAX_SPACE + 1];
+#pragma unroll
+  for (int v = 0; v < SQD_MAX_SPACE + 1; ++v) acc[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double r = 0.0;
+    double xv[SQD_MAX_SPACE + 1];
+#pragma unroll
+    for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
+      if (v < nvec) {
+        xv[v] = X[(int64_t)v * stride + i];
+        r += coef.v[v] * (AX[(int64_t)v * stride + i] - e * xv[v]);
+      }
+    const double t = r / (hdiag[i] - e + 1e-4);
+    out[i] = t;
+    rr += r * r;
+    tt += t * t;
+#pragma unroll
+    for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
+      if (v < nvec) acc[v] += xv[v] * t;
+  }
+  double s = block_sum(rr, red);
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 0] = s;
+  s = block_sum(tt, red);
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 1] = s;
+#pragma unroll
+  for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
+    if (v < nvec) {
+      const double sv = block_sum(acc[v], red);
+      if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 2 + v] = sv;
+    }
+}
+
+// t <- scale * t - sum_v coef[v] X_v ;  partial[block] = |t|^2
+__global__ void k_orth(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef coef,
+                       double scale, double* __restrict__ t, double* __restrict__ partial) {
+  __shared__ double red[16];
+  double tt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = scale * t[i];
+    for (int v = 0; v < nvec; ++v) s -= coef.v[v] * X[(int64_t)v * stride + i];
+    t[i] = s;
+    tt += s * s;
+  }
+  const double s = block_sum(tt, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void k_scale(int64_t n, double a, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] *= a;
+}
+
+// per-block (min value, index) over hdiag; tril != 0 restricts to A >= B (pyscf _get_init_guess
+// when nelec_a == nelec_b and na == nb)
+__global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __restrict__ h,
+                         double* __restrict__ pmin, int64_t* __restrict__ pidx) {
+  __shared__ double sv[1024];
+  __shared__ int64_t si[1024];
+  double best = 1e300;
+  int64_t bi = -1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (tril_only && (i / nb) < (i % nb)) continue;
+    const double v = h[i];
+    if (v < best || (v == best && i < bi)) {
+      best = v;
+      bi = i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < (int)blockDim.x; ++t)
+      if (si[t] >= 0 && (sv[t] < best || (sv[t] == best && si[t] < bi) || bi < 0)) {
+        best = sv[t];
+        bi = si[t];
+      }
+    pmin[blockIdx.x] = best;
+    pidx[blockIdx.x] = bi;
+  }
+}
+
+__global__ void k_init_guess(int64_t n, int64_t addr, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = (i == addr) ? 1.0 : 0.0;
+    if (i == 0) v += 1e-5;
+    if (i == n - 1) v -= 1e-5;
+    x[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ host helpers
+static inline unsigned red_blocks(int64_t n) {
+  int64_t b = (n + RED_T - 1) / RED_T;
+  if (b > RED_BLOCKS) b = RED_BLOCKS;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// sums[0..nv) = column sums of the device partial array; one small D2H + sync
+static int fetch_sums(sqd_ctx* c, int nblocks, int width, int nv, double* sums) {
+  double* d_out = c->scal.as<double>();
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, c->stream, (const double*)c->partial.as<double>(), nblocks,
+                     width, nv, d_out);
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, d_out, sizeof(double) * nv, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  std::memcpy(sums, c->h_pinned, sizeof(double) * nv);
+  return SQD_OK;
+}
+
+// dots[v] = X_v . y for v < nvec (any nvec <= SQD_MAX_SPACE+1), fixed-order reduction
+static int multi_dot(sqd_ctx* c, const double* X, int64_t stride, int nvec, const double* y, double* dots) {
+  const int64_t n = c->D;
+  const unsigned nb = red_blocks(n);
+  for (int v0 = 0; v0 < nvec; v0 += NV) {
+    const int nv = (nvec - v0 < NV) ? (nvec - v0) : NV;
+    hipLaunchKernelGGL(k_dots, dim3(nb), dim3(RED_T), 0, c->stream, n, X + (int64_t)v0 * stride, stride, nv, y,
+                       c->partial.as<double>());
+    SQD_HIP_CHECK(hipGetLastError());
+    SQD_TRY(fetch_sums(c, (int)nb, NV, nv, dots + v0));
+  }
+  return SQD_OK;
+}
+
+int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
+  SQD_TRY(c->partial.reserve((size_t)RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  SQD_TRY(c->scal.reserve(1024));
+  return multi_dot(c, x, 0, 1, y, out);
+}
+
+// cyclic Jacobi for a small symmetric matrix; eigenvalues ascending in w, eigenvectors in columns of V
+static void jacobi_eigh(int n, const double* Ain, double* w, double* V) {
+  std::vector<double> A(Ain, Ain + n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = cs * akp - sn * akq;
+          A[k * n + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = cs * apk - sn * aqk;
+          A[q * n + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = cs * vkp - sn * vkq;
+          V[k * n + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) std::swap(order[i], order[j]);
+  std::vector<double> Vs(n * n);
+  for (int j = 0; j < n; ++j) {
+    w[j] = A[order[j] * n + order[j]];
+    for (int k = 0; k < n; ++k) Vs[k * n + j] = V[k * n + order[j]];
+  }
+  std::memcpy(V, Vs.data(), sizeof(double) * n * n);
+}
+
+int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st) {
+  if (!c->have_subspace) {
+    set_error("no subspace set");
+    return SQD_ERR_STATE;
+  }
+  const int64_t D = c->D;
+  int max_space = o->max_space;
+  if (max_space < 2) max_space = 2;
+  if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
+  const double tol = o->tol, toloose = std::sqrt(o->tol), lindep = o->lindep;
+  hipStream_t s = c->stream;
+  const int nvecs = max_space + 1;
+  SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
+  SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
+  SQD_TRY(c->sol.reserve((size_t)D * 8));
+  SQD_TRY(c->partial.reserve((size_t)RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  SQD_TRY(c->scal.reserve(1024));
+  double* X = c->X.as<double>();
+  double* AX = c->AX.as<double>();
+  const unsigned gb = red_blocks(D);
+  const int width = SQD_MAX_SPACE + 4;
+
+  SQD_HIP_CHECK(hipEventRecord(c->ev[2], s));
+  // ---- initial vector
+  if (ci0_host) {
+    SQD_HIP_CHECK(hipMemcpyAsync(X, ci0_host, D * 8, hipMemcpyHostToDevice, s));
+  } else {
+    const int tril_only = (c->nelec[0] == c->nelec[1] && c->na == c->nb) ? 1 : 0;
+    double* pmin = c->partial.as<double>();
+    int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
+    hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, s, D, c->nb, tril_only, (const double*)c->hdiag.as<double>(),
+                       pmin, pidx);
+    SQD_HIP_CHECK(hipGetLastError());
+    std::vector<double> hm(gb);
+    std::vector<int64_t> hi(gb);
+    SQD_HIP_CHECK(hipMemcpyAsync(hm.data(), pmin, gb * 8, hipMemcpyDeviceToHost, s));
+    SQD_HIP_CHECK(hipMemcpyAsync(hi.data(), pidx, gb * 8, hipMemcpyDeviceToHost, s));
+    SQD_HIP_CHECK(hipStreamSynchronize(s));
+    double best = 1e300;
+    int64_t addr = 0;
+    for (unsigned b = 0; b < gb; ++b)
+      if (hi[b] >= 0 && (hm[b] < best || (hm[b] == best && hi[b] < addr))) {
+        best = hm[b];
+        addr = hi[b];
+      }
+    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, addr, X);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  {
+    double nn;
+    SQD_TRY(multi_dot(c, X, 0, 1, X, &nn));
+    if (!(nn > 0.0)) {
+      set_error("initial vector has zero norm");
+      return SQD_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(nn), X);
+  }
+
+  std::vector<double> heff((size_t)nvecs * nvecs, 0.0), sub, w(nvecs), V((size_t)nvecs * nvecs);
+  std::vector<double> sums(width);
+  Coef coef;
+  int m = 1;  // basis size; X[m-1] is the newest vector, its sigma not yet built
+  double e = 0.0, elast = 0.0, rnorm = 0.0;
+  bool conv = false;
+  int nsig = 0, it = 0;
+  bool first = true;
+  for (it = 0; it < o->max_cycle; ++it) {
+    // sigma for the newest basis vector
+    SQD_TRY(apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift));
+    ++nsig;
+    // new column of the projected matrix
+    SQD_TRY(multi_dot(c, X, D, m, AX + (int64_t)(m - 1) * D, sums.data()));
+    for (int i = 0; i < m; ++i) heff[(size_t)i * nvecs + (m - 1)] = heff[(size_t)(m - 1) * nvecs + i] = sums[i];
+    sub.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) sub[(size_t)i * m + j] = heff[(size_t)i * nvecs + j];
+    jacobi_eigh(m, sub.data(), w.data(), V.data());
+    elast = e;
+    e = w[0];
+    const double de = first ? e : e - elast;
+    first = false;
+    for (int i = 0; i < m; ++i) coef.v[i] = V[(size_t)i * m + 0];
+    // residual, preconditioned correction (into X[m]) and its overlaps
+    double* tnew = X + (int64_t)m * D;
+    hipLaunchKernelGGL(k_residual_precond, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m, coef,
+                       e, (const double*)c->hdiag.as<double>(), tnew, c->partial.as<double>(), width);
+    SQD_HIP_CHECK(hipGetLastError());
+    SQD_TRY(fetch_sums(c, (int)gb, width, m + 2, sums.data()));
+    rnorm = std::sqrt(sums[0]);
+    if (o->verbose)
+      std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", it, m, e, de, rnorm);
+    if (std::fabs(de) < tol && rnorm < toloose) {
+      conv = true;
+      ++it;
+      break;
+    }
+    if (!(sums[0] > lindep) || !(sums[1] > 0.0)) {
+      conv = rnorm < toloose;
+      ++it;
+      break;
+    }
+    const double tn = std::sqrt(sums[1]);
+    Coef gs;
+    for (int i = 0; i < m; ++i) gs.v[i] = sums[2 + i] / tn;
+    hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, 1.0 / tn, tnew,
+                       c->partial.as<double>());
+    SQD_HIP_CHECK(hipGetLastError());
+    double n2;
+    SQD_TRY(fetch_sums(c, (int)gb, 1, 1, &n2));
+    if (!(n2 > lindep)) {
+      conv = rnorm < toloose;
+      ++it;
+      break;
+    }
+    hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(n2), tnew);
+    SQD_HIP_CHECK(hipGetLastError());
+    if (m + 1 > max_space) {
+      // collapse: X0 <- Ritz vector, AX0 <- A*Ritz (linear combination), X1 <- correction
+      double* x0 = c->sol.as<double>();
+      SQD_TRY(c->tmp1.reserve((size_t)D * 8));
+      double* ax0 = c->tmp1.as<double>();
+      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, coef, x0);
+      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)AX, D, m, coef, ax0);
+      SQD_HIP_CHECK(hipMemcpyAsync(X + D, tnew, D * 8, hipMemcpyDeviceToDevice, s));
+      SQD_HIP_CHECK(hipMemcpyAsync(X, x0, D * 8, hipMemcpyDeviceToDevice, s));
+      SQD_HIP_CHECK(hipMemcpyAsync(AX, ax0, D * 8, hipMemcpyDeviceToDevice, s));
+      std::fill(heff.begin(), heff.end(), 0.0);
+      heff[0] = e;
+      m = 2;
+    } else {
+      ++m;
+    }
+  }
+  // solution = Ritz vector of the last projected problem, normalised
+  {
+    const int mm = (conv || it >= o->max_cycle) ? m : m;
+    double* x0 = c->sol.as<double>();
+    hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, coef, x0);
+    SQD_HIP_CHECK(hipGetLastError());
+    double nn;
+    SQD_TRY(multi_dot(c, x0, 0, 1, x0, &nn));
+    if (nn > 0.0) hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(nn), x0);
+  }
+  SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
+  SQD_HIP_CHECK(hipStreamSynchronize(s));
+  float ms = 0.f;
+  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  c->have_solution = true;
+  if (st) {
+    st->converged = conv ? 1 : 0;
+    st->iterations = it;
+    st->n_sigma = nsig;
+    st->e_davidson = e;
+    st->residual = rnorm;
+    st->ms_total = ms;
+    st->ms_sigma = 0.0;
+    st->ms_setup = c->ms_setup;
+  }
+  return SQD_OK;
+}
+
+}  // namespace sqd

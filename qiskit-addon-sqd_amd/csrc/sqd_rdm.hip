@@ -1,0 +1,286 @@
+// Reduced density matrices of a subspace state from the same link tables the sigma kernel uses.
+//
+// Replaces pyscf SelectedCI.make_rdm1s / make_rdm1 / make_rdm2 (FCImake_rdm1a/b, FCItdm12kern_ab,
+// SCIrdm2_aaaa), which the reference calls at qiskit_addon_sqd/fermion.py:725-729, :821-826 and
+// :117-125 -- each of those calls rebuilds pyscf's link tables; here they are already resident.
+//
+// Conventions: dm1s[p,q] = <a+_p a_q>;  dm2[p,q,r,s] = sum_{st} <p+_s r+_t s_t q_s>.
+// Orbital occupancies (the diagonal of dm1s, the only part that feeds back into the SQD loop) are
+// reduced in a fixed order and are bitwise reproducible; off-diagonal bins use f64 atomics.
+#include "sqd_common.h"
+
+namespace sqd {
+
+// w[A] = sum_B C[A,B]^2   (one wavefront per row)
+__global__ void k_row_norms(const double* __restrict__ C, int64_t na, int64_t nb, double* __restrict__ w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t A = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (A >= na) return;
+  double s = 0.0;
+  for (int64_t b = lane; b < nb; b += 64) {
+    const double v = C[A * nb + b];
+    s += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) w[A] = s;
+}
+// w[B] = sum_A C[A,B]^2   (thread per column: unit stride across lanes)
+__global__ void k_col_norms(const double* __restrict__ C, int64_t na, int64_t nb, double* __restrict__ w) {
+  const int64_t B = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (B >= nb) return;
+  double s = 0.0;
+  for (int64_t a = 0; a < na; ++a) {
+    const double v = C[a * nb + B];
+    s += v * v;
+  }
+  w[B] = s;
+}
+// out[l] = sum_B C[tgt_l,B] C[src_l,B]   (one wavefront per alpha link)
+__global__ void k_rowpair_dots(const double* __restrict__ C, int64_t nb, int64_t nl, const uint32_t* __restrict__ tgt,
+                               const uint32_t* __restrict__ src, int src_stride, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t l = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (l >= nl) return;
+  const double* r0 = C + (int64_t)tgt[l] * nb;
+  const double* r1 = C + (int64_t)src[(int64_t)l * src_stride] * nb;
+  double s = 0.0;
+  for (int64_t b = lane; b < nb; b += 64) s += r0[b] * r1[b];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (lane == 0) out[l] = s;
+}
+// out[l] = sum_A C[A,tgt_l] C[A,src_l]   (thread per beta link)
+__global__ void k_colpair_dots(const double* __restrict__ C, int64_t na, int64_t nb, int64_t nl,
+                               const uint32_t* __restrict__ tgt, const uint32_t* __restrict__ src, int src_stride,
+                               double* __restrict__ out) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nl) return;
+  const int64_t b0 = tgt[l], b1 = src[(int64_t)l * src_stride];
+  double s = 0.0;
+  for (int64_t a = 0; a < na; ++a) s += C[a * nb + b0] * C[a * nb + b1];
+  out[l] = s;
+}
+
+// occ[p] = sum_I [p in I] w[I]   (fixed order)
+__global__ void k_occupancy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ w, int norb,
+                            double* __restrict__ dm1 /*[norb*norb], diagonal written*/) {
+  const int p = threadIdx.x;
+  if (p >= norb) return;
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i)
+    if ((strs[i] >> p) & 1ull) s += w[i];
+  dm1[p * norb + p] = s;
+}
+
+__global__ void k_rdm1_singles(int64_t nl, const SRec* __restrict__ rec, const double* __restrict__ dots, int norb,
+                               double* __restrict__ dm1) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nl) return;
+  const uint32_t m = rec[l].meta;
+  atomicAdd(&dm1[srec_cre(m) * norb + srec_des(m)], srec_sign(m) * dots[l]);
+}
+
+// ---- dm2 same-spin pieces (operator index order [p,q,r,s] <-> a+_p a+_r a_s a_q)
+__device__ inline int64_t i4(int n, int p, int q, int r, int s) { return (((int64_t)p * n + q) * n + r) * n + s; }
+
+__global__ void k_rdm2_diag(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ w, int norb,
+                            double* __restrict__ dm2) {
+  // thread per (p,r) pair, fixed-order loop over strings
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= norb * norb) return;
+  const int p = idx / norb, r = idx % norb;
+  if (p == r) return;
+  const uint64_t mask = (1ull << p) | (1ull << r);
+  double s = 0.0;
+  for (int64_t i = 0; i < n; ++i)
+    if ((strs[i] & mask) == mask) s += w[i];
+  atomicAdd(&dm2[i4(norb, p, p, r, r)], s);
+  atomicAdd(&dm2[i4(norb, p, r, r, p)], -s);
+}
+__global__ void k_rdm2_singles(const uint64_t* __restrict__ strs, int64_t nl, const SRec* __restrict__ rec,
+                               const double* __restrict__ dots, int norb, double* __restrict__ dm2) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nl) return;
+  const uint32_t m = rec[l].meta;
+  const int a = srec_cre(m), b = srec_des(m);
+  const double ov = srec_sign(m) * dots[l];
+  uint64_t occ = strs[rec[l].src] & ~(1ull << b);
+  while (occ) {
+    const int k = __ffsll((long long)occ) - 1;
+    occ &= occ - 1;
+    atomicAdd(&dm2[i4(norb, a, b, k, k)], ov);
+    atomicAdd(&dm2[i4(norb, k, k, a, b)], ov);
+    atomicAdd(&dm2[i4(norb, a, k, k, b)], -ov);
+    atomicAdd(&dm2[i4(norb, k, b, a, k)], -ov);
+  }
+}
+__global__ void k_rdm2_doubles(int64_t nl, const uint32_t* __restrict__ orb, const double* __restrict__ dots, int norb,
+                               double* __restrict__ dm2) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nl) return;
+  const uint32_t o = orb[l];
+  const int p = o & 63, r = (o >> 6) & 63, q = (o >> 12) & 63, s = (o >> 18) & 63;
+  const double ov = ((o >> 31) ? -1.0 : 1.0) * dots[l];
+  atomicAdd(&dm2[i4(norb, p, q, r, s)], ov);
+  atomicAdd(&dm2[i4(norb, r, s, p, q)], ov);
+  atomicAdd(&dm2[i4(norb, p, s, r, q)], -ov);
+  atomicAdd(&dm2[i4(norb, r, q, p, s)], -ov);
+}
+
+// ---- dm2 opposite-spin: extended link lists (singles + one diagonal pseudo-link per occupied orbital)
+struct XLink {
+  uint32_t tgt, src;
+  uint32_t pq;     // cre | des<<6
+  float sign;
+};
+__global__ void k_xlinks(const uint64_t* __restrict__ strs, int64_t n, int nocc, int64_t n_s,
+                         const uint32_t* __restrict__ s_row, const SRec* __restrict__ s_rec, XLink* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_s) {
+    const uint32_t m = s_rec[i].meta;
+    out[i] = XLink{s_row[i], s_rec[i].src, srec_cre(m) | (srec_des(m) << 6), (float)srec_sign(m)};
+  } else if (i < n_s + n * nocc) {
+    const int64_t j = i - n_s;
+    const int64_t I = j / nocc;
+    int k = (int)(j % nocc);
+    uint64_t occ = strs[I];
+    for (int t = 0; t < k; ++t) occ &= occ - 1;
+    const uint32_t p = (uint32_t)(__ffsll((long long)occ) - 1);
+    out[i] = XLink{(uint32_t)I, (uint32_t)I, p | (p << 6), 1.0f};
+  }
+}
+// G[p,q,r,s] += sa sb C[tgt_a,tgt_b] C[src_a,src_b]  over all (alpha xlink, beta xlink) pairs
+__global__ void k_rdm2_ab(const double* __restrict__ C, int64_t nb, int64_t la, int64_t lb,
+                          const XLink* __restrict__ xa, const XLink* __restrict__ xb, int norb,
+                          double* __restrict__ G) {
+  const int64_t ib = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ib >= lb) return;
+  const XLink b = xb[ib];
+  const int r = b.pq & 63, s = (b.pq >> 6) & 63;
+  for (int64_t ia = blockIdx.y; ia < la; ia += gridDim.y) {
+    const XLink a = xa[ia];
+    const int p = a.pq & 63, q = (a.pq >> 6) & 63;
+    const double v = (double)(a.sign * b.sign) * C[(int64_t)a.tgt * nb + b.tgt] * C[(int64_t)a.src * nb + b.src];
+    if (v != 0.0) atomicAdd(&G[i4(norb, p, q, r, s)], v);
+  }
+}
+// dm2 += G + G^T(2,3,0,1)
+__global__ void k_rdm2_symm_add(int norb, const double* __restrict__ G, double* __restrict__ dm2) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n2 = (int64_t)norb * norb;
+  if (idx >= n2 * n2) return;
+  const int64_t pq = idx / n2, rs = idx % n2;
+  dm2[idx] += G[idx] + G[rs * n2 + pq];
+}
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+// link dots for one spin into `dots` (singles first, then doubles); norms into w
+static int spin_link_dots(sqd_ctx* c, int spin, const double* C, double* w, double* dots_s, double* dots_d) {
+  const SpinTables& t = c->sp[spin];
+  hipStream_t st = c->stream;
+  if (spin == 0) {
+    hipLaunchKernelGGL(k_row_norms, dim3(nblk(t.n, 4)), dim3(256), 0, st, C, c->na, c->nb, w);
+    if (t.n_s > 0)
+      hipLaunchKernelGGL(k_rowpair_dots, dim3(nblk(t.n_s, 4)), dim3(256), 0, st, C, c->nb, t.n_s,
+                         (const uint32_t*)t.s_row.as<uint32_t>(), (const uint32_t*)t.s_rec.as<uint32_t>(), 2, dots_s);
+    if (t.n_d > 0 && dots_d)
+      hipLaunchKernelGGL(k_rowpair_dots, dim3(nblk(t.n_d, 4)), dim3(256), 0, st, C, c->nb, t.n_d,
+                         (const uint32_t*)t.d_row.as<uint32_t>(), (const uint32_t*)t.d_src.as<uint32_t>(), 1, dots_d);
+  } else {
+    hipLaunchKernelGGL(k_col_norms, dim3(nblk(t.n, 256)), dim3(256), 0, st, C, c->na, c->nb, w);
+    if (t.n_s > 0)
+      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, C, c->na, c->nb, t.n_s,
+                         (const uint32_t*)t.s_row.as<uint32_t>(), (const uint32_t*)t.s_rec.as<uint32_t>(), 2, dots_s);
+    if (t.n_d > 0 && dots_d)
+      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, C, c->na, c->nb, t.n_d,
+                         (const uint32_t*)t.d_row.as<uint32_t>(), (const uint32_t*)t.d_src.as<uint32_t>(), 1, dots_d);
+  }
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
+int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
+  const int norb = c->norb;
+  const int64_t n2 = (int64_t)norb * norb;
+  hipStream_t st = c->stream;
+  int64_t need = 2 * n2;
+  for (int s = 0; s < 2; ++s) need += c->sp[s].n + c->sp[s].n_s;
+  SQD_TRY(c->scratch.reserve((size_t)need * 8 + 64));
+  double* base = c->scratch.as<double>();
+  double* dm = base;  // [2][n2]
+  SQD_HIP_CHECK(hipMemsetAsync(dm, 0, 2 * n2 * 8, st));
+  double* p = base + 2 * n2;
+  for (int s = 0; s < 2; ++s) {
+    const SpinTables& t = c->sp[s];
+    double* w = p;
+    double* dots = p + t.n;
+    p += t.n + t.n_s;
+    SQD_TRY(spin_link_dots(c, s, d_c, w, dots, nullptr));
+    hipLaunchKernelGGL(k_occupancy, dim3(1), dim3(64), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
+                       (const double*)w, norb, dm + s * n2);
+    if (t.n_s > 0)
+      hipLaunchKernelGGL(k_rdm1_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, t.n_s,
+                         (const SRec*)t.s_rec.as<SRec>(), (const double*)dots, norb, dm + s * n2);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  SQD_HIP_CHECK(hipMemcpyAsync(dm1a, dm, n2 * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipMemcpyAsync(dm1b, dm + n2, n2 * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  return SQD_OK;
+}
+
+int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
+  const int norb = c->norb;
+  const int64_t n2 = (int64_t)norb * norb, n4 = n2 * n2;
+  hipStream_t st = c->stream;
+  // layout of scratch: dm2[n4] | G[n4] | per-spin { w[n] | dots_s[n_s] | dots_d[n_d] } | xlinks
+  int64_t need = 2 * n4;
+  int64_t xl[2];
+  for (int s = 0; s < 2; ++s) {
+    need += c->sp[s].n + c->sp[s].n_s + c->sp[s].n_d;
+    xl[s] = c->sp[s].n_s + c->sp[s].n * c->sp[s].nocc;
+  }
+  const size_t xbytes = (size_t)(xl[0] + xl[1]) * sizeof(XLink);
+  SQD_TRY(c->scratch.reserve((size_t)need * 8 + xbytes + 256));
+  double* base = c->scratch.as<double>();
+  double* dm2 = base;
+  double* G = base + n4;
+  SQD_HIP_CHECK(hipMemsetAsync(dm2, 0, 2 * n4 * 8, st));
+  double* p = base + 2 * n4;
+  XLink* xlink[2];
+  xlink[0] = reinterpret_cast<XLink*>(base + need);
+  xlink[1] = xlink[0] + xl[0];
+  for (int s = 0; s < 2; ++s) {
+    const SpinTables& t = c->sp[s];
+    double* w = p;
+    double* ds = p + t.n;
+    double* dd = ds + t.n_s;
+    p += t.n + t.n_s + t.n_d;
+    SQD_TRY(spin_link_dots(c, s, d_c, w, ds, dd));
+    hipLaunchKernelGGL(k_rdm2_diag, dim3(nblk(n2, 64)), dim3(64), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
+                       (const double*)w, norb, dm2);
+    if (t.n_s > 0)
+      hipLaunchKernelGGL(k_rdm2_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st,
+                         (const uint64_t*)t.strs.as<uint64_t>(), t.n_s, (const SRec*)t.s_rec.as<SRec>(),
+                         (const double*)ds, norb, dm2);
+    if (t.n_d > 0)
+      hipLaunchKernelGGL(k_rdm2_doubles, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, t.n_d,
+                         (const uint32_t*)t.d_orb.as<uint32_t>(), (const double*)dd, norb, dm2);
+    hipLaunchKernelGGL(k_xlinks, dim3(nblk(xl[s], 256)), dim3(256), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
+                       t.nocc, t.n_s, (const uint32_t*)t.s_row.as<uint32_t>(), (const SRec*)t.s_rec.as<SRec>(),
+                       xlink[s]);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (xl[0] > 0 && xl[1] > 0) {
+    unsigned gy = (unsigned)(xl[0] < 1024 ? xl[0] : 1024);
+    hipLaunchKernelGGL(k_rdm2_ab, dim3(nblk(xl[1], 256), gy), dim3(256), 0, st, d_c, c->nb, xl[0], xl[1],
+                       (const XLink*)xlink[0], (const XLink*)xlink[1], norb, G);
+  }
+  hipLaunchKernelGGL(k_rdm2_symm_add, dim3(nblk(n4, 256)), dim3(256), 0, st, norb, (const double*)G, dm2);
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_HIP_CHECK(hipMemcpyAsync(dm2_host, dm2, n4 * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  return SQD_OK;
+}
+
+}  // namespace sqd

@@ -1,0 +1,291 @@
+// sigma = P H P c on the alpha x beta product subspace (the Davidson matvec), plus P S^2 P c.
+//
+// Replaces pyscf selected_ci.contract_2e (SCIcontract_2e_aaaa x2 + SCIcontract_2e_bbaa, with its
+// per-call O(norb^4) integral re-packing and two transposes of C) and selected_ci.contract_ss /
+// the fix_spin_ penalty; reference call sites qiskit_addon_sqd/fermion.py:721-723, :810-818, :830.
+//
+// Formulation (exact, no dense (string x norb^2) intermediate, no multiplications by zero):
+//   sigma[A,B] = hdiag[A,B] C[A,B]
+//     + sum_{A'}  Ha[A,A'] C[A',B]                                  same-spin alpha (singles+doubles)
+//     + sum_{B'}  Hb[B,B'] C[A,B']                                  same-spin beta
+//     + sum_{(A',pq,s) in Sa(A)} s * Jb[B][pq] * C[A',B]            alpha single x beta occupation
+//     + sum_{(B',rs,t) in Sb(B)} t * Ja[A][rs] * C[A,B']            beta single x alpha occupation
+//     + sum_{Sa(A)} sum_{Sb(B)} s t (pq|rs) C[A',B']                single x single
+//   (S^2 adds  -sum Ea_qp Eb_pq  = one extra entry in the (pq|..) row, and a diagonal term.)
+//
+// gfx950 mapping: one workgroup owns one alpha string A (one row of sigma) and keeps its
+// accumulators in registers.  For a batch of up to K alpha links it stages, coalesced, the K source
+// rows C[A',:] and the K integral rows (pq|:) into LDS (160 KB/CU holds 8 rows at nb ~ 2000), then
+// every lane walks the sliced-ELL single-excitation list of its beta string and gathers from LDS.
+// Global memory is only ever read with unit stride; all irregular accesses hit LDS.
+#include <cmath>
+#include <cstdlib>
+
+#include "sqd_common.h"
+
+namespace sqd {
+
+struct SigmaArgs {
+  const double* c;
+  double* sigma;
+  int64_t na, nb;
+  int nnorb, nb_pad, K;
+  int mode;  // 0: H (+ penalty when spin), 1: pure S^2
+  int spin;
+  double ss, shift, szterm;
+  const uint64_t* strs_a;
+  const uint64_t* strs_b;
+  const double* hdiag;
+  const int64_t* sa_ptr;
+  const SRec* sa_rec;
+  const double* sa_val;
+  const int64_t* da_ptr;
+  const uint32_t* da_src;
+  const double* da_val;
+  const double* ja_row;
+  const int64_t* sb_ptr;
+  const int64_t* db_ptr;
+  const int64_t* esb_sl;
+  const SRec* esb_rec;
+  const double* esb_val;
+  const int64_t* edb_sl;
+  const uint32_t* edb_src;
+  const double* edb_val;
+  const double* jbT;
+  const double* eri_pp;
+};
+
+template <int R>
+__global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  const int T = blockDim.x, tid = threadIdx.x;
+  const int64_t A = blockIdx.x;
+  const int64_t nb = g.nb;
+  const int nnorb = g.nnorb;
+  double* Crow = smem;                          // [K][nb_pad]
+  double* W2 = smem + (int64_t)g.K * g.nb_pad;  // [K][2*nnorb]
+  const int w2s = 2 * nnorb;
+  const double* __restrict__ C = g.c;
+  const uint64_t sA = g.strs_a[A];
+
+  // ---- pass 0: own row.  slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
+  for (int64_t i = tid; i < nb; i += T) Crow[i] = C[A * nb + i];
+  for (int i = tid; i < nnorb; i += T) {
+    const double w = (g.mode == 0) ? g.ja_row[A * nnorb + i] : 0.0;
+    W2[2 * i] = w;
+    W2[2 * i + 1] = w;
+  }
+  __syncthreads();
+
+  double acc[R];
+  const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
+  const int64_t da0 = g.da_ptr[A], da1 = g.da_ptr[A + 1];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t B = tid + (int64_t)r * T;
+    double a = 0.0;
+    if (B < nb) {
+      const double occ_term = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
+      double d;
+      if (g.mode == 0) {
+        d = g.hdiag[A * nb + B];
+        if (g.spin) d += g.shift * (occ_term - g.ss);
+      } else {
+        d = occ_term;
+      }
+      a = d * Crow[B];
+      if (g.mode == 0) {
+        // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0)
+        {
+          const int64_t base = g.esb_sl[B >> 6] + (B & 63);
+          const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
+          for (int k = 0; k < cnt; ++k) {
+            const SRec rec = g.esb_rec[base + (int64_t)k * 64];
+            const double v = g.esb_val[base + (int64_t)k * 64];
+            a += (v + srec_sign(rec.meta) * W2[srec_widx(rec.meta)]) * Crow[rec.src];
+          }
+        }
+        // beta same-spin doubles
+        {
+          const int64_t base = g.edb_sl[B >> 6] + (B & 63);
+          const int cnt = (int)(g.db_ptr[B + 1] - g.db_ptr[B]);
+          for (int k = 0; k < cnt; ++k) a += g.edb_val[base + (int64_t)k * 64] * Crow[g.edb_src[base + (int64_t)k * 64]];
+        }
+        // alpha same-spin singles + doubles: unit-stride row reads
+        for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + B];
+        for (int64_t l = da0; l < da1; ++l) a += g.da_val[l] * C[(int64_t)g.da_src[l] * nb + B];
+      }
+    }
+    acc[r] = a;
+  }
+
+  // ---- alpha single links, K at a time
+  for (int64_t l0 = sa0; l0 < sa1; l0 += g.K) {
+    const int kb = (int)((sa1 - l0 < g.K) ? (sa1 - l0) : g.K);
+    __syncthreads();  // previous batch fully consumed
+    for (int j = 0; j < kb; ++j) {
+      const SRec rec = g.sa_rec[l0 + j];
+      const double sg = srec_sign(rec.meta);
+      const int widx = (int)srec_widx(rec.meta);
+      const int pair = widx >> 1, dir = widx & 1;
+      const double* __restrict__ src = C + (int64_t)rec.src * nb;
+      double* cr = Crow + (int64_t)j * g.nb_pad;
+      double* w2 = W2 + (int64_t)j * w2s;
+      for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
+      for (int i = tid; i < nnorb; i += T) {
+        const double w = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
+        double w0 = w, w1 = w;
+        if (i == pair && (g.mode == 1 || g.spin)) {
+          // S^2 couples this alpha link (cre a, des b) to the beta link (cre b, des a): opposite dir
+          const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+          if (dir) w0 += pen; else w1 += pen;
+        }
+        w2[2 * i] = w0;
+        w2[2 * i + 1] = w1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      if (B < nb) {
+        double a = 0.0;
+        if (g.mode == 0) {
+          for (int j = 0; j < kb; ++j) {
+            const int pair = (int)(srec_widx(g.sa_rec[l0 + j].meta) >> 1);
+            a += g.jbT[(int64_t)pair * nb + B] * Crow[(int64_t)j * g.nb_pad + B];
+          }
+        }
+        const int64_t base = g.esb_sl[B >> 6] + (B & 63);
+        const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
+        for (int k = 0; k < cnt; ++k) {
+          const SRec rec = g.esb_rec[base + (int64_t)k * 64];
+          const int widx = (int)srec_widx(rec.meta);
+          const double* cr = Crow + rec.src;
+          const double* w2 = W2 + widx;
+          double t = 0.0;
+          for (int j = 0; j < kb; ++j) t += w2[(int64_t)j * w2s] * cr[(int64_t)j * g.nb_pad];
+          a += srec_sign(rec.meta) * t;
+        }
+        acc[r] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t B = tid + (int64_t)r * T;
+    if (B < nb) g.sigma[A * nb + B] = acc[r];
+  }
+}
+
+// y = a*x + b*y
+__global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * y[i];
+}
+
+template <int R>
+static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g, int T, size_t shmem) {
+  if (shmem > 64 * 1024) {
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  }
+  hipLaunchKernelGGL((k_sigma<R>), dim3((unsigned)g.na), dim3(T), shmem, c->stream, g);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
+int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift) {
+  if (!c->have_subspace) {
+    set_error("no subspace set");
+    return SQD_ERR_STATE;
+  }
+  SigmaArgs g;
+  const SpinTables& a = c->sp[0];
+  const SpinTables& b = c->sp[1];
+  g.c = d_c;
+  g.sigma = d_sigma;
+  g.na = c->na;
+  g.nb = c->nb;
+  g.nnorb = c->nnorb;
+  g.nb_pad = (int)((c->nb + 1) & ~int64_t(1));
+  g.mode = mode;
+  g.spin = spin ? 1 : 0;
+  g.ss = ss;
+  g.shift = shift;
+  const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+  g.szterm = sz * (sz + 1.0);
+  g.strs_a = a.strs.as<uint64_t>();
+  g.strs_b = b.strs.as<uint64_t>();
+  g.hdiag = c->hdiag.as<double>();
+  g.sa_ptr = a.s_ptr.as<int64_t>();
+  g.sa_rec = a.s_rec.as<SRec>();
+  g.sa_val = a.s_val.as<double>();
+  g.da_ptr = a.d_ptr.as<int64_t>();
+  g.da_src = a.d_src.as<uint32_t>();
+  g.da_val = a.d_val.as<double>();
+  g.ja_row = a.jrow.as<double>();
+  g.sb_ptr = b.s_ptr.as<int64_t>();
+  g.db_ptr = b.d_ptr.as<int64_t>();
+  g.esb_sl = b.es_sl.as<int64_t>();
+  g.esb_rec = b.es_rec.as<SRec>();
+  g.esb_val = b.es_val.as<double>();
+  g.edb_sl = b.ed_sl.as<int64_t>();
+  g.edb_src = b.ed_src.as<uint32_t>();
+  g.edb_val = b.ed_val.as<double>();
+  g.jbT = b.jT.as<double>();
+  g.eri_pp = c->eri_pp.as<double>();
+
+  // geometry: T threads cover the row in R strides; K rows staged per batch within the LDS budget
+  int T = (int)(((c->nb + 63) / 64) * 64);
+  if (T > 1024) T = 1024;
+  const int R = (int)((c->nb + T - 1) / T);
+  const size_t row_bytes = ((size_t)g.nb_pad + 2 * (size_t)g.nnorb) * 8;
+  const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
+  if (row_bytes > budget || R > 16) {
+    set_error("beta string count " + std::to_string(c->nb) + " exceeds the LDS-resident row limit of this build");
+    return SQD_ERR_LIMIT;
+  }
+  size_t soft = 96 * 1024;
+  if (soft > budget) soft = budget;
+  int K = (int)(soft / row_bytes);
+  if (K < 1) K = 1;
+  if (K > 8) K = 8;
+  g.K = K;
+  const size_t shmem = (size_t)K * row_bytes;
+  if (R <= 1) return launch_sigma_r<1>(c, g, T, shmem);
+  if (R <= 2) return launch_sigma_r<2>(c, g, T, shmem);
+  if (R <= 4) return launch_sigma_r<4>(c, g, T, shmem);
+  if (R <= 8) return launch_sigma_r<8>(c, g, T, shmem);
+  return launch_sigma_r<16>(c, g, T, shmem);
+}
+
+int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift) {
+  if (use_spin == 3) {
+    const double sz = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    use_spin = (ss < sz * (sz + 1.0) + 0.1) ? 1 : 2;
+  }
+  if (use_spin == 0) return launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0);
+  if (use_spin == 1) return launch_sigma(c, d_c, d_sigma, 0, true, ss, shift);
+  if (use_spin != 2) {
+    set_error("use_spin must be 0..3");
+    return SQD_ERR_INVALID;
+  }
+  // sigma = H c + shift * (S^2 - ss)^2 c     (pyscf fix_spin_, second form)
+  const int64_t D = c->D;
+  SQD_TRY(c->tmp1.reserve(D * 8));
+  SQD_TRY(c->tmp2.reserve(D * 8));
+  double* t1 = c->tmp1.as<double>();
+  double* t2 = c->tmp2.as<double>();
+  const unsigned nb_ = (unsigned)((D + 255) / 256 > 2048 ? 2048 : (D + 255) / 256);
+  SQD_TRY(launch_sigma(c, d_c, t1, 1, false, 0.0, 0.0));                            // t1 = S^2 c
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, d_c, 1.0, t1);  // t1 -= ss c
+  SQD_TRY(launch_sigma(c, t1, t2, 1, false, 0.0, 0.0));                              // t2 = S^2 t1
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, (const double*)t1, 1.0, t2);  // t2 -= ss t1
+  SQD_TRY(launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0));                        // sigma = H c
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, shift, (const double*)t2, 1.0, d_sigma);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
+}  // namespace sqd
