@@ -49,6 +49,7 @@ class SQDNativeError(RuntimeError):
 class DavidsonOpts(C.Structure):
     _fields_ = [
         ("tol", C.c_double),
+        ("tol_residual", C.c_double),
         ("lindep", C.c_double),
         ("max_cycle", C.c_int),
         ("max_space", C.c_int),
@@ -263,6 +264,7 @@ class Context:
         ci0=None,
         *,
         tol: float = 1e-9,
+        tol_residual: float | None = None,
         lindep: float = 1e-14,
         max_cycle: int = 100,
         max_space: int = 12,
@@ -275,6 +277,7 @@ class Context:
         self._lib.sqd_davidson_default_opts(C.byref(opts))
         opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
         opts.verbose = int(verbose)
+        opts.tol_residual = float(tol_residual) if tol_residual else 0.0
         if spin_sq is not None:
             opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
         stats = DavidsonStats()

@@ -58,6 +58,15 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
       return SQD_ERR_HIP;
     }
   }
+  c->sig_ev.resize(2 * 128, nullptr);
+  for (auto& evt : c->sig_ev) {
+    e = hipEventCreate(&evt);
+    if (e != hipSuccess) {
+      set_error(std::string("hipEventCreate: ") + hipGetErrorString(e));
+      delete c;
+      return SQD_ERR_HIP;
+    }
+  }
   e = hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double), hipHostMallocDefault);
   if (e != hipSuccess) {
     set_error(std::string("hipHostMalloc: ") + hipGetErrorString(e));
@@ -85,6 +94,8 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   c->sp[1].release();
   for (int i = 0; i < 4; ++i)
     if (c->ev[i]) e = hipEventDestroy(c->ev[i]);
+  for (auto& evt : c->sig_ev)
+    if (evt) e = hipEventDestroy(evt);
   if (c->h_pinned) e = hipHostFree(c->h_pinned);
   if (c->stream) e = hipStreamDestroy(c->stream);
   delete c;
@@ -225,6 +236,7 @@ SQD_API int sqd_contract_ss(sqd_ctx* c, const double* cvec, double* outv) {
 SQD_API void sqd_davidson_default_opts(sqd_davidson_opts* o) {
   if (!o) return;
   o->tol = 1e-9;
+  o->tol_residual = 0.0;
   o->lindep = 1e-14;
   o->max_cycle = 100;
   o->max_space = 12;

@@ -95,6 +95,7 @@ struct sqd_ctx {
   int lds_bytes = 160 * 1024;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> sig_ev;  // (start, stop) pairs bracketing the sigma launches of a Davidson run
   // integrals
   sqd::DevBuf h1, eri4, eri_pp, jm, km;  // eri_pp[nnorb][nnorb]; jm/km[norb][norb]
   // subspace

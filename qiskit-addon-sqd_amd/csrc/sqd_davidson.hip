@@ -17,26 +17,13 @@
 #include <cstring>
 
 #include "sqd_common.h"
+#include "sqd_device.h"
 
 namespace sqd {
 
-constexpr int NV = 16;        // vectors per fused reduction launch
+constexpr int NV = 16;       // vectors per fused reduction launch
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_T = 256;
-
-__device__ inline double block_sum(double v, double* red) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  double s = 0.0;
-  if (threadIdx.x == 0) {
-    const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; ++w) s += red[w];
-  }
-  return s;  // valid on thread 0
-}
 
 // partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
 __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
@@ -59,13 +46,16 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
 }
 
 // out[v] = sum_b partial[b*width + v]
+// one workgroup per value v; fixed partition + fixed tree => bitwise reproducible
 __global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, int nv,
                                   double* __restrict__ out) {
-  const int v = threadIdx.x;
-  if (v >= nv) return;
+  __shared__ double red[16];
+  const int v = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * width + v];
-  out[v] = s;
+  if (v < nv)
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[(int64_t)b * width + v];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0 && v < nv) out[v] = s;
 }
 
 struct Coef {
@@ -84,9 +74,28 @@ __global__ void k_lincomb(int64_t n, const double* __restrict__ X, int64_t strid
 
 // r = sum_v coef[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to `out`.
 // partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]
+// Diagonal of the spin penalty for the preconditioner (pyscf leaves hdiag un-shifted, which makes
+// the (S^2-ss)^2 form crawl; the operator is unchanged, only the preconditioner is better):
+//   form 1: shift (d - ss);  form 2: shift ((d - ss)^2 + n_flip),  d = sz(sz+1) + |B\A|, n_flip = |B\A||A\B|
+struct PenaltyDiag {
+  int form;
+  double shift, ss, szterm;
+  const uint64_t* sa;
+  const uint64_t* sb;
+  int64_t nb;
+};
+__device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
+  if (p.form == 0) return 0.0;
+  const uint64_t A = p.sa[i / p.nb], B = p.sb[i % p.nb];
+  const double nba = (double)__popcll(B & ~A);
+  const double d = p.szterm + nba - p.ss;
+  if (p.form == 1) return p.shift * d;
+  return p.shift * (d * d + nba * (double)__popcll(A & ~B));
+}
+
 __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
                                    int64_t stride, int nvec, const Coef coef, double e,
-                                   const double* __restrict__ hdiag, double* __restrict__ out,
+                                   const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
                                    double* __restrict__ partial, int width) {
   __shared__ double red[16];
   double rr = 0.0, tt = 0.0;
@@ -102,7 +111,7 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
         xv[v] = X[(int64_t)v * stride + i];
         r += coef.v[v] * (AX[(int64_t)v * stride + i] - e * xv[v]);
       }
-    const double t = r / (hdiag[i] - e + 1e-4);
+    const double t = r / (hdiag[i] + penalty_diag(pd, i) - e + 1e-4);
     out[i] = t;
     rr += r * r;
     tt += t * t;
@@ -192,8 +201,8 @@ static inline unsigned red_blocks(int64_t n) {
 // sums[0..nv) = column sums of the device partial array; one small D2H + sync
 static int fetch_sums(sqd_ctx* c, int nblocks, int width, int nv, double* sums) {
   double* d_out = c->scal.as<double>();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, c->stream, (const double*)c->partial.as<double>(), nblocks,
-                     width, nv, d_out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nv), dim3(128), 0, c->stream, (const double*)c->partial.as<double>(),
+                     nblocks, width, nv, d_out);
   SQD_HIP_CHECK(hipGetLastError());
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, d_out, sizeof(double) * nv, hipMemcpyDeviceToHost, c->stream));
   SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -277,7 +286,8 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   int max_space = o->max_space;
   if (max_space < 2) max_space = 2;
   if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
-  const double tol = o->tol, toloose = std::sqrt(o->tol), lindep = o->lindep;
+  const double tol = o->tol, lindep = o->lindep;
+  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
   hipStream_t s = c->stream;
   const int nvecs = max_space + 1;
   SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
@@ -326,17 +336,35 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(nn), X);
   }
 
+  PenaltyDiag pd;
+  {
+    int form = o->use_spin;
+    const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    if (form == 3) form = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+    const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+    pd.form = form;
+    pd.shift = o->shift;
+    pd.ss = o->ss;
+    pd.szterm = sz * (sz + 1.0);
+    pd.sa = c->sp[0].strs.as<uint64_t>();
+    pd.sb = c->sp[1].strs.as<uint64_t>();
+    pd.nb = c->nb;
+  }
   std::vector<double> heff((size_t)nvecs * nvecs, 0.0), sub, w(nvecs), V((size_t)nvecs * nvecs);
   std::vector<double> sums(width);
   Coef coef;
   int m = 1;  // basis size; X[m-1] is the newest vector, its sigma not yet built
+  int mc = 1; // number of basis vectors the current Ritz coefficients refer to
+  coef.v[0] = 1.0;
   double e = 0.0, elast = 0.0, rnorm = 0.0;
   bool conv = false;
   int nsig = 0, it = 0;
   bool first = true;
   for (it = 0; it < o->max_cycle; ++it) {
     // sigma for the newest basis vector
+    if (nsig < (int)c->sig_ev.size() / 2) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nsig], s));
     SQD_TRY(apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift));
+    if (nsig < (int)c->sig_ev.size() / 2) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nsig + 1], s));
     ++nsig;
     // new column of the projected matrix
     SQD_TRY(multi_dot(c, X, D, m, AX + (int64_t)(m - 1) * D, sums.data()));
@@ -350,10 +378,11 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     const double de = first ? e : e - elast;
     first = false;
     for (int i = 0; i < m; ++i) coef.v[i] = V[(size_t)i * m + 0];
+    mc = m;
     // residual, preconditioned correction (into X[m]) and its overlaps
     double* tnew = X + (int64_t)m * D;
     hipLaunchKernelGGL(k_residual_precond, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m, coef,
-                       e, (const double*)c->hdiag.as<double>(), tnew, c->partial.as<double>(), width);
+                       e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width);
     SQD_HIP_CHECK(hipGetLastError());
     SQD_TRY(fetch_sums(c, (int)gb, width, m + 2, sums.data()));
     rnorm = std::sqrt(sums[0]);
@@ -397,13 +426,16 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
       std::fill(heff.begin(), heff.end(), 0.0);
       heff[0] = e;
       m = 2;
+      coef.v[0] = 1.0;  // the Ritz vector is now X0
+      coef.v[1] = 0.0;
+      mc = 1;
     } else {
       ++m;
     }
   }
   // solution = Ritz vector of the last projected problem, normalised
   {
-    const int mm = (conv || it >= o->max_cycle) ? m : m;
+    const int mm = mc;
     double* x0 = c->sol.as<double>();
     hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, coef, x0);
     SQD_HIP_CHECK(hipGetLastError());
@@ -423,7 +455,14 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     st->e_davidson = e;
     st->residual = rnorm;
     st->ms_total = ms;
-    st->ms_sigma = 0.0;
+    double msig = 0.0;
+    const int nev = nsig < (int)c->sig_ev.size() / 2 ? nsig : (int)c->sig_ev.size() / 2;
+    for (int i = 0; i < nev; ++i) {
+      float t = 0.f;
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[2 * i], c->sig_ev[2 * i + 1]));
+      msig += t;
+    }
+    st->ms_sigma = (nev > 0) ? msig * nsig / nev : 0.0;
     st->ms_setup = c->ms_setup;
   }
   return SQD_OK;

@@ -8,6 +8,7 @@
 // Orbital occupancies (the diagonal of dm1s, the only part that feeds back into the SQD loop) are
 // reduced in a fixed order and are bitwise reproducible; off-diagonal bins use f64 atomics.
 #include "sqd_common.h"
+#include "sqd_device.h"
 
 namespace sqd {
 
@@ -24,16 +25,24 @@ __global__ void k_row_norms(const double* __restrict__ C, int64_t na, int64_t nb
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
   if (lane == 0) w[A] = s;
 }
-// w[B] = sum_A C[A,B]^2   (thread per column: unit stride across lanes)
+// w[B] = sum_A C[A,B]^2.  Workgroup = 64 columns (unit stride across a wave) x RL row lanes that
+// split the A loop; partials meet in LDS and are added in fixed order.
 __global__ void k_col_norms(const double* __restrict__ C, int64_t na, int64_t nb, double* __restrict__ w) {
-  const int64_t B = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (B >= nb) return;
+  __shared__ double red[1024];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6, RL = blockDim.x >> 6;
+  const int64_t B = (int64_t)blockIdx.x * 64 + col;
   double s = 0.0;
-  for (int64_t a = 0; a < na; ++a) {
-    const double v = C[a * nb + B];
-    s += v * v;
+  if (B < nb)
+    for (int64_t a = rl; a < na; a += RL) {
+      const double v = C[a * nb + B];
+      s += v * v;
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && B < nb) {
+    for (int r = 1; r < RL; ++r) s += red[r * 64 + col];
+    w[B] = s;
   }
-  w[B] = s;
 }
 // out[l] = sum_B C[tgt_l,B] C[src_l,B]   (one wavefront per alpha link)
 __global__ void k_rowpair_dots(const double* __restrict__ C, int64_t nb, int64_t nl, const uint32_t* __restrict__ tgt,
@@ -52,23 +61,32 @@ __global__ void k_rowpair_dots(const double* __restrict__ C, int64_t nb, int64_t
 __global__ void k_colpair_dots(const double* __restrict__ C, int64_t na, int64_t nb, int64_t nl,
                                const uint32_t* __restrict__ tgt, const uint32_t* __restrict__ src, int src_stride,
                                double* __restrict__ out) {
-  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nl) return;
-  const int64_t b0 = tgt[l], b1 = src[(int64_t)l * src_stride];
+  __shared__ double red[1024];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6, RL = blockDim.x >> 6;
+  const int64_t l = (int64_t)blockIdx.x * 64 + col;
   double s = 0.0;
-  for (int64_t a = 0; a < na; ++a) s += C[a * nb + b0] * C[a * nb + b1];
-  out[l] = s;
+  if (l < nl) {
+    const int64_t b0 = tgt[l], b1 = src[(int64_t)l * src_stride];
+    for (int64_t a = rl; a < na; a += RL) s += C[a * nb + b0] * C[a * nb + b1];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && l < nl) {
+    for (int r = 1; r < RL; ++r) s += red[r * 64 + col];
+    out[l] = s;
+  }
 }
 
-// occ[p] = sum_I [p in I] w[I]   (fixed order)
+// occ[p] = sum_I [p in I] w[I]: one workgroup per orbital, fixed partition + fixed tree
 __global__ void k_occupancy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ w, int norb,
                             double* __restrict__ dm1 /*[norb*norb], diagonal written*/) {
-  const int p = threadIdx.x;
-  if (p >= norb) return;
+  __shared__ double red[16];
+  const int p = blockIdx.x;
   double s = 0.0;
-  for (int64_t i = 0; i < n; ++i)
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
     if ((strs[i] >> p) & 1ull) s += w[i];
-  dm1[p * norb + p] = s;
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) dm1[p * norb + p] = s;
 }
 
 __global__ void k_rdm1_singles(int64_t nl, const SRec* __restrict__ rec, const double* __restrict__ dots, int norb,
@@ -187,12 +205,12 @@ static int spin_link_dots(sqd_ctx* c, int spin, const double* C, double* w, doub
       hipLaunchKernelGGL(k_rowpair_dots, dim3(nblk(t.n_d, 4)), dim3(256), 0, st, C, c->nb, t.n_d,
                          (const uint32_t*)t.d_row.as<uint32_t>(), (const uint32_t*)t.d_src.as<uint32_t>(), 1, dots_d);
   } else {
-    hipLaunchKernelGGL(k_col_norms, dim3(nblk(t.n, 256)), dim3(256), 0, st, C, c->na, c->nb, w);
+    hipLaunchKernelGGL(k_col_norms, dim3(nblk(t.n, 64)), dim3(512), 0, st, C, c->na, c->nb, w);
     if (t.n_s > 0)
-      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, C, c->na, c->nb, t.n_s,
+      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_s, 64)), dim3(512), 0, st, C, c->na, c->nb, t.n_s,
                          (const uint32_t*)t.s_row.as<uint32_t>(), (const uint32_t*)t.s_rec.as<uint32_t>(), 2, dots_s);
     if (t.n_d > 0 && dots_d)
-      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, C, c->na, c->nb, t.n_d,
+      hipLaunchKernelGGL(k_colpair_dots, dim3(nblk(t.n_d, 64)), dim3(512), 0, st, C, c->na, c->nb, t.n_d,
                          (const uint32_t*)t.d_row.as<uint32_t>(), (const uint32_t*)t.d_src.as<uint32_t>(), 1, dots_d);
   }
   SQD_HIP_CHECK(hipGetLastError());
@@ -216,7 +234,7 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
     double* dots = p + t.n;
     p += t.n + t.n_s;
     SQD_TRY(spin_link_dots(c, s, d_c, w, dots, nullptr));
-    hipLaunchKernelGGL(k_occupancy, dim3(1), dim3(64), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
+    hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
                        (const double*)w, norb, dm + s * n2);
     if (t.n_s > 0)
       hipLaunchKernelGGL(k_rdm1_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, t.n_s,

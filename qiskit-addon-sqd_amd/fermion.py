@@ -1,0 +1,374 @@
+"""Drop-in for the subspace-eigensolver surface of ``qiskit_addon_sqd.fermion``.
+
+Same names, argument meaning, return types and error behaviour as the reference
+(``qiskit_addon_sqd/fermion.py``): ``SCIState`` (:57-139), ``SCIResult`` (:142-159),
+``solve_sci_batch`` (:643-681), ``solve_sci`` (:684-742), ``solve_fermion`` (:745-845),
+``bitstring_matrix_to_ci_strs`` (:1004-1035), ``_check_ci_strs`` (:1075-1097).  Where the reference
+hands the problem to pyscf (``kernel_fixed_space``, ``make_rdm1s/1/2``, ``spin_square``) this module
+calls ``libsqd_hip.so`` through ``_capi`` -- HIP kernels on gfx950, no pyscf/jax/qiskit imports and no
+CPU fallback.
+"""
+
+from __future__ import annotations
+
+import threading
+import zlib
+from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Sequence
+
+import numpy as np
+
+from . import _capi
+from .counts import bitstring_matrix_to_integers
+
+# pyscf kernel_fixed_space keyword arguments accepted for API compatibility.
+_PYSCF_KWARGS = {
+    "ci0", "tol", "lindep", "max_cycle", "max_space", "nroots", "davidson_only", "max_memory",
+    "verbose", "ecore", "pspace_size", "orbsym", "wfnsym", "tol_residual",
+}  # fmt: skip
+
+
+# --------------------------------------------------------------------------- contexts
+_CTX_LOCK = threading.Lock()
+_CTX_CACHE: "OrderedDict[tuple, _capi.Context]" = OrderedDict()
+_CTX_CACHE_MAX = 4
+
+
+def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
+    h = np.ascontiguousarray(hcore, dtype=np.float64)
+    e = np.ascontiguousarray(eri, dtype=np.float64).ravel()
+    step = max(1, e.size // 8192)
+    return (device, h.shape[0], zlib.crc32(h.tobytes()), zlib.crc32(e[::step].tobytes()), float(e.sum()))
+
+
+def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0) -> _capi.Context:
+    """Context (device-resident integral tables + arenas) for this Hamiltonian, cached so that the
+    SQD loop's repeated calls with the same integrals do not re-upload or re-pack them."""
+    key = _ham_key(hcore, eri, device)
+    with _CTX_LOCK:
+        ctx = _CTX_CACHE.pop(key, None)
+        if ctx is None:
+            ctx = _capi.Context(hcore, eri, device=device)
+        _CTX_CACHE[key] = ctx
+        while len(_CTX_CACHE) > _CTX_CACHE_MAX:
+            _, old = _CTX_CACHE.popitem(last=False)
+            old.close()
+    return ctx
+
+
+def clear_context_cache() -> None:
+    with _CTX_LOCK:
+        while _CTX_CACHE:
+            _, old = _CTX_CACHE.popitem()
+            old.close()
+
+
+def _state_context(norb: int, device: int = 0) -> _capi.Context:
+    """Context for observables that do not depend on the integrals (RDMs, S^2)."""
+    return _get_context(np.zeros((norb, norb)), np.zeros((norb,) * 4), device)
+
+
+# --------------------------------------------------------------------------- result types
+@dataclass(frozen=True)
+class SCIState:
+    """The amplitudes and determinants describing a quantum state (reference ``fermion.py:57-139``)."""
+
+    amplitudes: np.ndarray
+    """``M x N`` array, ``amplitudes[i][j]`` is the amplitude of (``ci_strs_a[i]``, ``ci_strs_b[j]``)."""
+
+    ci_strs_a: np.ndarray
+    """The alpha determinants."""
+
+    ci_strs_b: np.ndarray
+    """The beta determinants."""
+
+    norb: int
+    """The number of spatial orbitals."""
+
+    nelec: tuple[int, int]
+    """The numbers of alpha and beta electrons."""
+
+    def __post_init__(self):
+        object.__setattr__(self, "amplitudes", np.asarray(self.amplitudes))
+        if self.amplitudes.shape != (len(self.ci_strs_a), len(self.ci_strs_b)):
+            raise ValueError(
+                f"'amplitudes' shape must be ({len(self.ci_strs_a)}, {len(self.ci_strs_b)}) "
+                f"but got {self.amplitudes.shape}"
+            )
+
+    def save(self, filename):
+        """Save the SCIState object to an .npz file (same keys as the reference, ``fermion.py:90-99``)."""
+        np.savez(
+            filename,
+            amplitudes=self.amplitudes,
+            ci_strs_a=self.ci_strs_a,
+            ci_strs_b=self.ci_strs_b,
+            norb=self.norb,
+            nelec=self.nelec,
+        )
+
+    @classmethod
+    def load(cls, filename):
+        """Load an SCIState object from an .npz file (``fermion.py:101-111``)."""
+        with np.load(filename) as data:
+            return cls(
+                data["amplitudes"],
+                data["ci_strs_a"],
+                data["ci_strs_b"],
+                norb=data["norb"],
+                nelec=tuple(data["nelec"]),
+            )
+
+    def _ctx(self) -> _capi.Context:
+        ctx = _state_context(int(self.norb))
+        ctx.set_subspace(self.ci_strs_a, self.ci_strs_b)
+        return ctx
+
+    def rdm(self, rank: int = 1, spin_summed: bool = False) -> np.ndarray:
+        """Compute reduced density matrix (``fermion.py:113-128``)."""
+        if rank == 1:
+            dm_a, dm_b = self._ctx().rdm1s(self.amplitudes)
+            if spin_summed:
+                return dm_a + dm_b
+            return np.stack([dm_a, dm_b])
+        if rank == 2:
+            if spin_summed:
+                return self._ctx().rdm2(self.amplitudes)
+            raise NotImplementedError(
+                "Spin-resolved rank-2 reduced density matrices are not provided by this build; "
+                "use spin_summed=True."
+            )
+        raise NotImplementedError(
+            f"Computing the rank {rank} reduced density matrix is currently not supported."
+        )
+
+    def spin_square(self) -> float:
+        """Return spin squared (``fermion.py:130-134``)."""
+        return self._ctx().spin_square(self.amplitudes)
+
+    def orbital_occupancies(self) -> tuple[np.ndarray, np.ndarray]:
+        """Average orbital occupancies (``fermion.py:136-139``)."""
+        dm_a, dm_b = self._ctx().rdm1s(self.amplitudes)
+        return np.diagonal(dm_a).copy(), np.diagonal(dm_b).copy()
+
+
+@dataclass(frozen=True)
+class SCIResult:
+    """Result of an SCI calculation (reference ``fermion.py:142-159``)."""
+
+    energy: float
+    """The SCI energy."""
+
+    sci_state: SCIState
+    """The SCI state."""
+
+    orbital_occupancies: tuple[np.ndarray, np.ndarray]
+    """The average orbital occupancies."""
+
+    rdm1: np.ndarray | None = None
+    """Spin-summed 1-particle reduced density matrix."""
+
+    rdm2: np.ndarray | None = None
+    """Spin-summed 2-particle reduced density matrix."""
+
+
+# --------------------------------------------------------------------------- string formatting
+def bitstring_matrix_to_ci_strs(
+    bitstring_matrix: np.ndarray, open_shell: bool = False
+) -> tuple[np.ndarray, np.ndarray]:
+    """Convert bitstrings (rows) into integer representations of determinants.
+
+    Reference ``fermion.py:1004-1035``: left half = spin-down, right half = spin-up, unique and
+    sorted per spin; closed shell => the union is used for both.  Returns ``(alpha, beta)``.
+    """
+    norb = bitstring_matrix.shape[1] // 2
+    ci_strs_left = np.unique(bitstring_matrix_to_integers(bitstring_matrix[:, :norb]))
+    ci_strs_right = np.unique(bitstring_matrix_to_integers(bitstring_matrix[:, norb:]))
+    if not open_shell:
+        ci_strs_left = ci_strs_right = np.union1d(ci_strs_left, ci_strs_right)
+    return ci_strs_right, ci_strs_left
+
+
+def _popcounts(strs) -> np.ndarray:
+    arr = np.asarray(strs)
+    if arr.dtype == object:
+        return np.array([bin(int(x)).count("1") for x in arr], dtype=np.int64)
+    return np.bitwise_count(arr.astype(np.uint64)).astype(np.int64)
+
+
+def _check_ci_strs(ci_strs: tuple[np.ndarray, np.ndarray]) -> tuple[np.ndarray, np.ndarray]:
+    """Make sure the hamming weight is consistent in all determinants (``fermion.py:1075-1097``;
+    same error text, vectorised popcount instead of a Python loop over every string)."""
+    addr_up, addr_dn = ci_strs
+    for name, addr in (("Spin-up", addr_up), ("Spin-down", addr_dn)):
+        ham = _popcounts(addr)
+        bad = np.nonzero(ham != ham[0])[0]
+        if bad.size:
+            i = int(bad[0])
+            raise ValueError(
+                f"{name} CI string in index 0 has hamming weight {int(ham[0])}, but CI string in "
+                f"index {i} has hamming weight {int(ham[i])}."
+            )
+    return np.sort(np.unique(addr_up)), np.sort(np.unique(addr_dn))
+
+
+# --------------------------------------------------------------------------- solvers
+def _davidson_kwargs(kwargs: dict) -> dict:
+    unknown = set(kwargs) - _PYSCF_KWARGS
+    if unknown:
+        raise TypeError(f"unexpected keyword argument(s) for kernel_fixed_space: {sorted(unknown)}")
+    nroots = kwargs.get("nroots")
+    if nroots not in (None, 1):
+        raise NotImplementedError("only nroots=1 is supported")
+    out = {}
+    for k in ("tol", "tol_residual", "lindep", "max_cycle", "max_space"):
+        if kwargs.get(k) is not None:
+            out[k] = kwargs[k]
+    verbose = kwargs.get("verbose")
+    out["verbose"] = 1 if isinstance(verbose, int) and verbose >= 5 else 0
+    ci0 = kwargs.get("ci0")
+    if ci0 is not None:
+        if isinstance(ci0, (list, tuple)):
+            ci0 = ci0[0]
+        out["ci0"] = np.asarray(ci0, dtype=np.float64)
+    return out
+
+
+def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs):
+    """Shared core: tables -> Davidson -> observables, all on the device."""
+    ctx.set_subspace(ci_strs[0], ci_strs[1])
+    dk = _davidson_kwargs(kwargs)
+    ci0 = dk.pop("ci0", None)
+    amps, stats = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, **dk)
+    return amps, stats
+
+
+def solve_sci_batch(
+    ci_strings: list[tuple[np.ndarray, np.ndarray]],
+    one_body_tensor: np.ndarray,
+    two_body_tensor: np.ndarray,
+    norb: int,
+    nelec: tuple[int, int],
+    *,
+    spin_sq: float | None = None,
+    devices: Sequence[int] | None = None,
+    **kwargs,
+) -> list[SCIResult]:
+    """Diagonalize Hamiltonian in subspaces (reference ``fermion.py:643-681``).
+
+    The reference solves the batches one after another; they are independent, so with
+    ``devices=[0, 1, ...]`` batch ``i`` runs on ``devices[i % len(devices)]`` (one host thread and one
+    context per device; ctypes releases the GIL during native calls).  Default: device 0.
+    """
+    if not devices or len(devices) == 1 or len(ci_strings) <= 1:
+        dev = devices[0] if devices else 0
+        return [
+            solve_sci(ci_strs, one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
+                      device=dev, **kwargs)
+            for ci_strs in ci_strings
+        ]  # fmt: skip
+
+    def work(dev_slot):
+        dev = devices[dev_slot]
+        out = {}
+        for i in range(dev_slot, len(ci_strings), len(devices)):
+            out[i] = solve_sci(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec,
+                               spin_sq=spin_sq, device=dev, **kwargs)  # fmt: skip
+        return out
+
+    results: dict[int, SCIResult] = {}
+    with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+        for part in pool.map(work, range(len(devices))):
+            results.update(part)
+    return [results[i] for i in range(len(ci_strings))]
+
+
+def solve_sci(
+    ci_strings: tuple[np.ndarray, np.ndarray],
+    one_body_tensor: np.ndarray,
+    two_body_tensor: np.ndarray,
+    norb: int,
+    nelec: tuple[int, int],
+    *,
+    spin_sq: float | None = None,
+    device: int = 0,
+    compute_rdms: bool = True,
+    **kwargs,
+) -> SCIResult:
+    """Diagonalize Hamiltonian in subspace defined by CI strings (reference ``fermion.py:684-742``).
+
+    As in the reference: ``norb`` is re-read from ``one_body_tensor``; the spin penalty uses pyscf's
+    default strength 0.2 (``fix_spin_(myci, ss=spin_sq)``, :715); the energy is recomputed from the
+    returned state, not taken from the Davidson eigenvalue (:717-732); ``rdm1``/``rdm2`` are populated.
+    ``compute_rdms=False`` skips the norb^4 ``rdm2`` (then ``rdm1``/``rdm2`` are ``None``).
+    """
+    one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
+    norb, _ = one_body_tensor.shape
+    ctx = _get_context(one_body_tensor, two_body_tensor, device)
+    strs_a, strs_b = ci_strings
+    amps, _stats = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs)
+    if tuple(int(x) for x in nelec) != ctx.nelec:
+        raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
+    dm1a, dm1b = ctx.rdm1s()
+    occupancies = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
+    if compute_rdms:
+        dm1 = dm1a + dm1b
+        dm2 = ctx.rdm2()
+        two = np.asarray(two_body_tensor, dtype=np.float64).reshape((norb,) * 4)
+        energy = float(np.einsum("pr,pr->", dm1, one_body_tensor) + 0.5 * np.einsum("prqs,prqs->", dm2, two))
+    else:
+        dm1 = dm2 = None
+        energy = ctx.energy()
+    sci_state = SCIState(
+        amplitudes=amps,
+        ci_strs_a=np.asarray(strs_a),
+        ci_strs_b=np.asarray(strs_b),
+        norb=norb,
+        nelec=tuple(int(x) for x in nelec),
+    )
+    return SCIResult(energy, sci_state, orbital_occupancies=occupancies, rdm1=dm1, rdm2=dm2)
+
+
+def solve_fermion(
+    bitstring_matrix: tuple[np.ndarray, np.ndarray] | np.ndarray,
+    /,
+    hcore: np.ndarray,
+    eri: np.ndarray,
+    *,
+    open_shell: bool = False,
+    spin_sq: float | None = None,
+    shift: float = 0.1,
+    device: int = 0,
+    **kwargs,
+) -> tuple[float, SCIState, tuple[np.ndarray, np.ndarray], float]:
+    """Approximate the ground state given molecular integrals and a set of electronic configurations.
+
+    Reference ``fermion.py:745-845``; same arguments and the same 4-tuple
+    ``(energy, SCIState, (occ_a, occ_b), spin_squared)``.
+    """
+    if isinstance(bitstring_matrix, tuple):
+        ci_strs = bitstring_matrix
+    else:
+        ci_strs = bitstring_matrix_to_ci_strs(bitstring_matrix, open_shell=open_shell)
+    ci_strs = _check_ci_strs(ci_strs)
+
+    hcore = np.asarray(hcore, dtype=np.float64)
+    norb = hcore.shape[0]
+    ctx = _get_context(hcore, eri, device)
+    amps, _stats = _solve(ctx, ci_strs, spin_sq, shift, kwargs)
+    num_up, num_dn = ctx.nelec
+
+    dm1a, dm1b = ctx.rdm1s()
+    avg_occupancy = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
+    e_sci = ctx.energy()  # <c|H|c>, the quantity the reference rebuilds from rdm1/rdm2 (:825-827)
+    spin_squared = ctx.spin_square()
+    sci_state = SCIState(
+        amplitudes=amps,
+        ci_strs_a=ci_strs[0],
+        ci_strs_b=ci_strs[1],
+        norb=norb,
+        nelec=(num_up, num_dn),
+    )
+    return e_sci, sci_state, avg_occupancy, spin_squared

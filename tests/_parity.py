@@ -1,0 +1,88 @@
+"""Shared parity checks: the native path (real HIP library on the GPU box, or the kernel-logic
+emulator on CPU) against the numpy oracle on the same seeded inputs."""
+import numpy as np
+
+from oracle import sqd_oracle as O
+from qiskit_addon_sqd_amd import _capi
+
+
+def make_problem(norb, nelec, na, nb, seed, hf=False):
+    h1, eri = O.synthetic_integrals(norb, seed=seed)
+    gen = O.hf_centred_strings if hf else O.random_strings
+    sa = gen(norb, nelec[0], na, seed + 1)
+    sb = gen(norb, nelec[1], nb, seed + 2)
+    return h1, eri, sa, sb
+
+
+def check_link_tables(ctx, sa, sb, norb, h1=None, eri=None):
+    """Bit-exact CI-string addressing: targets, sources, orbitals, pair indices, signs."""
+    for spin, strs in enumerate((sa, sb)):
+        sl = O.single_links(strs, norb)
+        g = ctx.single_links(spin)
+        assert len(g["tgt"]) == len(sl["tgt"])
+        for ko, kg in (("tgt", "tgt"), ("src", "src"), ("p", "cre"), ("q", "des"), ("sign", "sign")):
+            assert np.array_equal(sl[ko], g[kg]), (spin, ko)
+        assert np.array_equal(O.pair_index(sl["p"], sl["q"]), g["pair"])
+        dl = O.double_links(strs, norb)
+        g2 = ctx.double_links(spin)
+        assert len(g2["tgt"]) == len(dl["tgt"])
+        for k in ("tgt", "src", "sign"):
+            assert np.array_equal(dl[k], g2[k]), (spin, k)
+        assert np.array_equal(np.stack([dl["p"], dl["r"], dl["q"], dl["s"]], 1).reshape(-1, 4), g2["orbs"])
+        if eri is not None and len(dl["tgt"]):
+            p, r, q, s = dl["p"], dl["r"], dl["q"], dl["s"]
+            ref = dl["sign"] * (eri[p, q, r, s] - eri[p, s, r, q])
+            assert np.allclose(g2["value"], ref, rtol=0, atol=1e-13)
+
+
+def check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng, tol=1e-11):
+    H = O.build_php(h1, eri, sa, sb, norb)
+    S2 = O.build_spin_square(sa, sb, norb, nelec)
+    D = len(sa) * len(sb)
+    scale = max(1.0, np.abs(H).max())
+    assert np.allclose(ctx.hdiag().ravel(), np.diag(H), rtol=0, atol=tol * scale)
+    c = rng.standard_normal((len(sa), len(sb)))
+    assert np.allclose(ctx.sigma(c).ravel(), H @ c.ravel(), rtol=0, atol=tol * scale * np.sqrt(D))
+    assert np.allclose(ctx.contract_ss(c).ravel(), S2 @ c.ravel(), rtol=0, atol=tol * np.sqrt(D) * 10)
+    ss, shift = 0.75, 0.3
+    ref = (H + shift * (S2 - ss * np.eye(D))) @ c.ravel()
+    assert np.allclose(ctx.sigma(c, 1, ss, shift).ravel(), ref, rtol=0, atol=tol * scale * np.sqrt(D))
+    P = S2 - 2.0 * np.eye(D)
+    ref = (H + shift * (P @ P)) @ c.ravel()
+    assert np.allclose(ctx.sigma(c, 2, 2.0, shift).ravel(), ref, rtol=0, atol=10 * tol * scale * np.sqrt(D))
+    return H, S2
+
+
+def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=True):
+    amps, st = ctx.davidson()
+    w, v = np.linalg.eigh(H)
+    assert st["converged"] == 1
+    assert abs(st["e_davidson"] - w[0]) < e_tol
+    assert abs(ctx.energy() - w[0]) < e_tol
+    gap = w[1] - w[0] if len(w) > 1 else 1.0
+    if gap > 1e-4:
+        assert abs(abs(amps.ravel() @ v[:, 0]) - 1.0) < 1e-5
+    assert abs(ctx.spin_square() - amps.ravel() @ S2 @ amps.ravel()) < 1e-9
+    d1a, d1b = ctx.rdm1s()
+    r1a, r1b = O.make_rdm1s(amps, sa, sb, norb)
+    assert np.allclose(d1a, r1a, atol=1e-12) and np.allclose(d1b, r1b, atol=1e-12)
+    assert abs(np.trace(d1a) - bin(int(sa[0])).count("1")) < 1e-10
+    if with_rdm2:
+        d2 = ctx.rdm2()
+        assert np.allclose(d2, O.make_rdm2(amps, sa, sb, norb), atol=1e-12)
+        e_rdm = O.energy_from_rdms(h1, eri, d1a + d1b, d2)
+        assert abs(e_rdm - ctx.energy()) < 1e-10
+        n = np.trace(d1a) + np.trace(d1b)
+        assert abs(np.einsum("ppqq->", d2) - n * (n - 1)) < 1e-9
+    return amps, st
+
+
+def run_full_parity(lib, norb, nelec, na, nb, seed, hf=False, with_rdm2=True):
+    h1, eri, sa, sb = make_problem(norb, nelec, na, nb, seed, hf)
+    rng = np.random.default_rng(seed)
+    with _capi.Context(h1, eri, lib=lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert (ctx.na, ctx.nb, ctx.nelec) == (len(sa), len(sb), tuple(nelec))
+        check_link_tables(ctx, sa, sb, norb, h1, eri)
+        H, S2 = check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng)
+        check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, with_rdm2=with_rdm2)

@@ -1,0 +1,75 @@
+"""CPU logic tests: the unmodified HIP kernel sources, compiled by g++ against tests/emu and run by
+OS threads, checked against the numpy oracle.  These are NOT the parity tests proper (those are
+``-m gpu`` in test_gpu_parity.py); they catch indexing/sign/bounds bugs without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import sqd_oracle as O
+from qiskit_addon_sqd_amd import _capi
+
+from _parity import check_link_tables, check_operators, make_problem, run_full_parity
+
+
+@pytest.mark.parametrize(
+    "norb,nelec,na,nb,seed,hf",
+    [
+        (6, (3, 2), 12, 9, 5, False),
+        (7, (3, 3), 20, 20, 7, True),
+        (5, (1, 4), 5, 4, 9, False),   # nalpha < nbeta, single alpha electron (no alpha doubles)
+        (4, (2, 2), 6, 6, 3, False),   # complete space (FCI limit)
+    ],
+)
+def test_emu_full_parity(emu_lib, norb, nelec, na, nb, seed, hf):
+    run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf)
+
+
+def test_emu_h2_minimal(emu_lib):
+    # H2 / STO-3G textbook integrals: 2 electrons in 2 orbitals, 2x2 subspace
+    h1 = np.diag([-1.2525, -0.4759])
+    eri = np.zeros((2, 2, 2, 2))
+    eri[0, 0, 0, 0], eri[1, 1, 1, 1] = 0.6746, 0.6974
+    eri[0, 0, 1, 1] = eri[1, 1, 0, 0] = 0.6636
+    for p, q, r, s in [(0, 1, 0, 1), (0, 1, 1, 0), (1, 0, 0, 1), (1, 0, 1, 0)]:
+        eri[p, q, r, s] = 0.1813
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace([1, 2], [1, 2])
+        amps, st = ctx.davidson()
+        e = ctx.energy()
+    H = O.jw_project(O.jw_hamiltonian(h1, eri), [1, 2], [1, 2], 2)
+    assert abs(e - np.linalg.eigvalsh(H)[0]) < 1e-10
+    assert abs(e + 0.7137 - (-1.1373)) < 1e-3  # literature total energy, 4 digits
+
+
+def test_emu_one_by_one(emu_lib):
+    h1, eri, sa, sb = make_problem(5, (2, 2), 1, 1, 4)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        amps, st = ctx.davidson()
+        assert st["converged"] == 1 and amps.shape == (1, 1) and abs(abs(amps[0, 0]) - 1) < 1e-12
+        assert abs(ctx.energy() - O.make_hdiag(h1, eri, sa, sb, 5)[0, 0]) < 1e-12
+
+
+def test_emu_ragged_widths(emu_lib):
+    # nb not a multiple of 64 and > 64: exercises sliced-ELL slice boundaries and partial waves
+    norb, nelec = 9, (2, 3)
+    h1, eri, sa, sb = make_problem(norb, nelec, 7, 70, 21)
+    rng = np.random.default_rng(0)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        check_link_tables(ctx, sa, sb, norb, h1, eri)
+        check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng)
+
+
+def test_emu_invalid_inputs(emu_lib):
+    h1, eri, sa, sb = make_problem(6, (3, 2), 5, 4, 1)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        bad = sa.copy()
+        bad[2] = 0b1111  # Hamming weight 4 instead of 3
+        with pytest.raises(ValueError, match="hamming weight"):
+            ctx.set_subspace(np.sort(bad), sb)
+        with pytest.raises(ValueError, match="strictly ascending"):
+            ctx.set_subspace(sa[::-1].copy(), sb)
+        with pytest.raises(ValueError, match="empty"):
+            ctx.set_subspace(np.array([], dtype=np.int64), sb)
+        with pytest.raises(_capi.SQDNativeError, match="no subspace"):
+            ctx.hdiag()
