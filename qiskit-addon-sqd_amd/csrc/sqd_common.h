@@ -70,6 +70,7 @@ struct SpinTables {
   DevBuf d_src;                  // u32[n_d]
   DevBuf d_orb;                  // u32[n_d]
   DevBuf d_val;                  // f64[n_d] sign*((pq|rs)-(ps|rq))
+  DevBuf hs_ptr, hs_src, hs_val; // merged same-spin CSR {src, value}: singles then doubles per row (row role)
   DevBuf jrow;                   // f64[n][nnorb]   J[I][pair] = sum_{k in I} (pair|kk)   (row role)
   DevBuf jT;                     // f64[nnorb][n]   transposed copy                        (col role)
   // sliced ELL (slice = 64 consecutive strings), records of slice b start at *_sl[b], entry
@@ -82,8 +83,18 @@ struct SpinTables {
   void release();
 };
 
-struct Timer {
-  hipEvent_t a = nullptr, b = nullptr;
+// One workgroup's worth of sigma work (see build_sigma_work in sqd_tables.hip)
+struct WorkItem {
+  int64_t begin;   // first link: index into the alpha singles arrays (type 1) or the merged hs arrays (0, 2)
+  uint32_t A;      // alpha string = row of sigma
+  uint16_t type;   // 0 own row, 1 alpha-single batch, 2 same-spin AXPY chunk
+  uint16_t count;  // links in this item
+  int32_t slot;    // -1: write sigma[A,:] directly; else partial row index
+  int32_t pad;
+};
+struct MultiRow {
+  uint32_t A;
+  int32_t slot0, nslots;
 };
 
 }  // namespace sqd
@@ -104,6 +115,14 @@ struct sqd_ctx {
   int nelec[2] = {0, 0};
   sqd::SpinTables sp[2];
   sqd::DevBuf hdiag;        // f64[D]
+  // sigma work list + launch geometry (fixed per subspace)
+  std::vector<int64_t> h_sptr, h_dptr;
+  std::vector<sqd::WorkItem> h_items;
+  std::vector<sqd::MultiRow> h_multi;
+  sqd::DevBuf items, multi, sig_partial;
+  int64_t n_items = 0, n_multi = 0, n_slots = 0;
+  int sig_T = 64, sig_R = 1, sig_K = 1, sig_nb_pad = 0;
+  size_t sig_shmem = 0;
   // Davidson workspace
   sqd::DevBuf X, AX;        // (max_space+1) * D each
   sqd::DevBuf sol;          // f64[D] resident solution

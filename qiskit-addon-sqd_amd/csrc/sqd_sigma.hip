@@ -13,11 +13,12 @@
 //     + sum_{Sa(A)} sum_{Sb(B)} s t (pq|rs) C[A',B']                single x single
 //   (S^2 adds  -sum Ea_qp Eb_pq  = one extra entry in the (pq|..) row, and a diagonal term.)
 //
-// gfx950 mapping: one workgroup owns one alpha string A (one row of sigma) and keeps its
-// accumulators in registers.  For a batch of up to K alpha links it stages, coalesced, the K source
-// rows C[A',:] and the K integral rows (pq|:) into LDS (160 KB/CU holds 8 rows at nb ~ 2000), then
-// every lane walks the sliced-ELL single-excitation list of its beta string and gathers from LDS.
-// Global memory is only ever read with unit stride; all irregular accesses hit LDS.
+// gfx950 mapping: the launch is a list of work items (built once per subspace, sqd_tables.hip), one
+// workgroup each, so that the few highly connected strings around the Hartree-Fock determinant do not
+// serialise it.  A workgroup keeps its slice of one sigma row in registers.  For a batch of up to K
+// alpha single links it stages, coalesced, the K source rows C[A',:] and the K integral rows (pq|:)
+// into LDS, then every lane walks the sliced-ELL single-excitation list of its beta string and gathers
+// from LDS.  Global memory is only ever read with unit stride; all irregular accesses hit LDS.
 #include <cmath>
 #include <cstdlib>
 
@@ -28,6 +29,8 @@ namespace sqd {
 struct SigmaArgs {
   const double* c;
   double* sigma;
+  double* partial;
+  const WorkItem* items;
   int64_t na, nb;
   int nnorb, nb_pad, K;
   int mode;  // 0: H (+ penalty when spin), 1: pure S^2
@@ -36,12 +39,9 @@ struct SigmaArgs {
   const uint64_t* strs_a;
   const uint64_t* strs_b;
   const double* hdiag;
-  const int64_t* sa_ptr;
-  const SRec* sa_rec;
-  const double* sa_val;
-  const int64_t* da_ptr;
-  const uint32_t* da_src;
-  const double* da_val;
+  const SRec* sa_rec;     // alpha singles (CSR order)
+  const uint32_t* ha_src; // alpha merged same-spin links
+  const double* ha_val;
   const double* ja_row;
   const int64_t* sb_ptr;
   const int64_t* db_ptr;
@@ -59,72 +59,69 @@ template <int R>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
   const int T = blockDim.x, tid = threadIdx.x;
-  const int64_t A = blockIdx.x;
+  const WorkItem it = g.items[blockIdx.x];
+  const int64_t A = it.A;
   const int64_t nb = g.nb;
   const int nnorb = g.nnorb;
   double* Crow = smem;                          // [K][nb_pad]
   double* W2 = smem + (int64_t)g.K * g.nb_pad;  // [K][2*nnorb]
   const int w2s = 2 * nnorb;
   const double* __restrict__ C = g.c;
-  const uint64_t sA = g.strs_a[A];
-
-  // ---- pass 0: own row.  slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
-  for (int64_t i = tid; i < nb; i += T) Crow[i] = C[A * nb + i];
-  for (int i = tid; i < nnorb; i += T) {
-    const double w = (g.mode == 0) ? g.ja_row[A * nnorb + i] : 0.0;
-    W2[2 * i] = w;
-    W2[2 * i + 1] = w;
-  }
-  __syncthreads();
-
   double acc[R];
-  const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
-  const int64_t da0 = g.da_ptr[A], da1 = g.da_ptr[A + 1];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int64_t B = tid + (int64_t)r * T;
-    double a = 0.0;
-    if (B < nb) {
-      const double occ_term = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
-      double d;
-      if (g.mode == 0) {
-        d = g.hdiag[A * nb + B];
-        if (g.spin) d += g.shift * (occ_term - g.ss);
-      } else {
-        d = occ_term;
+  for (int r = 0; r < R; ++r) acc[r] = 0.0;
+
+  if (it.type == 0) {
+    // ---- own row: slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
+    const uint64_t sA = g.strs_a[A];
+    for (int64_t i = tid; i < nb; i += T) Crow[i] = C[A * nb + i];
+    if (g.mode == 0)
+      for (int i = tid; i < nnorb; i += T) {
+        const double w = g.ja_row[A * nnorb + i];
+        W2[2 * i] = w;
+        W2[2 * i + 1] = w;
       }
-      a = d * Crow[B];
-      if (g.mode == 0) {
-        // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0)
-        {
-          const int64_t base = g.esb_sl[B >> 6] + (B & 63);
-          const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
-          for (int k = 0; k < cnt; ++k) {
-            const SRec rec = g.esb_rec[base + (int64_t)k * 64];
-            const double v = g.esb_val[base + (int64_t)k * 64];
-            a += (v + srec_sign(rec.meta) * W2[srec_widx(rec.meta)]) * Crow[rec.src];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      if (B < nb) {
+        const double occ_term = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
+        double d;
+        if (g.mode == 0) {
+          d = g.hdiag[A * nb + B];
+          if (g.spin) d += g.shift * (occ_term - g.ss);
+        } else {
+          d = occ_term;
+        }
+        double a = d * Crow[B];
+        if (g.mode == 0) {
+          {  // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0)
+            const int64_t base = g.esb_sl[B >> 6] + (B & 63);
+            const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
+            for (int k = 0; k < cnt; ++k) {
+              const SRec rec = g.esb_rec[base + (int64_t)k * 64];
+              const double v = g.esb_val[base + (int64_t)k * 64];
+              a += (v + srec_sign(rec.meta) * W2[srec_widx(rec.meta)]) * Crow[rec.src];
+            }
           }
+          {  // beta same-spin doubles
+            const int64_t base = g.edb_sl[B >> 6] + (B & 63);
+            const int cnt = (int)(g.db_ptr[B + 1] - g.db_ptr[B]);
+            for (int k = 0; k < cnt; ++k)
+              a += g.edb_val[base + (int64_t)k * 64] * Crow[g.edb_src[base + (int64_t)k * 64]];
+          }
+          // first same-spin alpha links of this row: unit-stride row reads
+          for (int64_t l = it.begin; l < it.begin + it.count; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
         }
-        // beta same-spin doubles
-        {
-          const int64_t base = g.edb_sl[B >> 6] + (B & 63);
-          const int cnt = (int)(g.db_ptr[B + 1] - g.db_ptr[B]);
-          for (int k = 0; k < cnt; ++k) a += g.edb_val[base + (int64_t)k * 64] * Crow[g.edb_src[base + (int64_t)k * 64]];
-        }
-        // alpha same-spin singles + doubles: unit-stride row reads
-        for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + B];
-        for (int64_t l = da0; l < da1; ++l) a += g.da_val[l] * C[(int64_t)g.da_src[l] * nb + B];
+        acc[r] = a;
       }
     }
-    acc[r] = a;
-  }
-
-  // ---- alpha single links, K at a time
-  for (int64_t l0 = sa0; l0 < sa1; l0 += g.K) {
-    const int kb = (int)((sa1 - l0 < g.K) ? (sa1 - l0) : g.K);
-    __syncthreads();  // previous batch fully consumed
+  } else if (it.type == 1) {
+    // ---- a batch of alpha single links: stage their source rows (signed) and integral rows
+    const int kb = it.count;
     for (int j = 0; j < kb; ++j) {
-      const SRec rec = g.sa_rec[l0 + j];
+      const SRec rec = g.sa_rec[it.begin + j];
       const double sg = srec_sign(rec.meta);
       const int widx = (int)srec_widx(rec.meta);
       const int pair = widx >> 1, dir = widx & 1;
@@ -152,7 +149,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         double a = 0.0;
         if (g.mode == 0) {
           for (int j = 0; j < kb; ++j) {
-            const int pair = (int)(srec_widx(g.sa_rec[l0 + j].meta) >> 1);
+            const int pair = (int)(srec_widx(g.sa_rec[it.begin + j].meta) >> 1);
             a += g.jbT[(int64_t)pair * nb + B] * Crow[(int64_t)j * g.nb_pad + B];
           }
         }
@@ -160,21 +157,45 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
         for (int k = 0; k < cnt; ++k) {
           const SRec rec = g.esb_rec[base + (int64_t)k * 64];
-          const int widx = (int)srec_widx(rec.meta);
           const double* cr = Crow + rec.src;
-          const double* w2 = W2 + widx;
+          const double* w2 = W2 + srec_widx(rec.meta);
           double t = 0.0;
           for (int j = 0; j < kb; ++j) t += w2[(int64_t)j * w2s] * cr[(int64_t)j * g.nb_pad];
           a += srec_sign(rec.meta) * t;
         }
-        acc[r] += a;
+        acc[r] = a;
+      }
+    }
+  } else {
+    // ---- a chunk of same-spin alpha links (singles' one-body part and doubles): row AXPYs
+    if (g.mode == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t B = tid + (int64_t)r * T;
+        if (B < nb) {
+          double a = 0.0;
+          for (int64_t l = it.begin; l < it.begin + it.count; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
+          acc[r] = a;
+        }
       }
     }
   }
+  double* __restrict__ out = (it.slot < 0) ? (g.sigma + A * nb) : (g.partial + (int64_t)it.slot * nb);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t B = tid + (int64_t)r * T;
-    if (B < nb) g.sigma[A * nb + B] = acc[r];
+    if (B < nb) out[B] = acc[r];
+  }
+}
+
+// sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items
+__global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
+                               double* __restrict__ sigma) {
+  const MultiRow mr = rows[blockIdx.x];
+  for (int64_t B = threadIdx.x; B < nb; B += blockDim.x) {
+    double s = 0.0;
+    for (int j = 0; j < mr.nslots; ++j) s += partial[(int64_t)(mr.slot0 + j) * nb + B];
+    sigma[(int64_t)mr.A * nb + B] = s;
   }
 }
 
@@ -185,12 +206,12 @@ __global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, doubl
 }
 
 template <int R>
-static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g, int T, size_t shmem) {
-  if (shmem > 64 * 1024) {
+static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
+  if (c->sig_shmem > 64 * 1024) {
     SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
   }
-  hipLaunchKernelGGL((k_sigma<R>), dim3((unsigned)g.na), dim3(T), shmem, c->stream, g);
+  hipLaunchKernelGGL((k_sigma<R>), dim3((unsigned)c->n_items), dim3(c->sig_T), c->sig_shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }
@@ -205,10 +226,13 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   const SpinTables& b = c->sp[1];
   g.c = d_c;
   g.sigma = d_sigma;
+  g.partial = c->sig_partial.as<double>();
+  g.items = c->items.as<WorkItem>();
   g.na = c->na;
   g.nb = c->nb;
   g.nnorb = c->nnorb;
-  g.nb_pad = (int)((c->nb + 1) & ~int64_t(1));
+  g.nb_pad = c->sig_nb_pad;
+  g.K = c->sig_K;
   g.mode = mode;
   g.spin = spin ? 1 : 0;
   g.ss = ss;
@@ -218,12 +242,9 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.strs_a = a.strs.as<uint64_t>();
   g.strs_b = b.strs.as<uint64_t>();
   g.hdiag = c->hdiag.as<double>();
-  g.sa_ptr = a.s_ptr.as<int64_t>();
   g.sa_rec = a.s_rec.as<SRec>();
-  g.sa_val = a.s_val.as<double>();
-  g.da_ptr = a.d_ptr.as<int64_t>();
-  g.da_src = a.d_src.as<uint32_t>();
-  g.da_val = a.d_val.as<double>();
+  g.ha_src = a.hs_src.as<uint32_t>();
+  g.ha_val = a.hs_val.as<double>();
   g.ja_row = a.jrow.as<double>();
   g.sb_ptr = b.s_ptr.as<int64_t>();
   g.db_ptr = b.d_ptr.as<int64_t>();
@@ -236,28 +257,21 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.jbT = b.jT.as<double>();
   g.eri_pp = c->eri_pp.as<double>();
 
-  // geometry: T threads cover the row in R strides; K rows staged per batch within the LDS budget
-  int T = (int)(((c->nb + 63) / 64) * 64);
-  if (T > 1024) T = 1024;
-  const int R = (int)((c->nb + T - 1) / T);
-  const size_t row_bytes = ((size_t)g.nb_pad + 2 * (size_t)g.nnorb) * 8;
-  const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
-  if (row_bytes > budget || R > 16) {
-    set_error("beta string count " + std::to_string(c->nb) + " exceeds the LDS-resident row limit of this build");
-    return SQD_ERR_LIMIT;
+  const int R = c->sig_R;
+  int rc;
+  if (R <= 1) rc = launch_sigma_r<1>(c, g);
+  else if (R <= 2) rc = launch_sigma_r<2>(c, g);
+  else if (R <= 4) rc = launch_sigma_r<4>(c, g);
+  else if (R <= 8) rc = launch_sigma_r<8>(c, g);
+  else rc = launch_sigma_r<16>(c, g);
+  if (rc != SQD_OK) return rc;
+  if (c->n_multi > 0) {
+    hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi), dim3(c->sig_T > 256 ? 256 : c->sig_T), 0, c->stream,
+                       (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
+                       d_sigma);
+    SQD_HIP_CHECK(hipGetLastError());
   }
-  size_t soft = 96 * 1024;
-  if (soft > budget) soft = budget;
-  int K = (int)(soft / row_bytes);
-  if (K < 1) K = 1;
-  if (K > 8) K = 8;
-  g.K = K;
-  const size_t shmem = (size_t)K * row_bytes;
-  if (R <= 1) return launch_sigma_r<1>(c, g, T, shmem);
-  if (R <= 2) return launch_sigma_r<2>(c, g, T, shmem);
-  if (R <= 4) return launch_sigma_r<4>(c, g, T, shmem);
-  if (R <= 8) return launch_sigma_r<8>(c, g, T, shmem);
-  return launch_sigma_r<16>(c, g, T, shmem);
+  return SQD_OK;
 }
 
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift) {

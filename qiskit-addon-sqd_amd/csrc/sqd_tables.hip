@@ -12,6 +12,8 @@
 // wave ballot + prefix popcount.  The links of a string therefore come out sorted by source
 // address, which is this build's canonical (bit-exact, testable) order.  Integral values are
 // attached by a second, fully occupied thread-per-link pass.
+#include <algorithm>
+
 #include "sqd_common.h"
 
 namespace sqd {
@@ -45,7 +47,7 @@ void DevBuf::release() {
 }
 void SpinTables::release() {
   DevBuf* all[] = {&strs, &e_str, &s_ptr, &d_ptr, &s_row, &d_row, &s_rec, &s_val, &d_src, &d_orb,
-                   &d_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val};
+                   &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val};
   for (DevBuf* b : all) b->release();
 }
 
@@ -314,6 +316,98 @@ __global__ void k_fill_ell_doubles(const int64_t* __restrict__ ptr, int64_t n, c
   }
 }
 
+// merged same-spin CSR: row i = its single links (value incl. sign) followed by its double links
+__global__ void k_merge_hs(int64_t n, const int64_t* __restrict__ s_ptr, const int64_t* __restrict__ d_ptr,
+                           const SRec* __restrict__ s_rec, const double* __restrict__ s_val,
+                           const uint32_t* __restrict__ d_src, const double* __restrict__ d_val,
+                           int64_t* __restrict__ hs_ptr, uint32_t* __restrict__ hs_src, double* __restrict__ hs_val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const int64_t o = s_ptr[i] + d_ptr[i];
+  hs_ptr[i] = o;
+  if (i == n) return;
+  const int64_t s0 = s_ptr[i], ns = s_ptr[i + 1] - s0, d0 = d_ptr[i], nd = d_ptr[i + 1] - d0;
+  for (int64_t k = 0; k < ns; ++k) {
+    hs_src[o + k] = s_rec[s0 + k].src;
+    hs_val[o + k] = s_val[s0 + k];
+  }
+  for (int64_t k = 0; k < nd; ++k) {
+    hs_src[o + ns + k] = d_src[d0 + k];
+    hs_val[o + ns + k] = d_val[d0 + k];
+  }
+}
+
+// ------------------------------------------------------------------ sigma work list (host)
+// The sigma kernel runs one workgroup per work item so that a few highly connected strings (the
+// Hartree-Fock neighbourhood) do not serialise the launch:
+//   type 0  own row: diagonal, beta links on the LDS-staged row, first L0 same-spin alpha links
+//   type 1  a batch of <= K alpha single links (K source rows + K integral rows staged in LDS)
+//   type 2  a chunk of <= L further same-spin alpha links (unit-stride row AXPYs)
+// A row with a single item writes sigma directly; otherwise items write partial rows that
+// k_sigma_reduce adds in fixed order.
+static int build_sigma_work(sqd_ctx* c) {
+  const int64_t na = c->na, nb = c->nb;
+  // geometry
+  int T = (int)(((nb + 63) / 64) * 64);
+  if (T > 1024) T = 1024;
+  const int R = (int)((nb + T - 1) / T);
+  const int nb_pad = (int)((nb + 1) & ~int64_t(1));
+  const size_t row_bytes = ((size_t)nb_pad + 2 * (size_t)c->nnorb) * 8;
+  const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
+  if (row_bytes > budget || R > 16) {
+    set_error("beta string count " + std::to_string(nb) + " exceeds the LDS-resident row limit of this build");
+    return SQD_ERR_LIMIT;
+  }
+  int K = (int)((40 * 1024) / row_bytes);
+  if (K < 1) K = 1;
+  if (K > 4) K = 4;
+  c->sig_T = T;
+  c->sig_R = R;
+  c->sig_K = K;
+  c->sig_nb_pad = nb_pad;
+  c->sig_shmem = (size_t)K * row_bytes;
+  const int L0 = 16, L = 32;
+  std::vector<WorkItem>& items = c->h_items;
+  std::vector<MultiRow>& multi = c->h_multi;
+  items.clear();
+  multi.clear();
+  int32_t nslots = 0;
+  std::vector<WorkItem> row;
+  for (int64_t A = 0; A < na; ++A) {
+    row.clear();
+    const int64_t s0 = c->h_sptr[A], s1 = c->h_sptr[A + 1];
+    const int64_t h0 = s0 + c->h_dptr[A], h1 = s1 + c->h_dptr[A + 1];
+    WorkItem own{h0, (uint32_t)A, 0, (uint16_t)((h1 - h0 < L0) ? (h1 - h0) : L0), -1, 0};
+    row.push_back(own);
+    for (int64_t l = s0; l < s1; l += K)
+      row.push_back(WorkItem{l, (uint32_t)A, 1, (uint16_t)((s1 - l < K) ? (s1 - l) : K), -1, 0});
+    for (int64_t l = h0 + L0; l < h1; l += L)
+      row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
+    if (row.size() > 1) {
+      multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
+      for (auto& it : row) it.slot = nslots++;
+    }
+    items.insert(items.end(), row.begin(), row.end());
+  }
+  // heaviest item class first (LDS-staged batches), then own rows, then AXPY chunks
+  std::stable_sort(items.begin(), items.end(), [](const WorkItem& a, const WorkItem& b) {
+    auto rank = [](const WorkItem& w) { return w.type == 1 ? 0 : (w.type == 0 ? 1 : 2); };
+    return rank(a) < rank(b);
+  });
+  c->n_items = (int64_t)items.size();
+  c->n_multi = (int64_t)multi.size();
+  c->n_slots = nslots;
+  SQD_TRY(c->items.reserve(items.size() * sizeof(WorkItem)));
+  SQD_TRY(c->multi.reserve((multi.size() + 1) * sizeof(MultiRow)));
+  SQD_TRY(c->sig_partial.reserve((size_t)nslots * nb * 8 + 8));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->items.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
+                               c->stream));
+  if (!multi.empty())
+    SQD_HIP_CHECK(hipMemcpyAsync(c->multi.p, multi.data(), multi.size() * sizeof(MultiRow), hipMemcpyHostToDevice,
+                                 c->stream));
+  return SQD_OK;
+}
+
 // ------------------------------------------------------------------ host orchestration
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
@@ -413,6 +507,11 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s], t.s_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
     SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s + 1], t.d_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
   }
+  // the alpha row pointers also go to the host: the sigma work list is cut there
+  c->h_sptr.resize(na + 1);
+  c->h_dptr.resize(na + 1);
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_sptr.data(), c->sp[0].s_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_dptr.data(), c->sp[0].d_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipStreamSynchronize(st));
   // pass 2: fill + decorate
   for (int s = 0; s < 2; ++s) {
@@ -444,6 +543,13 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                        c->h1.as<double>(), c->jm.as<double>(), c->km.as<double>(), norb, t.e_str.as<double>());
     const int64_t nj = t.n * nnorb;
     if (s == 0) {
+      // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY work items
+      SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
+      SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
+      SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
+      hipLaunchKernelGGL(k_merge_hs, dim3(nblk(t.n + 1, 256)), dim3(256), 0, st, t.n, t.s_ptr.as<int64_t>(),
+                         t.d_ptr.as<int64_t>(), t.s_rec.as<SRec>(), t.s_val.as<double>(), t.d_src.as<uint32_t>(),
+                         t.d_val.as<double>(), t.hs_ptr.as<int64_t>(), t.hs_src.as<uint32_t>(), t.hs_val.as<double>());
       SQD_TRY(t.jrow.reserve(nj * 8));
       hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
                          c->eri_pp.as<double>(), nnorb, 0, t.jrow.as<double>());
@@ -493,6 +599,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   c->D = na * nb;
   c->nelec[0] = nocc[0];
   c->nelec[1] = nocc[1];
+  SQD_TRY(build_sigma_work(c));
   SQD_TRY(c->hdiag.reserve((size_t)c->D * 8));
   hipLaunchKernelGGL(k_hdiag, dim3(nblk(c->D, 256)), dim3(256), 0, st, c->sp[0].strs.as<uint64_t>(),
                      c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
