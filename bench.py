@@ -14,8 +14,8 @@ A *step* is one complete native ``solve_fermion`` on one batch: CI-string link t
 the device from the string lists, Davidson to pyscf's default tolerance (tol 1e-9) from pyscf's
 initial guess, then <c|H|c>, orbital occupancies (rdm1 diagonals), <S^2>, and the amplitude matrix
 returned to the host.  Integrals are resident in HBM (context created before the timed region).
-For N > 1 every step ends with the path's only exchange: an all-gather of (E, occ_a, occ_b) over RCCL
-and an argmin (reference semantics, fermion.py:577).  ``value`` = sigma-vectors built by all ranks /
+For N > 1 every step ends with the path's only exchange: one all-reduce of the (E, occ_a, occ_b)
+records over RCCL and an argmin (reference semantics, fermion.py:577).  ``value`` = sigma-vectors built by all ranks /
 max-over-ranks wall time of the K steps.
 """
 from __future__ import annotations
@@ -135,9 +135,11 @@ def main():
     def exchange(e, oa, ob):
         if dist is None:
             return e, oa, ob
-        rec = torch.tensor(np.concatenate([[e], oa, ob]), device=dev, dtype=torch.float64)
-        allrec = torch.empty((world, rec.numel()), device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(allrec, rec)
+        # same exchange as qiskit_addon_sqd_amd.distributed: ONE all-reduce(sum) of a table whose rows are
+        # zero except the owner's record [E, occ_a, occ_b]  (61 doubles per batch at norb = 30)
+        allrec = torch.zeros((world, 1 + 2 * args.norb), device=dev, dtype=torch.float64)
+        allrec[rank] = torch.from_numpy(np.concatenate([[e], oa, ob])).to(dev)
+        dist.all_reduce(allrec, op=dist.ReduceOp.SUM)
         best = int(torch.argmin(allrec[:, 0]).item())
         row = allrec[best].cpu().numpy()
         return row[0], row[1 : 1 + args.norb], row[1 + args.norb :]
@@ -202,7 +204,7 @@ def main():
                              f"determinants, 1 subsample batch per GPU"),
                 "norb": args.norb, "nelec": [args.nelec, args.nelec], "na": args.na, "nb": args.nb,
                 "strings": args.strings, "spin_sq": args.spin_sq,
-                "parallelism": f"batch-per-gpu x{world}" + (" + all_gather(E,occ)->argmin" if world > 1 else ""),
+                "parallelism": f"batch-per-gpu x{world}" + (" + all_reduce(E,occ)->argmin" if world > 1 else ""),
             },
             "wall_to_e0_ms": 1e3 * elapsed_max / args.steps,
             "sigma_per_solve": nsig / args.steps,

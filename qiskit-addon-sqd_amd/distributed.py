@@ -1,0 +1,118 @@
+"""Batch-parallel ``sci_solver`` for one process per GPU (``torch.distributed``; backend "nccl" is
+RCCL over xGMI on MI355X, "gloo" for CPU tests).
+
+The reference's SQD loop hands a list of independent subspaces to ``sci_solver`` and documents that
+call as its only collective step (``qiskit_addon_sqd/fermion.py:316-333``, ``:432``;
+``docs/guides/hpc_acceleration.rst:52-57``); its default solver runs them serially (:670-681).
+Here batch ``i`` is solved by rank ``i % world`` with no communication during the solve.  Afterwards
+ONE all-reduce (sum of a table whose rows are zero except on the owning rank -- i.e. a gather) makes
+every batch's ``[E, occ_a, occ_b]`` record known everywhere (``(1 + 2 norb) * 8`` bytes per batch:
+latency-bound, xGMI bandwidth irrelevant), and the winner's amplitude matrix -- the only large object
+the loop consumes (``fermion.py:608-631``) -- is broadcast from its owner.
+
+Reference semantics (v0.13) = argmin over energies, take that batch's occupancies (``fermion.py:577,
+:604-605``): ``occupancy_reduce="best"``.  ``"mean"`` replaces every result's occupancies by the batch
+average (the older tutorial workflow / BASELINE north_star wording), computed from the same table.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import numpy as np
+
+from .fermion import SCIResult, SCIState, solve_sci
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
+    return dist
+
+
+def shard_indices(num_batches: int, rank: int, world: int) -> list[int]:
+    """Batches owned by ``rank``: round-robin, ``i % world == rank``."""
+    return list(range(rank, num_batches, world))
+
+
+def solve_sci_batch_distributed(
+    ci_strings: Sequence[tuple[np.ndarray, np.ndarray]],
+    one_body_tensor: np.ndarray,
+    two_body_tensor: np.ndarray,
+    norb: int,
+    nelec: tuple[int, int],
+    *,
+    spin_sq: float | None = None,
+    group=None,
+    device: int | None = None,
+    occupancy_reduce: str = "best",
+    local_solver: Callable[..., SCIResult] | None = None,
+    **kwargs,
+) -> list[SCIResult]:
+    """Collective drop-in for ``solve_sci_batch`` (same positional signature, so it can be passed as
+    ``sci_solver=`` to the SQD loop on every rank).
+
+    Returns one ``SCIResult`` per batch on every rank.  ``energy`` and ``orbital_occupancies`` are
+    populated for all batches; ``sci_state`` is populated for the batches this rank solved and for the
+    lowest-energy batch (broadcast), ``None`` otherwise; ``rdm1``/``rdm2`` only for local batches.
+    """
+    if occupancy_reduce not in ("best", "mean"):
+        raise ValueError("occupancy_reduce must be 'best' or 'mean'")
+    import torch
+
+    dist = _dist()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    on_gpu = backend == "nccl"
+    if device is None:
+        device = torch.cuda.current_device() if on_gpu else 0
+    tdev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
+    solver = local_solver or solve_sci
+    norb = int(np.asarray(one_body_tensor).shape[0])
+    nb = len(ci_strings)
+    width = 1 + 2 * norb
+
+    # ---- independent solves, no communication
+    local: dict[int, SCIResult] = {}
+    table = np.zeros((nb, width))
+    for i in shard_indices(nb, rank, world):
+        res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
+                     device=device, **kwargs)  # fmt: skip
+        local[i] = res
+        table[i, 0] = res.energy
+        table[i, 1 : 1 + norb] = res.orbital_occupancies[0]
+        table[i, 1 + norb :] = res.orbital_occupancies[1]
+
+    # ---- the path's single exchange: all-reduce(sum) of the per-batch records
+    t = torch.from_numpy(table).to(tdev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    table = t.cpu().numpy()
+    best = int(np.argmin(table[:, 0]))
+    owner = best % world
+
+    # ---- winner's state to every rank
+    sa, sb = ci_strings[best]
+    if rank == owner:
+        amps = np.ascontiguousarray(local[best].sci_state.amplitudes, dtype=np.float64)
+    else:
+        amps = np.empty((len(sa), len(sb)))
+    ta = torch.from_numpy(amps).to(tdev)
+    src = dist.get_global_rank(group, owner) if group is not None else owner
+    dist.broadcast(ta, src=src, group=group)
+    amps = ta.cpu().numpy()
+
+    mean_occ = (table[:, 1 : 1 + norb].mean(axis=0), table[:, 1 + norb :].mean(axis=0))
+    out: list[SCIResult] = []
+    for i in range(nb):
+        occ = mean_occ if occupancy_reduce == "mean" else (table[i, 1 : 1 + norb].copy(), table[i, 1 + norb :].copy())
+        if i in local:
+            r = local[i]
+            out.append(SCIResult(float(table[i, 0]), r.sci_state, occ, rdm1=r.rdm1, rdm2=r.rdm2))
+        elif i == best:
+            state = SCIState(amps, np.asarray(sa), np.asarray(sb), norb=norb, nelec=tuple(int(x) for x in nelec))
+            out.append(SCIResult(float(table[i, 0]), state, occ))
+        else:
+            out.append(SCIResult(float(table[i, 0]), None, occ))  # type: ignore[arg-type]
+    return out

@@ -1,0 +1,53 @@
+"""Worker of tests/test_distributed.py: one rank of a world_size-2 gloo group on CPU.  The local solves
+go through the kernel-logic emulator (tests/emu); the exchange logic under test is the real one."""
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    import torch.distributed as dist
+
+    from oracle import sqd_oracle as O
+    from qiskit_addon_sqd_amd import _capi
+    from qiskit_addon_sqd_amd.distributed import shard_indices, solve_sci_batch_distributed
+    from qiskit_addon_sqd_amd.fermion import solve_sci_batch
+
+    emu = os.environ["SQD_EMU_LIB"]
+    _capi._LIB = _capi.bind(ctypes.CDLL(emu))
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}",
+                            rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    norb, nelec = 6, (3, 3)
+    h1, eri = O.synthetic_integrals(norb, seed=5)
+    batches = [(O.random_strings(norb, 3, 6 + i, 10 + i), O.random_strings(norb, 3, 5 + i, 20 + i)) for i in range(3)]
+    res = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False)
+    serial = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False)
+    best = int(np.argmin([r.energy for r in serial]))
+    mine = shard_indices(len(batches), rank, world)
+    assert len(res) == 3
+    for i, (r, s) in enumerate(zip(res, serial)):
+        assert abs(r.energy - s.energy) < 1e-12, (i, r.energy, s.energy)
+        assert np.allclose(r.orbital_occupancies[0], s.orbital_occupancies[0], atol=1e-12)
+        assert np.allclose(r.orbital_occupancies[1], s.orbital_occupancies[1], atol=1e-12)
+        if i in mine or i == best:
+            assert np.allclose(np.abs(r.sci_state.amplitudes), np.abs(s.sci_state.amplitudes), atol=1e-10)
+        else:
+            assert r.sci_state is None
+    rm = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False, occupancy_reduce="mean")
+    mean_a = np.mean([s.orbital_occupancies[0] for s in serial], axis=0)
+    assert all(np.allclose(r.orbital_occupancies[0], mean_a, atol=1e-12) for r in rm)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok")
+
+
+if __name__ == "__main__":
+    main()

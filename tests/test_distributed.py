@@ -1,0 +1,39 @@
+"""Multi-process CPU test (gloo, world_size 2) of the batch-sharded ``sci_solver``: round-robin
+ownership, the single all-reduce of (E, occ) records, argmin, winner broadcast, 'mean' option."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_indices():
+    from qiskit_addon_sqd_amd.distributed import shard_indices
+
+    assert shard_indices(8, 0, 8) == [0] and shard_indices(8, 7, 8) == [7]
+    assert shard_indices(5, 1, 2) == [1, 3] and shard_indices(1, 1, 2) == []
+    assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
+
+
+def test_two_rank_gloo_batch_sharding(emu_lib):
+    from conftest import EMU_LIB
+
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SQD_EMU_LIB=str(EMU_LIB), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "_dist_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"rank {rank} ok" in out

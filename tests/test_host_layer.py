@@ -1,0 +1,111 @@
+"""CPU tests of the host layer: golden vectors of the reference for the integer functions the package
+re-implements, the C-ABI library's symbol table, and the Python API (fermion.py) driven through the
+kernel-logic emulator (tests/emu) -- no GPU, no compute calls into libsqd_hip.so."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import sqd_oracle as O
+from qiskit_addon_sqd_amd import _capi
+from qiskit_addon_sqd_amd.counts import bitstring_matrix_to_integers
+from qiskit_addon_sqd_amd.fermion import (SCIResult, SCIState, _check_ci_strs, bitstring_matrix_to_ci_strs,
+                                          solve_fermion, solve_sci, solve_sci_batch)
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = json.loads((ROOT / "tests" / "golden" / "integer_layer.json").read_text())
+
+
+@pytest.mark.parametrize("key", [k for k in GOLD if k.startswith("b2i_")])
+def test_bitstring_matrix_to_integers_golden(key):
+    case = GOLD[key]
+    out = bitstring_matrix_to_integers(np.array(case["matrix"], dtype=bool))
+    assert [str(int(x)) for x in out] == case["out"]
+    assert str(out.dtype) == case["dtype"]
+
+
+@pytest.mark.parametrize("key", [k for k in GOLD if k.startswith("ci_")])
+def test_bitstring_matrix_to_ci_strs_golden(key):
+    case = GOLD[key]
+    a, b = bitstring_matrix_to_ci_strs(np.array(case["matrix"], dtype=bool), open_shell=case["open_shell"])
+    assert [str(int(x)) for x in a] == case["a"] and [str(int(x)) for x in b] == case["b"]
+    if "dtype" in case:
+        assert str(np.asarray(a).dtype) == case["dtype"]
+
+
+def test_check_ci_strs_golden():
+    ok = GOLD["check_ok"]
+    oa, ob = _check_ci_strs((np.array(ok["a"]), np.array(ok["b"])))
+    assert oa.tolist() == ok["out_a"] and ob.tolist() == ok["out_b"]
+    for key in ("check_bad_up", "check_bad_dn"):
+        case = GOLD[key]
+        with pytest.raises(ValueError) as exc:
+            _check_ci_strs((np.array(case["a"]), np.array(case["b"])))
+        assert str(exc.value) == case["error"]
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """libsqd_hip.so (hipcc, gfx950) must load on a GPU-less box and export every function that
+    include/sqd_hip.h declares; no compute call is made here."""
+    header = (ROOT / "include" / "sqd_hip.h").read_text()
+    declared = set(re.findall(r"\b(sqd_[a-z0-9_]+)\s*\(", header)) - {"sqd_ctx"}
+    assert declared == set(_capi.EXPORTED_SYMBOLS)
+    lib = _capi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.sqd_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_capi, "_LIB", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", tmp_path / "libsqd_hip.so")
+    with pytest.raises(_capi.SQDNativeError, match="no CPU fallback"):
+        _capi.load_library()
+
+
+def test_scistate_validation_and_roundtrip(tmp_path):
+    with pytest.raises(ValueError, match="'amplitudes' shape must be"):
+        SCIState(np.zeros((2, 3)), np.array([1, 2]), np.array([1, 2]), 2, (1, 1))
+    st = SCIState(np.arange(6.0).reshape(2, 3), np.array([1, 2]), np.array([1, 2, 4]), norb=3, nelec=(1, 1))
+    st.save(tmp_path / "s.npz")
+    back = SCIState.load(tmp_path / "s.npz")
+    assert np.array_equal(back.amplitudes, st.amplitudes) and np.array_equal(back.ci_strs_b, st.ci_strs_b)
+    assert int(back.norb) == 3 and tuple(back.nelec) == (1, 1)
+    with np.load(tmp_path / "s.npz") as data:  # reference npz schema (fermion.py:90-99)
+        assert set(data.files) == {"amplitudes", "ci_strs_a", "ci_strs_b", "norb", "nelec"}
+    with pytest.raises(NotImplementedError):
+        st.rdm(rank=3)
+
+
+def test_python_api_through_emulator(emu_backend):
+    norb, nelec = 6, (3, 2)
+    h1, eri = O.synthetic_integrals(norb, seed=3)
+    sa = O.hf_centred_strings(norb, 3, 10, 1)
+    sb = O.hf_centred_strings(norb, 2, 8, 2)
+    e, state, occ, s2 = solve_fermion((sa, sb), h1, eri)
+    e_ref, amps_ref, occ_ref, s2_ref, _ = O.solve_fermion_dense((sa, sb), h1, eri)
+    assert abs(e - e_ref) < 1e-8 and abs(s2 - s2_ref) < 1e-6
+    assert np.allclose(occ[0], occ_ref[0], atol=1e-6) and np.allclose(occ[1], occ_ref[1], atol=1e-6)
+    assert state.nelec == (3, 2) and state.amplitudes.shape == (10, 8)
+    # bitstring-matrix input path (left half = beta, right half = alpha), open shell
+    from qiskit_addon_sqd_amd.synthetic import bitstring_matrix_from_strings
+
+    mat = bitstring_matrix_from_strings(sa[:8], sb, norb)
+    e2, st2, _, _ = solve_fermion(mat, h1, eri, open_shell=True)
+    assert np.array_equal(st2.ci_strs_a, np.unique(sa[:8])) and np.array_equal(st2.ci_strs_b, sb)
+    # solve_sci / solve_sci_batch: SCIResult with rdm1/rdm2 and energy from the RDMs (fermion.py:725-742)
+    res = solve_sci((sa, sb), h1, eri, norb, nelec)
+    assert isinstance(res, SCIResult) and abs(res.energy - e_ref) < 1e-8
+    assert abs(np.trace(res.rdm1) - 5) < 1e-9 and res.rdm2.shape == (6,) * 4
+    assert np.allclose(res.sci_state.orbital_occupancies()[0], res.orbital_occupancies[0], atol=1e-12)
+    with pytest.raises(ValueError, match="does not match"):
+        solve_sci((sa, sb), h1, eri, norb, (2, 2))
+    with pytest.raises(ValueError, match="hamming weight"):
+        solve_fermion((np.array([7, 3]), sb), h1, eri)
+    with pytest.raises(TypeError):
+        solve_fermion((sa, sb), h1, eri, bogus_kwarg=1)
+    out = solve_sci_batch([(sa, sb), (sa[:5], sb[:4])], h1, eri, norb, nelec, compute_rdms=False)
+    assert len(out) == 2 and out[0].rdm2 is None and out[0].energy <= out[1].energy + 1e-9
