@@ -65,10 +65,8 @@ def one_step(ctx, sa, sb, spin_sq):
     """Native body of solve_fermion (qiskit_addon_sqd_amd/fermion.py) on a resident Hamiltonian."""
     ctx.set_subspace(sa, sb)
     amps, st = ctx.davidson(spin_sq=spin_sq, shift=0.1)
-    e = ctx.energy()
-    d1a, d1b = ctx.rdm1s()
-    s2 = ctx.spin_square()
-    return e, np.diagonal(d1a), np.diagonal(d1b), s2, st, amps
+    e, s2, occ_a, occ_b = ctx.observables()
+    return e, occ_a, occ_b, s2, st, amps
 
 
 def cpu_baseline(args, h1, eri, sa, sb, n_sigma_gpu):

@@ -122,6 +122,10 @@ int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0,
  * sqd_spin_square: <c|S^2|c> (pyscf spin_square, fermion.py:830,:133).
  * sqd_rdm1s: dm1a/dm1b[p*norb+q] = <a+_p a_q> per spin (pyscf make_rdm1s, fermion.py:725,:821,:121).
  * sqd_rdm2: spin-summed dm2[p,q,r,s] = sum_{st} <p+_s r+_t s_t q_s> (pyscf make_rdm2, fermion.py:729,:826). */
+/* sqd_observables: everything reference solve_fermion derives from the state after the Davidson
+ * (fermion.py:820-830) in one call with one host synchronisation: e = <c|H|c>/<c|c>, s2 = <c|S^2|c>/<c|c>,
+ * occ_a/occ_b[norb] = diagonals of dm1a/dm1b. */
+int sqd_observables(sqd_ctx* ctx, const double* amps, double* e, double* s2, double* occ_a, double* occ_b);
 int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
 int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
 int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);

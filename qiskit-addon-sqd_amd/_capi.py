@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "sqd_contract_ss",
     "sqd_davidson_default_opts",
     "sqd_davidson",
+    "sqd_observables",
     "sqd_energy",
     "sqd_spin_square",
     "sqd_rdm1s",
@@ -98,6 +99,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_davidson_default_opts.argtypes = [C.POINTER(DavidsonOpts)]
     lib.sqd_davidson_default_opts.restype = None
     lib.sqd_davidson.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats)]
+    lib.sqd_observables.argtypes = [_ctxp, _dp, _dp, _dp, _dp, _dp]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
@@ -297,6 +299,14 @@ class Context:
             return None, None
         a = _as_f64(amps).reshape(self.na, self.nb)
         return a, _ptr(a)
+
+    def observables(self, amps=None):
+        """(energy, spin_square, occ_a, occ_b) of the state in one native call / one device sync."""
+        keep, p = self._state(amps)
+        e, s2 = C.c_double(), C.c_double()
+        oa, ob = np.empty(self.norb), np.empty(self.norb)
+        self._check(self._lib.sqd_observables(self._h, p, C.byref(e), C.byref(s2), _ptr(oa), _ptr(ob)))
+        return float(e.value), float(s2.value), oa, ob
 
     def energy(self, amps=None) -> float:
         keep, p = self._state(amps)

@@ -115,6 +115,9 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
     set_error("no subspace set");     \
     return SQD_ERR_STATE;             \
   }
+// table inspection uses blocking copies: drain the context stream first (set_subspace returns
+// without synchronising)
+#define DRAIN(c) SQD_HIP_CHECK(hipStreamSynchronize((c)->stream))
 
 SQD_API int sqd_set_subspace(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb) {
   CTX_ENTER(c);
@@ -150,6 +153,7 @@ SQD_API int sqd_single_links(sqd_ctx* c, int spin, int32_t* tgt, int32_t* src, i
   if (n == 0) return SQD_OK;
   std::vector<SRec> rec(n);
   std::vector<uint32_t> row(n);
+  DRAIN(c);
   SQD_HIP_CHECK(hipMemcpy(rec.data(), t.s_rec.p, n * sizeof(SRec), hipMemcpyDeviceToHost));
   SQD_HIP_CHECK(hipMemcpy(row.data(), t.s_row.p, n * 4, hipMemcpyDeviceToHost));
   if (value) SQD_HIP_CHECK(hipMemcpy(value, t.s_val.p, n * 8, hipMemcpyDeviceToHost));
@@ -174,6 +178,7 @@ SQD_API int sqd_double_links(sqd_ctx* c, int spin, int32_t* tgt, int32_t* src, i
   const int64_t n = t.n_d;
   if (n == 0) return SQD_OK;
   std::vector<uint32_t> row(n), sr(n), ob(n);
+  DRAIN(c);
   SQD_HIP_CHECK(hipMemcpy(row.data(), t.d_row.p, n * 4, hipMemcpyDeviceToHost));
   SQD_HIP_CHECK(hipMemcpy(sr.data(), t.d_src.p, n * 4, hipMemcpyDeviceToHost));
   SQD_HIP_CHECK(hipMemcpy(ob.data(), t.d_orb.p, n * 4, hipMemcpyDeviceToHost));
@@ -195,6 +200,7 @@ SQD_API int sqd_double_links(sqd_ctx* c, int spin, int32_t* tgt, int32_t* src, i
 SQD_API int sqd_hdiag(sqd_ctx* c, double* out) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  DRAIN(c);
   SQD_HIP_CHECK(hipMemcpy(out, c->hdiag.p, c->D * 8, hipMemcpyDeviceToHost));
   return SQD_OK;
 }
@@ -293,6 +299,26 @@ static int expectation(sqd_ctx* c, const double* amps, int mode, double* outv) {
     return SQD_ERR_INVALID;
   }
   *outv = num / den;
+  return SQD_OK;
+}
+
+SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s2, double* occ_a, double* occ_b) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  const double* d = nullptr;
+  SQD_TRY(state_ptr(c, amps, &d));
+  std::vector<double> out(3 + 2 * c->norb);
+  SQD_TRY(dev_observables(c, d, out.data()));
+  if (!(out[2] > 0.0)) {
+    set_error("state has zero norm");
+    return SQD_ERR_INVALID;
+  }
+  if (e) *e = out[0] / out[2];
+  if (s2) *s2 = out[1] / out[2];
+  for (int p = 0; p < c->norb; ++p) {
+    if (occ_a) occ_a[p] = out[3 + p] / out[2];
+    if (occ_b) occ_b[p] = out[3 + c->norb + p] / out[2];
+  }
   return SQD_OK;
 }
 

@@ -150,4 +150,5 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
 int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
+int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 }  // namespace sqd

@@ -28,7 +28,7 @@ constexpr int RED_T = 256;
 // partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
 __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
                        const double* __restrict__ y, double* __restrict__ partial) {
-  __shared__ double red[16];
+  __shared__ double red[16 * NV];
   double acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
@@ -38,11 +38,9 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
     for (int v = 0; v < NV; ++v)
       if (v < nvec) acc[v] += X[(int64_t)v * stride + i] * yv;
   }
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const double s = block_sum(acc[v], red);
-    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * NV + v] = s;
-  }
+  block_sum_multi<NV>(acc, nvec, red);
+  if ((int)threadIdx.x < nvec)
+    partial[(int64_t)blockIdx.x * NV + threadIdx.x] = block_sum_multi_get<NV>(red, threadIdx.x);
 }
 
 // out[v] = sum_b partial[b*width + v]
@@ -93,42 +91,36 @@ __device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
   return p.shift * (d * d + nba * (double)__popcll(A & ~B));
 }
 
+template <int MV>
 __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
                                    int64_t stride, int nvec, const Coef coef, double e,
                                    const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
                                    double* __restrict__ partial, int width) {
-  __shared__ double red[16];
-  double rr = 0.0, tt = 0.0;
-  double acc[SQD_MAX_SPACE + 1];
+  // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
+  __shared__ double red[16 * (MV + 2)];
+  double vals[MV + 2];
 #pragma unroll
-  for (int v = 0; v < SQD_MAX_SPACE + 1; ++v) acc[v] = 0.0;
+  for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double r = 0.0;
-    double xv[SQD_MAX_SPACE + 1];
+    double xv[MV];
 #pragma unroll
-    for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
+    for (int v = 0; v < MV; ++v)
       if (v < nvec) {
         xv[v] = X[(int64_t)v * stride + i];
         r += coef.v[v] * (AX[(int64_t)v * stride + i] - e * xv[v]);
       }
     const double t = r / (hdiag[i] + penalty_diag(pd, i) - e + 1e-4);
     out[i] = t;
-    rr += r * r;
-    tt += t * t;
+    vals[0] += r * r;
+    vals[1] += t * t;
 #pragma unroll
-    for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
-      if (v < nvec) acc[v] += xv[v] * t;
+    for (int v = 0; v < MV; ++v)
+      if (v < nvec) vals[2 + v] += xv[v] * t;
   }
-  double s = block_sum(rr, red);
-  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 0] = s;
-  s = block_sum(tt, red);
-  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 1] = s;
-#pragma unroll
-  for (int v = 0; v < SQD_MAX_SPACE + 1; ++v)
-    if (v < nvec) {
-      const double sv = block_sum(acc[v], red);
-      if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * width + 2 + v] = sv;
-    }
+  block_sum_multi<MV + 2>(vals, nvec + 2, red);
+  if ((int)threadIdx.x < nvec + 2)
+    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
 }
 
 // t <- scale * t - sum_v coef[v] X_v ;  partial[block] = |t|^2
@@ -198,15 +190,37 @@ static inline unsigned red_blocks(int64_t n) {
   return (unsigned)b;
 }
 
-// sums[0..nv) = column sums of the device partial array; one small D2H + sync
+// Device scalar block: scal[0] = 1/|t'| (0 if linearly dependent), scal[1] = |t'|^2 of the last
+// orthogonalisation, scal[2..] = outputs of the latest reduction.
+constexpr int SCAL_RED = 2;
+
+// |t'|^2 from the per-block partials -> normalisation factor, kept on the device (no host round trip)
+__global__ void k_norm_to_scale(const double* __restrict__ partial, int nblocks, double lindep, double* __restrict__ scal) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[b];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    scal[1] = s;
+    scal[0] = (s > lindep) ? 1.0 / sqrt(s) : 0.0;
+  }
+}
+__global__ void k_scale_dev(int64_t n, const double* __restrict__ scal, double* __restrict__ x) {
+  const double a = scal[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] *= a;
+}
+
+// sums[0..nv) = column sums of the device partial array; one small D2H + sync.  The same copy brings
+// scal[0..2) along (state of the last device-side normalisation) into c->h_pinned[0..2).
 static int fetch_sums(sqd_ctx* c, int nblocks, int width, int nv, double* sums) {
-  double* d_out = c->scal.as<double>();
+  double* scal = c->scal.as<double>();
   hipLaunchKernelGGL(k_reduce_partials, dim3(nv), dim3(128), 0, c->stream, (const double*)c->partial.as<double>(),
-                     nblocks, width, nv, d_out);
+                     nblocks, width, nv, scal + SCAL_RED);
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, d_out, sizeof(double) * nv, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, scal, sizeof(double) * (nv + SCAL_RED), hipMemcpyDeviceToHost, c->stream));
   SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-  std::memcpy(sums, c->h_pinned, sizeof(double) * nv);
+  std::memcpy(sums, c->h_pinned + SCAL_RED, sizeof(double) * nv);
   return SQD_OK;
 }
 
@@ -357,7 +371,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   int mc = 1; // number of basis vectors the current Ritz coefficients refer to
   coef.v[0] = 1.0;
   double e = 0.0, elast = 0.0, rnorm = 0.0;
-  bool conv = false;
+  bool conv = false, pending_norm_check = false;
   int nsig = 0, it = 0;
   bool first = true;
   for (it = 0; it < o->max_cycle; ++it) {
@@ -368,6 +382,17 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     ++nsig;
     // new column of the projected matrix
     SQD_TRY(multi_dot(c, X, D, m, AX + (int64_t)(m - 1) * D, sums.data()));
+    if (pending_norm_check) {
+      pending_norm_check = false;
+      if (!(c->h_pinned[1] > lindep)) {
+        // the last correction vector was linearly dependent on the basis (it was zeroed on the
+        // device): stop with the Ritz vector of the previous projected problem (pyscf: 'Linear
+        // dependency in trial subspace')
+        conv = rnorm < toloose;
+        --nsig;
+        break;
+      }
+    }
     for (int i = 0; i < m; ++i) heff[(size_t)i * nvecs + (m - 1)] = heff[(size_t)(m - 1) * nvecs + i] = sums[i];
     sub.assign((size_t)m * m, 0.0);
     for (int i = 0; i < m; ++i)
@@ -381,8 +406,13 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     mc = m;
     // residual, preconditioned correction (into X[m]) and its overlaps
     double* tnew = X + (int64_t)m * D;
-    hipLaunchKernelGGL(k_residual_precond, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m, coef,
-                       e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width);
+    if (max_space <= 12)
+      hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m,
+                         coef, e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width);
+    else
+      hipLaunchKernelGGL((k_residual_precond<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X,
+                         (const double*)AX, D, m, coef, e, (const double*)c->hdiag.as<double>(), pd, tnew,
+                         c->partial.as<double>(), width);
     SQD_HIP_CHECK(hipGetLastError());
     SQD_TRY(fetch_sums(c, (int)gb, width, m + 2, sums.data()));
     rnorm = std::sqrt(sums[0]);
@@ -404,15 +434,12 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, 1.0 / tn, tnew,
                        c->partial.as<double>());
     SQD_HIP_CHECK(hipGetLastError());
-    double n2;
-    SQD_TRY(fetch_sums(c, (int)gb, 1, 1, &n2));
-    if (!(n2 > lindep)) {
-      conv = rnorm < toloose;
-      ++it;
-      break;
-    }
-    hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(n2), tnew);
+    // normalise on the device; the norm is inspected at the next host sync (linear-dependence check)
+    hipLaunchKernelGGL(k_norm_to_scale, dim3(1), dim3(128), 0, s, (const double*)c->partial.as<double>(), (int)gb, lindep,
+                       c->scal.as<double>());
+    hipLaunchKernelGGL(k_scale_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)c->scal.as<double>(), tnew);
     SQD_HIP_CHECK(hipGetLastError());
+    pending_norm_check = true;
     if (m + 1 > max_space) {
       // collapse: X0 <- Ritz vector, AX0 <- A*Ritz (linear combination), X1 <- correction
       double* x0 = c->sol.as<double>();
@@ -448,6 +475,11 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   float ms = 0.f;
   SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
   c->have_solution = true;
+  if (c->ms_setup < 0.0) {
+    float tms = 0.f;
+    SQD_HIP_CHECK(hipEventElapsedTime(&tms, c->ev[0], c->ev[1]));
+    c->ms_setup = tms;
+  }
   if (st) {
     st->converged = conv ? 1 : 0;
     st->iterations = it;

@@ -20,4 +20,28 @@ __device__ inline double block_sum(double v, double* red) {
   return s;
 }
 
+// Sum N per-thread values over the workgroup with ONE barrier: shuffle tree inside each wave, lane 0
+// parks the wave totals in LDS (red[wave*N + v]), thread v adds the waves in order.  Thread v (< n)
+// returns the total of value v in `vals[0]`... callers read it through `block_sum_multi_get`.
+template <int N>
+__device__ inline void block_sum_multi(double (&vals)[N], int n, double* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int v = 0; v < N; ++v)
+    if (v < n) {
+      double x = vals[v];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+      if (lane == 0) red[wave * N + v] = x;
+    }
+  __syncthreads();
+}
+// after block_sum_multi: total of value v (any thread may call; v < n)
+template <int N>
+__device__ inline double block_sum_multi_get(const double* red, int v) {
+  const int nw = (blockDim.x + 63) >> 6;
+  double s = 0.0;
+  for (int w = 0; w < nw; ++w) s += red[w * N + v];
+  return s;
+}
+
 }  // namespace sqd

@@ -78,15 +78,44 @@ __global__ void k_colpair_dots(const double* __restrict__ C, int64_t na, int64_t
 }
 
 // occ[p] = sum_I [p in I] w[I]: one workgroup per orbital, fixed partition + fixed tree
-__global__ void k_occupancy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ w, int norb,
-                            double* __restrict__ dm1 /*[norb*norb], diagonal written*/) {
+__global__ void k_occupancy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ w, int stride,
+                            double* __restrict__ out /* out[p*stride] */) {
   __shared__ double red[16];
   const int p = blockIdx.x;
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
     if ((strs[i] >> p) & 1ull) s += w[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) dm1[p * norb + p] = s;
+  if (threadIdx.x == 0) out[(int64_t)p * stride] = s;
+}
+
+// partial[block*3 + {0,1,2}] = (a.c, b.c, c.c)
+__global__ void k_expect3(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                          const double* __restrict__ cv, double* __restrict__ partial) {
+  __shared__ double red[16];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double x = cv[i];
+    s0 += a[i] * x;
+    s1 += b[i] * x;
+    s2 += x * x;
+  }
+  s0 = block_sum(s0, red);
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = s0;
+    partial[blockIdx.x * 3 + 1] = s1;
+    partial[blockIdx.x * 3 + 2] = s2;
+  }
+}
+// out[v] = sum_b partial[b*3+v], one workgroup per v
+__global__ void k_reduce3(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[b * 3 + blockIdx.x];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 __global__ void k_rdm1_singles(int64_t nl, const SRec* __restrict__ rec, const double* __restrict__ dots, int norb,
@@ -235,7 +264,7 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
     p += t.n + t.n_s;
     SQD_TRY(spin_link_dots(c, s, d_c, w, dots, nullptr));
     hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
-                       (const double*)w, norb, dm + s * n2);
+                       (const double*)w, norb + 1, dm + s * n2);
     if (t.n_s > 0)
       hipLaunchKernelGGL(k_rdm1_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, t.n_s,
                          (const SRec*)t.s_rec.as<SRec>(), (const double*)dots, norb, dm + s * n2);
@@ -244,6 +273,41 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
   SQD_HIP_CHECK(hipMemcpyAsync(dm1a, dm, n2 * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipMemcpyAsync(dm1b, dm + n2, n2 * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipStreamSynchronize(st));
+  return SQD_OK;
+}
+
+// One call, one host synchronisation: out = { <c|H|c>, <c|S^2|c>, <c|c>, occ_a[norb], occ_b[norb] }
+// (occupancies un-normalised).  This is everything solve_fermion needs after the Davidson
+// (reference fermion.py:820-830) without building the off-diagonal RDM elements.
+int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
+  const int norb = c->norb;
+  hipStream_t st = c->stream;
+  const int64_t D = c->D;
+  SQD_TRY(c->tmp1.reserve((size_t)D * 8));
+  SQD_TRY(c->tmp2.reserve((size_t)D * 8));
+  const int nres = 3 + 2 * norb;
+  SQD_TRY(c->scratch.reserve((size_t)(c->na + c->nb + nres + 3 * 512) * 8 + 64));
+  double* wa = c->scratch.as<double>();
+  double* wb = wa + c->na;
+  double* res = wb + c->nb;
+  double* part = res + nres;
+  SQD_TRY(launch_sigma(c, d_c, c->tmp1.as<double>(), 0, false, 0.0, 0.0));
+  SQD_TRY(launch_sigma(c, d_c, c->tmp2.as<double>(), 1, false, 0.0, 0.0));
+  int nblk3 = (int)((D + 255) / 256);
+  if (nblk3 > 512) nblk3 = 512;
+  hipLaunchKernelGGL(k_expect3, dim3(nblk3), dim3(256), 0, st, D, (const double*)c->tmp1.as<double>(),
+                     (const double*)c->tmp2.as<double>(), d_c, part);
+  hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(128), 0, st, (const double*)part, nblk3, res);
+  hipLaunchKernelGGL(k_row_norms, dim3(nblk(c->na, 4)), dim3(256), 0, st, d_c, c->na, c->nb, wa);
+  hipLaunchKernelGGL(k_col_norms, dim3(nblk(c->nb, 64)), dim3(512), 0, st, d_c, c->na, c->nb, wb);
+  hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)c->sp[0].strs.as<uint64_t>(), c->na,
+                     (const double*)wa, 1, res + 3);
+  hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)c->sp[1].strs.as<uint64_t>(), c->nb,
+                     (const double*)wb, 1, res + 3 + norb);
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, res, nres * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  for (int i = 0; i < nres; ++i) out_host[i] = c->h_pinned[i];
   return SQD_OK;
 }
 

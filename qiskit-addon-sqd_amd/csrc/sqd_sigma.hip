@@ -55,6 +55,28 @@ struct SigmaArgs {
   const double* eri_pp;
 };
 
+// sum_l val[l] * C[src[l], B] over a chunk of same-spin links: the row reads are independent, so they
+// are issued PF at a time before any is consumed (memory-level parallelism instead of a load-use chain)
+__device__ inline double axpy_chunk(const double* __restrict__ C, const uint32_t* __restrict__ src,
+                                    const double* __restrict__ val, int64_t begin, int count, int64_t nb, int64_t B) {
+  constexpr int PF = 8;
+  const int64_t end = begin + count;
+  double a = 0.0;
+  for (int64_t l0 = begin; l0 < end; l0 += PF) {
+    double x[PF], v[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (l0 + u < end) {
+        v[u] = val[l0 + u];
+        x[u] = C[(int64_t)src[l0 + u] * nb + B];
+      }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (l0 + u < end) a += v[u] * x[u];
+  }
+  return a;
+}
+
 template <int R>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
@@ -99,20 +121,42 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
           {  // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0)
             const int64_t base = g.esb_sl[B >> 6] + (B & 63);
             const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
-            for (int k = 0; k < cnt; ++k) {
-              const SRec rec = g.esb_rec[base + (int64_t)k * 64];
-              const double v = g.esb_val[base + (int64_t)k * 64];
-              a += (v + srec_sign(rec.meta) * W2[srec_widx(rec.meta)]) * Crow[rec.src];
+            constexpr int PF = 4;
+            for (int k0 = 0; k0 < cnt; k0 += PF) {
+              SRec recs[PF];
+              double vals[PF];
+#pragma unroll
+              for (int u = 0; u < PF; ++u)
+                if (k0 + u < cnt) {
+                  recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+                  vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
+                }
+#pragma unroll
+              for (int u = 0; u < PF; ++u)
+                if (k0 + u < cnt)
+                  a += (vals[u] + srec_sign(recs[u].meta) * W2[srec_widx(recs[u].meta)]) * Crow[recs[u].src];
             }
           }
           {  // beta same-spin doubles
             const int64_t base = g.edb_sl[B >> 6] + (B & 63);
             const int cnt = (int)(g.db_ptr[B + 1] - g.db_ptr[B]);
-            for (int k = 0; k < cnt; ++k)
-              a += g.edb_val[base + (int64_t)k * 64] * Crow[g.edb_src[base + (int64_t)k * 64]];
+            constexpr int PF = 8;
+            for (int k0 = 0; k0 < cnt; k0 += PF) {
+              uint32_t srcs[PF];
+              double vals[PF];
+#pragma unroll
+              for (int u = 0; u < PF; ++u)
+                if (k0 + u < cnt) {
+                  srcs[u] = g.edb_src[base + (int64_t)(k0 + u) * 64];
+                  vals[u] = g.edb_val[base + (int64_t)(k0 + u) * 64];
+                }
+#pragma unroll
+              for (int u = 0; u < PF; ++u)
+                if (k0 + u < cnt) a += vals[u] * Crow[srcs[u]];
+            }
           }
           // first same-spin alpha links of this row: unit-stride row reads
-          for (int64_t l = it.begin; l < it.begin + it.count; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
+          a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
         acc[r] = a;
       }
@@ -155,13 +199,23 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         }
         const int64_t base = g.esb_sl[B >> 6] + (B & 63);
         const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
-        for (int k = 0; k < cnt; ++k) {
-          const SRec rec = g.esb_rec[base + (int64_t)k * 64];
-          const double* cr = Crow + rec.src;
-          const double* w2 = W2 + srec_widx(rec.meta);
-          double t = 0.0;
-          for (int j = 0; j < kb; ++j) t += w2[(int64_t)j * w2s] * cr[(int64_t)j * g.nb_pad];
-          a += srec_sign(rec.meta) * t;
+        // link records are fetched PF at a time (independent coalesced loads in flight together),
+        // then consumed against LDS
+        constexpr int PF = 8;
+        for (int k0 = 0; k0 < cnt; k0 += PF) {
+          SRec recs[PF];
+#pragma unroll
+          for (int u = 0; u < PF; ++u)
+            if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+#pragma unroll
+          for (int u = 0; u < PF; ++u)
+            if (k0 + u < cnt) {
+              const double* cr = Crow + recs[u].src;
+              const double* w2 = W2 + srec_widx(recs[u].meta);
+              double t = 0.0;
+              for (int j = 0; j < kb; ++j) t += w2[(int64_t)j * w2s] * cr[(int64_t)j * g.nb_pad];
+              a += srec_sign(recs[u].meta) * t;
+            }
         }
         acc[r] = a;
       }
@@ -173,9 +227,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       for (int r = 0; r < R; ++r) {
         const int64_t B = tid + (int64_t)r * T;
         if (B < nb) {
-          double a = 0.0;
-          for (int64_t l = it.begin; l < it.begin + it.count; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
-          acc[r] = a;
+          acc[r] = axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
       }
     }
@@ -188,13 +240,22 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   }
 }
 
-// sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items
+// sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items.
+// Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
+// partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
 __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
                                double* __restrict__ sigma) {
+  __shared__ double red[1024];
   const MultiRow mr = rows[blockIdx.x];
-  for (int64_t B = threadIdx.x; B < nb; B += blockDim.x) {
-    double s = 0.0;
-    for (int j = 0; j < mr.nslots; ++j) s += partial[(int64_t)(mr.slot0 + j) * nb + B];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6, SL = blockDim.x >> 6;
+  const int64_t B = (int64_t)blockIdx.y * 64 + col;
+  double s = 0.0;
+  if (B < nb)
+    for (int j = sl; j < mr.nslots; j += SL) s += partial[(int64_t)(mr.slot0 + j) * nb + B];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && B < nb) {
+    for (int r = 1; r < SL; ++r) s += red[r * 64 + col];
     sigma[(int64_t)mr.A * nb + B] = s;
   }
 }
@@ -266,7 +327,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   else rc = launch_sigma_r<16>(c, g);
   if (rc != SQD_OK) return rc;
   if (c->n_multi > 0) {
-    hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi), dim3(c->sig_T > 256 ? 256 : c->sig_T), 0, c->stream,
+    hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
                        d_sigma);
     SQD_HIP_CHECK(hipGetLastError());

@@ -501,6 +501,27 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SpinTables& t = c->sp[s];
     SQD_TRY(build_spin_links_count(c, t, d_cnt));  // scratch reused: stream order serialises
   }
+  // sliced-ELL geometry of the column role (beta) depends only on the counts: widths -> offsets now,
+  // so that every size the host needs arrives with ONE synchronisation
+  int64_t et[2];
+  {
+    SpinTables& t = c->sp[1];
+    int64_t* w_s = c->scratch.as<int64_t>() + 2 * maxn;
+    int64_t* w_d = w_s + t.n_slices + 1;
+    SQD_TRY(t.es_sl.reserve((t.n_slices + 1) * 8));
+    SQD_TRY(t.ed_sl.reserve((t.n_slices + 1) * 8));
+    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.s_ptr.as<int64_t>(), t.n,
+                       t.n_slices, w_s);
+    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.d_ptr.as<int64_t>(), t.n,
+                       t.n_slices, w_d);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_s, t.es_sl.as<int64_t>(),
+                       t.n_slices);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_d, t.ed_sl.as<int64_t>(),
+                       t.n_slices);
+    SQD_HIP_CHECK(hipGetLastError());
+    SQD_HIP_CHECK(hipMemcpyAsync(&et[0], t.es_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
+    SQD_HIP_CHECK(hipMemcpyAsync(&et[1], t.ed_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
+  }
   int64_t tot[4];
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
@@ -560,25 +581,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     }
     SQD_HIP_CHECK(hipGetLastError());
   }
-  // sliced ELL copies for the column role (beta): widths -> offsets -> totals -> fill
+  // sliced ELL copies for the column role (beta)
   {
     SpinTables& t = c->sp[1];
-    int64_t* w_s = c->scratch.as<int64_t>();
-    int64_t* w_d = w_s + t.n_slices + 1;
-    SQD_TRY(t.es_sl.reserve((t.n_slices + 1) * 8));
-    SQD_TRY(t.ed_sl.reserve((t.n_slices + 1) * 8));
-    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.s_ptr.as<int64_t>(), t.n,
-                       t.n_slices, w_s);
-    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.d_ptr.as<int64_t>(), t.n,
-                       t.n_slices, w_d);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_s, t.es_sl.as<int64_t>(),
-                       t.n_slices);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_d, t.ed_sl.as<int64_t>(),
-                       t.n_slices);
-    int64_t et[2];
-    SQD_HIP_CHECK(hipMemcpyAsync(&et[0], t.es_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
-    SQD_HIP_CHECK(hipMemcpyAsync(&et[1], t.ed_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
-    SQD_HIP_CHECK(hipStreamSynchronize(st));
     SQD_TRY(t.es_rec.reserve((size_t)et[0] * sizeof(SRec)));
     SQD_TRY(t.es_val.reserve((size_t)et[0] * 8));
     SQD_TRY(t.ed_src.reserve((size_t)et[1] * 4));
@@ -605,11 +610,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                      c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
                      c->hdiag.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
+  // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
   SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
-  SQD_HIP_CHECK(hipStreamSynchronize(st));
-  float ms = 0.f;
-  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-  c->ms_setup = ms;
+  c->ms_setup = -1.0;
   c->have_subspace = true;
   return SQD_OK;
 }

@@ -360,10 +360,10 @@ def solve_fermion(
     amps, _stats = _solve(ctx, ci_strs, spin_sq, shift, kwargs)
     num_up, num_dn = ctx.nelec
 
-    dm1a, dm1b = ctx.rdm1s()
-    avg_occupancy = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
-    e_sci = ctx.energy()  # <c|H|c>, the quantity the reference rebuilds from rdm1/rdm2 (:825-827)
-    spin_squared = ctx.spin_square()
+    # one native call: <c|H|c> (the quantity the reference rebuilds from rdm1/rdm2, :825-827), <S^2> (:830)
+    # and the rdm1s diagonals (:821-822)
+    e_sci, spin_squared, occ_a, occ_b = ctx.observables()
+    avg_occupancy = (occ_a, occ_b)
     sci_state = SCIState(
         amplitudes=amps,
         ci_strs_a=ci_strs[0],

@@ -67,6 +67,9 @@ def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=
     r1a, r1b = O.make_rdm1s(amps, sa, sb, norb)
     assert np.allclose(d1a, r1a, atol=1e-12) and np.allclose(d1b, r1b, atol=1e-12)
     assert abs(np.trace(d1a) - bin(int(sa[0])).count("1")) < 1e-10
+    e_o, s2_o, oa, ob = ctx.observables()  # fused path used by solve_fermion
+    assert abs(e_o - ctx.energy()) < 1e-11 and abs(s2_o - ctx.spin_square()) < 1e-11
+    assert np.allclose(oa, np.diag(d1a), atol=1e-12) and np.allclose(ob, np.diag(d1b), atol=1e-12)
     if with_rdm2:
         d2 = ctx.rdm2()
         assert np.allclose(d2, O.make_rdm2(amps, sa, sb, norb), atol=1e-12)
