@@ -75,7 +75,12 @@ struct SpinTables {
   DevBuf jT;                     // f64[nnorb][n]   transposed copy                        (col role)
   // sliced ELL (slice = 64 consecutive strings), records of slice b start at *_sl[b], entry
   // (k, lane) lives at *_sl[b] + k*64 + lane
-  DevBuf es_sl, ed_sl;           // i64[n_slices+1]
+  DevBuf es_sl, ed_sl;           // i64[slices+1] over the n+nx virtual rows
+  // capped ELL: virtual rows of <= cap links; rows [0,n) = first chunk of each string, rows
+  // [n, n+nx) = overflow chunks; xptr[B]..xptr[B+1] = overflow rows owned by string B
+  int cap = 32;
+  int64_t nx_s = 0, nx_d = 0;
+  DevBuf vs_cnt, vs_xptr, vs_start, vd_cnt, vd_xptr, vd_start;  // i32 / i32 / i64
   DevBuf es_rec;                 // SRec
   DevBuf es_val;                 // f64
   DevBuf ed_src;                 // u32
@@ -95,6 +100,12 @@ struct WorkItem {
 struct MultiRow {
   uint32_t A;
   int32_t slot0, nslots;
+};
+// host copy of the capped-ELL descriptors (see sqd_tables.hip)
+struct VRowsHost {
+  std::vector<int32_t> vcnt, xptr;
+  std::vector<int64_t> vstart, sl;
+  int64_t nx = 0, total = 0;
 };
 
 }  // namespace sqd
@@ -116,9 +127,10 @@ struct sqd_ctx {
   sqd::SpinTables sp[2];
   sqd::DevBuf hdiag;        // f64[D]
   // sigma work list + launch geometry (fixed per subspace)
-  std::vector<int64_t> h_sptr, h_dptr;
+  std::vector<int64_t> h_sptr, h_dptr, h_sptr_b, h_dptr_b;
   std::vector<sqd::WorkItem> h_items;
   std::vector<sqd::MultiRow> h_multi;
+  sqd::VRowsHost hv_s, hv_d;
   sqd::DevBuf items, multi, sig_partial;
   int64_t n_items = 0, n_multi = 0, n_slots = 0;
   int sig_T = 64, sig_R = 1, sig_K = 1, sig_nb_pad = 0;

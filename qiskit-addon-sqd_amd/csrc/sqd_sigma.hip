@@ -34,6 +34,7 @@ struct SigmaArgs {
   int64_t na, nb;
   int nnorb, nb_pad, K;
   int mode;  // 0: H (+ penalty when spin), 1: pure S^2
+  int type_mask;  // profiling hook (env SQD_SIGMA_TYPES): bit t set = execute work items of type t; default 7
   int spin;
   double ss, shift, szterm;
   const uint64_t* strs_a;
@@ -43,8 +44,13 @@ struct SigmaArgs {
   const uint32_t* ha_src; // alpha merged same-spin links
   const double* ha_val;
   const double* ja_row;
-  const int64_t* sb_ptr;
-  const int64_t* db_ptr;
+  // beta lists as capped sliced ELL over virtual rows (sqd_tables.hip): rows [0,nb) first chunks,
+  // rows [nb, nb+nx) overflow chunks, xptr[B]..xptr[B+1] = overflow rows of string B
+  const int32_t* vs_cnt;
+  const int32_t* vs_xptr;
+  const int32_t* vd_cnt;
+  const int32_t* vd_xptr;
+  int nx_s, nx_d;
   const int64_t* esb_sl;
   const SRec* esb_rec;
   const double* esb_val;
@@ -77,7 +83,87 @@ __device__ inline double axpy_chunk(const double* __restrict__ C, const uint32_t
   return a;
 }
 
-template <int R>
+// ---- one virtual row of a beta list against LDS-staged data.  Link records are fetched PF at a time
+// (independent coalesced loads in flight together), then consumed against LDS.
+// singles on the own row: sum (value + sign * W[widx]) * Crow[src]
+__device__ inline double vrow_singles_own(const SigmaArgs& g, int64_t v, const double* Crow, const double* W2) {
+  const int64_t base = g.esb_sl[v >> 6] + (v & 63);
+  const int cnt = g.vs_cnt[v];
+  constexpr int PF = 4;
+  double a = 0.0;
+  for (int k0 = 0; k0 < cnt; k0 += PF) {
+    SRec recs[PF];
+    double vals[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) {
+        recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+        vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
+      }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) a += (vals[u] + srec_sign(recs[u].meta) * W2[srec_widx(recs[u].meta) >> 1]) * Crow[recs[u].src];
+  }
+  return a;
+}
+// doubles on the own row: sum value * Crow[src]
+__device__ inline double vrow_doubles_own(const SigmaArgs& g, int64_t v, const double* Crow) {
+  const int64_t base = g.edb_sl[v >> 6] + (v & 63);
+  const int cnt = g.vd_cnt[v];
+  constexpr int PF = 8;
+  double a = 0.0;
+  for (int k0 = 0; k0 < cnt; k0 += PF) {
+    uint32_t srcs[PF];
+    double vals[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) {
+        srcs[u] = g.edb_src[base + (int64_t)(k0 + u) * 64];
+        vals[u] = g.edb_val[base + (int64_t)(k0 + u) * 64];
+      }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) a += vals[u] * Crow[srcs[u]];
+  }
+  return a;
+}
+// singles against a batch of kb staged alpha links: sum sign * sum_j W[j][pair] * Crow[j][src].
+// SPIN: the S^2 operator couples alpha link j (cre a, des b) to the one beta link with the same orbital
+// pair and the opposite direction (cre b, des a); penw[j] is that beta link's widx, pen the coefficient.
+constexpr int KMAX = 4;
+template <bool SPIN>
+__device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const double* Crow, const double* W, int kb,
+                                            int ws, const int (&penw)[KMAX], double pen) {
+  const int64_t base = g.esb_sl[v >> 6] + (v & 63);
+  const int cnt = g.vs_cnt[v];
+  constexpr int PF = 8;
+  double a = 0.0;
+  for (int k0 = 0; k0 < cnt; k0 += PF) {
+    SRec recs[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (k0 + u < cnt) {
+        const int widx = (int)srec_widx(recs[u].meta);
+        const double* cr = Crow + recs[u].src;
+        const double* w = W + (widx >> 1);
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < kb) {
+            double wj = w[(int64_t)j * ws];
+            if (SPIN) wj += (widx == penw[j]) ? pen : 0.0;
+            t += wj * cr[(int64_t)j * g.nb_pad];
+          }
+        a += srec_sign(recs[u].meta) * t;
+      }
+  }
+  return a;
+}
+
+template <int R, bool SPIN>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
   const int T = blockDim.x, tid = threadIdx.x;
@@ -87,22 +173,30 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   const int nnorb = g.nnorb;
   double* Crow = smem;                          // [K][nb_pad]
   double* W2 = smem + (int64_t)g.K * g.nb_pad;  // [K][2*nnorb]
-  const int w2s = 2 * nnorb;
+  const int w2s = (nnorb + 1) & ~1;            // one integral row per staged link
+  double* part_s = W2 + (int64_t)g.K * w2s;  // [nx_s] partial sums of overflow single rows
+  double* part_d = part_s + g.nx_s;          // [nx_d]
   const double* __restrict__ C = g.c;
   double acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.0;
 
-  if (it.type == 0) {
+  if (!((g.type_mask >> it.type) & 1)) {
+    // profiling hook only: skipped item classes write zeros
+  } else if (it.type == 0) {
     // ---- own row: slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
     const uint64_t sA = g.strs_a[A];
     for (int64_t i = tid; i < nb; i += T) Crow[i] = C[A * nb + i];
     if (g.mode == 0)
       for (int i = tid; i < nnorb; i += T) {
-        const double w = g.ja_row[A * nnorb + i];
-        W2[2 * i] = w;
-        W2[2 * i + 1] = w;
+        W2[i] = g.ja_row[A * nnorb + i];
       }
+    __syncthreads();
+    // overflow chunks of heavily connected beta strings: partial sums through LDS
+    if (g.mode == 0) {
+      for (int v = tid; v < g.nx_s; v += T) part_s[v] = vrow_singles_own(g, nb + v, Crow, W2);
+      for (int v = tid; v < g.nx_d; v += T) part_d[v] = vrow_doubles_own(g, nb + v, Crow);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -118,43 +212,11 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         }
         double a = d * Crow[B];
         if (g.mode == 0) {
-          {  // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0)
-            const int64_t base = g.esb_sl[B >> 6] + (B & 63);
-            const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
-            constexpr int PF = 4;
-            for (int k0 = 0; k0 < cnt; k0 += PF) {
-              SRec recs[PF];
-              double vals[PF];
-#pragma unroll
-              for (int u = 0; u < PF; ++u)
-                if (k0 + u < cnt) {
-                  recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
-                  vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
-                }
-#pragma unroll
-              for (int u = 0; u < PF; ++u)
-                if (k0 + u < cnt)
-                  a += (vals[u] + srec_sign(recs[u].meta) * W2[srec_widx(recs[u].meta)]) * Crow[recs[u].src];
-            }
-          }
-          {  // beta same-spin doubles
-            const int64_t base = g.edb_sl[B >> 6] + (B & 63);
-            const int cnt = (int)(g.db_ptr[B + 1] - g.db_ptr[B]);
-            constexpr int PF = 8;
-            for (int k0 = 0; k0 < cnt; k0 += PF) {
-              uint32_t srcs[PF];
-              double vals[PF];
-#pragma unroll
-              for (int u = 0; u < PF; ++u)
-                if (k0 + u < cnt) {
-                  srcs[u] = g.edb_src[base + (int64_t)(k0 + u) * 64];
-                  vals[u] = g.edb_val[base + (int64_t)(k0 + u) * 64];
-                }
-#pragma unroll
-              for (int u = 0; u < PF; ++u)
-                if (k0 + u < cnt) a += vals[u] * Crow[srcs[u]];
-            }
-          }
+          // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0), beta doubles
+          a += vrow_singles_own(g, B, Crow, W2);
+          for (int x = g.vs_xptr[B]; x < g.vs_xptr[B + 1]; ++x) a += part_s[x];
+          a += vrow_doubles_own(g, B, Crow);
+          for (int x = g.vd_xptr[B]; x < g.vd_xptr[B + 1]; ++x) a += part_d[x];
           // first same-spin alpha links of this row: unit-stride row reads
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
@@ -164,27 +226,26 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   } else if (it.type == 1) {
     // ---- a batch of alpha single links: stage their source rows (signed) and integral rows
     const int kb = it.count;
-    for (int j = 0; j < kb; ++j) {
-      const SRec rec = g.sa_rec[it.begin + j];
-      const double sg = srec_sign(rec.meta);
-      const int widx = (int)srec_widx(rec.meta);
-      const int pair = widx >> 1, dir = widx & 1;
-      const double* __restrict__ src = C + (int64_t)rec.src * nb;
-      double* cr = Crow + (int64_t)j * g.nb_pad;
-      double* w2 = W2 + (int64_t)j * w2s;
-      for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
-      for (int i = tid; i < nnorb; i += T) {
-        const double w = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
-        double w0 = w, w1 = w;
-        if (i == pair && (g.mode == 1 || g.spin)) {
-          // S^2 couples this alpha link (cre a, des b) to the beta link (cre b, des a): opposite dir
-          const double pen = (g.mode == 1) ? -1.0 : -g.shift;
-          if (dir) w0 += pen; else w1 += pen;
-        }
-        w2[2 * i] = w0;
-        w2[2 * i + 1] = w1;
+    int penw[KMAX];
+    const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      penw[j] = -1;
+      if (j < kb) {
+        const SRec rec = g.sa_rec[it.begin + j];
+        const double sg = srec_sign(rec.meta);
+        const int widx = (int)srec_widx(rec.meta);
+        const int pair = widx >> 1;
+        penw[j] = widx ^ 1;  // same pair, opposite direction
+        const double* __restrict__ src = C + (int64_t)rec.src * nb;
+        double* cr = Crow + (int64_t)j * g.nb_pad;
+        double* w2 = W2 + (int64_t)j * w2s;
+        for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
+        for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
       }
     }
+    __syncthreads();
+    for (int v = tid; v < g.nx_s; v += T) part_s[v] = vrow_singles_batch<SPIN>(g, nb + v, Crow, W2, kb, w2s, penw, pen);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -197,26 +258,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
             a += g.jbT[(int64_t)pair * nb + B] * Crow[(int64_t)j * g.nb_pad + B];
           }
         }
-        const int64_t base = g.esb_sl[B >> 6] + (B & 63);
-        const int cnt = (int)(g.sb_ptr[B + 1] - g.sb_ptr[B]);
-        // link records are fetched PF at a time (independent coalesced loads in flight together),
-        // then consumed against LDS
-        constexpr int PF = 8;
-        for (int k0 = 0; k0 < cnt; k0 += PF) {
-          SRec recs[PF];
-#pragma unroll
-          for (int u = 0; u < PF; ++u)
-            if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
-#pragma unroll
-          for (int u = 0; u < PF; ++u)
-            if (k0 + u < cnt) {
-              const double* cr = Crow + recs[u].src;
-              const double* w2 = W2 + srec_widx(recs[u].meta);
-              double t = 0.0;
-              for (int j = 0; j < kb; ++j) t += w2[(int64_t)j * w2s] * cr[(int64_t)j * g.nb_pad];
-              a += srec_sign(recs[u].meta) * t;
-            }
-        }
+        a += vrow_singles_batch<SPIN>(g, B, Crow, W2, kb, w2s, penw, pen);
+        for (int x = g.vs_xptr[B]; x < g.vs_xptr[B + 1]; ++x) a += part_s[x];
         acc[r] = a;
       }
     }
@@ -266,15 +309,19 @@ __global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, doubl
     y[i] = a * x[i] + b * y[i];
 }
 
-template <int R>
-static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
+template <int R, bool SPIN>
+static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
   if (c->sig_shmem > 64 * 1024) {
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R>),
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
   }
-  hipLaunchKernelGGL((k_sigma<R>), dim3((unsigned)c->n_items), dim3(c->sig_T), c->sig_shmem, c->stream, g);
+  hipLaunchKernelGGL((k_sigma<R, SPIN>), dim3((unsigned)c->n_items), dim3(c->sig_T), c->sig_shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
+}
+template <int R>
+static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
+  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true>(c, g) : launch_sigma_rs<R, false>(c, g);
 }
 
 int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift) {
@@ -295,6 +342,8 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.nb_pad = c->sig_nb_pad;
   g.K = c->sig_K;
   g.mode = mode;
+  g.type_mask = 7;
+  if (const char* env = std::getenv("SQD_SIGMA_TYPES")) g.type_mask = std::atoi(env);
   g.spin = spin ? 1 : 0;
   g.ss = ss;
   g.shift = shift;
@@ -307,8 +356,12 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.ha_src = a.hs_src.as<uint32_t>();
   g.ha_val = a.hs_val.as<double>();
   g.ja_row = a.jrow.as<double>();
-  g.sb_ptr = b.s_ptr.as<int64_t>();
-  g.db_ptr = b.d_ptr.as<int64_t>();
+  g.vs_cnt = b.vs_cnt.as<int32_t>();
+  g.vs_xptr = b.vs_xptr.as<int32_t>();
+  g.vd_cnt = b.vd_cnt.as<int32_t>();
+  g.vd_xptr = b.vd_xptr.as<int32_t>();
+  g.nx_s = (int)b.nx_s;
+  g.nx_d = (int)b.nx_d;
   g.esb_sl = b.es_sl.as<int64_t>();
   g.esb_rec = b.es_rec.as<SRec>();
   g.esb_val = b.es_val.as<double>();

@@ -13,6 +13,7 @@
 // address, which is this build's canonical (bit-exact, testable) order.  Integral values are
 // attached by a second, fully occupied thread-per-link pass.
 #include <algorithm>
+#include <cstdlib>
 
 #include "sqd_common.h"
 
@@ -47,7 +48,8 @@ void DevBuf::release() {
 }
 void SpinTables::release() {
   DevBuf* all[] = {&strs, &e_str, &s_ptr, &d_ptr, &s_row, &d_row, &s_rec, &s_val, &d_src, &d_orb,
-                   &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val};
+                   &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val,
+                   &vs_cnt, &vs_xptr, &vs_start, &vd_cnt, &vd_xptr, &vd_start};
   for (DevBuf* b : all) b->release();
 }
 
@@ -280,40 +282,73 @@ __global__ void k_hdiag(const uint64_t* __restrict__ strs_a, const double* __res
   hdiag[A * nb + B] = v;
 }
 
-// ------------------------------------------------------------------ sliced ELL (column role)
-__global__ void k_slice_width(const int64_t* __restrict__ ptr, int64_t n, int64_t n_slices, int64_t* __restrict__ w64) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_slices) return;
-  int64_t w = 0;
-  for (int64_t i = b * 64; i < b * 64 + 64 && i < n; ++i) {
-    const int64_t c = ptr[i + 1] - ptr[i];
-    w = c > w ? c : w;
+// ------------------------------------------------------------------ capped sliced ELL (column role)
+// Lanes of the sigma kernel map to beta strings, so one string with hundreds of links (the
+// Hartree-Fock neighbourhood) would stall its whole wavefront.  Lists are therefore cut into
+// *virtual rows* of at most CAP links: virtual row B (< n) holds the first CAP links of string B,
+// the overflow chunks of all strings follow as rows n .. n+nx-1 (owner order), and xptr[B]..xptr[B+1]
+// names the overflow rows of B.  Storage is sliced ELL over the n+nx virtual rows: entry (k, lane)
+// of slice b at sl[b] + 64 k + lane.  The descriptors are computed on the host from the CSR pointers
+// (they arrive with the one synchronisation of set_subspace); the fill runs on the device.
+__global__ void k_fill_vell_singles(int64_t nv, const int32_t* __restrict__ vcnt, const int64_t* __restrict__ vstart,
+                                    const int64_t* __restrict__ sl, const SRec* __restrict__ rec,
+                                    const double* __restrict__ val, SRec* __restrict__ erec,
+                                    double* __restrict__ eval) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const int64_t base = sl[v >> 6] + (v & 63);
+  const int64_t p0 = vstart[v];
+  const int cnt = vcnt[v];
+  for (int k = 0; k < cnt; ++k) {
+    erec[base + (int64_t)k * 64] = rec[p0 + k];
+    eval[base + (int64_t)k * 64] = val[p0 + k];
   }
-  w64[b] = w * 64;
 }
-__global__ void k_fill_ell_singles(const int64_t* __restrict__ ptr, int64_t n, const int64_t* __restrict__ sl,
-                                   const SRec* __restrict__ rec, const double* __restrict__ val,
-                                   SRec* __restrict__ erec, double* __restrict__ eval) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t base = sl[i >> 6] + (i & 63);
-  const int64_t p0 = ptr[i], cnt = ptr[i + 1] - p0;
-  for (int64_t k = 0; k < cnt; ++k) {
-    erec[base + k * 64] = rec[p0 + k];
-    eval[base + k * 64] = val[p0 + k];
+__global__ void k_fill_vell_doubles(int64_t nv, const int32_t* __restrict__ vcnt, const int64_t* __restrict__ vstart,
+                                    const int64_t* __restrict__ sl, const uint32_t* __restrict__ src,
+                                    const double* __restrict__ val, uint32_t* __restrict__ esrc,
+                                    double* __restrict__ eval) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const int64_t base = sl[v >> 6] + (v & 63);
+  const int64_t p0 = vstart[v];
+  const int cnt = vcnt[v];
+  for (int k = 0; k < cnt; ++k) {
+    esrc[base + (int64_t)k * 64] = src[p0 + k];
+    eval[base + (int64_t)k * 64] = val[p0 + k];
   }
 }
-__global__ void k_fill_ell_doubles(const int64_t* __restrict__ ptr, int64_t n, const int64_t* __restrict__ sl,
-                                   const uint32_t* __restrict__ src, const double* __restrict__ val,
-                                   uint32_t* __restrict__ esrc, double* __restrict__ eval) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t base = sl[i >> 6] + (i & 63);
-  const int64_t p0 = ptr[i], cnt = ptr[i + 1] - p0;
-  for (int64_t k = 0; k < cnt; ++k) {
-    esrc[base + k * 64] = src[p0 + k];
-    eval[base + k * 64] = val[p0 + k];
+
+// host side of the above: virtual-row descriptors from a CSR pointer array
+static void make_vrows(const std::vector<int64_t>& ptr, int64_t n, int cap, VRowsHost& out) {
+  out.xptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t cnt = ptr[i + 1] - ptr[i];
+    const int64_t extra = cnt > cap ? (cnt - 1) / cap : 0;
+    out.xptr[i + 1] = out.xptr[i] + (int32_t)extra;
   }
+  out.nx = out.xptr[n];
+  const int64_t nv = n + out.nx;
+  out.vcnt.assign(nv, 0);
+  out.vstart.assign(nv, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t cnt = ptr[i + 1] - ptr[i];
+    out.vcnt[i] = (int32_t)(cnt < cap ? cnt : cap);
+    out.vstart[i] = ptr[i];
+    for (int64_t j = 0, rem = cnt - cap; rem > 0; ++j, rem -= cap) {
+      const int64_t v = n + out.xptr[i] + j;
+      out.vcnt[v] = (int32_t)(rem < cap ? rem : cap);
+      out.vstart[v] = ptr[i] + cap * (j + 1);
+    }
+  }
+  const int64_t nsl = (nv + 63) / 64;
+  out.sl.assign(nsl + 1, 0);
+  for (int64_t b = 0; b < nsl; ++b) {
+    int32_t w = 0;
+    for (int64_t v = b * 64; v < b * 64 + 64 && v < nv; ++v) w = out.vcnt[v] > w ? out.vcnt[v] : w;
+    out.sl[b + 1] = out.sl[b] + 64 * (int64_t)w;
+  }
+  out.total = out.sl[nsl];
 }
 
 // merged same-spin CSR: row i = its single links (value incl. sign) followed by its double links
@@ -352,20 +387,20 @@ static int build_sigma_work(sqd_ctx* c) {
   if (T > 1024) T = 1024;
   const int R = (int)((nb + T - 1) / T);
   const int nb_pad = (int)((nb + 1) & ~int64_t(1));
-  const size_t row_bytes = ((size_t)nb_pad + 2 * (size_t)c->nnorb) * 8;
+  const size_t row_bytes = ((size_t)nb_pad + (size_t)((c->nnorb + 1) & ~1)) * 8;  // one C row + one integral row
   const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
   if (row_bytes > budget || R > 16) {
     set_error("beta string count " + std::to_string(nb) + " exceeds the LDS-resident row limit of this build");
     return SQD_ERR_LIMIT;
   }
-  int K = (int)((40 * 1024) / row_bytes);
+  int K = (int)((26 * 1024) / row_bytes);  // <= ~26 KB of staging per workgroup: >= 5 workgroups per CU
   if (K < 1) K = 1;
   if (K > 4) K = 4;
   c->sig_T = T;
   c->sig_R = R;
   c->sig_K = K;
   c->sig_nb_pad = nb_pad;
-  c->sig_shmem = (size_t)K * row_bytes;
+  c->sig_shmem = (size_t)K * row_bytes + (size_t)(c->sp[1].nx_s + c->sp[1].nx_d) * 8;
   const int L0 = 16, L = 32;
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
@@ -501,38 +536,22 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SpinTables& t = c->sp[s];
     SQD_TRY(build_spin_links_count(c, t, d_cnt));  // scratch reused: stream order serialises
   }
-  // sliced-ELL geometry of the column role (beta) depends only on the counts: widths -> offsets now,
-  // so that every size the host needs arrives with ONE synchronisation
-  int64_t et[2];
-  {
-    SpinTables& t = c->sp[1];
-    int64_t* w_s = c->scratch.as<int64_t>() + 2 * maxn;
-    int64_t* w_d = w_s + t.n_slices + 1;
-    SQD_TRY(t.es_sl.reserve((t.n_slices + 1) * 8));
-    SQD_TRY(t.ed_sl.reserve((t.n_slices + 1) * 8));
-    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.s_ptr.as<int64_t>(), t.n,
-                       t.n_slices, w_s);
-    hipLaunchKernelGGL(k_slice_width, dim3(nblk(t.n_slices, 64)), dim3(64), 0, st, t.d_ptr.as<int64_t>(), t.n,
-                       t.n_slices, w_d);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_s, t.es_sl.as<int64_t>(),
-                       t.n_slices);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, st, (const int64_t*)w_d, t.ed_sl.as<int64_t>(),
-                       t.n_slices);
-    SQD_HIP_CHECK(hipGetLastError());
-    SQD_HIP_CHECK(hipMemcpyAsync(&et[0], t.es_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
-    SQD_HIP_CHECK(hipMemcpyAsync(&et[1], t.ed_sl.as<int64_t>() + t.n_slices, 8, hipMemcpyDeviceToHost, st));
-  }
   int64_t tot[4];
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s], t.s_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
     SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s + 1], t.d_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
   }
-  // the alpha row pointers also go to the host: the sigma work list is cut there
+  // the row pointers also go to the host: the sigma work list (alpha) and the capped-ELL geometry
+  // (beta) are cut there
   c->h_sptr.resize(na + 1);
   c->h_dptr.resize(na + 1);
+  c->h_sptr_b.resize(nb + 1);
+  c->h_dptr_b.resize(nb + 1);
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_sptr.data(), c->sp[0].s_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_dptr.data(), c->sp[0].d_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_sptr_b.data(), c->sp[1].s_ptr.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_dptr_b.data(), c->sp[1].d_ptr.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipStreamSynchronize(st));
   // pass 2: fill + decorate
   for (int s = 0; s < 2; ++s) {
@@ -581,21 +600,49 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     }
     SQD_HIP_CHECK(hipGetLastError());
   }
-  // sliced ELL copies for the column role (beta)
+  // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
   {
     SpinTables& t = c->sp[1];
-    SQD_TRY(t.es_rec.reserve((size_t)et[0] * sizeof(SRec)));
-    SQD_TRY(t.es_val.reserve((size_t)et[0] * 8));
-    SQD_TRY(t.ed_src.reserve((size_t)et[1] * 4));
-    SQD_TRY(t.ed_val.reserve((size_t)et[1] * 8));
+    VRowsHost& vs = c->hv_s;  // context members: they must outlive the asynchronous uploads
+    VRowsHost& vd = c->hv_d;
+    int cap = 32;
+    if (const char* env = std::getenv("SQD_ELL_CAP")) {  // test hook: force tiny chunks to exercise the overflow path
+      const int v = std::atoi(env);
+      if (v >= 1) cap = v;
+    }
+    for (;; cap *= 2) {
+      make_vrows(c->h_sptr_b, nb, cap, vs);
+      make_vrows(c->h_dptr_b, nb, cap, vd);
+      if ((vs.nx + vd.nx) * 8 <= 48 * 1024 || cap >= (1 << 20)) break;  // overflow partials live in LDS
+    }
+    t.cap = cap;
+    t.nx_s = vs.nx;
+    t.nx_d = vd.nx;
+    struct Up { DevBuf* buf; const void* src; size_t bytes; };
+    const Up ups[] = {
+        {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_xptr, vs.xptr.data(), vs.xptr.size() * 4},
+        {&t.vs_start, vs.vstart.data(), vs.vstart.size() * 8}, {&t.es_sl, vs.sl.data(), vs.sl.size() * 8},
+        {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_xptr, vd.xptr.data(), vd.xptr.size() * 4},
+        {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
+    };
+    for (const Up& u : ups) {
+      SQD_TRY(u.buf->reserve(u.bytes + 8));
+      SQD_HIP_CHECK(hipMemcpyAsync(u.buf->p, u.src, u.bytes, hipMemcpyHostToDevice, st));
+    }
+    SQD_TRY(t.es_rec.reserve((size_t)vs.total * sizeof(SRec) + 8));
+    SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
+    SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
+    SQD_TRY(t.ed_val.reserve((size_t)vd.total * 8 + 8));
     if (t.n_s > 0)
-      hipLaunchKernelGGL(k_fill_ell_singles, dim3(nblk(t.n, 256)), dim3(256), 0, st, t.s_ptr.as<int64_t>(), t.n,
-                         t.es_sl.as<int64_t>(), t.s_rec.as<SRec>(), t.s_val.as<double>(), t.es_rec.as<SRec>(),
-                         t.es_val.as<double>());
+      hipLaunchKernelGGL(k_fill_vell_singles, dim3(nblk(nb + vs.nx, 256)), dim3(256), 0, st, nb + vs.nx,
+                         (const int32_t*)t.vs_cnt.as<int32_t>(), (const int64_t*)t.vs_start.as<int64_t>(),
+                         (const int64_t*)t.es_sl.as<int64_t>(), (const SRec*)t.s_rec.as<SRec>(),
+                         (const double*)t.s_val.as<double>(), t.es_rec.as<SRec>(), t.es_val.as<double>());
     if (t.n_d > 0)
-      hipLaunchKernelGGL(k_fill_ell_doubles, dim3(nblk(t.n, 256)), dim3(256), 0, st, t.d_ptr.as<int64_t>(), t.n,
-                         t.ed_sl.as<int64_t>(), t.d_src.as<uint32_t>(), t.d_val.as<double>(), t.ed_src.as<uint32_t>(),
-                         t.ed_val.as<double>());
+      hipLaunchKernelGGL(k_fill_vell_doubles, dim3(nblk(nb + vd.nx, 256)), dim3(256), 0, st, nb + vd.nx,
+                         (const int32_t*)t.vd_cnt.as<int32_t>(), (const int64_t*)t.vd_start.as<int64_t>(),
+                         (const int64_t*)t.ed_sl.as<int64_t>(), (const uint32_t*)t.d_src.as<uint32_t>(),
+                         (const double*)t.d_val.as<double>(), t.ed_src.as<uint32_t>(), t.ed_val.as<double>());
     SQD_HIP_CHECK(hipGetLastError());
   }
   // diagonal

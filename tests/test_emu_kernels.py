@@ -23,6 +23,14 @@ def test_emu_full_parity(emu_lib, norb, nelec, na, nb, seed, hf):
     run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf)
 
 
+def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
+    # SQD_ELL_CAP=3 cuts the beta link lists into many overflow chunks (virtual rows): the partial sums
+    # that travel through LDS must reproduce the same sigma / ground state
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
+    run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False)
+
+
 def test_emu_h2_minimal(emu_lib):
     # H2 / STO-3G textbook integrals: 2 electrons in 2 orbitals, 2x2 subspace
     h1 = np.diag([-1.2525, -0.4759])

@@ -26,11 +26,18 @@ pytestmark = pytest.mark.gpu
         (4, (2, 2), 6, 6, 3, False),      # FCI limit
         (10, (5, 5), 40, 37, 11, True),   # D = 1480
         (12, (4, 6), 30, 70, 13, False),  # ragged: nb crosses a 64-slice boundary
-        (8, (4, 4), 70, 70, 17, False),   # complete alpha/beta spaces C(8,4)=70 -> FCI
+        (8, (4, 4), 70, 70, 17, False),   # complete alpha/beta spaces C(8,4)=70 -> FCI; 36 doubles/string > ELL cap
+        (12, (2, 6), 3, 924, 19, False),  # complete beta space: 36 singles + 225 doubles per string (overflow rows)
     ],
 )
 def test_full_parity(hip_lib, norb, nelec, na, nb, seed, hf):
     run_full_parity(hip_lib, norb, nelec, na, nb, seed, hf, with_rdm2=(norb <= 10))
+
+
+def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
+    run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
 
 
 def test_h2_sto3g(hip_lib):
