@@ -73,6 +73,14 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
     delete c;
     return SQD_ERR_HIP;
   }
+  e = hipHostMalloc((void**)&c->h_mail, 1024 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->d_mail, c->h_mail, 0);
+  if (e != hipSuccess) {
+    set_error(std::string("hipHostMalloc(mapped): ") + hipGetErrorString(e));
+    delete c;
+    return SQD_ERR_HIP;
+  }
+  std::memset(c->h_mail, 0, 1024 * sizeof(double));
   int rc = build_integral_tables(c, h1, eri);
   if (rc != SQD_OK) {
     sqd_ctx_destroy(c);
@@ -89,7 +97,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->stream) e = hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
-                    &c->items, &c->multi, &c->sig_partial};
+                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();
@@ -98,6 +106,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   for (auto& evt : c->sig_ev)
     if (evt) e = hipEventDestroy(evt);
   if (c->h_pinned) e = hipHostFree(c->h_pinned);
+  if (c->h_mail) e = hipHostFree(c->h_mail);
   if (c->stream) e = hipStreamDestroy(c->stream);
   delete c;
   return SQD_OK;

@@ -32,8 +32,15 @@ void set_error(const std::string& msg);
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;          // true: p points into another DevBuf (never freed or grown here)
   int reserve(size_t bytes);  // contents are NOT preserved on growth
   void release();
+  void set_view(void* q) {
+    if (!view) release();
+    p = q;
+    cap = 0;
+    view = true;
+  }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -75,12 +82,13 @@ struct SpinTables {
   DevBuf jT;                     // f64[nnorb][n]   transposed copy                        (col role)
   // sliced ELL (slice = 64 consecutive strings), records of slice b start at *_sl[b], entry
   // (k, lane) lives at *_sl[b] + k*64 + lane
-  DevBuf es_sl, ed_sl;           // i64[slices+1] over the n+nx virtual rows
-  // capped ELL: virtual rows of <= cap links; rows [0,n) = first chunk of each string, rows
-  // [n, n+nx) = overflow chunks; xptr[B]..xptr[B+1] = overflow rows owned by string B
-  int cap = 32;
-  int64_t nx_s = 0, nx_d = 0;
-  DevBuf vs_cnt, vs_xptr, vs_start, vd_cnt, vd_xptr, vd_start;  // i32 / i32 / i64
+  DevBuf es_sl, ed_sl;           // i64[slices+1] over the virtual rows
+  // capped ELL: every list is cut into virtual rows of <= cap links, ordered so that a wavefront sees
+  // rows of equal length: all full rows first (grouped by owner string), then the tails by descending
+  // length.  own[3B..3B+2] = {first full row, number of full rows, tail row or -1} of string B.
+  int cap = 8;
+  int64_t nv_s = 0, nv_d = 0;
+  DevBuf vs_cnt, vs_own, vs_start, vd_cnt, vd_own, vd_start;  // i32[nv] / i32[3n] / i64[nv]
   DevBuf es_rec;                 // SRec
   DevBuf es_val;                 // f64
   DevBuf ed_src;                 // u32
@@ -103,9 +111,9 @@ struct MultiRow {
 };
 // host copy of the capped-ELL descriptors (see sqd_tables.hip)
 struct VRowsHost {
-  std::vector<int32_t> vcnt, xptr;
+  std::vector<int32_t> vcnt, own;
   std::vector<int64_t> vstart, sl;
-  int64_t nx = 0, total = 0;
+  int64_t nv = 0, total = 0;
 };
 
 }  // namespace sqd
@@ -127,7 +135,11 @@ struct sqd_ctx {
   sqd::SpinTables sp[2];
   sqd::DevBuf hdiag;        // f64[D]
   // sigma work list + launch geometry (fixed per subspace)
-  std::vector<int64_t> h_sptr, h_dptr, h_sptr_b, h_dptr_b;
+  sqd::DevBuf d_blob;               // packed capped-ELL descriptors (one upload); views in SpinTables
+  std::vector<char> h_blob;
+  sqd::DevBuf ptrs;                 // [s_ptr_a | d_ptr_a | s_ptr_b | d_ptr_b]; SpinTables::s_ptr/d_ptr are views
+  std::vector<int64_t> h_ptrs;      // host copy of the same
+  const int64_t *h_sptr = nullptr, *h_dptr = nullptr, *h_sptr_b = nullptr, *h_dptr_b = nullptr;
   std::vector<sqd::WorkItem> h_items;
   std::vector<sqd::MultiRow> h_multi;
   sqd::VRowsHost hv_s, hv_d;
@@ -145,6 +157,11 @@ struct sqd_ctx {
   sqd::DevBuf scal;         // small device scalars
   sqd::DevBuf scratch;      // misc (counts, scans)
   double* h_pinned = nullptr;  // pinned host scratch (>= 4096 doubles)
+  // host-visible mailbox (fine-grained pinned memory): small reductions are written here by the device
+  // and the host spins on the sequence word instead of paying a copy + stream synchronisation
+  double* h_mail = nullptr;    // host pointer; [0] = sequence word (as int64), [8..] = payload
+  double* d_mail = nullptr;    // the same memory as seen from the device
+  int64_t mail_seq = 0;
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
 };

@@ -12,6 +12,7 @@
 // norms cross to the host per iteration.  BLAS-1 work is fused: one pass builds residual +
 // preconditioned correction + its overlaps with the basis; reductions are fixed-order (bitwise
 // reproducible run to run).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -147,8 +148,6 @@ __global__ void k_scale(int64_t n, double a, double* __restrict__ x) {
 // when nelec_a == nelec_b and na == nb)
 __global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __restrict__ h,
                          double* __restrict__ pmin, int64_t* __restrict__ pidx) {
-  __shared__ double sv[1024];
-  __shared__ int64_t si[1024];
   double best = 1e300;
   int64_t bi = -1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -159,27 +158,41 @@ __global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __r
       bi = i;
     }
   }
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
-  __syncthreads();
+  block_argmin(best, bi);
   if (threadIdx.x == 0) {
-    for (int t = 1; t < (int)blockDim.x; ++t)
-      if (si[t] >= 0 && (sv[t] < best || (sv[t] == best && si[t] < bi) || bi < 0)) {
-        best = sv[t];
-        bi = si[t];
-      }
     pmin[blockIdx.x] = best;
     pidx[blockIdx.x] = bi;
   }
 }
 
-__global__ void k_init_guess(int64_t n, int64_t addr, double* __restrict__ x) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double v = (i == addr) ? 1.0 : 0.0;
-    if (i == 0) v += 1e-5;
-    if (i == n - 1) v -= 1e-5;
-    x[i] = v;
+// second stage (ONE workgroup): global argmin of the per-block candidates -> addr[0], on the device
+__global__ void k_argmin_final(const double* __restrict__ pmin, const int64_t* __restrict__ pidx, int nblocks,
+                               int64_t* __restrict__ addr) {
+  double best = 1e300;
+  int64_t bi = -1;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const double v = pmin[b];
+    const int64_t i = pidx[b];
+    if (i >= 0 && (v < best || (v == best && i < bi) || bi < 0)) {
+      best = v;
+      bi = i;
+    }
   }
+  block_argmin(best, bi);
+  if (threadIdx.x == 0) addr[0] = bi < 0 ? 0 : bi;
+}
+
+// pyscf get_init_guess: unit vector at addr, +1e-5 on the first and -1e-5 on the last element,
+// normalised here with the closed-form norm (no reduction, no host round trip)
+__global__ void k_init_guess(int64_t n, const int64_t* __restrict__ addr_ptr, double* __restrict__ x) {
+  const int64_t addr = addr_ptr[0];
+  auto f = [=](int64_t i) { return ((i == addr) ? 1.0 : 0.0) + ((i == 0) ? 1e-5 : 0.0) - ((i == n - 1) ? 1e-5 : 0.0); };
+  double nn = f(0) * f(0);
+  if (n - 1 != 0) nn += f(n - 1) * f(n - 1);
+  if (addr != 0 && addr != n - 1) nn += f(addr) * f(addr);
+  const double inv = 1.0 / sqrt(nn);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = f(i) * inv;
 }
 
 // ------------------------------------------------------------------ host helpers
@@ -211,16 +224,68 @@ __global__ void k_scale_dev(int64_t n, const double* __restrict__ scal, double* 
     x[i] *= a;
 }
 
-// sums[0..nv) = column sums of the device partial array; one small D2H + sync.  The same copy brings
-// scal[0..2) along (state of the last device-side normalisation) into c->h_pinned[0..2).
+// Final stage of a reduction + hand-over to the host in ONE single-workgroup kernel: column sums of
+// the partial array (fixed order), written with scal[0..2) straight into the host-visible mailbox,
+// then a system-scope fence and the sequence word.  The host spins on that word (bounded) -- no copy
+// engine, no stream synchronisation on the critical path.
+constexpr int MAIL_PAYLOAD = 8;  // doubles; mail[0] is the sequence word
+template <int MAXV>
+__global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks, int width, int nv,
+                                 const double* __restrict__ scal, double* __restrict__ mail, long long seq) {
+  __shared__ double red[16 * MAXV];
+  double vals[MAXV];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) vals[v] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+      if (v < nv) vals[v] += partial[(int64_t)b * width + v];
+  }
+  block_sum_multi<MAXV>(vals, nv, red);
+  if ((int)threadIdx.x < nv) mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = block_sum_multi_get<MAXV>(red, threadIdx.x);
+  if (threadIdx.x == 0) {
+    mail[MAIL_PAYLOAD + 0] = scal[0];
+    mail[MAIL_PAYLOAD + 1] = scal[1];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *reinterpret_cast<volatile long long*>(mail) = seq;
+  }
+}
+
+// sums[0..nv) = column sums of the device partial array; c->h_pinned[0..2) = scal[0..2).
 static int fetch_sums(sqd_ctx* c, int nblocks, int width, int nv, double* sums) {
-  double* scal = c->scal.as<double>();
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nv), dim3(128), 0, c->stream, (const double*)c->partial.as<double>(),
-                     nblocks, width, nv, scal + SCAL_RED);
+  const long long seq = ++c->mail_seq;
+  if (nv <= 16)
+    hipLaunchKernelGGL((k_reduce_to_mail<16>), dim3(1), dim3(128), 0, c->stream, (const double*)c->partial.as<double>(),
+                       nblocks, width, nv, (const double*)c->scal.as<double>(), c->d_mail, seq);
+  else
+    hipLaunchKernelGGL((k_reduce_to_mail<SQD_MAX_SPACE + 4>), dim3(1), dim3(128), 0, c->stream,
+                       (const double*)c->partial.as<double>(), nblocks, width, nv, (const double*)c->scal.as<double>(),
+                       c->d_mail, seq);
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, scal, sizeof(double) * (nv + SCAL_RED), hipMemcpyDeviceToHost, c->stream));
-  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-  std::memcpy(sums, c->h_pinned + SCAL_RED, sizeof(double) * nv);
+  volatile long long* flag = reinterpret_cast<volatile long long*>(c->h_mail);
+  bool seen = false;
+  for (long spin = 0; spin < 20000000L; ++spin) {
+    if (*flag == seq) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) {  // fall back to a plain synchronisation (also surfaces asynchronous kernel errors)
+    SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*flag != seq) {
+      set_error("device mailbox was not written");
+      return SQD_ERR_HIP;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  c->h_pinned[0] = c->h_mail[MAIL_PAYLOAD + 0];
+  c->h_pinned[1] = c->h_mail[MAIL_PAYLOAD + 1];
+  for (int v = 0; v < nv; ++v) sums[v] = c->h_mail[MAIL_PAYLOAD + SCAL_RED + v];
   return SQD_OK;
 }
 
@@ -324,23 +389,12 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
     hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, s, D, c->nb, tril_only, (const double*)c->hdiag.as<double>(),
                        pmin, pidx);
-    SQD_HIP_CHECK(hipGetLastError());
-    std::vector<double> hm(gb);
-    std::vector<int64_t> hi(gb);
-    SQD_HIP_CHECK(hipMemcpyAsync(hm.data(), pmin, gb * 8, hipMemcpyDeviceToHost, s));
-    SQD_HIP_CHECK(hipMemcpyAsync(hi.data(), pidx, gb * 8, hipMemcpyDeviceToHost, s));
-    SQD_HIP_CHECK(hipStreamSynchronize(s));
-    double best = 1e300;
-    int64_t addr = 0;
-    for (unsigned b = 0; b < gb; ++b)
-      if (hi[b] >= 0 && (hm[b] < best || (hm[b] == best && hi[b] < addr))) {
-        best = hm[b];
-        addr = hi[b];
-      }
-    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, addr, X);
+    int64_t* d_addr = reinterpret_cast<int64_t*>(c->scal.as<double>() + 100);
+    hipLaunchKernelGGL(k_argmin_final, dim3(1), dim3(256), 0, s, (const double*)pmin, (const int64_t*)pidx, (int)gb, d_addr);
+    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, (const int64_t*)d_addr, X);
     SQD_HIP_CHECK(hipGetLastError());
   }
-  {
+  if (ci0_host) {  // a user vector still needs its norm; the built-in guess is normalised in closed form
     double nn;
     SQD_TRY(multi_dot(c, X, 0, 1, X, &nn));
     if (!(nn > 0.0)) {
@@ -464,11 +518,15 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   {
     const int mm = mc;
     double* x0 = c->sol.as<double>();
-    hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, coef, x0);
+    // X is orthonormal and the Ritz coefficients have unit norm, so the combination is normalised to
+    // rounding (the observables divide by <c|c> anyway); no extra reduction + host round trip
+    double cn = 0.0;
+    for (int i = 0; i < mm; ++i) cn += coef.v[i] * coef.v[i];
+    Coef cf = coef;
+    if (cn > 0.0)
+      for (int i = 0; i < mm; ++i) cf.v[i] = coef.v[i] / std::sqrt(cn);
+    hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, cf, x0);
     SQD_HIP_CHECK(hipGetLastError());
-    double nn;
-    SQD_TRY(multi_dot(c, x0, 0, 1, x0, &nn));
-    if (nn > 0.0) hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(nn), x0);
   }
   SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
   SQD_HIP_CHECK(hipStreamSynchronize(s));

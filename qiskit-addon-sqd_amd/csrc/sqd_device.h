@@ -45,3 +45,35 @@ __device__ inline double block_sum_multi_get(const double* red, int v) {
 }
 
 }  // namespace sqd
+
+namespace sqd {
+// (value, index) minimum over the workgroup, ties to the lower index; result valid on thread 0.
+// Lanes without a candidate pass index -1.
+__device__ inline void block_argmin(double& best, int64_t& bi) {
+  __shared__ double s_v[16];
+  __shared__ long long s_i[16];
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_down(best, off);
+    const long long oi = __shfl_down((long long)bi, off);
+    if (oi >= 0 && (bi < 0 || ov < best || (ov == best && oi < bi))) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    s_v[wave] = best;
+    s_i[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w)
+      if (s_i[w] >= 0 && (bi < 0 || s_v[w] < best || (s_v[w] == best && s_i[w] < bi))) {
+        best = s_v[w];
+        bi = s_i[w];
+      }
+  }
+}
+}  // namespace sqd

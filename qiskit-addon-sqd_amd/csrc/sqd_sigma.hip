@@ -44,13 +44,13 @@ struct SigmaArgs {
   const uint32_t* ha_src; // alpha merged same-spin links
   const double* ha_val;
   const double* ja_row;
-  // beta lists as capped sliced ELL over virtual rows (sqd_tables.hip): rows [0,nb) first chunks,
-  // rows [nb, nb+nx) overflow chunks, xptr[B]..xptr[B+1] = overflow rows of string B
+  // beta lists as capped sliced ELL over virtual rows (sqd_tables.hip); own[3B..] = {first full row,
+  // number of full rows, tail row or -1} of string B
   const int32_t* vs_cnt;
-  const int32_t* vs_xptr;
+  const int32_t* vs_own;
   const int32_t* vd_cnt;
-  const int32_t* vd_xptr;
-  int nx_s, nx_d;
+  const int32_t* vd_own;
+  int nv_s, nv_d;
   const int64_t* esb_sl;
   const SRec* esb_rec;
   const double* esb_val;
@@ -127,13 +127,21 @@ __device__ inline double vrow_doubles_own(const SigmaArgs& g, int64_t v, const d
   }
   return a;
 }
+// string B's share of a list: its contiguous run of full rows, then its tail (fixed order)
+__device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B, const double* part) {
+  const int f0 = own[3 * B], nfull = own[3 * B + 1], tail = own[3 * B + 2];
+  double a = 0.0;
+  for (int x = 0; x < nfull; ++x) a += part[f0 + x];
+  if (tail >= 0) a += part[tail];
+  return a;
+}
+
 // singles against a batch of kb staged alpha links: sum sign * sum_j W[j][pair] * Crow[j][src].
 // SPIN: the S^2 operator couples alpha link j (cre a, des b) to the one beta link with the same orbital
 // pair and the opposite direction (cre b, des a); penw[j] is that beta link's widx, pen the coefficient.
-constexpr int KMAX = 4;
 template <bool SPIN>
 __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const double* Crow, const double* W, int kb,
-                                            int ws, const int (&penw)[KMAX], double pen) {
+                                            int ws, const int* penw, double pen) {
   const int64_t base = g.esb_sl[v >> 6] + (v & 63);
   const int cnt = g.vs_cnt[v];
   constexpr int PF = 8;
@@ -150,13 +158,11 @@ __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const
         const double* cr = Crow + recs[u].src;
         const double* w = W + (widx >> 1);
         double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-          if (j < kb) {
-            double wj = w[(int64_t)j * ws];
-            if (SPIN) wj += (widx == penw[j]) ? pen : 0.0;
-            t += wj * cr[(int64_t)j * g.nb_pad];
-          }
+        for (int j = 0; j < kb; ++j) {
+          double wj = w[(int64_t)j * ws];
+          if (SPIN) wj += (widx == penw[j]) ? pen : 0.0;
+          t += wj * cr[(int64_t)j * g.nb_pad];
+        }
         a += srec_sign(recs[u].meta) * t;
       }
   }
@@ -174,8 +180,9 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   double* Crow = smem;                          // [K][nb_pad]
   double* W2 = smem + (int64_t)g.K * g.nb_pad;  // [K][2*nnorb]
   const int w2s = (nnorb + 1) & ~1;            // one integral row per staged link
-  double* part_s = W2 + (int64_t)g.K * w2s;  // [nx_s] partial sums of overflow single rows
-  double* part_d = part_s + g.nx_s;          // [nx_d]
+  double* part_s = W2 + (int64_t)g.K * w2s;  // [nv_s] partial sums of the singles' virtual rows
+  double* part_d = part_s + g.nv_s;          // [nv_d] ... of the doubles' virtual rows
+  int* penw = reinterpret_cast<int*>(part_d + g.nv_d);  // [K] S^2 partner widx of each staged link
   const double* __restrict__ C = g.c;
   double acc[R];
 #pragma unroll
@@ -192,10 +199,10 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         W2[i] = g.ja_row[A * nnorb + i];
       }
     __syncthreads();
-    // overflow chunks of heavily connected beta strings: partial sums through LDS
+    // every virtual row of the beta lists, by whichever thread comes next; partial sums through LDS
     if (g.mode == 0) {
-      for (int v = tid; v < g.nx_s; v += T) part_s[v] = vrow_singles_own(g, nb + v, Crow, W2);
-      for (int v = tid; v < g.nx_d; v += T) part_d[v] = vrow_doubles_own(g, nb + v, Crow);
+      for (int v = tid; v < g.nv_s; v += T) part_s[v] = vrow_singles_own(g, v, Crow, W2);
+      for (int v = tid; v < g.nv_d; v += T) part_d[v] = vrow_doubles_own(g, v, Crow);
     }
     __syncthreads();
 #pragma unroll
@@ -213,10 +220,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         double a = d * Crow[B];
         if (g.mode == 0) {
           // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0), beta doubles
-          a += vrow_singles_own(g, B, Crow, W2);
-          for (int x = g.vs_xptr[B]; x < g.vs_xptr[B + 1]; ++x) a += part_s[x];
-          a += vrow_doubles_own(g, B, Crow);
-          for (int x = g.vd_xptr[B]; x < g.vd_xptr[B + 1]; ++x) a += part_d[x];
+          a += own_rows_sum(g.vs_own, B, part_s);
+          a += own_rows_sum(g.vd_own, B, part_d);
           // first same-spin alpha links of this row: unit-stride row reads
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
@@ -226,26 +231,21 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   } else if (it.type == 1) {
     // ---- a batch of alpha single links: stage their source rows (signed) and integral rows
     const int kb = it.count;
-    int penw[KMAX];
     const double pen = (g.mode == 1) ? -1.0 : -g.shift;
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      penw[j] = -1;
-      if (j < kb) {
-        const SRec rec = g.sa_rec[it.begin + j];
-        const double sg = srec_sign(rec.meta);
-        const int widx = (int)srec_widx(rec.meta);
-        const int pair = widx >> 1;
-        penw[j] = widx ^ 1;  // same pair, opposite direction
-        const double* __restrict__ src = C + (int64_t)rec.src * nb;
-        double* cr = Crow + (int64_t)j * g.nb_pad;
-        double* w2 = W2 + (int64_t)j * w2s;
-        for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
-        for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
-      }
+    for (int j = 0; j < kb; ++j) {
+      const SRec rec = g.sa_rec[it.begin + j];
+      const double sg = srec_sign(rec.meta);
+      const int widx = (int)srec_widx(rec.meta);
+      const int pair = widx >> 1;
+      if (tid == 0) penw[j] = widx ^ 1;  // same pair, opposite direction
+      const double* __restrict__ src = C + (int64_t)rec.src * nb;
+      double* cr = Crow + (int64_t)j * g.nb_pad;
+      double* w2 = W2 + (int64_t)j * w2s;
+      for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
+      for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
     }
     __syncthreads();
-    for (int v = tid; v < g.nx_s; v += T) part_s[v] = vrow_singles_batch<SPIN>(g, nb + v, Crow, W2, kb, w2s, penw, pen);
+    for (int v = tid; v < g.nv_s; v += T) part_s[v] = vrow_singles_batch<SPIN>(g, v, Crow, W2, kb, w2s, penw, pen);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -258,8 +258,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
             a += g.jbT[(int64_t)pair * nb + B] * Crow[(int64_t)j * g.nb_pad + B];
           }
         }
-        a += vrow_singles_batch<SPIN>(g, B, Crow, W2, kb, w2s, penw, pen);
-        for (int x = g.vs_xptr[B]; x < g.vs_xptr[B + 1]; ++x) a += part_s[x];
+        a += own_rows_sum(g.vs_own, B, part_s);
         acc[r] = a;
       }
     }
@@ -357,11 +356,11 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.ha_val = a.hs_val.as<double>();
   g.ja_row = a.jrow.as<double>();
   g.vs_cnt = b.vs_cnt.as<int32_t>();
-  g.vs_xptr = b.vs_xptr.as<int32_t>();
+  g.vs_own = b.vs_own.as<int32_t>();
   g.vd_cnt = b.vd_cnt.as<int32_t>();
-  g.vd_xptr = b.vd_xptr.as<int32_t>();
-  g.nx_s = (int)b.nx_s;
-  g.nx_d = (int)b.nx_d;
+  g.vd_own = b.vd_own.as<int32_t>();
+  g.nv_s = (int)b.nv_s;
+  g.nv_d = (int)b.nv_d;
   g.esb_sl = b.es_sl.as<int64_t>();
   g.esb_rec = b.es_rec.as<SRec>();
   g.esb_val = b.es_val.as<double>();

@@ -14,6 +14,7 @@
 // attached by a second, fully occupied thread-per-link pass.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "sqd_common.h"
 
@@ -21,6 +22,10 @@ namespace sqd {
 
 // ------------------------------------------------------------------ small helpers
 int DevBuf::reserve(size_t bytes) {
+  if (view) {
+    p = nullptr;
+    view = false;
+  }
   if (bytes <= cap && p) return SQD_OK;
   if (p) {
     hipError_t e = hipFree(p);
@@ -39,6 +44,11 @@ int DevBuf::reserve(size_t bytes) {
   return SQD_OK;
 }
 void DevBuf::release() {
+  if (view) {
+    p = nullptr;
+    view = false;
+    return;
+  }
   if (p) {
     hipError_t e = hipFree(p);
     (void)e;
@@ -49,7 +59,7 @@ void DevBuf::release() {
 void SpinTables::release() {
   DevBuf* all[] = {&strs, &e_str, &s_ptr, &d_ptr, &s_row, &d_row, &s_rec, &s_val, &d_src, &d_orb,
                    &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val,
-                   &vs_cnt, &vs_xptr, &vs_start, &vd_cnt, &vd_xptr, &vd_start};
+                   &vs_cnt, &vs_own, &vs_start, &vd_cnt, &vd_own, &vd_start};
   for (DevBuf* b : all) b->release();
 }
 
@@ -283,13 +293,15 @@ __global__ void k_hdiag(const uint64_t* __restrict__ strs_a, const double* __res
 }
 
 // ------------------------------------------------------------------ capped sliced ELL (column role)
-// Lanes of the sigma kernel map to beta strings, so one string with hundreds of links (the
-// Hartree-Fock neighbourhood) would stall its whole wavefront.  Lists are therefore cut into
-// *virtual rows* of at most CAP links: virtual row B (< n) holds the first CAP links of string B,
-// the overflow chunks of all strings follow as rows n .. n+nx-1 (owner order), and xptr[B]..xptr[B+1]
-// names the overflow rows of B.  Storage is sliced ELL over the n+nx virtual rows: entry (k, lane)
-// of slice b at sl[b] + 64 k + lane.  The descriptors are computed on the host from the CSR pointers
-// (they arrive with the one synchronisation of set_subspace); the fill runs on the device.
+// Lanes of the sigma kernel would map to beta strings, so one string with hundreds of links (the
+// Hartree-Fock neighbourhood) would stall its whole wavefront and leave the LDS pipe running mostly
+// masked-off lanes.  Every list is therefore cut into *virtual rows* of at most CAP links that are
+// processed by whichever thread comes next, in an order that keeps wavefronts uniform: all full
+// rows first (grouped by owner), then the tails by descending length.  Row partial sums meet in LDS
+// and each string adds its own rows (one contiguous run + one tail) in fixed order.  Storage is
+// sliced ELL over the ordered rows: entry (k, lane) of slice b at sl[b] + 64 k + lane.  Descriptors
+// are computed on the host from the CSR pointers (they arrive with the one synchronisation of
+// set_subspace); the fill runs on the device.
 __global__ void k_fill_vell_singles(int64_t nv, const int32_t* __restrict__ vcnt, const int64_t* __restrict__ vstart,
                                     const int64_t* __restrict__ sl, const SRec* __restrict__ rec,
                                     const double* __restrict__ val, SRec* __restrict__ erec,
@@ -320,32 +332,41 @@ __global__ void k_fill_vell_doubles(int64_t nv, const int32_t* __restrict__ vcnt
 }
 
 // host side of the above: virtual-row descriptors from a CSR pointer array
-static void make_vrows(const std::vector<int64_t>& ptr, int64_t n, int cap, VRowsHost& out) {
-  out.xptr.assign(n + 1, 0);
+static void make_vrows(const int64_t* ptr, int64_t n, int cap, VRowsHost& out) {
+  out.own.assign(3 * n, 0);
+  out.vcnt.clear();
+  out.vstart.clear();
+  // full rows, grouped by owner
   for (int64_t i = 0; i < n; ++i) {
     const int64_t cnt = ptr[i + 1] - ptr[i];
-    const int64_t extra = cnt > cap ? (cnt - 1) / cap : 0;
-    out.xptr[i + 1] = out.xptr[i] + (int32_t)extra;
-  }
-  out.nx = out.xptr[n];
-  const int64_t nv = n + out.nx;
-  out.vcnt.assign(nv, 0);
-  out.vstart.assign(nv, 0);
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t cnt = ptr[i + 1] - ptr[i];
-    out.vcnt[i] = (int32_t)(cnt < cap ? cnt : cap);
-    out.vstart[i] = ptr[i];
-    for (int64_t j = 0, rem = cnt - cap; rem > 0; ++j, rem -= cap) {
-      const int64_t v = n + out.xptr[i] + j;
-      out.vcnt[v] = (int32_t)(rem < cap ? rem : cap);
-      out.vstart[v] = ptr[i] + cap * (j + 1);
+    const int64_t nfull = cnt / cap;
+    out.own[3 * i + 0] = (int32_t)out.vcnt.size();
+    out.own[3 * i + 1] = (int32_t)nfull;
+    out.own[3 * i + 2] = -1;
+    for (int64_t j = 0; j < nfull; ++j) {
+      out.vcnt.push_back(cap);
+      out.vstart.push_back(ptr[i] + j * cap);
     }
   }
-  const int64_t nsl = (nv + 63) / 64;
+  // tails by descending length (stable in owner)
+  std::vector<std::pair<int32_t, int64_t>> tails;  // (length, owner)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t rem = (ptr[i + 1] - ptr[i]) % cap;
+    if (rem > 0) tails.emplace_back((int32_t)rem, i);
+  }
+  std::stable_sort(tails.begin(), tails.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  for (const auto& t : tails) {
+    const int64_t i = t.second;
+    out.own[3 * i + 2] = (int32_t)out.vcnt.size();
+    out.vcnt.push_back(t.first);
+    out.vstart.push_back(ptr[i + 1] - t.first);
+  }
+  out.nv = (int64_t)out.vcnt.size();
+  const int64_t nsl = (out.nv + 63) / 64;
   out.sl.assign(nsl + 1, 0);
   for (int64_t b = 0; b < nsl; ++b) {
     int32_t w = 0;
-    for (int64_t v = b * 64; v < b * 64 + 64 && v < nv; ++v) w = out.vcnt[v] > w ? out.vcnt[v] : w;
+    for (int64_t v = b * 64; v < b * 64 + 64 && v < out.nv; ++v) w = out.vcnt[v] > w ? out.vcnt[v] : w;
     out.sl[b + 1] = out.sl[b] + 64 * (int64_t)w;
   }
   out.total = out.sl[nsl];
@@ -382,25 +403,45 @@ __global__ void k_merge_hs(int64_t n, const int64_t* __restrict__ s_ptr, const i
 // k_sigma_reduce adds in fixed order.
 static int build_sigma_work(sqd_ctx* c) {
   const int64_t na = c->na, nb = c->nb;
-  // geometry
-  int T = (int)(((nb + 63) / 64) * 64);
-  if (T > 1024) T = 1024;
+  // geometry: T threads cover the row in R strides; the beta virtual rows are spread over all T
+  // threads; K alpha links (source row + integral row each) are staged per batch within the LDS budget
+  const SpinTables& tb = c->sp[1];
+  const int64_t nvmax = tb.nv_s > tb.nv_d ? tb.nv_s : tb.nv_d;
+  // threads per workgroup (measured on MI355X, profiles/r01/sigma_geometry_sweep.txt): 512 up to
+  // nb = 2048 (two waves per SIMD leave room for 5 workgroups per CU), 1024 beyond; never more than
+  // the row or the virtual-row lists can occupy
+  int64_t want = nb > nvmax ? nb : nvmax;
+  int T = (int)(((want + 63) / 64) * 64);
+  const int tmax = (nb <= 2048) ? 512 : 1024;
+  if (T > tmax) T = tmax;
+  if (T < 64) T = 64;
+  if (const char* env = std::getenv("SQD_SIGMA_T")) {  // tuning hook
+    const int v = (std::atoi(env) / 64) * 64;
+    if (v >= 64 && v <= 1024) T = v;
+  }
   const int R = (int)((nb + T - 1) / T);
   const int nb_pad = (int)((nb + 1) & ~int64_t(1));
   const size_t row_bytes = ((size_t)nb_pad + (size_t)((c->nnorb + 1) & ~1)) * 8;  // one C row + one integral row
+  const size_t part_bytes = (size_t)(tb.nv_s + tb.nv_d) * 8 + 64;
   const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
-  if (row_bytes > budget || R > 16) {
+  if (row_bytes + part_bytes > budget || R > 16) {
     set_error("beta string count " + std::to_string(nb) + " exceeds the LDS-resident row limit of this build");
     return SQD_ERR_LIMIT;
   }
-  int K = (int)((26 * 1024) / row_bytes);  // <= ~26 KB of staging per workgroup: >= 5 workgroups per CU
+  size_t stage = 96 * 1024;
+  if (stage + part_bytes > budget) stage = budget - part_bytes;
+  int K = (int)(stage / row_bytes);
   if (K < 1) K = 1;
-  if (K > 4) K = 4;
+  if (K > 4) K = 4;  // more links per batch lengthen the batch without saving launches (same sweep)
+  if (const char* env = std::getenv("SQD_SIGMA_K")) {  // tuning hook
+    const int v = std::atoi(env);
+    if (v >= 1 && v <= K) K = v;
+  }
   c->sig_T = T;
   c->sig_R = R;
   c->sig_K = K;
   c->sig_nb_pad = nb_pad;
-  c->sig_shmem = (size_t)K * row_bytes + (size_t)(c->sp[1].nx_s + c->sp[1].nx_d) * 8;
+  c->sig_shmem = (size_t)K * row_bytes + part_bytes;
   const int L0 = 16, L = 32;
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
@@ -418,7 +459,7 @@ static int build_sigma_work(sqd_ctx* c) {
       row.push_back(WorkItem{l, (uint32_t)A, 1, (uint16_t)((s1 - l < K) ? (s1 - l) : K), -1, 0});
     for (int64_t l = h0 + L0; l < h1; l += L)
       row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
-    if (row.size() > 1) {
+    if (row.size() > 1) {  // several items: partial rows + fixed-order reduce
       multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
       for (auto& it : row) it.slot = nslots++;
     }
@@ -496,9 +537,7 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
 }
 
 static int build_spin_links_count(sqd_ctx* c, SpinTables& t, int64_t* d_cnt) {
-  const int64_t n = t.n;
-  SQD_TRY(t.s_ptr.reserve((n + 1) * 8));
-  SQD_TRY(t.d_ptr.reserve((n + 1) * 8));
+  const int64_t n = t.n;  // t.s_ptr / t.d_ptr are views into c->ptrs (set by the caller)
   int64_t* cnt_s = d_cnt;
   int64_t* cnt_d = d_cnt + n;
   hipLaunchKernelGGL(k_count_links, dim3(nblk(n, 4)), dim3(256), 0, c->stream, t.strs.as<uint64_t>(), n, cnt_s, cnt_d);
@@ -531,28 +570,31 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_HIP_CHECK(hipMemcpyAsync(t.strs.p, hs[s], t.n * 8, hipMemcpyHostToDevice, st));
   }
   // pass 1: counts + CSR pointers for both spins, one host sync for the totals
+  // all four CSR pointer arrays live in one device buffer so that ONE copy brings them (and with them
+  // every total the host needs) back: the sigma work list (alpha) and the capped-ELL geometry (beta)
+  // are cut on the host from these pointers
+  const int64_t nptr = 2 * (na + 1) + 2 * (nb + 1);
+  SQD_TRY(c->ptrs.reserve((size_t)nptr * 8));
+  {
+    int64_t* base = c->ptrs.as<int64_t>();
+    c->sp[0].s_ptr.set_view(base);
+    c->sp[0].d_ptr.set_view(base + (na + 1));
+    c->sp[1].s_ptr.set_view(base + 2 * (na + 1));
+    c->sp[1].d_ptr.set_view(base + 2 * (na + 1) + (nb + 1));
+  }
   int64_t* d_cnt = c->scratch.as<int64_t>();
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     SQD_TRY(build_spin_links_count(c, t, d_cnt));  // scratch reused: stream order serialises
   }
-  int64_t tot[4];
-  for (int s = 0; s < 2; ++s) {
-    SpinTables& t = c->sp[s];
-    SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s], t.s_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
-    SQD_HIP_CHECK(hipMemcpyAsync(&tot[2 * s + 1], t.d_ptr.as<int64_t>() + t.n, 8, hipMemcpyDeviceToHost, st));
-  }
-  // the row pointers also go to the host: the sigma work list (alpha) and the capped-ELL geometry
-  // (beta) are cut there
-  c->h_sptr.resize(na + 1);
-  c->h_dptr.resize(na + 1);
-  c->h_sptr_b.resize(nb + 1);
-  c->h_dptr_b.resize(nb + 1);
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_sptr.data(), c->sp[0].s_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_dptr.data(), c->sp[0].d_ptr.p, (na + 1) * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_sptr_b.data(), c->sp[1].s_ptr.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_dptr_b.data(), c->sp[1].d_ptr.p, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
+  c->h_ptrs.resize(nptr);
+  SQD_HIP_CHECK(hipMemcpyAsync(c->h_ptrs.data(), c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipStreamSynchronize(st));
+  c->h_sptr = c->h_ptrs.data();
+  c->h_dptr = c->h_sptr + (na + 1);
+  c->h_sptr_b = c->h_dptr + (na + 1);
+  c->h_dptr_b = c->h_sptr_b + (nb + 1);
+  const int64_t tot[4] = {c->h_sptr[na], c->h_dptr[na], c->h_sptr_b[nb], c->h_dptr_b[nb]};
   // pass 2: fill + decorate
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
@@ -605,41 +647,49 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SpinTables& t = c->sp[1];
     VRowsHost& vs = c->hv_s;  // context members: they must outlive the asynchronous uploads
     VRowsHost& vd = c->hv_d;
-    int cap = 32;
-    if (const char* env = std::getenv("SQD_ELL_CAP")) {  // test hook: force tiny chunks to exercise the overflow path
+    int cap = 8;
+    if (const char* env = std::getenv("SQD_ELL_CAP")) {  // test hook: force tiny rows
       const int v = std::atoi(env);
       if (v >= 1) cap = v;
     }
     for (;; cap *= 2) {
       make_vrows(c->h_sptr_b, nb, cap, vs);
       make_vrows(c->h_dptr_b, nb, cap, vd);
-      if ((vs.nx + vd.nx) * 8 <= 48 * 1024 || cap >= (1 << 20)) break;  // overflow partials live in LDS
+      if ((vs.nv + vd.nv) * 8 <= 40 * 1024 || cap >= (1 << 20)) break;  // row partial sums live in LDS
     }
     t.cap = cap;
-    t.nx_s = vs.nx;
-    t.nx_d = vd.nx;
+    t.nv_s = vs.nv;
+    t.nv_d = vd.nv;
+    // all descriptors travel in ONE host blob / ONE copy; the per-array DevBufs are views into it
     struct Up { DevBuf* buf; const void* src; size_t bytes; };
     const Up ups[] = {
-        {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_xptr, vs.xptr.data(), vs.xptr.size() * 4},
+        {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_own, vs.own.data(), vs.own.size() * 4},
         {&t.vs_start, vs.vstart.data(), vs.vstart.size() * 8}, {&t.es_sl, vs.sl.data(), vs.sl.size() * 8},
-        {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_xptr, vd.xptr.data(), vd.xptr.size() * 4},
+        {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_own, vd.own.data(), vd.own.size() * 4},
         {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
     };
+    size_t blob = 0;
+    for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);
+    c->h_blob.resize(blob + 16);
+    SQD_TRY(c->d_blob.reserve(blob + 16));
+    size_t off = 0;
     for (const Up& u : ups) {
-      SQD_TRY(u.buf->reserve(u.bytes + 8));
-      SQD_HIP_CHECK(hipMemcpyAsync(u.buf->p, u.src, u.bytes, hipMemcpyHostToDevice, st));
+      if (u.bytes) std::memcpy(c->h_blob.data() + off, u.src, u.bytes);
+      u.buf->set_view(static_cast<char*>(c->d_blob.p) + off);
+      off += (u.bytes + 15) & ~size_t(15);
     }
+    if (blob) SQD_HIP_CHECK(hipMemcpyAsync(c->d_blob.p, c->h_blob.data(), blob, hipMemcpyHostToDevice, st));
     SQD_TRY(t.es_rec.reserve((size_t)vs.total * sizeof(SRec) + 8));
     SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
     SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
     SQD_TRY(t.ed_val.reserve((size_t)vd.total * 8 + 8));
     if (t.n_s > 0)
-      hipLaunchKernelGGL(k_fill_vell_singles, dim3(nblk(nb + vs.nx, 256)), dim3(256), 0, st, nb + vs.nx,
+      hipLaunchKernelGGL(k_fill_vell_singles, dim3(nblk(vs.nv, 256)), dim3(256), 0, st, vs.nv,
                          (const int32_t*)t.vs_cnt.as<int32_t>(), (const int64_t*)t.vs_start.as<int64_t>(),
                          (const int64_t*)t.es_sl.as<int64_t>(), (const SRec*)t.s_rec.as<SRec>(),
                          (const double*)t.s_val.as<double>(), t.es_rec.as<SRec>(), t.es_val.as<double>());
     if (t.n_d > 0)
-      hipLaunchKernelGGL(k_fill_vell_doubles, dim3(nblk(nb + vd.nx, 256)), dim3(256), 0, st, nb + vd.nx,
+      hipLaunchKernelGGL(k_fill_vell_doubles, dim3(nblk(vd.nv, 256)), dim3(256), 0, st, vd.nv,
                          (const int32_t*)t.vd_cnt.as<int32_t>(), (const int64_t*)t.vd_start.as<int64_t>(),
                          (const int64_t*)t.ed_sl.as<int64_t>(), (const uint32_t*)t.d_src.as<uint32_t>(),
                          (const double*)t.d_val.as<double>(), t.ed_src.as<uint32_t>(), t.ed_val.as<double>());

@@ -41,7 +41,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeMaxSharedMemoryPerBlock = 2 };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 
 #define __global__
 #define __device__
@@ -115,6 +115,8 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
 
 // NOTE: kernels must reach every __syncthreads / wave builtin with all threads
 // of the block / wave (no early return before one) -- true of good GPU code too.
+inline void __threadfence_system() {}
+inline void __threadfence() {}
 inline void __syncthreads() { emu::cur_block()->bar->arrive_and_wait(); }
 
 inline unsigned long long __ballot(int pred) {
@@ -189,6 +191,7 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMall
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc((void**)p, n); }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
