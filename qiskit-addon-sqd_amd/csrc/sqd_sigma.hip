@@ -193,7 +193,9 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   } else if (it.type == 0) {
     // ---- own row: slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
     const uint64_t sA = g.strs_a[A];
-    for (int64_t i = tid; i < nb; i += T) Crow[i] = C[A * nb + i];
+    // the own row and the diagonal are touched exactly once per sigma: stream them past the L2
+    // (non-temporal) so that the link lists, which every workgroup re-reads, stay resident
+    for (int64_t i = tid; i < nb; i += T) Crow[i] = __builtin_nontemporal_load(&C[A * nb + i]);
     if (g.mode == 0)
       for (int i = tid; i < nnorb; i += T) {
         W2[i] = g.ja_row[A * nnorb + i];
@@ -209,13 +211,12 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     for (int r = 0; r < R; ++r) {
       const int64_t B = tid + (int64_t)r * T;
       if (B < nb) {
-        const double occ_term = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
         double d;
         if (g.mode == 0) {
-          d = g.hdiag[A * nb + B];
-          if (g.spin) d += g.shift * (occ_term - g.ss);
+          d = __builtin_nontemporal_load(&g.hdiag[A * nb + B]);
+          if (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~sA) - g.ss);
         } else {
-          d = occ_term;
+          d = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
         }
         double a = d * Crow[B];
         if (g.mode == 0) {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t B = tid + (int64_t)r * T;
-    if (B < nb) out[B] = acc[r];
+    if (B < nb) __builtin_nontemporal_store(acc[r], &out[B]);
   }
 }
 

@@ -115,6 +115,8 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
 
 // NOTE: kernels must reach every __syncthreads / wave builtin with all threads
 // of the block / wave (no early return before one) -- true of good GPU code too.
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
 inline void __threadfence_system() {}
 inline void __threadfence() {}
 inline void __syncthreads() { emu::cur_block()->bar->arrive_and_wait(); }
