@@ -1,0 +1,184 @@
+"""Host-side sample processing on either side of the solver seam.
+
+Behavioural restatement -- same results AND the same consumption of the numpy ``Generator`` stream --
+of the reference's ``counts.bit_array_to_arrays`` (``counts.py:45-61``),
+``subsampling.postselect_by_hamming_right_and_left`` / ``subsample`` (``subsampling.py:96-211``) and
+``configuration_recovery.recover_configurations`` (``configuration_recovery.py:59-306``).  It is pinned
+by ``tests/golden/sqd_loop.json`` (the reference's own loop, run under import stubs, with every list of
+CI strings it hands to ``sci_solver`` recorded) and by the reference's literal known answers.
+
+The random choices stay numpy's (``Generator.choice(p=, replace=False)``): bit-for-bit reproducibility
+of a seeded SQD run against the reference requires the identical stream, so this is host work by
+design, not a kernel.  What is restructured: flip weights depend only on (orbital, bit value), so they
+are computed once per call instead of once per bitstring, and rows that already have the right
+Hamming weights are never visited.
+"""
+
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- counts
+def bool_matrix_to_arrays(bool_array: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Unique rows (sorted as ``np.unique(axis=0)`` sorts them) and their empirical probabilities."""
+    bool_array = np.asarray(bool_array, dtype=bool)
+    bitstrings, counts = np.unique(bool_array, axis=0, return_counts=True)
+    return bitstrings, counts / bool_array.shape[0]
+
+
+def bit_array_to_arrays(bit_array) -> tuple[np.ndarray, np.ndarray]:
+    """qiskit ``BitArray`` (anything with ``.array``, ``.num_bits``, ``.num_shots``) or a plain bool
+    matrix -> (bitstring matrix, probabilities); reference ``counts.py:45-61``."""
+    if hasattr(bit_array, "num_bits") and hasattr(bit_array, "array"):
+        bools = np.unpackbits(bit_array.array, axis=-1)[..., -bit_array.num_bits :].astype(bool)
+        bitstrings, counts = np.unique(bools, axis=0, return_counts=True)
+        return bitstrings, counts / bit_array.num_shots
+    return bool_matrix_to_arrays(bit_array)
+
+
+def counts_to_arrays(counts) -> tuple[np.ndarray, np.ndarray]:
+    """Counts dictionary -> (bitstring matrix, probabilities); reference ``counts.py:24-42``."""
+    if not counts:
+        return np.array([]), np.array([])
+    total = sum(counts.values())
+    mat = np.array([[bit == "1" for bit in bitstring] for bitstring in counts])
+    return mat, np.array([c / total for c in counts.values()])
+
+
+# ----------------------------------------------------------------------------- post-selection / subsampling
+def postselect_by_hamming_right_and_left(
+    bitstring_matrix: np.ndarray, probabilities: np.ndarray, *, hamming_right: int, hamming_left: int
+) -> tuple[np.ndarray, np.ndarray]:
+    """Keep the bitstrings whose right / left halves have the requested Hamming weights and renormalise
+    their probabilities (reference ``subsampling.py:96-144``, same error messages)."""
+    if hamming_left < 0 or hamming_right < 0:
+        raise ValueError("Hamming weight must be specified with a non-negative integer.")
+    n_bitstrings, n_bits = bitstring_matrix.shape
+    if n_bits % 2:
+        raise ValueError(f"The length of the bitstrings must be even. Instead, got {n_bits}.")
+    if len(probabilities) != n_bitstrings:
+        raise ValueError(
+            "The number of elements in the probabilities array must match the number of rows in the bitstring matrix."
+        )
+    norb = n_bits // 2
+    keep = (np.sum(bitstring_matrix[:, norb:], axis=1) == hamming_right) & (
+        np.sum(bitstring_matrix[:, :norb], axis=1) == hamming_left
+    )
+    probs = probabilities[keep]
+    probs /= np.sum(probs)
+    return bitstring_matrix[keep], probs
+
+
+def subsample(
+    bitstring_matrix: np.ndarray,
+    probabilities: np.ndarray,
+    samples_per_batch: int,
+    num_batches: int,
+    rand_seed: np.random.Generator | int | None = None,
+) -> list[np.ndarray]:
+    """``num_batches`` batches, each drawn without replacement with the given probabilities
+    (reference ``subsampling.py:147-211``; one ``Generator.choice`` per batch, same arguments)."""
+    if bitstring_matrix.shape[0] < 1:
+        return [np.array([])] * num_batches
+    if len(probabilities) != bitstring_matrix.shape[0]:
+        raise ValueError(
+            "The number of elements in the probabilities array must match the number of rows in the bitstring matrix."
+        )
+    if samples_per_batch < 1:
+        raise ValueError("Samples per batch must be specified with a positive integer.")
+    if num_batches < 1:
+        raise ValueError("The number of batches must be specified with a positive integer.")
+    rng = np.random.default_rng(rand_seed)
+    n = bitstring_matrix.shape[0]
+    if samples_per_batch >= n:
+        return [bitstring_matrix[np.arange(n)] for _ in range(num_batches)]
+    pool = np.arange(n).astype("int")
+    return [
+        bitstring_matrix[rng.choice(pool, samples_per_batch, replace=False, p=probabilities)] for _ in range(num_batches)
+    ]
+
+
+# ----------------------------------------------------------------------------- configuration recovery
+def _flip_weight_up(ratio: float, occ: np.ndarray, eps: float = 0.01) -> np.ndarray:
+    """Weight for turning a 0 into a 1 given the expected filling ``ratio`` and the orbital occupancy
+    (piecewise linear, reference ``configuration_recovery.py:131-159``), for all orbitals at once."""
+    occ = np.asarray(occ, dtype=float)
+    below = occ * eps / ratio if ratio != 0 else np.zeros_like(occ)
+    if ratio == 1.0:
+        above = np.full_like(occ, eps)
+    else:
+        slope = (1 - eps) / (1 - ratio)
+        above = occ * slope + (1 - slope)
+    return np.where(occ < ratio, below, above)
+
+
+def _flip_weight_down(ratio: float, occ: np.ndarray, eps: float = 0.01) -> np.ndarray:
+    """Weight for turning a 1 into a 0 (``configuration_recovery.py:162-178``)."""
+    return _flip_weight_up(1 - ratio, 1 - np.asarray(occ, dtype=float), eps)
+
+
+def _repair_half(bits: np.ndarray, w_up: np.ndarray, w_down: np.ndarray, target: int, rng) -> None:
+    """Bring one half of a bitstring (a view, modified in place) to Hamming weight ``target`` by
+    flipping bits drawn without replacement with the occupancy-informed weights
+    (``configuration_recovery.py:230-304``: same ``Generator.choice`` call, same arguments)."""
+    weights = np.where(bits, w_down, w_up)
+    weights = np.minimum(1, np.maximum(0, weights))
+    if not np.any(weights):
+        return
+    weights /= np.sum(weights)
+    excess = np.sum(bits) - target
+    if excess > 0:
+        candidates = np.where(bits)[0]
+        p = weights[bits] / np.sum(weights[bits])
+        bits[rng.choice(candidates, size=round(excess), replace=False, p=p)] = False
+    elif excess < 0:
+        empty = np.logical_not(bits)
+        candidates = np.where(empty)[0]
+        p = weights[empty] / np.sum(weights[empty])
+        bits[rng.choice(candidates, size=round(np.abs(excess)), replace=False, p=p)] = True
+
+
+def recover_configurations(
+    bitstring_matrix: np.ndarray,
+    probabilities: Sequence[float] | np.ndarray,
+    avg_occupancies: tuple[np.ndarray, np.ndarray],
+    num_elec_a: int,
+    num_elec_b: int,
+    rand_seed: np.random.Generator | int | None = None,
+) -> tuple[np.ndarray, np.ndarray]:
+    """Refine bitstrings toward the target Hamming weights using the average orbital occupancies
+    (reference ``configuration_recovery.py:59-128``).  Bit ``i`` (< norb) is the spin-down partner of
+    bit ``i + norb``; ``avg_occupancies = (occ_a, occ_b)`` indexed by orbital (LSB = rightmost bit)."""
+    rng = np.random.default_rng(rand_seed)
+    if num_elec_a < 0 or num_elec_b < 0:
+        raise ValueError("The numbers of electrons must be specified as non-negative integers.")
+    bitstring_matrix = np.asarray(bitstring_matrix, dtype=bool)
+    norb = bitstring_matrix.shape[1] // 2
+    # column c of the left half is beta orbital norb-1-c; of the right half alpha orbital norb-1-c
+    occs = np.flip(np.asarray(avg_occupancies)).flatten()
+    occ_left, occ_right = occs[:norb], occs[norb:]
+    up_l, dn_l = _flip_weight_up(num_elec_b / norb, occ_left), _flip_weight_down(num_elec_b / norb, occ_left)
+    up_r, dn_r = _flip_weight_up(num_elec_a / norb, occ_right), _flip_weight_down(num_elec_a / norb, occ_right)
+
+    out = bitstring_matrix.copy()
+    wrong = (bitstring_matrix[:, :norb].sum(axis=1) != num_elec_b) | (bitstring_matrix[:, norb:].sum(axis=1) != num_elec_a)
+    for i in np.nonzero(wrong)[0]:  # left (beta) half first, then right (alpha): the reference's stream order
+        _repair_half(out[i, :norb], up_l, dn_l, num_elec_b, rng)
+        _repair_half(out[i, norb:], up_r, dn_r, num_elec_a, rng)
+
+    # merge duplicates in first-occurrence order, adding their probabilities in row order
+    merged: dict[bytes, float] = {}
+    first: list[int] = []
+    for i, freq in enumerate(probabilities):
+        key = out[i].tobytes()
+        if key in merged:
+            merged[key] += freq
+        else:
+            merged[key] = 0.0 + freq
+            first.append(i)
+    freqs = np.array(list(merged.values()))
+    freqs = np.abs(freqs) / np.sum(np.abs(freqs))
+    return out[first], freqs

@@ -1,0 +1,167 @@
+"""The configuration-recovery loop around the solver seam, free of qiskit / pyscf / jax imports.
+
+Drop-in for reference ``qiskit_addon_sqd.fermion.diagonalize_fermionic_hamiltonian``
+(``fermion.py:204-462``) with the same signature, validation messages, random-stream consumption
+and result, and with this package's HIP-backed ``solve_sci_batch`` as the default ``sci_solver``.
+``bit_array`` may be a qiskit ``BitArray`` (duck-typed) or a plain bool matrix of samples.
+
+Per iteration (reference ``:415-459``): build the batches of CI strings (post-selection or
+configuration recovery, subsampling, ordering by frequency with requested and carry-over strings
+first, truncation, sorting -- ``_prepare_ci_strings`` ``:472-560``), hand the whole list to
+``sci_solver`` (the only collective step), then pick the lowest-energy batch, test convergence
+against the previous iteration and extract the carry-over strings
+(``_process_sci_results`` ``:563-640``).  Pinned by ``tests/golden/sqd_loop.json``.
+"""
+
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+
+from .counts import bitstring_matrix_to_integers
+from .fermion import SCIResult, solve_sci_batch
+from .sampling import bit_array_to_arrays, postselect_by_hamming_right_and_left, recover_configurations, subsample
+
+
+def _first_occurrences(vals: np.ndarray) -> np.ndarray:
+    """Unique values in order of first appearance."""
+    _, idx = np.unique(vals, return_index=True)
+    idx.sort()
+    return vals[idx]
+
+
+def _by_descending_count(strings: np.ndarray, counts: np.ndarray) -> np.ndarray:
+    return strings[np.argsort(counts)[::-1]]
+
+
+def _batch_strings(samples, norb, symmetrize_spin, include_a, include_b, carry_a, carry_b, max_dim_a, max_dim_b):
+    """One batch of sampled bitstrings -> sorted (alpha, beta) CI strings: requested strings first, then
+    carry-over, then sampled half-strings by descending frequency; first occurrences; truncated."""
+    sa, ca = np.unique(bitstring_matrix_to_integers(samples[:, norb:]), return_counts=True)
+    sb, cb = np.unique(bitstring_matrix_to_integers(samples[:, :norb]), return_counts=True)
+    if symmetrize_spin:
+        pooled = _by_descending_count(np.concatenate((sa, sb)), np.concatenate((ca, cb)))
+        merged = _first_occurrences(np.concatenate((include_a, include_b, carry_a, pooled)))[:max_dim_a]
+        strs_a = strs_b = merged
+    else:
+        strs_a = _first_occurrences(np.concatenate((include_a, carry_a, _by_descending_count(sa, ca))))[:max_dim_a]
+        strs_b = _first_occurrences(np.concatenate((include_b, carry_b, _by_descending_count(sb, cb))))[:max_dim_b]
+    strs_a.sort()
+    strs_b.sort()
+    return strs_a, strs_b
+
+
+def _carryover(result: SCIResult, threshold: float, symmetrize_spin: bool):
+    """Strings whose determinants carry |amplitude| >= threshold, by descending marginal weight."""
+    state = result.sci_state
+    amps = state.amplitudes
+    mag = np.abs(amps.reshape(-1))
+    order = np.argsort(mag)
+    big = order[np.searchsorted(mag, threshold, sorter=order) :]
+    ia, ib = np.divmod(big, amps.shape[1])
+    ia, ib = np.unique(ia), np.unique(ib)
+    keep_a, keep_b = state.ci_strs_a[ia], state.ci_strs_b[ib]
+    wa = np.sum(np.abs(amps[ia]) ** 2, axis=1)
+    wb = np.sum(np.abs(amps[:, ib]) ** 2, axis=0)
+    if symmetrize_spin:
+        both = _first_occurrences(_by_descending_count(np.concatenate((keep_a, keep_b)), np.concatenate((wa, wb))))
+        return both, both
+    return _by_descending_count(keep_a, wa), _by_descending_count(keep_b, wb)
+
+
+def diagonalize_fermionic_hamiltonian(
+    one_body_tensor: np.ndarray,
+    two_body_tensor: np.ndarray,
+    bit_array,
+    samples_per_batch: int,
+    norb: int,
+    nelec: tuple[int, int],
+    *,
+    num_batches: int = 1,
+    energy_tol: float = 1e-8,
+    occupancies_tol: float = 1e-5,
+    max_iterations: int = 100,
+    sci_solver: Callable[..., list[SCIResult]] | None = None,
+    symmetrize_spin: bool = False,
+    include_configurations=None,
+    initial_occupancies: tuple[np.ndarray, np.ndarray] | None = None,
+    carryover_threshold: float = 1e-4,
+    max_dim: int | tuple[int, int] | None = None,
+    callback: Callable[[list[SCIResult]], None] | None = None,
+    seed: int | np.random.Generator | None = None,
+) -> SCIResult:
+    """Sample-based quantum diagonalization with self-consistent configuration recovery; returns the
+    lowest-energy ``SCIResult`` seen.  Arguments as in the reference (``fermion.py:204-340``)."""
+    if max_iterations < 1:
+        raise ValueError("Maximum number of iterations must be at least 1.")
+    n_alpha, n_beta = nelec
+    if symmetrize_spin and n_alpha != n_beta:
+        raise ValueError(
+            "Spin symmetrization is only possible if the numbers of alpha and beta "
+            f"electrons are equal. Instead, got {n_alpha} and {n_beta}."
+        )
+    max_dim_a, max_dim_b = max_dim if isinstance(max_dim, tuple) else (max_dim, max_dim)
+    if symmetrize_spin and max_dim_a != max_dim_b:
+        raise ValueError(
+            "When requesting spin symmetrization, the maximum dimension must be "
+            "the same for both spin alpha and spin beta. "
+            f"Instead, got {max_dim_a} and {max_dim_b}"
+        )
+    if include_configurations is None:
+        include_a = include_b = np.array([], dtype=int)
+    elif isinstance(include_configurations, tuple):
+        include_a, include_b = include_configurations
+    else:
+        include_a = include_b = include_configurations
+    include_a, include_b = np.unique(include_a), np.unique(include_b)
+
+    rng = np.random.default_rng(seed)
+    solver = sci_solver if sci_solver is not None else solve_sci_batch
+    raw_bitstrings, raw_probs = bit_array_to_arrays(bit_array)
+
+    occupancies = initial_occupancies
+    best: SCIResult | None = None
+    current: SCIResult | None = None
+    carry_a = carry_b = np.array([], dtype=np.int64)
+
+    for _ in range(max_iterations):
+        # ---- configurations for this iteration
+        if occupancies is None:
+            bitstrings, probs = postselect_by_hamming_right_and_left(
+                raw_bitstrings, raw_probs, hamming_right=n_alpha, hamming_left=n_beta
+            )
+            if not bitstrings.size:
+                raise ValueError(
+                    "The input bit array did not contain any valid bitstrings. "
+                    "Either pass a bit array that contains at least one valid bitstring "
+                    "(with the correct right and left Hamming weights), or specify a value for initial_occupancies."
+                )
+        else:
+            bitstrings, probs = recover_configurations(raw_bitstrings, raw_probs, occupancies, n_alpha, n_beta, rand_seed=rng)
+        batches = subsample(bitstrings, probs, samples_per_batch=samples_per_batch, num_batches=num_batches, rand_seed=rng)
+        ci_strings = [
+            _batch_strings(b, norb, symmetrize_spin, include_a, include_b, carry_a, carry_b, max_dim_a, max_dim_b)
+            for b in batches
+        ]
+
+        # ---- the seam (reference fermion.py:432)
+        results = solver(ci_strings, one_body_tensor, two_body_tensor, norb, nelec)
+        if callback is not None:
+            callback(results)
+
+        # ---- bookkeeping
+        winner = min(results, key=lambda r: r.energy)
+        if best is None or winner.energy < best.energy:
+            best = winner
+        if (
+            current is not None
+            and abs(current.energy - winner.energy) < energy_tol
+            and np.linalg.norm(np.ravel(occupancies) - np.ravel(winner.orbital_occupancies), ord=np.inf) < occupancies_tol
+        ):
+            break
+        current = winner
+        occupancies = winner.orbital_occupancies
+        carry_a, carry_b = _carryover(winner, carryover_threshold, symmetrize_spin)
+
+    return best

@@ -183,3 +183,33 @@ def test_python_api_solve_fermion(hip_lib):
     assert np.allclose(res.sci_state.rdm(1, spin_summed=True), res.rdm1, atol=1e-12)
     batch = solve_sci_batch([(sa, sb), (sa[:10], sb[:8])], h1, eri, norb, nelec)
     assert len(batch) == 2 and batch[0].energy <= batch[1].energy + 1e-9
+
+
+def test_sqd_loop_end_to_end_on_gpu(hip_lib):
+    """Whole SQD loop with the HIP solver as ``sci_solver`` against the same loop driven by the dense
+    numpy oracle: identical CI strings at the seam every iteration, energies within 1e-8 Ha."""
+    import json
+    from pathlib import Path
+
+    from qiskit_addon_sqd_amd.fermion import SCIResult, SCIState, solve_sci_batch
+    from qiskit_addon_sqd_amd.sqd import diagonalize_fermionic_hamiltonian
+
+    g = json.loads((Path(__file__).parent / "golden" / "sqd_loop.json").read_text())["loop_open"]
+    norb, nelec = g["norb"], tuple(g["nelec"])
+    h1, eri = O.synthetic_integrals(norb, seed=g["integrals_seed"])
+    seen = []
+
+    def gpu_solver(ci_strings, one, two, norb_, nelec_):
+        seen.append([(np.asarray(a).copy(), np.asarray(b).copy()) for a, b in ci_strings])
+        return solve_sci_batch(ci_strings, one, two, norb_, nelec_, tol_residual=1e-9)
+
+    res = diagonalize_fermionic_hamiltonian(
+        h1, eri, np.array(g["noisy"], dtype=bool), samples_per_batch=g["samples_per_batch"], norb=norb, nelec=nelec,
+        num_batches=g["num_batches"], max_iterations=g["max_iterations"], symmetrize_spin=False, max_dim=None,
+        sci_solver=gpu_solver, carryover_threshold=g["carryover_threshold"], seed=g["seed"])
+    assert len(seen) == len(g["calls"])
+    for mine, ref in zip(seen, g["calls"]):
+        for (a, b), r in zip(mine, ref):
+            assert a.tolist() == r["a"] and b.tolist() == r["b"]
+    assert abs(res.energy - g["energy"]) < 1e-8
+    assert np.allclose(np.abs(res.sci_state.amplitudes), np.array(g["abs_amplitudes"]), atol=1e-6)
