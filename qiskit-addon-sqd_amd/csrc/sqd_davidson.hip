@@ -197,7 +197,7 @@ __global__ void k_init_guess(int64_t n, const int64_t* __restrict__ addr_ptr, do
 
 // ------------------------------------------------------------------ host helpers
 static inline unsigned red_blocks(int64_t n) {
-  int64_t b = (n + RED_T - 1) / RED_T;
+  int64_t b = (n + 4 * RED_T - 1) / (4 * RED_T);  // >= 4 elements per thread: fewer partials to fold
   if (b > RED_BLOCKS) b = RED_BLOCKS;
   if (b < 1) b = 1;
   return (unsigned)b;

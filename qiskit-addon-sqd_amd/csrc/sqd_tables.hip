@@ -231,25 +231,27 @@ __global__ void k_decorate_doubles(const uint64_t* __restrict__ strs, int64_t n_
 __global__ void k_string_energy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ h1,
                                 const double* __restrict__ jm, const double* __restrict__ km, int norb,
                                 double* __restrict__ e_str) {
-  const int64_t I = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // one wavefront per string: lane l takes the orbital pairs (i, j) = (l / nocc, l % nocc), l += 64;
+  // the shuffle tree adds them in fixed order
+  const int lane = threadIdx.x & 63;
+  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= n) return;
   const uint64_t s = strs[I];
+  const int nocc = __popcll(s);
   double e = 0.0;
-  uint64_t oi = s;
-  while (oi) {
-    const int i = ctz64(oi);
-    oi &= oi - 1;
-    e += h1[i * norb + i];
-    uint64_t oj = s;
-    double t = 0.0;
-    while (oj) {
-      const int j = ctz64(oj);
-      oj &= oj - 1;
-      t += jm[i * norb + j] - km[i * norb + j];
-    }
-    e += 0.5 * t;
+  for (int p = lane; p < nocc * nocc; p += 64) {
+    const int a = p / nocc, b = p % nocc;
+    uint64_t t = s;
+    for (int k = 0; k < a; ++k) t &= t - 1;
+    const int i = ctz64(t);
+    t = s;
+    for (int k = 0; k < b; ++k) t &= t - 1;
+    const int j = ctz64(t);
+    e += 0.5 * (jm[i * norb + j] - km[i * norb + j]);
+    if (a == b) e += h1[i * norb + i];
   }
-  e_str[I] = e;
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
+  if (lane == 0) e_str[I] = e;
 }
 
 // J[I][pair] = sum_{k in I} (pair|kk).  transposed == 0: out[I*nnorb + pair]; else out[pair*n + I]
@@ -442,7 +444,10 @@ static int build_sigma_work(sqd_ctx* c) {
   c->sig_K = K;
   c->sig_nb_pad = nb_pad;
   c->sig_shmem = (size_t)K * row_bytes + part_bytes;
-  const int L0 = 16, L = 32;
+  // same-spin links folded into the own-row item: sparse sets (few links per row) take all of them there
+  // and need no partial rows / reduce launch; well-connected sets keep the own-row item short
+  const int64_t hs_total = c->h_sptr[na] + c->h_dptr[na];
+  const int L0 = (hs_total <= 24 * na) ? 32 : 16, L = 32;
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();
@@ -536,15 +541,41 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
   return SQD_OK;
 }
 
-static int build_spin_links_count(sqd_ctx* c, SpinTables& t, int64_t* d_cnt) {
-  const int64_t n = t.n;  // t.s_ptr / t.d_ptr are views into c->ptrs (set by the caller)
-  int64_t* cnt_s = d_cnt;
-  int64_t* cnt_d = d_cnt + n;
-  hipLaunchKernelGGL(k_count_links, dim3(nblk(n, 4)), dim3(256), 0, c->stream, t.strs.as<uint64_t>(), n, cnt_s, cnt_d);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, c->stream, (const int64_t*)cnt_s, t.s_ptr.as<int64_t>(), n);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(256), 0, c->stream, (const int64_t*)cnt_d, t.d_ptr.as<int64_t>(), n);
-  SQD_HIP_CHECK(hipGetLastError());
-  return SQD_OK;
+// four independent exclusive scans in one launch (one workgroup each)
+struct ScanJobs {
+  const int64_t* in[4];
+  int64_t* out[4];
+  int64_t n[4];
+};
+__global__ void k_exclusive_scan4(const ScanJobs jobs) {
+  __shared__ int64_t sums[1024];
+  const int64_t* __restrict__ in = jobs.in[blockIdx.x];
+  int64_t* __restrict__ out = jobs.out[blockIdx.x];
+  const int64_t n = jobs.n[blockIdx.x];
+  const int T = blockDim.x, tid = threadIdx.x;
+  const int64_t chunk = (n + T - 1) / T;
+  const int64_t lo = (int64_t)tid * chunk;
+  const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += in[i];
+  sums[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < T; ++t) {
+      const int64_t v = sums[t];
+      sums[t] = run;
+      run += v;
+    }
+    out[n] = run;
+  }
+  __syncthreads();
+  int64_t run = sums[tid];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
 }
 
 int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb) {
@@ -582,10 +613,23 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->sp[1].s_ptr.set_view(base + 2 * (na + 1));
     c->sp[1].d_ptr.set_view(base + 2 * (na + 1) + (nb + 1));
   }
-  int64_t* d_cnt = c->scratch.as<int64_t>();
-  for (int s = 0; s < 2; ++s) {
-    SpinTables& t = c->sp[s];
-    SQD_TRY(build_spin_links_count(c, t, d_cnt));  // scratch reused: stream order serialises
+  {
+    int64_t* d_cnt = c->scratch.as<int64_t>();  // [cnt_s_a | cnt_d_a | cnt_s_b | cnt_d_b], maxn each
+    ScanJobs jobs;
+    for (int s = 0; s < 2; ++s) {
+      SpinTables& t = c->sp[s];
+      int64_t* cnt_s = d_cnt + (2 * s) * maxn;
+      int64_t* cnt_d = d_cnt + (2 * s + 1) * maxn;
+      hipLaunchKernelGGL(k_count_links, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n, cnt_s, cnt_d);
+      jobs.in[2 * s] = cnt_s;
+      jobs.out[2 * s] = t.s_ptr.as<int64_t>();
+      jobs.n[2 * s] = t.n;
+      jobs.in[2 * s + 1] = cnt_d;
+      jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
+      jobs.n[2 * s + 1] = t.n;
+    }
+    hipLaunchKernelGGL(k_exclusive_scan4, dim3(4), dim3(256), 0, st, jobs);
+    SQD_HIP_CHECK(hipGetLastError());
   }
   c->h_ptrs.resize(nptr);
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_ptrs.data(), c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
@@ -621,7 +665,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                          c->eri4.as<double>(), norb);
     // per-string tables
     SQD_TRY(t.e_str.reserve(t.n * 8));
-    hipLaunchKernelGGL(k_string_energy, dim3(nblk(t.n, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
+    hipLaunchKernelGGL(k_string_energy, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
                        c->h1.as<double>(), c->jm.as<double>(), c->km.as<double>(), norb, t.e_str.as<double>());
     const int64_t nj = t.n * nnorb;
     if (s == 0) {
