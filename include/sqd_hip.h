@@ -137,6 +137,25 @@ int sqd_time_sigma(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift
 /* Populated-link count and algorithmic bytes of one sigma (SURVEY 8d formula) for the current subspace. */
 int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
 
+/* ---- qubit / Pauli path (reference qiskit_addon_sqd/qubit.py) -----------------
+ * Projection of sum_t c_t P_t onto the subspace spanned by the computational basis states `rows`
+ * (strictly ascending unsigned integers of the bitstrings, column 0 = most significant bit; d of them).
+ * Terms are grouped by x mask: group g has mask xmask[g] and the terms group_ptr[g] .. group_ptr[g+1];
+ * term t has z mask zmask[t] and coefficient coef[2t] + i coef[2t+1] which must already include
+ * i^{popcount(x & z)} (the Y phase).  Result is CSR with row = input configuration and column =
+ * connected configuration, A[r, index(rows[r] ^ x)] = sum_t coef_t (-1)^{popcount(rows[r] & z_t)} -- the
+ * summed output of reference matrix_elements_from_pauli (qubit.py:167-240) over the term loop of
+ * project_operator_to_subspace (qubit.py:127-142).
+ * sqd_pauli_count: uploads, counts, scans; returns indptr[d+1] (may be NULL), nnz and a plan.
+ * sqd_pauli_fill : indices[nnz], data[2*nnz] (re, im interleaved); ms_kernels = device time of both passes.
+ * sqd_pauli_free : releases the plan. */
+typedef struct sqd_pauli_plan sqd_pauli_plan;
+int sqd_pauli_count(int device, const uint64_t* rows, int64_t d, int ngroups, const uint64_t* xmask,
+                    const int64_t* group_ptr, const uint64_t* zmask, const double* coef, int64_t* indptr_out,
+                    int64_t* nnz_out, sqd_pauli_plan** plan_out);
+int sqd_pauli_fill(sqd_pauli_plan* plan, int64_t* indices, double* data, double* ms_kernels);
+int sqd_pauli_free(sqd_pauli_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ EXPORTED_SYMBOLS = (
     "sqd_rdm2",
     "sqd_time_sigma",
     "sqd_sigma_bytes",
+    "sqd_pauli_count",
+    "sqd_pauli_fill",
+    "sqd_pauli_free",
 )
 
 
@@ -106,6 +109,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_rdm2.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
+    lib.sqd_pauli_count.argtypes = [C.c_int, _u64p, C.c_int64, C.c_int, _u64p, _i64p, _u64p, _dp, _i64p, _i64p,
+                                    C.POINTER(_ctxp)]
+    lib.sqd_pauli_fill.argtypes = [_ctxp, _i64p, _dp, _dp]
+    lib.sqd_pauli_free.argtypes = [_ctxp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("sqd_last_error", "sqd_davidson_default_opts"):
