@@ -69,6 +69,21 @@ def one_step(ctx, sa, sb, spin_sq):
     return e, occ_a, occ_b, s2, st, amps
 
 
+def pmc_traffic_bytes(args):
+    """HBM bytes per k_sigma launch from the committed rocprofv3 PMC passes of THIS workload (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    bench.py cannot collect counters itself.  None when no matching profile is committed."""
+    if (args.norb, args.nelec, args.na, args.nb, args.strings) != (30, 8, 317, 317, "uniform"):
+        return None
+    f = ROOT / "profiles" / "r01" / "pmc" / "v3_uniform317_pmc_summary.json"
+    try:
+        d = json.loads(f.read_text())
+        key = [k for k in d["FETCH_SIZE"] if "k_sigma<" in k][0]
+        return (2.0 * d["FETCH_SIZE"][key]["avg_KB"] + d["WRITE_SIZE"][key]["avg_KB"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, h1, eri, sa, sb, n_sigma_gpu):
     """Reference-algorithm port (oracle O2: pyscf's dense gather/dgemm/scatter formulation, OpenMP over
     strings + sequential OpenBLAS dgemm) on this box's host cores; bounded sample of the same workload."""
@@ -217,7 +232,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(args),
                 "bytes_per_launch": bytes_sigma,
                 "avg_launch_ms": t_sigma_ms,
                 "note": "algorithmic bytes = 16 D + 8 links + 8 (nnorb_s^2 + nnorb_a^2) (SURVEY 8d); working set is "

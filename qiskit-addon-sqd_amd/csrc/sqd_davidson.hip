@@ -24,7 +24,7 @@ namespace sqd {
 
 constexpr int NV = 16;       // vectors per fused reduction launch
 constexpr int RED_BLOCKS = 512;
-constexpr int RED_T = 256;
+constexpr int RED_T = 512;    // 8 waves per workgroup: half as many partials to fold as with 256
 
 // partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
 __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
@@ -197,7 +197,7 @@ __global__ void k_init_guess(int64_t n, const int64_t* __restrict__ addr_ptr, do
 
 // ------------------------------------------------------------------ host helpers
 static inline unsigned red_blocks(int64_t n) {
-  int64_t b = (n + 4 * RED_T - 1) / (4 * RED_T);  // >= 4 elements per thread: fewer partials to fold
+  int64_t b = (n + RED_T - 1) / RED_T;  // one element per thread while the grid lasts: latency, not bandwidth
   if (b > RED_BLOCKS) b = RED_BLOCKS;
   if (b < 1) b = 1;
   return (unsigned)b;
@@ -315,10 +315,13 @@ static void jacobi_eigh(int n, const double* Ain, double* w, double* V) {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 100; ++sweep) {
-    double off = 0.0;
-    for (int i = 0; i < n; ++i)
+    double off = 0.0, dia = 0.0;
+    for (int i = 0; i < n; ++i) {
+      dia += A[i * n + i] * A[i * n + i];
       for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
-    if (off < 1e-300) break;
+    }
+    // converged to working precision (quadratic convergence: one more sweep would change nothing)
+    if (off <= 1e-32 * dia || off < 1e-300) break;
     for (int p = 0; p < n; ++p)
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[p * n + q];
@@ -484,16 +487,30 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     }
     const double tn = std::sqrt(sums[1]);
     Coef gs;
-    for (int i = 0; i < m; ++i) gs.v[i] = sums[2 + i] / tn;
-    hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, 1.0 / tn, tnew,
-                       c->partial.as<double>());
-    SQD_HIP_CHECK(hipGetLastError());
-    // normalise on the device; the norm is inspected at the next host sync (linear-dependence check)
-    hipLaunchKernelGGL(k_norm_to_scale, dim3(1), dim3(128), 0, s, (const double*)c->partial.as<double>(), (int)gb, lindep,
-                       c->scal.as<double>());
-    hipLaunchKernelGGL(k_scale_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)c->scal.as<double>(), tnew);
-    SQD_HIP_CHECK(hipGetLastError());
-    pending_norm_check = true;
+    double c2 = 0.0;
+    for (int i = 0; i < m; ++i) {
+      gs.v[i] = sums[2 + i] / tn;
+      c2 += gs.v[i] * gs.v[i];
+    }
+    if (1.0 - c2 > 1e-3) {
+      // The basis is orthonormal, so |t/tn - sum c_i X_i|^2 = 1 - sum c_i^2 is known before the vector is
+      // formed: orthogonalise AND normalise in one pass (relative error of the norm <= eps / (1 - c2)).
+      const double inv = 1.0 / std::sqrt(1.0 - c2);
+      for (int i = 0; i < m; ++i) gs.v[i] *= inv;
+      hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, inv / tn, tnew,
+                         c->partial.as<double>());
+      SQD_HIP_CHECK(hipGetLastError());
+    } else {
+      // correction nearly inside the span: explicit norm after orthogonalisation (device side; the norm
+      // is inspected at the next host round trip for the linear-dependence check)
+      hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, 1.0 / tn, tnew,
+                         c->partial.as<double>());
+      hipLaunchKernelGGL(k_norm_to_scale, dim3(1), dim3(128), 0, s, (const double*)c->partial.as<double>(), (int)gb, lindep,
+                         c->scal.as<double>());
+      hipLaunchKernelGGL(k_scale_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)c->scal.as<double>(), tnew);
+      SQD_HIP_CHECK(hipGetLastError());
+      pending_norm_check = true;
+    }
     if (m + 1 > max_space) {
       // collapse: X0 <- Ritz vector, AX0 <- A*Ritz (linear combination), X1 <- correction
       double* x0 = c->sol.as<double>();

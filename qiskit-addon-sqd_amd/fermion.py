@@ -33,20 +33,24 @@ _PYSCF_KWARGS = {
 # --------------------------------------------------------------------------- contexts
 _CTX_LOCK = threading.Lock()
 _CTX_CACHE: "OrderedDict[tuple, _capi.Context]" = OrderedDict()
-_CTX_CACHE_MAX = 4
+_CTX_CACHE_MAX = 16
 
 
 def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
+    # fingerprint, not a full hash: every entry of hcore plus ~8k strided entries of eri (the loop calls
+    # this once per solve; a full pass over norb^4 doubles would cost more than a small solve)
     h = np.ascontiguousarray(hcore, dtype=np.float64)
-    e = np.ascontiguousarray(eri, dtype=np.float64).ravel()
+    e = np.asarray(eri).reshape(-1)
     step = max(1, e.size // 8192)
-    return (device, h.shape[0], zlib.crc32(h.tobytes()), zlib.crc32(e[::step].tobytes()), float(e.sum()))
+    sample = np.ascontiguousarray(e[::step], dtype=np.float64)
+    return (device, h.shape[0], e.size, zlib.crc32(h.tobytes()), zlib.crc32(sample.tobytes()))
 
 
-def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0) -> _capi.Context:
+def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int = 0) -> _capi.Context:
     """Context (device-resident integral tables + arenas) for this Hamiltonian, cached so that the
-    SQD loop's repeated calls with the same integrals do not re-upload or re-pack them."""
-    key = _ham_key(hcore, eri, device)
+    SQD loop's repeated calls with the same integrals do not re-upload or re-pack them.  ``slot``
+    distinguishes the contexts of concurrent host threads on one device (a context is not re-entrant)."""
+    key = _ham_key(hcore, eri, device) + (slot,)
     with _CTX_LOCK:
         ctx = _CTX_CACHE.pop(key, None)
         if ctx is None:
@@ -254,14 +258,20 @@ def solve_sci_batch(
     *,
     spin_sq: float | None = None,
     devices: Sequence[int] | None = None,
+    concurrency: int = 1,
     **kwargs,
 ) -> list[SCIResult]:
     """Diagonalize Hamiltonian in subspaces (reference ``fermion.py:643-681``).
 
     The reference solves the batches one after another; they are independent, so with
     ``devices=[0, 1, ...]`` batch ``i`` runs on ``devices[i % len(devices)]`` (one host thread and one
-    context per device; ctypes releases the GIL during native calls).  Default: device 0.
+    context per device; ctypes releases the GIL during native calls).  ``concurrency=k`` runs ``k``
+    solves at a time on each device (own context + HIP stream each): a 1e5-determinant solve is
+    latency-bound and leaves most of the GPU idle, so independent batches overlap well.
+    Default: device 0, one at a time.
     """
+    if concurrency > 1:
+        devices = [d for d in (devices or [0]) for _ in range(concurrency)]
     if not devices or len(devices) == 1 or len(ci_strings) <= 1:
         dev = devices[0] if devices else 0
         return [
@@ -275,7 +285,7 @@ def solve_sci_batch(
         out = {}
         for i in range(dev_slot, len(ci_strings), len(devices)):
             out[i] = solve_sci(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec,
-                               spin_sq=spin_sq, device=dev, **kwargs)  # fmt: skip
+                               spin_sq=spin_sq, device=dev, _slot=dev_slot, **kwargs)  # fmt: skip
         return out
 
     results: dict[int, SCIResult] = {}
@@ -295,6 +305,7 @@ def solve_sci(
     spin_sq: float | None = None,
     device: int = 0,
     compute_rdms: bool = True,
+    _slot: int = 0,
     **kwargs,
 ) -> SCIResult:
     """Diagonalize Hamiltonian in subspace defined by CI strings (reference ``fermion.py:684-742``).
@@ -306,21 +317,22 @@ def solve_sci(
     """
     one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
     norb, _ = one_body_tensor.shape
-    ctx = _get_context(one_body_tensor, two_body_tensor, device)
+    ctx = _get_context(one_body_tensor, two_body_tensor, device, _slot)
     strs_a, strs_b = ci_strings
     amps, _stats = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs)
     if tuple(int(x) for x in nelec) != ctx.nelec:
         raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
-    dm1a, dm1b = ctx.rdm1s()
-    occupancies = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
     if compute_rdms:
+        dm1a, dm1b = ctx.rdm1s()
+        occupancies = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
         dm1 = dm1a + dm1b
         dm2 = ctx.rdm2()
         two = np.asarray(two_body_tensor, dtype=np.float64).reshape((norb,) * 4)
         energy = float(np.einsum("pr,pr->", dm1, one_body_tensor) + 0.5 * np.einsum("prqs,prqs->", dm2, two))
     else:
         dm1 = dm2 = None
-        energy = ctx.energy()
+        energy, _s2, occ_a, occ_b = ctx.observables()  # one native call, one device round trip
+        occupancies = (occ_a, occ_b)
     sci_state = SCIState(
         amplitudes=amps,
         ci_strs_a=np.asarray(strs_a),

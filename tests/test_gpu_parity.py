@@ -213,3 +213,20 @@ def test_sqd_loop_end_to_end_on_gpu(hip_lib):
             assert a.tolist() == r["a"] and b.tolist() == r["b"]
     assert abs(res.energy - g["energy"]) < 1e-8
     assert np.allclose(np.abs(res.sci_state.amplitudes), np.array(g["abs_amplitudes"]), atol=1e-6)
+
+
+def test_concurrent_batches_on_one_gpu(hip_lib):
+    """``concurrency=k``: k host threads, each with its own context + stream on the same device; results
+    must equal the one-at-a-time run bit for bit (every reduction is fixed-order)."""
+    from qiskit_addon_sqd_amd.fermion import solve_sci_batch
+
+    norb, nelec = 10, (5, 5)
+    h1, eri = O.synthetic_integrals(norb)
+    batches = [(O.hf_centred_strings(norb, 5, 30 + 3 * i, 10 + i), O.hf_centred_strings(norb, 5, 28 + 2 * i, 40 + i))
+               for i in range(6)]
+    seq = solve_sci_batch(batches, h1, eri, norb, nelec, spin_sq=0.0, compute_rdms=False)
+    par = solve_sci_batch(batches, h1, eri, norb, nelec, spin_sq=0.0, compute_rdms=False, concurrency=3)
+    for a, b in zip(seq, par):
+        assert a.energy == b.energy
+        assert np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
+        assert np.array_equal(a.orbital_occupancies[0], b.orbital_occupancies[0])
