@@ -89,6 +89,9 @@ struct SpinTables {
   int cap = 8;
   int64_t nv_s = 0, nv_d = 0;
   DevBuf vs_cnt, vs_own, vs_start, vd_cnt, vd_own, vd_start;  // i32[nv] / i32[3n] / i64[nv]
+  // column chunks (one unless the row is too long for LDS): virtual rows of chunk k are
+  // [v*_chunk[k], v*_chunk[k+1]), all owned by strings of that chunk
+  DevBuf vs_chunk, vd_chunk;     // i32[nchunks+1]
   DevBuf es_rec;                 // SRec
   DevBuf es_val;                 // f64
   DevBuf ed_src;                 // u32
@@ -111,9 +114,9 @@ struct MultiRow {
 };
 // host copy of the capped-ELL descriptors (see sqd_tables.hip)
 struct VRowsHost {
-  std::vector<int32_t> vcnt, own;
+  std::vector<int32_t> vcnt, own, chunk;
   std::vector<int64_t> vstart, sl;
-  int64_t nv = 0, total = 0;
+  int64_t nv = 0, total = 0, nv_max = 0;  // nv_max: most virtual rows in one column chunk
 };
 
 }  // namespace sqd
@@ -147,6 +150,9 @@ struct sqd_ctx {
   int64_t n_items = 0, n_multi = 0, n_slots = 0;
   int sig_T = 64, sig_R = 1, sig_K = 1, sig_nb_pad = 0;
   size_t sig_shmem = 0;
+  bool sig_lds_rows = true;      // C rows staged in LDS (false: rows too long, read from global/L2)
+  int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
+  int sig_nchunks = 1;
   // Davidson workspace
   sqd::DevBuf X, AX;        // (max_space+1) * D each
   sqd::DevBuf sol;          // f64[D] resident solution

@@ -51,6 +51,12 @@ struct SigmaArgs {
   const int32_t* vd_cnt;
   const int32_t* vd_own;
   int nv_s, nv_d;
+  // column chunks (gridDim.y): chunk k covers columns [k*chunk_cols, ...) and the virtual rows
+  // [v*_chunk[k], v*_chunk[k+1]); nvs_max / nvd_max = longest such range (LDS partial-sum arrays)
+  const int32_t* vs_chunk;
+  const int32_t* vd_chunk;
+  int64_t chunk_cols;
+  int nvs_max, nvd_max;
   const int64_t* esb_sl;
   const SRec* esb_rec;
   const double* esb_val;
@@ -128,11 +134,12 @@ __device__ inline double vrow_doubles_own(const SigmaArgs& g, int64_t v, const d
   return a;
 }
 // string B's share of a list: its contiguous run of full rows, then its tail (fixed order)
-__device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B, const double* part) {
-  const int f0 = own[3 * B], nfull = own[3 * B + 1], tail = own[3 * B + 2];
+// (part[] holds the rows of one column chunk, whose first row is v0)
+__device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B, const double* part, int v0) {
+  const int f0 = own[3 * B] - v0, nfull = own[3 * B + 1], tail = own[3 * B + 2];
   double a = 0.0;
   for (int x = 0; x < nfull; ++x) a += part[f0 + x];
-  if (tail >= 0) a += part[tail];
+  if (tail >= 0) a += part[tail - v0];
   return a;
 }
 
@@ -169,7 +176,9 @@ __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const
   return a;
 }
 
-template <int R, bool SPIN>
+// LDSROW: the C rows of an item are staged in LDS (the tuned path).  !LDSROW: rows too long for LDS are
+// read in place (global memory / L2), one alpha link per batch; everything else is unchanged.
+template <int R, bool SPIN, bool LDSROW>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
   const int T = blockDim.x, tid = threadIdx.x;
@@ -177,12 +186,18 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   const int64_t A = it.A;
   const int64_t nb = g.nb;
   const int nnorb = g.nnorb;
-  double* Crow = smem;                          // [K][nb_pad]
-  double* W2 = smem + (int64_t)g.K * g.nb_pad;  // [K][2*nnorb]
+  // this workgroup's column chunk and the virtual rows owned by its strings
+  const int chunk = blockIdx.y;
+  const int64_t B0 = (int64_t)chunk * g.chunk_cols;
+  const int64_t Bend = (B0 + g.chunk_cols < nb) ? B0 + g.chunk_cols : nb;
+  const int vs0 = g.vs_chunk[chunk], vs1 = g.vs_chunk[chunk + 1];
+  const int vd0 = g.vd_chunk[chunk], vd1 = g.vd_chunk[chunk + 1];
+  double* Crow = smem;                                          // [K][nb_pad]   (LDSROW only)
+  double* W2 = smem + (LDSROW ? (int64_t)g.K * g.nb_pad : 0);   // [K][2*nnorb]
   const int w2s = (nnorb + 1) & ~1;            // one integral row per staged link
-  double* part_s = W2 + (int64_t)g.K * w2s;  // [nv_s] partial sums of the singles' virtual rows
-  double* part_d = part_s + g.nv_s;          // [nv_d] ... of the doubles' virtual rows
-  int* penw = reinterpret_cast<int*>(part_d + g.nv_d);  // [K] S^2 partner widx of each staged link
+  double* part_s = W2 + (int64_t)g.K * w2s;  // [nvs_max] partial sums of the singles' virtual rows
+  double* part_d = part_s + g.nvs_max;       // [nvd_max] ... of the doubles' virtual rows
+  int* penw = reinterpret_cast<int*>(part_d + g.nvd_max);  // [K] S^2 partner widx of each staged link
   const double* __restrict__ C = g.c;
   double acc[R];
 #pragma unroll
@@ -195,7 +210,10 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     const uint64_t sA = g.strs_a[A];
     // the own row and the diagonal are touched exactly once per sigma: stream them past the L2
     // (non-temporal) so that the link lists, which every workgroup re-reads, stay resident
-    for (int64_t i = tid; i < nb; i += T) Crow[i] = __builtin_nontemporal_load(&C[A * nb + i]);
+    const double* crow0 = C + A * nb;
+    if (LDSROW) {
+      for (int64_t i = tid; i < nb; i += T) Crow[i] = __builtin_nontemporal_load(&C[A * nb + i]);
+    }
     if (g.mode == 0)
       for (int i = tid; i < nnorb; i += T) {
         W2[i] = g.ja_row[A * nnorb + i];
@@ -203,14 +221,19 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     __syncthreads();
     // every virtual row of the beta lists, by whichever thread comes next; partial sums through LDS
     if (g.mode == 0) {
-      for (int v = tid; v < g.nv_s; v += T) part_s[v] = vrow_singles_own(g, v, Crow, W2);
-      for (int v = tid; v < g.nv_d; v += T) part_d[v] = vrow_doubles_own(g, v, Crow);
+      if (LDSROW) {
+        for (int v = vs0 + tid; v < vs1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, Crow, W2);
+        for (int v = vd0 + tid; v < vd1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, Crow);
+      } else {
+        for (int v = vs0 + tid; v < vs1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, crow0, W2);
+        for (int v = vd0 + tid; v < vd1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, crow0);
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t B = tid + (int64_t)r * T;
-      if (B < nb) {
+      const int64_t B = B0 + tid + (int64_t)r * T;
+      if (B < Bend) {
         double d;
         if (g.mode == 0) {
           d = __builtin_nontemporal_load(&g.hdiag[A * nb + B]);
@@ -218,11 +241,11 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         } else {
           d = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
         }
-        double a = d * Crow[B];
+        double a = d * (LDSROW ? Crow[B] : crow0[B]);
         if (g.mode == 0) {
           // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0), beta doubles
-          a += own_rows_sum(g.vs_own, B, part_s);
-          a += own_rows_sum(g.vd_own, B, part_d);
+          a += own_rows_sum(g.vs_own, B, part_s, vs0);
+          a += own_rows_sum(g.vd_own, B, part_d, vd0);
           // first same-spin alpha links of this row: unit-stride row reads
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
@@ -231,35 +254,46 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     }
   } else if (it.type == 1) {
     // ---- a batch of alpha single links: stage their source rows (signed) and integral rows
-    const int kb = it.count;
+    const int kb = it.count;  // 1 when !LDSROW
     const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+    const SRec rec0 = g.sa_rec[it.begin];
+    const double* srow0 = C + (int64_t)rec0.src * nb;  // !LDSROW: the (unsigned) source row in place
+    const double sg0 = srec_sign(rec0.meta);
     for (int j = 0; j < kb; ++j) {
       const SRec rec = g.sa_rec[it.begin + j];
       const double sg = srec_sign(rec.meta);
       const int widx = (int)srec_widx(rec.meta);
       const int pair = widx >> 1;
       if (tid == 0) penw[j] = widx ^ 1;  // same pair, opposite direction
-      const double* __restrict__ src = C + (int64_t)rec.src * nb;
-      double* cr = Crow + (int64_t)j * g.nb_pad;
       double* w2 = W2 + (int64_t)j * w2s;
-      for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
+      if (LDSROW) {
+        const double* __restrict__ src = C + (int64_t)rec.src * nb;
+        double* cr = Crow + (int64_t)j * g.nb_pad;
+        for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
+      }
       for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
     }
     __syncthreads();
-    for (int v = tid; v < g.nv_s; v += T) part_s[v] = vrow_singles_batch<SPIN>(g, v, Crow, W2, kb, w2s, penw, pen);
+    if (LDSROW) {
+      for (int v = vs0 + tid; v < vs1; v += T)
+        part_s[v - vs0] = vrow_singles_batch<SPIN>(g, v, Crow, W2, kb, w2s, penw, pen);
+    } else {
+      for (int v = vs0 + tid; v < vs1; v += T)
+        part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN>(g, v, srow0, W2, 1, w2s, penw, pen);
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t B = tid + (int64_t)r * T;
-      if (B < nb) {
+      const int64_t B = B0 + tid + (int64_t)r * T;
+      if (B < Bend) {
         double a = 0.0;
         if (g.mode == 0) {
           for (int j = 0; j < kb; ++j) {
             const int pair = (int)(srec_widx(g.sa_rec[it.begin + j].meta) >> 1);
-            a += g.jbT[(int64_t)pair * nb + B] * Crow[(int64_t)j * g.nb_pad + B];
+            a += g.jbT[(int64_t)pair * nb + B] * (LDSROW ? Crow[(int64_t)j * g.nb_pad + B] : sg0 * srow0[B]);
           }
         }
-        a += own_rows_sum(g.vs_own, B, part_s);
+        a += own_rows_sum(g.vs_own, B, part_s, vs0);
         acc[r] = a;
       }
     }
@@ -268,8 +302,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     if (g.mode == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int64_t B = tid + (int64_t)r * T;
-        if (B < nb) {
+        const int64_t B = B0 + tid + (int64_t)r * T;
+        if (B < Bend) {
           acc[r] = axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
       }
@@ -278,8 +312,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   double* __restrict__ out = (it.slot < 0) ? (g.sigma + A * nb) : (g.partial + (int64_t)it.slot * nb);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int64_t B = tid + (int64_t)r * T;
-    if (B < nb) __builtin_nontemporal_store(acc[r], &out[B]);
+    const int64_t B = B0 + tid + (int64_t)r * T;
+    if (B < Bend) __builtin_nontemporal_store(acc[r], &out[B]);
   }
 }
 
@@ -309,19 +343,25 @@ __global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, doubl
     y[i] = a * x[i] + b * y[i];
 }
 
-template <int R, bool SPIN>
+template <int R, bool SPIN, bool LDSROW>
 static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
   if (c->sig_shmem > 64 * 1024) {
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN>),
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN, LDSROW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
   }
-  hipLaunchKernelGGL((k_sigma<R, SPIN>), dim3((unsigned)c->n_items), dim3(c->sig_T), c->sig_shmem, c->stream, g);
+  hipLaunchKernelGGL((k_sigma<R, SPIN, LDSROW>), dim3((unsigned)c->n_items, (unsigned)c->sig_nchunks), dim3(c->sig_T),
+                     c->sig_shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }
 template <int R>
 static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
-  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true>(c, g) : launch_sigma_rs<R, false>(c, g);
+  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true, true>(c, g) : launch_sigma_rs<R, false, true>(c, g);
+}
+// rows in global memory: R is 1 (test hook) or 4 (4096-column chunks of 1024 threads)
+template <int R>
+static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
+  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true, false>(c, g) : launch_sigma_rs<R, false, false>(c, g);
 }
 
 int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift) {
@@ -371,9 +411,16 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.jbT = b.jT.as<double>();
   g.eri_pp = c->eri_pp.as<double>();
 
+  g.vs_chunk = b.vs_chunk.as<int32_t>();
+  g.vd_chunk = b.vd_chunk.as<int32_t>();
+  g.chunk_cols = c->sig_chunk;
+  g.nvs_max = (int)c->hv_s.nv_max;
+  g.nvd_max = (int)c->hv_d.nv_max;
+
   const int R = c->sig_R;
   int rc;
-  if (R <= 1) rc = launch_sigma_r<1>(c, g);
+  if (!c->sig_lds_rows) rc = (R <= 1) ? launch_sigma_g<1>(c, g) : launch_sigma_g<4>(c, g);
+  else if (R <= 1) rc = launch_sigma_r<1>(c, g);
   else if (R <= 2) rc = launch_sigma_r<2>(c, g);
   else if (R <= 4) rc = launch_sigma_r<4>(c, g);
   else if (R <= 8) rc = launch_sigma_r<8>(c, g);

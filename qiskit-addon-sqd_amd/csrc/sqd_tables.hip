@@ -59,7 +59,7 @@ void DevBuf::release() {
 void SpinTables::release() {
   DevBuf* all[] = {&strs, &e_str, &s_ptr, &d_ptr, &s_row, &d_row, &s_rec, &s_val, &d_src, &d_orb,
                    &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val,
-                   &vs_cnt, &vs_own, &vs_start, &vd_cnt, &vd_own, &vd_start};
+                   &vs_cnt, &vs_own, &vs_start, &vd_cnt, &vd_own, &vd_start, &vs_chunk, &vd_chunk};
   for (DevBuf* b : all) b->release();
 }
 
@@ -334,35 +334,53 @@ __global__ void k_fill_vell_doubles(int64_t nv, const int32_t* __restrict__ vcnt
 }
 
 // host side of the above: virtual-row descriptors from a CSR pointer array
-static void make_vrows(const int64_t* ptr, int64_t n, int cap, VRowsHost& out) {
+// (owners are taken one column chunk at a time; a chunk's rows are contiguous and padded with empty
+// rows to a whole 64-row slice, so that slices never straddle chunks)
+static void make_vrows(const int64_t* ptr, int64_t n, int cap, int64_t chunk_cols, VRowsHost& out) {
   out.own.assign(3 * n, 0);
   out.vcnt.clear();
   out.vstart.clear();
-  // full rows, grouped by owner
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t cnt = ptr[i + 1] - ptr[i];
-    const int64_t nfull = cnt / cap;
-    out.own[3 * i + 0] = (int32_t)out.vcnt.size();
-    out.own[3 * i + 1] = (int32_t)nfull;
-    out.own[3 * i + 2] = -1;
-    for (int64_t j = 0; j < nfull; ++j) {
-      out.vcnt.push_back(cap);
-      out.vstart.push_back(ptr[i] + j * cap);
-    }
-  }
-  // tails by descending length (stable in owner)
+  out.chunk.clear();
+  out.nv_max = 0;
   std::vector<std::pair<int32_t, int64_t>> tails;  // (length, owner)
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t rem = (ptr[i + 1] - ptr[i]) % cap;
-    if (rem > 0) tails.emplace_back((int32_t)rem, i);
+  for (int64_t c0 = 0; c0 < n; c0 += chunk_cols) {
+    const int64_t c1 = (c0 + chunk_cols < n) ? c0 + chunk_cols : n;
+    const int64_t v0 = (int64_t)out.vcnt.size();
+    out.chunk.push_back((int32_t)v0);
+    // full rows, grouped by owner
+    for (int64_t i = c0; i < c1; ++i) {
+      const int64_t cnt = ptr[i + 1] - ptr[i];
+      const int64_t nfull = cnt / cap;
+      out.own[3 * i + 0] = (int32_t)out.vcnt.size();
+      out.own[3 * i + 1] = (int32_t)nfull;
+      out.own[3 * i + 2] = -1;
+      for (int64_t j = 0; j < nfull; ++j) {
+        out.vcnt.push_back(cap);
+        out.vstart.push_back(ptr[i] + j * cap);
+      }
+    }
+    // tails by descending length (stable in owner)
+    tails.clear();
+    for (int64_t i = c0; i < c1; ++i) {
+      const int64_t rem = (ptr[i + 1] - ptr[i]) % cap;
+      if (rem > 0) tails.emplace_back((int32_t)rem, i);
+    }
+    std::stable_sort(tails.begin(), tails.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    for (const auto& t : tails) {
+      const int64_t i = t.second;
+      out.own[3 * i + 2] = (int32_t)out.vcnt.size();
+      out.vcnt.push_back(t.first);
+      out.vstart.push_back(ptr[i + 1] - t.first);
+    }
+    if (c1 < n)
+      while (out.vcnt.size() % 64) {  // empty padding rows
+        out.vcnt.push_back(0);
+        out.vstart.push_back(0);
+      }
+    const int64_t used = (int64_t)out.vcnt.size() - v0;
+    if (used > out.nv_max) out.nv_max = used;
   }
-  std::stable_sort(tails.begin(), tails.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-  for (const auto& t : tails) {
-    const int64_t i = t.second;
-    out.own[3 * i + 2] = (int32_t)out.vcnt.size();
-    out.vcnt.push_back(t.first);
-    out.vstart.push_back(ptr[i + 1] - t.first);
-  }
+  out.chunk.push_back((int32_t)out.vcnt.size());
   out.nv = (int64_t)out.vcnt.size();
   const int64_t nsl = (out.nv + 63) / 64;
   out.sl.assign(nsl + 1, 0);
@@ -421,29 +439,39 @@ static int build_sigma_work(sqd_ctx* c) {
     const int v = (std::atoi(env) / 64) * 64;
     if (v >= 64 && v <= 1024) T = v;
   }
-  const int R = (int)((nb + T - 1) / T);
   const int nb_pad = (int)((nb + 1) & ~int64_t(1));
-  const size_t row_bytes = ((size_t)nb_pad + (size_t)((c->nnorb + 1) & ~1)) * 8;  // one C row + one integral row
-  const size_t part_bytes = (size_t)(tb.nv_s + tb.nv_d) * 8 + 64;
+  const size_t w2_bytes = (size_t)((c->nnorb + 1) & ~1) * 8;
+  const size_t row_bytes = (size_t)nb_pad * 8 + w2_bytes;  // one C row + one integral row
+  const size_t part_bytes = (size_t)(c->hv_s.nv_max + c->hv_d.nv_max) * 8 + 64;
   const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
-  if (row_bytes + part_bytes > budget || R > 16) {
-    set_error("beta string count " + std::to_string(nb) + " exceeds the LDS-resident row limit of this build");
-    return SQD_ERR_LIMIT;
+  int R, K;
+  if (c->sig_lds_rows) {
+    R = (int)((nb + T - 1) / T);
+    size_t stage = 96 * 1024;
+    if (stage + part_bytes > budget) stage = budget - part_bytes;
+    K = (int)(stage / row_bytes);
+    if (K < 1) K = 1;
+    if (K > 4) K = 4;  // more links per batch lengthen the batch without saving launches (same sweep)
+    if (const char* env = std::getenv("SQD_SIGMA_K")) {  // tuning hook
+      const int v = std::atoi(env);
+      if (v >= 1 && v <= K) K = v;
+    }
+    c->sig_shmem = (size_t)K * row_bytes + part_bytes;
+  } else {
+    // rows stay in global memory: one link per batch, workgroups of one column chunk
+    T = (int)(c->sig_chunk < 1024 ? c->sig_chunk : 1024);
+    R = (int)((c->sig_chunk + T - 1) / T);
+    K = 1;
+    c->sig_shmem = w2_bytes + part_bytes;
   }
-  size_t stage = 96 * 1024;
-  if (stage + part_bytes > budget) stage = budget - part_bytes;
-  int K = (int)(stage / row_bytes);
-  if (K < 1) K = 1;
-  if (K > 4) K = 4;  // more links per batch lengthen the batch without saving launches (same sweep)
-  if (const char* env = std::getenv("SQD_SIGMA_K")) {  // tuning hook
-    const int v = std::atoi(env);
-    if (v >= 1 && v <= K) K = v;
+  if (R > 16) {
+    set_error("beta string count " + std::to_string(nb) + " exceeds the sigma kernel's row geometry");
+    return SQD_ERR_LIMIT;
   }
   c->sig_T = T;
   c->sig_R = R;
   c->sig_K = K;
   c->sig_nb_pad = nb_pad;
-  c->sig_shmem = (size_t)K * row_bytes + part_bytes;
   // same-spin links folded into the own-row item: sparse sets (few links per row) take all of them there
   // and need no partial rows / reduce launch; well-connected sets keep the own-row item short
   const int64_t hs_total = c->h_sptr[na] + c->h_dptr[na];
@@ -696,11 +724,43 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       const int v = std::atoi(env);
       if (v >= 1) cap = v;
     }
-    for (;; cap *= 2) {
-      make_vrows(c->h_sptr_b, nb, cap, vs);
-      make_vrows(c->h_dptr_b, nb, cap, vd);
-      if ((vs.nv + vd.nv) * 8 <= 40 * 1024 || cap >= (1 << 20)) break;  // row partial sums live in LDS
+    // LDS plan of the sigma kernel: K staged C rows + K integral rows + the row partial sums of one
+    // column chunk.  Rows too long for that (nb beyond ~14 000) are not staged: the kernel then reads
+    // them from global memory (L2) and works on column chunks, whose partial sums may use the freed LDS.
+    const int cap0 = cap;
+    const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
+    const size_t w2_bytes = (size_t)((nnorb + 1) & ~1) * 8;
+    const size_t row_bytes = (size_t)((nb + 1) & ~int64_t(1)) * 8 + w2_bytes;
+    bool lds_rows = (row_bytes + 64 <= budget) && ((nb + 1023) / 1024 <= 16);
+    int64_t chunk_cols = nb;
+    int64_t forced = 0;
+    if (const char* env = std::getenv("SQD_SIGMA_GLOBAL_ROWS")) {  // test hook: chunk width, forces the fallback
+      forced = (std::atoll(env) / 64) * 64;
+      if (forced >= 64 && forced <= 1024) lds_rows = false;
+      else forced = 0;
     }
+    for (;;) {
+      if (!lds_rows) chunk_cols = forced ? forced : 4096;
+      const size_t target = lds_rows ? 40 * 1024 : 120 * 1024;
+      for (cap = cap0;; cap *= 2) {
+        make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
+        make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
+        if ((size_t)(vs.nv_max + vd.nv_max) * 8 <= target || cap >= (1 << 20)) break;
+      }
+      const size_t part_bytes = (size_t)(vs.nv_max + vd.nv_max) * 8 + 64;
+      if (lds_rows && row_bytes + part_bytes > budget) {
+        lds_rows = false;
+        continue;
+      }
+      if (!lds_rows && w2_bytes + part_bytes > budget) {
+        set_error("beta link lists of a " + std::to_string(chunk_cols) + "-column chunk exceed the LDS budget");
+        return SQD_ERR_LIMIT;
+      }
+      break;
+    }
+    c->sig_lds_rows = lds_rows;
+    c->sig_chunk = chunk_cols;
+    c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
     t.cap = cap;
     t.nv_s = vs.nv;
     t.nv_d = vd.nv;
@@ -711,6 +771,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
         {&t.vs_start, vs.vstart.data(), vs.vstart.size() * 8}, {&t.es_sl, vs.sl.data(), vs.sl.size() * 8},
         {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_own, vd.own.data(), vd.own.size() * 4},
         {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
+        {&t.vs_chunk, vs.chunk.data(), vs.chunk.size() * 4}, {&t.vd_chunk, vd.chunk.data(), vd.chunk.size() * 4},
     };
     size_t blob = 0;
     for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);

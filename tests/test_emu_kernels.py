@@ -31,6 +31,16 @@ def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
     run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False)
 
 
+def test_emu_global_row_fallback(emu_lib, monkeypatch):
+    # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
+    # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,
+    # the second ragged) with their own virtual-row ranges
+    monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
+    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False)
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    run_full_parity(emu_lib, 9, (2, 4), 7, 100, 29, True)
+
+
 def test_emu_h2_minimal(emu_lib):
     # H2 / STO-3G textbook integrals: 2 electrons in 2 orbitals, 2x2 subspace
     h1 = np.diag([-1.2525, -0.4759])

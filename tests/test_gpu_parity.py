@@ -40,6 +40,13 @@ def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
 
 
+def test_global_row_fallback_forced(hip_lib, monkeypatch):
+    # the path for rows that do not fit LDS, forced at a size the oracle can check (3 column chunks)
+    monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
+    run_full_parity(hip_lib, 10, (5, 5), 40, 150, 31, True)
+    run_full_parity(hip_lib, 12, (2, 6), 3, 924, 19, False)
+
+
 def test_h2_sto3g(hip_lib):
     h1 = np.diag([-1.2525, -0.4759])
     eri = np.zeros((2, 2, 2, 2))
@@ -144,6 +151,34 @@ def test_n2_sigma_vs_sparse_oracle(hip_lib):
         amps, st = ctx.davidson()
         w = np.linalg.eigvalsh(H)
         assert abs(ctx.energy() - w[0]) < 1e-8
+
+
+@pytest.mark.parametrize("hf", [False, True])
+def test_long_rows_against_transposed_problem(hip_lib, hf):
+    """20 000 beta strings: a C row (160 KB) does not fit LDS, so sigma takes the global-row / column-chunk
+    path.  With spin-restricted integrals the problem is symmetric under alpha<->beta exchange (a global
+    sign on the basis), so sigma of the transposed problem -- 20 000 alpha strings x 6 beta strings, the
+    LDS-staged path -- must give the transposed result; contract_ss and the penalty form likewise."""
+    norb = 30
+    h1, eri = O.synthetic_integrals(norb)
+    gen = O.hf_centred_strings if hf else O.random_strings
+    few, many = gen(norb, 8, 6, 41), gen(norb, 8, 20000, 43)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 20000))
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(few, many)
+        s_long = ctx.sigma(x)
+        p_long = ctx.sigma(x, use_spin=1, ss=0.0, shift=0.3)
+        ss_long = ctx.contract_ss(x)
+        ctx.set_subspace(many, few)
+        xt = np.ascontiguousarray(x.T)
+        s_t = ctx.sigma(xt)
+        p_t = ctx.sigma(xt, use_spin=1, ss=0.0, shift=0.3)
+        ss_t = ctx.contract_ss(xt)
+    scale = np.abs(s_t).max()
+    assert np.abs(s_long - s_t.T).max() < 1e-11 * scale
+    assert np.abs(p_long - p_t.T).max() < 1e-11 * scale
+    assert np.abs(ss_long - ss_t.T).max() < 1e-11 * np.abs(ss_t).max()
 
 
 def test_variational_monotonicity(hip_lib):
