@@ -94,6 +94,8 @@ typedef struct sqd_davidson_opts {
   double ss;         /* target S^2 value */
   double shift;      /* penalty strength (0.1 solve_fermion, 0.2 solve_sci) */
   int verbose;
+  int time_sigma_every; /* k > 0: bracket every k-th sigma launch of this context with HIP events (fills
+                           ms_sigma / n_sigma_timed; an event pair costs ~10 us of stream time); 0: none */
 } sqd_davidson_opts;
 
 typedef struct sqd_davidson_stats {
@@ -103,8 +105,9 @@ typedef struct sqd_davidson_stats {
   double e_davidson;   /* eigenvalue of H + penalty (pyscf's discarded return value, without ecore) */
   double residual;     /* final |r| */
   double ms_total;     /* device time of the Davidson loop (HIP events on the context stream) */
-  double ms_sigma;     /* device time summed over the sigma launches */
+  double ms_sigma;     /* device time summed over the TIMED sigma launches (see time_sigma_every) */
   double ms_setup;     /* device time of the last sqd_set_subspace */
+  int n_sigma_timed;   /* number of sigma launches bracketed by events in this run */
 } sqd_davidson_stats;
 
 void sqd_davidson_default_opts(sqd_davidson_opts* o);

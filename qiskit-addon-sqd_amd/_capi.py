@@ -61,6 +61,7 @@ class DavidsonOpts(C.Structure):
         ("ss", C.c_double),
         ("shift", C.c_double),
         ("verbose", C.c_int),
+        ("time_sigma_every", C.c_int),
     ]
 
 
@@ -74,6 +75,7 @@ class DavidsonStats(C.Structure):
         ("ms_total", C.c_double),
         ("ms_sigma", C.c_double),
         ("ms_setup", C.c_double),
+        ("n_sigma_timed", C.c_int),
     ]
 
 
@@ -281,11 +283,13 @@ class Context:
         shift: float = 0.2,
         verbose: int = 0,
         fetch: bool = True,
+        time_sigma_every: int = 0,
     ):
         opts = DavidsonOpts()
         self._lib.sqd_davidson_default_opts(C.byref(opts))
         opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
         opts.verbose = int(verbose)
+        opts.time_sigma_every = int(time_sigma_every)
         opts.tol_residual = float(tol_residual) if tol_residual else 0.0
         if spin_sq is not None:
             opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)

@@ -260,6 +260,7 @@ SQD_API void sqd_davidson_default_opts(sqd_davidson_opts* o) {
   o->ss = 0.0;
   o->shift = 0.2;
   o->verbose = 0;
+  o->time_sigma_every = 0;
 }
 
 SQD_API int sqd_davidson(sqd_ctx* c, const sqd_davidson_opts* opts, const double* ci0, double* amps,

@@ -168,6 +168,7 @@ struct sqd_ctx {
   double* h_mail = nullptr;    // host pointer; [0] = sequence word (as int64), [8..] = payload
   double* d_mail = nullptr;    // the same memory as seen from the device
   int64_t mail_seq = 0;
+  int64_t sigma_launches = 0;  // sigma launches of Davidson runs on this context (event sampling)
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
 };

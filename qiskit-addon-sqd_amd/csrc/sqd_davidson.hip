@@ -92,11 +92,16 @@ __device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
   return p.shift * (d * d + nba * (double)__popcll(A & ~B));
 }
 
+template <int N>
+__device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
+                                       double* __restrict__ dsums, double* mail, long long seq, double* red);
+
 template <int MV>
 __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
                                    int64_t stride, int nvec, const Coef coef, double e,
                                    const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
-                                   double* __restrict__ partial, int width) {
+                                   double* __restrict__ partial, int width, unsigned* counter,
+                                   double* __restrict__ dsums, double* mail, long long seq) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   double vals[MV + 2];
@@ -121,7 +126,8 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
   }
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   if ((int)threadIdx.x < nvec + 2)
-    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 2>(red, threadIdx.x));
+  finish_and_post<MV + 2>(partial, width, nvec + 2, counter, dsums, mail, seq, red);
 }
 
 // t <- scale * t - sum_v coef[v] X_v ;  partial[block] = |t|^2
@@ -184,8 +190,27 @@ __global__ void k_argmin_final(const double* __restrict__ pmin, const int64_t* _
 
 // pyscf get_init_guess: unit vector at addr, +1e-5 on the first and -1e-5 on the last element,
 // normalised here with the closed-form norm (no reduction, no host round trip)
-__global__ void k_init_guess(int64_t n, const int64_t* __restrict__ addr_ptr, double* __restrict__ x) {
-  const int64_t addr = addr_ptr[0];
+// (every workgroup repeats the final stage of the argmin over the <= RED_BLOCKS per-block candidates
+// instead of a separate single-workgroup launch)
+__global__ void k_init_guess(int64_t n, const double* __restrict__ pmin, const int64_t* __restrict__ pidx, int nblocks,
+                             double* __restrict__ x) {
+  __shared__ long long s_addr;
+  {
+    double best = 1e300;
+    int64_t bi = -1;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+      const double v = pmin[b];
+      const int64_t i = pidx[b];
+      if (i >= 0 && (v < best || (v == best && i < bi) || bi < 0)) {
+        best = v;
+        bi = i;
+      }
+    }
+    block_argmin(best, bi);
+    if (threadIdx.x == 0) s_addr = bi < 0 ? 0 : bi;
+    __syncthreads();
+  }
+  const int64_t addr = s_addr;
   auto f = [=](int64_t i) { return ((i == addr) ? 1.0 : 0.0) + ((i == 0) ? 1e-5 : 0.0) - ((i == n - 1) ? 1e-5 : 0.0); };
   double nn = f(0) * f(0);
   if (n - 1 != 0) nn += f(n - 1) * f(n - 1);
@@ -253,6 +278,138 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
     __threadfence_system();
     *reinterpret_cast<volatile long long*>(mail) = seq;
   }
+}
+
+// ---- fused reductions for the Davidson loop: the workgroup that arrives LAST folds the per-block
+// partials (fixed order => bitwise reproducible), leaves the totals on the device (dsums, for the
+// kernels that follow in the stream) and posts them to a host-visible mailbox.  No single-workgroup
+// reduction launch per hand-over, and the host is not needed between producer and consumer kernels.
+constexpr int MAIL_SLOT = 128;  // doubles per mailbox slot (slot 0: projected-matrix column, slot 1: residual)
+constexpr unsigned COUNT_GROUPS = 16;  // arrival counters: word 0 = groups done, words 1..16 = per group
+template <int N>
+__device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
+                                       double* __restrict__ dsums, double* mail, long long seq, double* red) {
+  __shared__ int s_last;
+  // the callers wrote their partials with coherent_store: once those stores have completed (waitcnt) the
+  // workgroup may be counted; no L2-wide fence (see sqd_device.h)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // two-level arrival count (COUNT_GROUPS group words + a top word): device-scope atomics on ONE word
+    // serialise at ~50 ns each, which for a few hundred workgroups costs more than the reduction itself
+    int last = 0;
+    const unsigned G = COUNT_GROUPS, grp = blockIdx.x % G;
+    const unsigned gsize = (gridDim.x - grp + G - 1) / G, ngroups = gridDim.x < G ? gridDim.x : G;
+    if (atomicAdd(&counter[1 + grp], 1u) == gsize - 1) {
+      atomicExch(&counter[1 + grp], 0u);  // ready for the next fused reduction on this stream
+      if (atomicAdd(&counter[0], 1u) == ngroups - 1) {
+        atomicExch(&counter[0], 0u);
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double vals[N];
+#pragma unroll
+  for (int v = 0; v < N; ++v) vals[v] = 0.0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      if (v < nv) vals[v] += coherent_load(&partial[(int64_t)b * width + v]);
+  }
+  block_sum_multi<N>(vals, nv, red);
+  if ((int)threadIdx.x < nv) {
+    const double s = block_sum_multi_get<N>(red, threadIdx.x);
+    dsums[threadIdx.x] = s;
+    mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = s;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *reinterpret_cast<volatile long long*>(mail) = seq;
+  }
+}
+
+// sums[0] = |X_{nvec-1}|^2, sums[1+v] = X_v . y  (v < nvec <= MV); y = A X_{nvec-1} in the Davidson loop
+template <int MV>
+__global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
+                            const double* __restrict__ y, double* __restrict__ partial, int width, unsigned* counter,
+                            double* __restrict__ dsums, double* mail, long long seq) {
+  __shared__ double red[16 * (MV + 1)];
+  double acc[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double yv = y[i];
+#pragma unroll
+    for (int v = 0; v < MV; ++v)
+      if (v < nvec) {
+        const double xv = X[(int64_t)v * stride + i];
+        acc[1 + v] += xv * yv;
+        if (v == nvec - 1) acc[0] += xv * xv;
+      }
+  }
+  block_sum_multi<MV + 1>(acc, nvec + 1, red);
+  if ((int)threadIdx.x < nvec + 1)
+    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
+  finish_and_post<MV + 1>(partial, width, nvec + 1, counter, dsums, mail, seq, red);
+}
+
+// t <- scale * t - sum_v g_v X_v with everything derived on the device from the residual kernel's totals
+// (dsums = {|r|^2, |t|^2, X_v . t}) and the per-vector normalisation factors sv (basis vector v is
+// sv_v * X_v): g'_v = sv_v (X_v . t) / |t|, c2 = sum g'_v^2.  The basis is orthonormal, so
+// |t/|t| - sum g'_v sv_v X_v|^2 = 1 - c2 is known before the vector is formed: when 1 - c2 > 1e-3 the
+// result is normalised in the same pass; otherwise it is left with its true (small) norm.  Either way the
+// next k_dots_post measures |X_new|^2 and the host carries 1/sqrt of it as sv_new, so no separate
+// normalisation pass and no host decision is needed here.
+__global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef sv,
+                           const double* __restrict__ dsums, double* __restrict__ t) {
+  __shared__ double g[SQD_MAX_SPACE + 2];
+  __shared__ double s_scale;
+  const double tt = dsums[1];
+  if ((int)threadIdx.x < nvec) g[threadIdx.x] = (tt > 0.0) ? sv.v[threadIdx.x] * dsums[2 + threadIdx.x] / sqrt(tt) : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double c2 = 0.0;
+    for (int v = 0; v < nvec; ++v) c2 += g[v] * g[v];
+    const double inv = (1.0 - c2 > 1e-3) ? 1.0 / sqrt(1.0 - c2) : 1.0;
+    s_scale = (tt > 0.0) ? inv / sqrt(tt) : 0.0;
+    for (int v = 0; v < nvec; ++v) g[v] *= inv * sv.v[v];
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = scale * t[i];
+    for (int v = 0; v < nvec; ++v) s -= g[v] * X[(int64_t)v * stride + i];
+    t[i] = s;
+  }
+}
+
+// host side of finish_and_post: wait for sequence word `seq` in mailbox slot `slot`, read nv totals
+static int wait_mail(sqd_ctx* c, int slot, long long seq, int nv, double* sums) {
+  const double* mail = c->h_mail + (size_t)slot * MAIL_SLOT;
+  volatile const long long* flag = reinterpret_cast<volatile const long long*>(mail);
+  bool seen = false;
+  for (long spin = 0; spin < 20000000L; ++spin) {
+    if (*flag == seq) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) {  // fall back to a plain synchronisation (also surfaces asynchronous kernel errors)
+    SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*flag != seq) {
+      set_error("device mailbox was not written");
+      return SQD_ERR_HIP;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int v = 0; v < nv; ++v) sums[v] = mail[MAIL_PAYLOAD + SCAL_RED + v];
+  return SQD_OK;
 }
 
 // sums[0..nv) = column sums of the device partial array; c->h_pinned[0..2) = scal[0..2).
@@ -392,20 +549,18 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
     hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, s, D, c->nb, tril_only, (const double*)c->hdiag.as<double>(),
                        pmin, pidx);
-    int64_t* d_addr = reinterpret_cast<int64_t*>(c->scal.as<double>() + 100);
-    hipLaunchKernelGGL(k_argmin_final, dim3(1), dim3(256), 0, s, (const double*)pmin, (const int64_t*)pidx, (int)gb, d_addr);
-    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, (const int64_t*)d_addr, X);
+    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, (const double*)pmin, (const int64_t*)pidx, (int)gb, X);
     SQD_HIP_CHECK(hipGetLastError());
   }
-  if (ci0_host) {  // a user vector still needs its norm; the built-in guess is normalised in closed form
-    double nn;
-    SQD_TRY(multi_dot(c, X, 0, 1, X, &nn));
-    if (!(nn > 0.0)) {
-      set_error("initial vector has zero norm");
-      return SQD_ERR_INVALID;
-    }
-    hipLaunchKernelGGL(k_scale, dim3(gb), dim3(RED_T), 0, s, D, 1.0 / std::sqrt(nn), X);
-  }
+  // (a user vector is not normalised on the device: the first fused reduction measures |X_0|^2 and the
+  // factor is carried in sv like that of every later basis vector)
+  double* scal = c->scal.as<double>();
+  double* dsums_col = scal + 8;    // totals of the latest k_dots_post
+  double* dsums_res = scal + 48;   // totals of the latest k_residual_precond (consumed by k_orth_dev)
+  unsigned* counter = reinterpret_cast<unsigned*>(scal + 104);
+  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, (COUNT_GROUPS + 1) * sizeof(unsigned), s));
+  double* mail_col = c->d_mail;
+  double* mail_res = c->d_mail + MAIL_SLOT;
 
   PenaltyDiag pd;
   {
@@ -423,101 +578,127 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   }
   std::vector<double> heff((size_t)nvecs * nvecs, 0.0), sub, w(nvecs), V((size_t)nvecs * nvecs);
   std::vector<double> sums(width);
-  Coef coef;
+  // Pipelined loop.  Per iteration the stream holds
+  //   sigma(X_new) -> k_dots_post [mailbox 0] -> (host: small eigenproblem) -> k_residual_precond [mailbox 1]
+  //   -> k_orth_dev -> (restart kernels)
+  // and the host enqueues the NEXT sigma + k_dots_post before it looks at mailbox 1: the residual norm only
+  // decides whether to stop, so the decision overlaps with the next sigma, and the one sigma in flight when
+  // the solve converges is discarded (never counted).  One host stall per iteration instead of two.
+  // Basis vector v is sv_v * X_v (sv_v = 1/|X_v|, measured by k_dots_post): normalisation never costs a pass.
+  Coef coef, raw, sv;
   int m = 1;  // basis size; X[m-1] is the newest vector, its sigma not yet built
   int mc = 1; // number of basis vectors the current Ritz coefficients refer to
   coef.v[0] = 1.0;
-  double e = 0.0, elast = 0.0, rnorm = 0.0;
-  bool conv = false, pending_norm_check = false;
-  int nsig = 0, it = 0;
+  sv.v[0] = 1.0;
+  double e = 0.0, elast = 0.0, rnorm = 0.0, de = 0.0;
+  bool conv = false, have_res = false, stop = false;
+  long long seq_res = 0;
+  int m_res = 0;  // basis size of the residual kernel whose mailbox is outstanding
+  int nsig = 0, nev = 0, it = 0;
+  // every time_sigma_every-th sigma launch of this context is bracketed by events (stats->ms_sigma); an
+  // event pair costs ~10 us of stream time, so this is sampling, and off unless asked for
+  const int ev_every = o->time_sigma_every > 0 ? o->time_sigma_every : 0;
+  const int max_ev = ev_every ? (int)c->sig_ev.size() / 2 : 0;
   bool first = true;
-  for (it = 0; it < o->max_cycle; ++it) {
-    // sigma for the newest basis vector
-    if (nsig < (int)c->sig_ev.size() / 2) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nsig], s));
-    SQD_TRY(apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift));
-    if (nsig < (int)c->sig_ev.size() / 2) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nsig + 1], s));
-    ++nsig;
-    // new column of the projected matrix
-    SQD_TRY(multi_dot(c, X, D, m, AX + (int64_t)(m - 1) * D, sums.data()));
-    if (pending_norm_check) {
-      pending_norm_check = false;
-      if (!(c->h_pinned[1] > lindep)) {
-        // the last correction vector was linearly dependent on the basis (it was zeroed on the
-        // device): stop with the Ritz vector of the previous projected problem (pyscf: 'Linear
-        // dependency in trial subspace')
-        conv = rnorm < toloose;
-        --nsig;
-        break;
-      }
+  // outcome of the outstanding residual hand-over: sets rnorm, conv, stop
+  auto settle_residual = [&]() -> int {
+    have_res = false;
+    SQD_TRY(wait_mail(c, 1, seq_res, m_res + 2, sums.data()));
+    rnorm = std::sqrt(sums[0]);
+    if (o->verbose)
+      std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", it - 1, m_res, e, de, rnorm);
+    if (std::fabs(de) < tol && rnorm < toloose) {
+      conv = true;
+      stop = true;
+    } else if (!(sums[0] > lindep) || !(sums[1] > 0.0)) {
+      conv = rnorm < toloose;
+      stop = true;
     }
-    for (int i = 0; i < m; ++i) heff[(size_t)i * nvecs + (m - 1)] = heff[(size_t)(m - 1) * nvecs + i] = sums[i];
+    return SQD_OK;
+  };
+  for (it = 0; it < o->max_cycle; ++it) {
+    // |dE| >= tol rules convergence out before the residual is known: only then is the next sigma enqueued
+    // ahead of the residual hand-over (nothing is wasted except on a linear-dependence stop)
+    if (have_res && std::fabs(de) < tol) {
+      SQD_TRY(settle_residual());
+      if (stop) break;
+    }
+    // sigma for the newest basis vector, and the new column of the projected matrix
+    const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
+    ++c->sigma_launches;
+    if (timed) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nev], s));
+    SQD_TRY(apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift));
+    if (timed) {
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nev + 1], s));
+      ++nev;
+    }
+    const long long seq_col = ++c->mail_seq;
+    if (max_space <= 12)
+      hipLaunchKernelGGL((k_dots_post<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
+                         (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
+                         mail_col, seq_col);
+    else
+      hipLaunchKernelGGL((k_dots_post<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
+                         (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
+                         mail_col, seq_col);
+    SQD_HIP_CHECK(hipGetLastError());
+    if (have_res) {
+      SQD_TRY(settle_residual());
+      if (stop) break;  // the sigma just enqueued is discarded
+    }
+    ++nsig;
+    SQD_TRY(wait_mail(c, 0, seq_col, m + 1, sums.data()));
+    const double nrm2 = sums[0];
+    if (it == 0 && !(nrm2 > 0.0)) {
+      set_error("initial vector has zero norm");
+      return SQD_ERR_INVALID;
+    }
+    if (!(nrm2 > lindep)) {
+      // the last correction vector was linearly dependent on the basis: stop with the Ritz vector of the
+      // previous projected problem (pyscf: 'Linear dependency in trial subspace')
+      conv = rnorm < toloose;
+      --nsig;
+      break;
+    }
+    sv.v[m - 1] = 1.0 / std::sqrt(nrm2);
+    for (int i = 0; i < m; ++i)
+      heff[(size_t)i * nvecs + (m - 1)] = heff[(size_t)(m - 1) * nvecs + i] = sums[1 + i] * sv.v[i] * sv.v[m - 1];
     sub.assign((size_t)m * m, 0.0);
     for (int i = 0; i < m; ++i)
       for (int j = 0; j < m; ++j) sub[(size_t)i * m + j] = heff[(size_t)i * nvecs + j];
     jacobi_eigh(m, sub.data(), w.data(), V.data());
     elast = e;
     e = w[0];
-    const double de = first ? e : e - elast;
+    de = first ? e : e - elast;
     first = false;
-    for (int i = 0; i < m; ++i) coef.v[i] = V[(size_t)i * m + 0];
+    for (int i = 0; i < m; ++i) {
+      coef.v[i] = V[(size_t)i * m + 0];
+      raw.v[i] = coef.v[i] * sv.v[i];  // coefficients on the stored (un-normalised) vectors
+    }
     mc = m;
-    // residual, preconditioned correction (into X[m]) and its overlaps
+    // residual, preconditioned correction (into X[m]) and its overlaps; then orthogonalisation on the device
     double* tnew = X + (int64_t)m * D;
+    seq_res = ++c->mail_seq;
+    m_res = m;
     if (max_space <= 12)
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m,
-                         coef, e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width);
+                         raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width, counter,
+                         dsums_res, mail_res, seq_res);
     else
       hipLaunchKernelGGL((k_residual_precond<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X,
-                         (const double*)AX, D, m, coef, e, (const double*)c->hdiag.as<double>(), pd, tnew,
-                         c->partial.as<double>(), width);
+                         (const double*)AX, D, m, raw, e, (const double*)c->hdiag.as<double>(), pd, tnew,
+                         c->partial.as<double>(), width, counter, dsums_res, mail_res, seq_res);
+    hipLaunchKernelGGL(k_orth_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv, (const double*)dsums_res,
+                       tnew);
     SQD_HIP_CHECK(hipGetLastError());
-    SQD_TRY(fetch_sums(c, (int)gb, width, m + 2, sums.data()));
-    rnorm = std::sqrt(sums[0]);
-    if (o->verbose)
-      std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", it, m, e, de, rnorm);
-    if (std::fabs(de) < tol && rnorm < toloose) {
-      conv = true;
-      ++it;
-      break;
-    }
-    if (!(sums[0] > lindep) || !(sums[1] > 0.0)) {
-      conv = rnorm < toloose;
-      ++it;
-      break;
-    }
-    const double tn = std::sqrt(sums[1]);
-    Coef gs;
-    double c2 = 0.0;
-    for (int i = 0; i < m; ++i) {
-      gs.v[i] = sums[2 + i] / tn;
-      c2 += gs.v[i] * gs.v[i];
-    }
-    if (1.0 - c2 > 1e-3) {
-      // The basis is orthonormal, so |t/tn - sum c_i X_i|^2 = 1 - sum c_i^2 is known before the vector is
-      // formed: orthogonalise AND normalise in one pass (relative error of the norm <= eps / (1 - c2)).
-      const double inv = 1.0 / std::sqrt(1.0 - c2);
-      for (int i = 0; i < m; ++i) gs.v[i] *= inv;
-      hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, inv / tn, tnew,
-                         c->partial.as<double>());
-      SQD_HIP_CHECK(hipGetLastError());
-    } else {
-      // correction nearly inside the span: explicit norm after orthogonalisation (device side; the norm
-      // is inspected at the next host round trip for the linear-dependence check)
-      hipLaunchKernelGGL(k_orth, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, gs, 1.0 / tn, tnew,
-                         c->partial.as<double>());
-      hipLaunchKernelGGL(k_norm_to_scale, dim3(1), dim3(128), 0, s, (const double*)c->partial.as<double>(), (int)gb, lindep,
-                         c->scal.as<double>());
-      hipLaunchKernelGGL(k_scale_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)c->scal.as<double>(), tnew);
-      SQD_HIP_CHECK(hipGetLastError());
-      pending_norm_check = true;
-    }
+    have_res = true;
     if (m + 1 > max_space) {
       // collapse: X0 <- Ritz vector, AX0 <- A*Ritz (linear combination), X1 <- correction
       double* x0 = c->sol.as<double>();
       SQD_TRY(c->tmp1.reserve((size_t)D * 8));
       double* ax0 = c->tmp1.as<double>();
-      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, coef, x0);
-      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)AX, D, m, coef, ax0);
+      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, raw, x0);
+      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)AX, D, m, raw, ax0);
       SQD_HIP_CHECK(hipMemcpyAsync(X + D, tnew, D * 8, hipMemcpyDeviceToDevice, s));
       SQD_HIP_CHECK(hipMemcpyAsync(X, x0, D * 8, hipMemcpyDeviceToDevice, s));
       SQD_HIP_CHECK(hipMemcpyAsync(AX, ax0, D * 8, hipMemcpyDeviceToDevice, s));
@@ -526,22 +707,23 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
       m = 2;
       coef.v[0] = 1.0;  // the Ritz vector is now X0
       coef.v[1] = 0.0;
+      sv.v[0] = 1.0;
       mc = 1;
     } else {
       ++m;
     }
   }
+  if (have_res) SQD_TRY(settle_residual());  // cycle limit reached: the last residual still decides `converged`
   // solution = Ritz vector of the last projected problem, normalised
   {
     const int mm = mc;
     double* x0 = c->sol.as<double>();
-    // X is orthonormal and the Ritz coefficients have unit norm, so the combination is normalised to
+    // the basis is orthonormal and the Ritz coefficients have unit norm, so the combination is normalised to
     // rounding (the observables divide by <c|c> anyway); no extra reduction + host round trip
     double cn = 0.0;
     for (int i = 0; i < mm; ++i) cn += coef.v[i] * coef.v[i];
     Coef cf = coef;
-    if (cn > 0.0)
-      for (int i = 0; i < mm; ++i) cf.v[i] = coef.v[i] / std::sqrt(cn);
+    for (int i = 0; i < mm; ++i) cf.v[i] = (cn > 0.0 ? coef.v[i] / std::sqrt(cn) : coef.v[i]) * sv.v[i];
     hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, cf, x0);
     SQD_HIP_CHECK(hipGetLastError());
   }
@@ -563,13 +745,13 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     st->residual = rnorm;
     st->ms_total = ms;
     double msig = 0.0;
-    const int nev = nsig < (int)c->sig_ev.size() / 2 ? nsig : (int)c->sig_ev.size() / 2;
     for (int i = 0; i < nev; ++i) {
       float t = 0.f;
       SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[2 * i], c->sig_ev[2 * i + 1]));
       msig += t;
     }
-    st->ms_sigma = (nev > 0) ? msig * nsig / nev : 0.0;
+    st->ms_sigma = msig;
+    st->n_sigma_timed = nev;
     st->ms_setup = c->ms_setup;
   }
   return SQD_OK;

@@ -173,6 +173,14 @@ template <class T> inline T atomicAdd(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());
   T old = *p; *p = old + v; return old;
 }
+template <class T> inline T atomicExch(T* p, T v) {
+  std::lock_guard<std::mutex> g(emu::atomic_mu());
+  T old = *p; *p = v; return old;
+}
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 template <class T> inline T atomicMax(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());
   T old = *p; if (v > old) *p = v; return old;
