@@ -67,8 +67,8 @@ def make_batch(args, seed):
 def one_step(ctx, sa, sb, spin_sq, time_every=0):
     """Native body of solve_fermion (qiskit_addon_sqd_amd/fermion.py) on a resident Hamiltonian."""
     ctx.set_subspace(sa, sb)
-    amps, st = ctx.davidson(spin_sq=spin_sq, shift=0.1, time_sigma_every=time_every)
-    e, s2, occ_a, occ_b = ctx.observables()
+    amps, st, (e, s2, occ_a, occ_b) = ctx.davidson(spin_sq=spin_sq, shift=0.1, time_sigma_every=time_every,
+                                                   observables=True)
     return e, occ_a, occ_b, s2, st, amps
 
 

@@ -129,6 +129,13 @@ int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0,
  * (fermion.py:820-830) in one call with one host synchronisation: e = <c|H|c>/<c|c>, s2 = <c|S^2|c>/<c|c>,
  * occ_a/occ_b[norb] = diagonals of dm1a/dm1b. */
 int sqd_observables(sqd_ctx* ctx, const double* amps, double* e, double* s2, double* occ_a, double* occ_b);
+
+/* sqd_solve = sqd_davidson + sqd_observables of the solution, as one call: everything reference
+ * solve_fermion does between building the solver and returning (fermion.py:803-830).  The observables'
+ * kernels run while the amplitudes travel to the host on a second stream; one host synchronisation.
+ * Any of amps / stats / e / s2 / occ_a / occ_b may be NULL. */
+int sqd_solve(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, double* amps,
+              sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b);
 int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
 int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
 int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "sqd_davidson_default_opts",
     "sqd_davidson",
     "sqd_observables",
+    "sqd_solve",
     "sqd_energy",
     "sqd_spin_square",
     "sqd_rdm1s",
@@ -105,6 +106,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_davidson_default_opts.restype = None
     lib.sqd_davidson.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats)]
     lib.sqd_observables.argtypes = [_ctxp, _dp, _dp, _dp, _dp, _dp]
+    lib.sqd_solve.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats), _dp, _dp, _dp, _dp]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
@@ -284,7 +286,11 @@ class Context:
         verbose: int = 0,
         fetch: bool = True,
         time_sigma_every: int = 0,
+        observables: bool = False,
     ):
+        """Ground state of the projected Hamiltonian.  Returns (amps, stats); with ``observables=True`` the
+        fused native call ``sqd_solve`` is used and (amps, stats, (energy, spin_square, occ_a, occ_b)) is
+        returned -- the observables' kernels overlap the transfer of the amplitudes."""
         opts = DavidsonOpts()
         self._lib.sqd_davidson_default_opts(C.byref(opts))
         opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
@@ -299,6 +305,15 @@ class Context:
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(self.na, self.nb)
             ci0p = _ptr(ci0)
+        if observables:
+            e, s2 = C.c_double(), C.c_double()
+            occ_a, occ_b = np.empty(self.norb), np.empty(self.norb)
+            self._check(
+                self._lib.sqd_solve(self._h, C.byref(opts), ci0p, _ptr(amps) if fetch else None, C.byref(stats),
+                                    C.byref(e), C.byref(s2), _ptr(occ_a), _ptr(occ_b))
+            )
+            return (amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_},
+                    (e.value, s2.value, occ_a, occ_b))
         self._check(
             self._lib.sqd_davidson(self._h, C.byref(opts), ci0p, _ptr(amps) if fetch else None, C.byref(stats))
         )

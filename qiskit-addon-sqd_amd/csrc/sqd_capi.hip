@@ -50,6 +50,13 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
     delete c;
     return SQD_ERR_HIP;
   }
+  e = hipStreamCreate(&c->copy_stream);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_sol);
+  if (e != hipSuccess) {
+    set_error(std::string("hipStreamCreate/hipEventCreate: ") + hipGetErrorString(e));
+    delete c;
+    return SQD_ERR_HIP;
+  }
   for (int i = 0; i < 4; ++i) {
     e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
@@ -107,6 +114,9 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
     if (evt) e = hipEventDestroy(evt);
   if (c->h_pinned) e = hipHostFree(c->h_pinned);
   if (c->h_mail) e = hipHostFree(c->h_mail);
+  if (c->h_amps) e = hipHostFree(c->h_amps);
+  if (c->ev_sol) e = hipEventDestroy(c->ev_sol);
+  if (c->copy_stream) e = hipStreamDestroy(c->copy_stream);
   if (c->stream) e = hipStreamDestroy(c->stream);
   delete c;
   return SQD_OK;
@@ -319,6 +329,59 @@ SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s
   SQD_TRY(state_ptr(c, amps, &d));
   std::vector<double> out(3 + 2 * c->norb);
   SQD_TRY(dev_observables(c, d, out.data()));
+  if (!(out[2] > 0.0)) {
+    set_error("state has zero norm");
+    return SQD_ERR_INVALID;
+  }
+  if (e) *e = out[0] / out[2];
+  if (s2) *s2 = out[1] / out[2];
+  for (int p = 0; p < c->norb; ++p) {
+    if (occ_a) occ_a[p] = out[3 + p] / out[2];
+    if (occ_b) occ_b[p] = out[3 + c->norb + p] / out[2];
+  }
+  return SQD_OK;
+}
+
+// One call for the whole of solve_fermion's device work: Davidson, then the observables' kernels on the
+// compute stream WHILE the amplitudes travel to the host on the copy stream; one synchronisation.
+SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* ci0, double* amps,
+                      sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  sqd_davidson_opts o;
+  if (opts) o = *opts; else sqd_davidson_default_opts(&o);
+  if (o.tol <= 0 || o.max_cycle < 1) {
+    set_error("bad Davidson options");
+    return SQD_ERR_INVALID;
+  }
+  SQD_TRY(run_davidson(c, &o, ci0, stats, /*defer_sync=*/true));
+  const size_t bytes = (size_t)c->D * 8;
+  // small states go through a pinned staging buffer (a truly asynchronous copy); large ones straight to
+  // the caller's memory
+  const bool staged = amps && bytes <= (size_t(64) << 20);
+  if (amps) {
+    SQD_HIP_CHECK(hipEventRecord(c->ev_sol, c->stream));
+    SQD_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_sol, 0));
+    if (staged) {
+      if (c->h_amps_cap < bytes) {
+        if (c->h_amps) SQD_HIP_CHECK(hipHostFree(c->h_amps));
+        c->h_amps = nullptr;
+        c->h_amps_cap = 0;
+        SQD_HIP_CHECK(hipHostMalloc((void**)&c->h_amps, bytes, hipHostMallocDefault));
+        c->h_amps_cap = bytes;
+      }
+      SQD_HIP_CHECK(hipMemcpyAsync(c->h_amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+  }
+  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>()));
+  if (amps && !staged)
+    SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+  if (amps) SQD_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+  if (staged) std::memcpy(amps, c->h_amps, bytes);
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  SQD_TRY(davidson_collect_timings(c, stats));
+  std::vector<double> out(3 + 2 * c->norb);
+  dev_observables_collect(c, out.data());
   if (!(out[2] > 0.0)) {
     set_error("state has zero norm");
     return SQD_ERR_INVALID;

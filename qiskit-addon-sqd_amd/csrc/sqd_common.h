@@ -171,6 +171,13 @@ struct sqd_ctx {
   int64_t sigma_launches = 0;  // sigma launches of Davidson runs on this context (event sampling)
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
+  // sqd_solve: amplitudes travel to a pinned staging buffer on their own stream while the observables'
+  // kernels run on the compute stream
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_sol = nullptr;
+  double* h_amps = nullptr;
+  size_t h_amps_cap = 0;
+  int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)
 };
 
 namespace sqd {
@@ -182,9 +189,15 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift);
 // blas-1 (sqd_davidson.hip)
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
-int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st);
+// defer_sync: return with the solution still being formed on the stream; the caller synchronises and
+// then calls davidson_collect_timings (the non-timing fields of *st are final on return either way)
+int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
+                 bool defer_sync = false);
+int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st);
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
 int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c);   // kernels + result copy, no synchronisation
+void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised
 }  // namespace sqd

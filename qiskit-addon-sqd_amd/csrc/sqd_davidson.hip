@@ -516,7 +516,8 @@ static void jacobi_eigh(int n, const double* Ain, double* w, double* V) {
   std::memcpy(V, Vs.data(), sizeof(double) * n * n);
 }
 
-int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st) {
+int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
+                 bool defer_sync) {
   if (!c->have_subspace) {
     set_error("no subspace set");
     return SQD_ERR_STATE;
@@ -728,30 +729,40 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     SQD_HIP_CHECK(hipGetLastError());
   }
   SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
-  SQD_HIP_CHECK(hipStreamSynchronize(s));
-  float ms = 0.f;
-  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
   c->have_solution = true;
-  if (c->ms_setup < 0.0) {
-    float tms = 0.f;
-    SQD_HIP_CHECK(hipEventElapsedTime(&tms, c->ev[0], c->ev[1]));
-    c->ms_setup = tms;
-  }
+  c->dav_nev = nev;
   if (st) {
     st->converged = conv ? 1 : 0;
     st->iterations = it;
     st->n_sigma = nsig;
     st->e_davidson = e;
     st->residual = rnorm;
+    st->ms_total = st->ms_sigma = st->ms_setup = 0.0;
+    st->n_sigma_timed = nev;
+  }
+  if (defer_sync) return SQD_OK;
+  SQD_HIP_CHECK(hipStreamSynchronize(s));
+  return davidson_collect_timings(c, st);
+}
+
+// event timings of the latest run (the stream must have been synchronised since)
+int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st) {
+  float ms = 0.f;
+  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  if (c->ms_setup < 0.0) {
+    float tms = 0.f;
+    SQD_HIP_CHECK(hipEventElapsedTime(&tms, c->ev[0], c->ev[1]));
+    c->ms_setup = tms;
+  }
+  if (st) {
     st->ms_total = ms;
     double msig = 0.0;
-    for (int i = 0; i < nev; ++i) {
+    for (int i = 0; i < c->dav_nev; ++i) {
       float t = 0.f;
       SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[2 * i], c->sig_ev[2 * i + 1]));
       msig += t;
     }
     st->ms_sigma = msig;
-    st->n_sigma_timed = nev;
     st->ms_setup = c->ms_setup;
   }
   return SQD_OK;

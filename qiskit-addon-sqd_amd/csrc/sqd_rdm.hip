@@ -280,6 +280,16 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
 // (occupancies un-normalised).  This is everything solve_fermion needs after the Davidson
 // (reference fermion.py:820-830) without building the off-diagonal RDM elements.
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
+  SQD_TRY(dev_observables_enqueue(c, d_c));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  dev_observables_collect(c, out_host);
+  return SQD_OK;
+}
+void dev_observables_collect(sqd_ctx* c, double* out_host) {
+  const int nres = 3 + 2 * c->norb;
+  for (int i = 0; i < nres; ++i) out_host[i] = c->h_pinned[i];
+}
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c) {
   const int norb = c->norb;
   hipStream_t st = c->stream;
   const int64_t D = c->D;
@@ -306,8 +316,6 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
                      (const double*)wb, 1, res + 3 + norb);
   SQD_HIP_CHECK(hipGetLastError());
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, res, nres * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipStreamSynchronize(st));
-  for (int i = 0; i < nres; ++i) out_host[i] = c->h_pinned[i];
   return SQD_OK;
 }
 

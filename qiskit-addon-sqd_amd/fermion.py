@@ -240,13 +240,16 @@ def _davidson_kwargs(kwargs: dict) -> dict:
     return out
 
 
-def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs):
-    """Shared core: tables -> Davidson -> observables, all on the device."""
+def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True):
+    """Shared core: tables -> Davidson (-> energy, <S^2>, occupancies in the same native call), all on the
+    device.  Returns (amps, stats, obs) with obs = (energy, spin_square, occ_a, occ_b) or None."""
     ctx.set_subspace(ci_strs[0], ci_strs[1])
     dk = _davidson_kwargs(kwargs)
     ci0 = dk.pop("ci0", None)
+    if observables:
+        return ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, observables=True, **dk)
     amps, stats = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, **dk)
-    return amps, stats
+    return amps, stats, None
 
 
 def solve_sci_batch(
@@ -319,7 +322,7 @@ def solve_sci(
     norb, _ = one_body_tensor.shape
     ctx = _get_context(one_body_tensor, two_body_tensor, device, _slot)
     strs_a, strs_b = ci_strings
-    amps, _stats = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs)
+    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not compute_rdms)
     if tuple(int(x) for x in nelec) != ctx.nelec:
         raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
     if compute_rdms:
@@ -331,7 +334,7 @@ def solve_sci(
         energy = float(np.einsum("pr,pr->", dm1, one_body_tensor) + 0.5 * np.einsum("prqs,prqs->", dm2, two))
     else:
         dm1 = dm2 = None
-        energy, _s2, occ_a, occ_b = ctx.observables()  # one native call, one device round trip
+        energy, _s2, occ_a, occ_b = obs  # from the fused native call (sqd_solve)
         occupancies = (occ_a, occ_b)
     sci_state = SCIState(
         amplitudes=amps,
@@ -369,12 +372,10 @@ def solve_fermion(
     hcore = np.asarray(hcore, dtype=np.float64)
     norb = hcore.shape[0]
     ctx = _get_context(hcore, eri, device)
-    amps, _stats = _solve(ctx, ci_strs, spin_sq, shift, kwargs)
+    # one native call (sqd_solve): Davidson, then <c|H|c> (the quantity the reference rebuilds from
+    # rdm1/rdm2, :825-827), <S^2> (:830) and the rdm1s diagonals (:821-822) while the amplitudes travel
+    amps, _stats, (e_sci, spin_squared, occ_a, occ_b) = _solve(ctx, ci_strs, spin_sq, shift, kwargs)
     num_up, num_dn = ctx.nelec
-
-    # one native call: <c|H|c> (the quantity the reference rebuilds from rdm1/rdm2, :825-827), <S^2> (:830)
-    # and the rdm1s diagonals (:821-822)
-    e_sci, spin_squared, occ_a, occ_b = ctx.observables()
     avg_occupancy = (occ_a, occ_b)
     sci_state = SCIState(
         amplitudes=amps,
