@@ -52,6 +52,7 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
   }
   e = hipStreamCreate(&c->copy_stream);
   if (e == hipSuccess) e = hipEventCreate(&c->ev_sol);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_aux);
   if (e != hipSuccess) {
     set_error(std::string("hipStreamCreate/hipEventCreate: ") + hipGetErrorString(e));
     delete c;
@@ -116,6 +117,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->h_mail) e = hipHostFree(c->h_mail);
   if (c->h_amps) e = hipHostFree(c->h_amps);
   if (c->ev_sol) e = hipEventDestroy(c->ev_sol);
+  if (c->ev_aux) e = hipEventDestroy(c->ev_aux);
   if (c->copy_stream) e = hipStreamDestroy(c->copy_stream);
   if (c->stream) e = hipStreamDestroy(c->stream);
   delete c;

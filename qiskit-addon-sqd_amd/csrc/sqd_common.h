@@ -175,6 +175,7 @@ struct sqd_ctx {
   // kernels run on the compute stream
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_sol = nullptr;
+  hipEvent_t ev_aux = nullptr;  // set_subspace: "CSR pointers are on the host" (later kernels keep running)
   double* h_amps = nullptr;
   size_t h_amps_cap = 0;
   int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)

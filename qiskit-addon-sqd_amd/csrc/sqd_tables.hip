@@ -397,17 +397,19 @@ __global__ void k_merge_hs(int64_t n, const int64_t* __restrict__ s_ptr, const i
                            const SRec* __restrict__ s_rec, const double* __restrict__ s_val,
                            const uint32_t* __restrict__ d_src, const double* __restrict__ d_val,
                            int64_t* __restrict__ hs_ptr, uint32_t* __restrict__ hs_src, double* __restrict__ hs_val) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // one wavefront per row (rows of the Hartree-Fock neighbourhood hold hundreds of links)
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i > n) return;
   const int64_t o = s_ptr[i] + d_ptr[i];
-  hs_ptr[i] = o;
+  if (lane == 0) hs_ptr[i] = o;
   if (i == n) return;
   const int64_t s0 = s_ptr[i], ns = s_ptr[i + 1] - s0, d0 = d_ptr[i], nd = d_ptr[i + 1] - d0;
-  for (int64_t k = 0; k < ns; ++k) {
+  for (int64_t k = lane; k < ns; k += 64) {
     hs_src[o + k] = s_rec[s0 + k].src;
     hs_val[o + k] = s_val[s0 + k];
   }
-  for (int64_t k = 0; k < nd; ++k) {
+  for (int64_t k = lane; k < nd; k += 64) {
     hs_src[o + ns + k] = d_src[d0 + k];
     hs_val[o + ns + k] = d_val[d0 + k];
   }
@@ -661,7 +663,31 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   c->h_ptrs.resize(nptr);
   SQD_HIP_CHECK(hipMemcpyAsync(c->h_ptrs.data(), c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  SQD_HIP_CHECK(hipEventRecord(c->ev_aux, st));
+  // everything that needs only the strings is queued BEHIND the copy and runs while the host waits for the
+  // pointers and cuts the work lists: per-string energies, occupation tables, the diagonal
+  SQD_TRY(c->hdiag.reserve((size_t)na * nb * 8));
+  for (int s = 0; s < 2; ++s) {
+    SpinTables& t = c->sp[s];
+    SQD_TRY(t.e_str.reserve(t.n * 8));
+    hipLaunchKernelGGL(k_string_energy, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
+                       c->h1.as<double>(), c->jm.as<double>(), c->km.as<double>(), norb, t.e_str.as<double>());
+    const int64_t nj = t.n * nnorb;
+    if (s == 0) {
+      SQD_TRY(t.jrow.reserve(nj * 8));
+      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
+                         c->eri_pp.as<double>(), nnorb, 0, t.jrow.as<double>());
+    } else {
+      SQD_TRY(t.jT.reserve(nj * 8));
+      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
+                         c->eri_pp.as<double>(), nnorb, 1, t.jT.as<double>());
+    }
+  }
+  hipLaunchKernelGGL(k_hdiag, dim3(nblk(na * nb, 256)), dim3(256), 0, st, c->sp[0].strs.as<uint64_t>(),
+                     c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
+                     c->hdiag.as<double>());
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_HIP_CHECK(hipEventSynchronize(c->ev_aux));
   c->h_sptr = c->h_ptrs.data();
   c->h_dptr = c->h_sptr + (na + 1);
   c->h_sptr_b = c->h_dptr + (na + 1);
@@ -691,26 +717,14 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       hipLaunchKernelGGL(k_decorate_doubles, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n_d,
                          t.d_row.as<uint32_t>(), t.d_src.as<uint32_t>(), t.d_orb.as<uint32_t>(), t.d_val.as<double>(),
                          c->eri4.as<double>(), norb);
-    // per-string tables
-    SQD_TRY(t.e_str.reserve(t.n * 8));
-    hipLaunchKernelGGL(k_string_energy, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                       c->h1.as<double>(), c->jm.as<double>(), c->km.as<double>(), norb, t.e_str.as<double>());
-    const int64_t nj = t.n * nnorb;
     if (s == 0) {
       // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY work items
       SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
       SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
       SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
-      hipLaunchKernelGGL(k_merge_hs, dim3(nblk(t.n + 1, 256)), dim3(256), 0, st, t.n, t.s_ptr.as<int64_t>(),
+      hipLaunchKernelGGL(k_merge_hs, dim3(nblk(t.n + 1, 4)), dim3(256), 0, st, t.n, t.s_ptr.as<int64_t>(),
                          t.d_ptr.as<int64_t>(), t.s_rec.as<SRec>(), t.s_val.as<double>(), t.d_src.as<uint32_t>(),
                          t.d_val.as<double>(), t.hs_ptr.as<int64_t>(), t.hs_src.as<uint32_t>(), t.hs_val.as<double>());
-      SQD_TRY(t.jrow.reserve(nj * 8));
-      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                         c->eri_pp.as<double>(), nnorb, 0, t.jrow.as<double>());
-    } else {
-      SQD_TRY(t.jT.reserve(nj * 8));
-      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                         c->eri_pp.as<double>(), nnorb, 1, t.jT.as<double>());
     }
     SQD_HIP_CHECK(hipGetLastError());
   }
@@ -807,11 +821,6 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   c->nelec[0] = nocc[0];
   c->nelec[1] = nocc[1];
   SQD_TRY(build_sigma_work(c));
-  SQD_TRY(c->hdiag.reserve((size_t)c->D * 8));
-  hipLaunchKernelGGL(k_hdiag, dim3(nblk(c->D, 256)), dim3(256), 0, st, c->sp[0].strs.as<uint64_t>(),
-                     c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
-                     c->hdiag.as<double>());
-  SQD_HIP_CHECK(hipGetLastError());
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
   SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
   c->ms_setup = -1.0;
