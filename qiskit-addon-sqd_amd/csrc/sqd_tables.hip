@@ -85,8 +85,8 @@ __global__ void k_pack_eri(const double* __restrict__ eri4, int norb, int nnorb,
 
 // ------------------------------------------------------------------ pair enumeration
 // One wavefront per target string I.  pc = popcount(I ^ J): 2 -> single, 4 -> double.
-__global__ void k_count_links(const uint64_t* __restrict__ strs, int64_t n, int64_t* __restrict__ cnt_s,
-                              int64_t* __restrict__ cnt_d) {
+__device__ inline void count_links_body(const uint64_t* __restrict__ strs, int64_t n, int64_t* __restrict__ cnt_s,
+                                        int64_t* __restrict__ cnt_d) {
   const int lane = threadIdx.x & 63;
   const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= n) return;  // whole wave leaves together
@@ -105,10 +105,10 @@ __global__ void k_count_links(const uint64_t* __restrict__ strs, int64_t n, int6
   }
 }
 
-__global__ void k_fill_links(const uint64_t* __restrict__ strs, int64_t n, const int64_t* __restrict__ s_ptr,
-                             const int64_t* __restrict__ d_ptr, SRec* __restrict__ s_rec,
-                             uint32_t* __restrict__ s_row, uint32_t* __restrict__ d_src,
-                             uint32_t* __restrict__ d_row) {
+__device__ inline void fill_links_body(const uint64_t* __restrict__ strs, int64_t n, const int64_t* __restrict__ s_ptr,
+                                       const int64_t* __restrict__ d_ptr, SRec* __restrict__ s_rec,
+                                       uint32_t* __restrict__ s_row, uint32_t* __restrict__ d_src,
+                                       uint32_t* __restrict__ d_row) {
   const int lane = threadIdx.x & 63;
   const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= n) return;
@@ -167,9 +167,10 @@ __global__ void k_exclusive_scan(const int64_t* __restrict__ in, int64_t* __rest
 
 // ------------------------------------------------------------------ link decoration
 // |I> = sign a+_cre a_des |J>;  value = sign * (h[cre,des] + sum_{k in J, k != des} (cre des|kk) - (cre k|k des))
-__global__ void k_decorate_singles(const uint64_t* __restrict__ strs, int64_t n_s, const uint32_t* __restrict__ s_row,
-                                   SRec* __restrict__ s_rec, double* __restrict__ s_val,
-                                   const double* __restrict__ h1, const double* __restrict__ eri4, int norb) {
+__device__ inline void decorate_singles_body(const uint64_t* __restrict__ strs, int64_t n_s,
+                                             const uint32_t* __restrict__ s_row, SRec* __restrict__ s_rec,
+                                             double* __restrict__ s_val, const double* __restrict__ h1,
+                                             const double* __restrict__ eri4, int norb) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= n_s) return;
   const uint64_t I = strs[s_row[l]];
@@ -195,9 +196,10 @@ __global__ void k_decorate_singles(const uint64_t* __restrict__ strs, int64_t n_
 }
 
 // |I> = sign a+_p a+_r a_s a_q |J>, p>r, q>s;  value = sign * ((pq|rs) - (ps|rq))
-__global__ void k_decorate_doubles(const uint64_t* __restrict__ strs, int64_t n_d, const uint32_t* __restrict__ d_row,
-                                   const uint32_t* __restrict__ d_src, uint32_t* __restrict__ d_orb,
-                                   double* __restrict__ d_val, const double* __restrict__ eri4, int norb) {
+__device__ inline void decorate_doubles_body(const uint64_t* __restrict__ strs, int64_t n_d,
+                                             const uint32_t* __restrict__ d_row, const uint32_t* __restrict__ d_src,
+                                             uint32_t* __restrict__ d_orb, double* __restrict__ d_val,
+                                             const double* __restrict__ eri4, int norb) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= n_d) return;
   const uint64_t I = strs[d_row[l]];
@@ -228,9 +230,9 @@ __global__ void k_decorate_doubles(const uint64_t* __restrict__ strs, int64_t n_
 
 // ------------------------------------------------------------------ per-string tables
 // e_str[I] = sum_{i in I} h_ii + 1/2 sum_{i,j in I} (J_ij - K_ij)
-__global__ void k_string_energy(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ h1,
-                                const double* __restrict__ jm, const double* __restrict__ km, int norb,
-                                double* __restrict__ e_str) {
+__device__ inline void string_energy_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ h1,
+                                          const double* __restrict__ jm, const double* __restrict__ km, int norb,
+                                          double* __restrict__ e_str) {
   // one wavefront per string: lane l takes the orbital pairs (i, j) = (l / nocc, l % nocc), l += 64;
   // the shuffle tree adds them in fixed order
   const int lane = threadIdx.x & 63;
@@ -255,8 +257,8 @@ __global__ void k_string_energy(const uint64_t* __restrict__ strs, int64_t n, co
 }
 
 // J[I][pair] = sum_{k in I} (pair|kk).  transposed == 0: out[I*nnorb + pair]; else out[pair*n + I]
-__global__ void k_jtable(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ eri_pp, int nnorb,
-                         int transposed, double* __restrict__ out) {
+__device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ eri_pp,
+                                   int nnorb, int transposed, double* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * nnorb) return;
   int64_t I, pair;
@@ -275,6 +277,50 @@ __global__ void k_jtable(const uint64_t* __restrict__ strs, int64_t n, const dou
     v += eri_pp[pair * nnorb + (int64_t)k * (k + 1) / 2 + k];
   }
   out[idx] = v;
+}
+
+// ---- both spins in one launch (gridDim.y = 2): at the sizes of one subsample batch these kernels run a few
+// microseconds each, less than it costs the host to enqueue one, so halving the launches is what counts
+struct SpinLinkArgs {
+  const uint64_t* strs;
+  int64_t n, n_s, n_d;
+  int64_t *cnt_s, *cnt_d;        // pass 1
+  int64_t *s_ptr, *d_ptr;        // pass 2
+  SRec* s_rec;
+  uint32_t *s_row, *d_src, *d_row, *d_orb;
+  double *s_val, *d_val;
+  double* e_str;
+  double* jtab;                  // jrow (alpha: [I][pair]) or jT (beta: [pair][I])
+  int transposed;
+};
+struct SpinLinkArgs2 {
+  SpinLinkArgs a[2];
+};
+__global__ void k_count_links2(const SpinLinkArgs2 p) {
+  const SpinLinkArgs& a = p.a[blockIdx.y];
+  count_links_body(a.strs, a.n, a.cnt_s, a.cnt_d);
+}
+__global__ void k_fill_links2(const SpinLinkArgs2 p) {
+  const SpinLinkArgs& a = p.a[blockIdx.y];
+  fill_links_body(a.strs, a.n, a.s_ptr, a.d_ptr, a.s_rec, a.s_row, a.d_src, a.d_row);
+}
+// singles and doubles of both spins: blockIdx.y = 2 * spin + (0 singles | 1 doubles)
+__global__ void k_decorate_links2(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ eri4,
+                                  int norb) {
+  const SpinLinkArgs& a = p.a[blockIdx.y >> 1];
+  if ((blockIdx.y & 1) == 0)
+    decorate_singles_body(a.strs, a.n_s, a.s_row, a.s_rec, a.s_val, h1, eri4, norb);
+  else
+    decorate_doubles_body(a.strs, a.n_d, a.d_row, a.d_src, a.d_orb, a.d_val, eri4, norb);
+}
+// per-string energies (blockIdx.y = spin) and occupation tables (blockIdx.y = 2 + spin)
+__global__ void k_string_tables2(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ jm,
+                                 const double* __restrict__ km, const double* __restrict__ eri_pp, int norb, int nnorb) {
+  const SpinLinkArgs& a = p.a[blockIdx.y & 1];
+  if (blockIdx.y < 2)
+    string_energy_body(a.strs, a.n, h1, jm, km, norb, a.e_str);
+  else
+    jtable_body(a.strs, a.n, eri_pp, nnorb, a.transposed, a.jtab);
 }
 
 // hdiag[A,B] = e_a[A] + e_b[B] + sum_{i in A} JT_b[tril(i,i)][B]
@@ -643,6 +689,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->sp[1].s_ptr.set_view(base + 2 * (na + 1));
     c->sp[1].d_ptr.set_view(base + 2 * (na + 1) + (nb + 1));
   }
+  SpinLinkArgs2 la;  // both spins' arguments, filled in as the buffers come to exist
+  std::memset(&la, 0, sizeof(la));
   {
     int64_t* d_cnt = c->scratch.as<int64_t>();  // [cnt_s_a | cnt_d_a | cnt_s_b | cnt_d_b], maxn each
     ScanJobs jobs;
@@ -650,7 +698,13 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       SpinTables& t = c->sp[s];
       int64_t* cnt_s = d_cnt + (2 * s) * maxn;
       int64_t* cnt_d = d_cnt + (2 * s + 1) * maxn;
-      hipLaunchKernelGGL(k_count_links, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n, cnt_s, cnt_d);
+      la.a[s].strs = t.strs.as<uint64_t>();
+      la.a[s].n = t.n;
+      la.a[s].cnt_s = cnt_s;
+      la.a[s].cnt_d = cnt_d;
+      la.a[s].s_ptr = t.s_ptr.as<int64_t>();
+      la.a[s].d_ptr = t.d_ptr.as<int64_t>();
+      if (s == 1) hipLaunchKernelGGL(k_count_links2, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la);
       jobs.in[2 * s] = cnt_s;
       jobs.out[2 * s] = t.s_ptr.as<int64_t>();
       jobs.n[2 * s] = t.n;
@@ -670,18 +724,16 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     SQD_TRY(t.e_str.reserve(t.n * 8));
-    hipLaunchKernelGGL(k_string_energy, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                       c->h1.as<double>(), c->jm.as<double>(), c->km.as<double>(), norb, t.e_str.as<double>());
-    const int64_t nj = t.n * nnorb;
-    if (s == 0) {
-      SQD_TRY(t.jrow.reserve(nj * 8));
-      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                         c->eri_pp.as<double>(), nnorb, 0, t.jrow.as<double>());
-    } else {
-      SQD_TRY(t.jT.reserve(nj * 8));
-      hipLaunchKernelGGL(k_jtable, dim3(nblk(nj, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                         c->eri_pp.as<double>(), nnorb, 1, t.jT.as<double>());
-    }
+    DevBuf& jt = (s == 0) ? t.jrow : t.jT;  // alpha: J[I][pair] (row role); beta: transposed (column role)
+    SQD_TRY(jt.reserve(t.n * nnorb * 8));
+    la.a[s].e_str = t.e_str.as<double>();
+    la.a[s].jtab = jt.as<double>();
+    la.a[s].transposed = s;
+  }
+  {
+    const unsigned gx_e = nblk(maxn, 4), gx_j = nblk(maxn * nnorb, 256);
+    hipLaunchKernelGGL(k_string_tables2, dim3(gx_e > gx_j ? gx_e : gx_j, 4), dim3(256), 0, st, la, c->h1.as<double>(),
+                       c->jm.as<double>(), c->km.as<double>(), c->eri_pp.as<double>(), norb, nnorb);
   }
   hipLaunchKernelGGL(k_hdiag, dim3(nblk(na * nb, 256)), dim3(256), 0, st, c->sp[0].strs.as<uint64_t>(),
                      c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
@@ -705,18 +757,27 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_TRY(t.d_row.reserve((size_t)t.n_d * 4));
     SQD_TRY(t.d_orb.reserve((size_t)t.n_d * 4));
     SQD_TRY(t.d_val.reserve((size_t)t.n_d * 8));
-    if (t.n_s + t.n_d > 0)
-      hipLaunchKernelGGL(k_fill_links, dim3(nblk(t.n, 4)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n,
-                         t.s_ptr.as<int64_t>(), t.d_ptr.as<int64_t>(), t.s_rec.as<SRec>(), t.s_row.as<uint32_t>(),
-                         t.d_src.as<uint32_t>(), t.d_row.as<uint32_t>());
-    if (t.n_s > 0)
-      hipLaunchKernelGGL(k_decorate_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n_s,
-                         t.s_row.as<uint32_t>(), t.s_rec.as<SRec>(), t.s_val.as<double>(), c->h1.as<double>(),
+    la.a[s].n_s = t.n_s;
+    la.a[s].n_d = t.n_d;
+    la.a[s].s_rec = t.s_rec.as<SRec>();
+    la.a[s].s_row = t.s_row.as<uint32_t>();
+    la.a[s].s_val = t.s_val.as<double>();
+    la.a[s].d_src = t.d_src.as<uint32_t>();
+    la.a[s].d_row = t.d_row.as<uint32_t>();
+    la.a[s].d_orb = t.d_orb.as<uint32_t>();
+    la.a[s].d_val = t.d_val.as<double>();
+  }
+  {
+    int64_t maxl = 0;
+    for (int64_t v : tot) maxl = v > maxl ? v : maxl;
+    if (maxl > 0) {
+      hipLaunchKernelGGL(k_fill_links2, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la);
+      hipLaunchKernelGGL(k_decorate_links2, dim3(nblk(maxl, 256), 4), dim3(256), 0, st, la, c->h1.as<double>(),
                          c->eri4.as<double>(), norb);
-    if (t.n_d > 0)
-      hipLaunchKernelGGL(k_decorate_doubles, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, t.strs.as<uint64_t>(), t.n_d,
-                         t.d_row.as<uint32_t>(), t.d_src.as<uint32_t>(), t.d_orb.as<uint32_t>(), t.d_val.as<double>(),
-                         c->eri4.as<double>(), norb);
+    }
+  }
+  for (int s = 0; s < 2; ++s) {
+    SpinTables& t = c->sp[s];
     if (s == 0) {
       // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY work items
       SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
