@@ -175,6 +175,7 @@ struct sqd_ctx {
   // kernels run on the compute stream
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_sol = nullptr;
+  const int* sigma_stop = nullptr;  // device flag honoured by the sigma launches of a Davidson run, else null
   hipEvent_t ev_aux = nullptr;  // set_subspace: "CSR pointers are on the host" (later kernels keep running)
   double* h_amps = nullptr;
   size_t h_amps_cap = 0;

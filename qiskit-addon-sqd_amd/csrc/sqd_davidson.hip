@@ -92,16 +92,25 @@ __device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
   return p.shift * (d * d + nba * (double)__popcll(A & ~B));
 }
 
+// When the residual totals say the solve is over -- (|dE| < tol and |r|^2 < tol2) or a vanishing residual /
+// correction -- the device raises *flag itself, so that work the host enqueued ahead (next sigma, ...) returns
+// at once.  The host applies the SAME comparisons to the same numbers.  flag == nullptr: no rule.
+struct StopRule {
+  int* flag;
+  int de_small;
+  double tol2, lindep;
+};
 template <int N>
 __device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
-                                       double* __restrict__ dsums, double* mail, long long seq, double* red);
+                                       double* __restrict__ dsums, double* mail, long long seq, double* red,
+                                       const StopRule rule);
 
 template <int MV>
 __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
                                    int64_t stride, int nvec, const Coef coef, double e,
                                    const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
                                    double* __restrict__ partial, int width, unsigned* counter,
-                                   double* __restrict__ dsums, double* mail, long long seq) {
+                                   double* __restrict__ dsums, double* mail, long long seq, const StopRule rule) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   double vals[MV + 2];
@@ -127,7 +136,7 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   if ((int)threadIdx.x < nvec + 2)
     coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 2>(red, threadIdx.x));
-  finish_and_post<MV + 2>(partial, width, nvec + 2, counter, dsums, mail, seq, red);
+  finish_and_post<MV + 2>(partial, width, nvec + 2, counter, dsums, mail, seq, red, rule);
 }
 
 // t <- scale * t - sum_v coef[v] X_v ;  partial[block] = |t|^2
@@ -288,7 +297,8 @@ constexpr int MAIL_SLOT = 128;  // doubles per mailbox slot (slot 0: projected-m
 constexpr unsigned COUNT_GROUPS = 16;  // arrival counters: word 0 = groups done, words 1..16 = per group
 template <int N>
 __device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
-                                       double* __restrict__ dsums, double* mail, long long seq, double* red) {
+                                       double* __restrict__ dsums, double* mail, long long seq, double* red,
+                                       const StopRule rule) {
   __shared__ int s_last;
   // the callers wrote their partials with coherent_store: once those stores have completed (waitcnt) the
   // workgroup may be counted; no L2-wide fence (see sqd_device.h)
@@ -325,6 +335,10 @@ __device__ inline void finish_and_post(const double* partial, int width, int nv,
     dsums[threadIdx.x] = s;
     mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = s;
   }
+  if (rule.flag && threadIdx.x == 0) {
+    const double s0 = block_sum_multi_get<N>(red, 0), s1 = block_sum_multi_get<N>(red, 1);
+    if ((rule.de_small && s0 < rule.tol2) || !(s0 > rule.lindep) || !(s1 > 0.0)) *rule.flag = 1;
+  }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -337,8 +351,9 @@ __device__ inline void finish_and_post(const double* partial, int width, int nv,
 template <int MV>
 __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
                             const double* __restrict__ y, double* __restrict__ partial, int width, unsigned* counter,
-                            double* __restrict__ dsums, double* mail, long long seq) {
+                            double* __restrict__ dsums, double* mail, long long seq, const int* stop) {
   __shared__ double red[16 * (MV + 1)];
+  if (stop && *stop) return;  // enqueued ahead of a residual that ended the solve: nobody waits for this
   double acc[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
@@ -355,7 +370,7 @@ __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t str
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
   if ((int)threadIdx.x < nvec + 1)
     coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
-  finish_and_post<MV + 1>(partial, width, nvec + 1, counter, dsums, mail, seq, red);
+  finish_and_post<MV + 1>(partial, width, nvec + 1, counter, dsums, mail, seq, red, StopRule{nullptr, 0, 0.0, 0.0});
 }
 
 // t <- scale * t - sum_v g_v X_v with everything derived on the device from the residual kernel's totals
@@ -366,9 +381,10 @@ __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t str
 // next k_dots_post measures |X_new|^2 and the host carries 1/sqrt of it as sv_new, so no separate
 // normalisation pass and no host decision is needed here.
 __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef sv,
-                           const double* __restrict__ dsums, double* __restrict__ t) {
+                           const double* __restrict__ dsums, double* __restrict__ t, const int* stop) {
   __shared__ double g[SQD_MAX_SPACE + 2];
   __shared__ double s_scale;
+  if (stop && *stop) return;
   const double tt = dsums[1];
   if ((int)threadIdx.x < nvec) g[threadIdx.x] = (tt > 0.0) ? sv.v[threadIdx.x] * dsums[2 + threadIdx.x] / sqrt(tt) : 0.0;
   __syncthreads();
@@ -559,7 +575,9 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   double* dsums_col = scal + 8;    // totals of the latest k_dots_post
   double* dsums_res = scal + 48;   // totals of the latest k_residual_precond (consumed by k_orth_dev)
   unsigned* counter = reinterpret_cast<unsigned*>(scal + 104);
-  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, (COUNT_GROUPS + 1) * sizeof(unsigned), s));
+  int* stop_flag = reinterpret_cast<int*>(scal + 120);
+  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, 17 * sizeof(double), s));  // arrival counters and the stop flag
+  const double tol2 = toloose * toloose;
   double* mail_col = c->d_mail;
   double* mail_res = c->d_mail + MAIL_SLOT;
 
@@ -608,15 +626,21 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     rnorm = std::sqrt(sums[0]);
     if (o->verbose)
       std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", it - 1, m_res, e, de, rnorm);
-    if (std::fabs(de) < tol && rnorm < toloose) {
+    // (the same comparisons, on the same numbers, as StopRule on the device)
+    if (std::fabs(de) < tol && sums[0] < tol2) {
       conv = true;
       stop = true;
     } else if (!(sums[0] > lindep) || !(sums[1] > 0.0)) {
-      conv = rnorm < toloose;
+      conv = sums[0] < tol2;
       stop = true;
     }
     return SQD_OK;
   };
+  c->sigma_stop = stop_flag;
+  struct StopGuard {  // the flag is only meaningful inside this run
+    sqd_ctx* c;
+    ~StopGuard() { c->sigma_stop = nullptr; }
+  } stop_guard{c};
   for (it = 0; it < o->max_cycle; ++it) {
     // |dE| >= tol rules convergence out before the residual is known: only then is the next sigma enqueued
     // ahead of the residual hand-over (nothing is wasted except on a linear-dependence stop)
@@ -637,11 +661,11 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     if (max_space <= 12)
       hipLaunchKernelGGL((k_dots_post<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
                          (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
-                         mail_col, seq_col);
+                         mail_col, seq_col, (const int*)stop_flag);
     else
       hipLaunchKernelGGL((k_dots_post<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
                          (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
-                         mail_col, seq_col);
+                         mail_col, seq_col, (const int*)stop_flag);
     SQD_HIP_CHECK(hipGetLastError());
     if (have_res) {
       SQD_TRY(settle_residual());
@@ -681,16 +705,17 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     double* tnew = X + (int64_t)m * D;
     seq_res = ++c->mail_seq;
     m_res = m;
+    const StopRule rule{stop_flag, std::fabs(de) < tol ? 1 : 0, tol2, lindep};
     if (max_space <= 12)
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m,
                          raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width, counter,
-                         dsums_res, mail_res, seq_res);
+                         dsums_res, mail_res, seq_res, rule);
     else
       hipLaunchKernelGGL((k_residual_precond<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X,
                          (const double*)AX, D, m, raw, e, (const double*)c->hdiag.as<double>(), pd, tnew,
-                         c->partial.as<double>(), width, counter, dsums_res, mail_res, seq_res);
+                         c->partial.as<double>(), width, counter, dsums_res, mail_res, seq_res, rule);
     hipLaunchKernelGGL(k_orth_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv, (const double*)dsums_res,
-                       tnew);
+                       tnew, (const int*)stop_flag);
     SQD_HIP_CHECK(hipGetLastError());
     have_res = true;
     if (m + 1 > max_space) {

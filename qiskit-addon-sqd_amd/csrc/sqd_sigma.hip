@@ -65,6 +65,9 @@ struct SigmaArgs {
   const double* edb_val;
   const double* jbT;
   const double* eri_pp;
+  // Davidson enqueues the next sigma before the host has seen the residual; when the device finds the
+  // solve finished it raises this flag and the launch returns at once (nullptr: unconditional)
+  const int* stop;
 };
 
 // sum_l val[l] * C[src[l], B] over a chunk of same-spin links: the row reads are independent, so they
@@ -181,6 +184,7 @@ __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const
 template <int R, bool SPIN, bool LDSROW>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
+  if (g.stop && *g.stop) return;  // uniform over the launch
   const int T = blockDim.x, tid = threadIdx.x;
   const WorkItem it = g.items[blockIdx.x];
   const int64_t A = it.A;
@@ -321,8 +325,9 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
 __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
-                               double* __restrict__ sigma) {
+                               double* __restrict__ sigma, const int* stop) {
   __shared__ double red[1024];
+  if (stop && *stop) return;
   const MultiRow mr = rows[blockIdx.x];
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6, SL = blockDim.x >> 6;
   const int64_t B = (int64_t)blockIdx.y * 64 + col;
@@ -416,6 +421,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.chunk_cols = c->sig_chunk;
   g.nvs_max = (int)c->hv_s.nv_max;
   g.nvd_max = (int)c->hv_d.nv_max;
+  g.stop = c->sigma_stop;
 
   const int R = c->sig_R;
   int rc;
@@ -429,7 +435,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (c->n_multi > 0) {
     hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
-                       d_sigma);
+                       d_sigma, g.stop);
     SQD_HIP_CHECK(hipGetLastError());
   }
   return SQD_OK;
