@@ -1,6 +1,7 @@
 """Shared parity checks: the native path (real HIP library on the GPU box, or the kernel-logic
 emulator on CPU) against the numpy oracle on the same seeded inputs."""
 import numpy as np
+import pytest
 
 from oracle import sqd_oracle as O
 from qiskit_addon_sqd_amd import _capi
@@ -53,7 +54,7 @@ def check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng, tol=1e-11):
     return H, S2
 
 
-def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=True):
+def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=True, variants=True):
     amps, st = ctx.davidson()
     w, v = np.linalg.eigh(H)
     assert st["converged"] == 1
@@ -77,10 +78,46 @@ def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=
         assert abs(e_rdm - ctx.energy()) < 1e-10
         n = np.trace(d1a) + np.trace(d1b)
         assert abs(np.einsum("ppqq->", d2) - n * (n - 1)) < 1e-9
+    if variants:
+        check_solver_variants(ctx, w, v, amps, st, e_tol)
     return amps, st
 
 
-def run_full_parity(lib, norb, nelec, na, nb, seed, hf=False, with_rdm2=True):
+def check_solver_variants(ctx, w, v, amps, st, e_tol):
+    """The same eigenpair through the other control-flow paths of the device Davidson: fused native call,
+    un-normalised user start vector, frequent restarts (max_space 2/3), a long basis (max_space 20, the
+    wide-register kernels), the cycle limit, and bitwise run-to-run reproducibility."""
+    D = amps.size
+    # fused call = Davidson + observables
+    a2, st2, (e2, s2_2, oa2, ob2) = ctx.davidson(observables=True)
+    assert np.array_equal(a2, amps) and st2["n_sigma"] == st["n_sigma"]  # reproducible to the bit
+    assert abs(e2 - w[0]) < e_tol and abs(oa2.sum() - round(oa2.sum())) < 1e-9
+    # a user vector far from normalised (the norm is measured by the first fused reduction, never applied)
+    rng = np.random.default_rng(D)
+    ci0 = 37.5 * (amps + 0.05 * rng.standard_normal(amps.shape))
+    a3, st3 = ctx.davidson(ci0)
+    assert st3["converged"] == 1 and abs(st3["e_davidson"] - w[0]) < e_tol
+    assert abs(np.linalg.norm(a3) - 1.0) < 1e-9
+    if D > 1:
+        with pytest.raises(Exception, match="zero norm"):
+            ctx.davidson(np.zeros_like(amps))
+    for ms in (2, 3, 6, 20):
+        _, stm = ctx.davidson(max_space=ms, max_cycle=400)
+        if ms <= 3:
+            # a restart every (other) iteration is close to preconditioned steepest descent: it may crawl on
+            # hard cases (400 cycles are not enough for the 70 x 70 FCI problem), but it stays variational
+            assert stm["e_davidson"] - w[0] > -1e-9 and (stm["converged"] == 0 or stm["e_davidson"] - w[0] < e_tol), stm
+        else:
+            assert stm["converged"] == 1 and abs(stm["e_davidson"] - w[0]) < e_tol, (ms, stm)
+    if st["n_sigma"] > 2:
+        a5, st5 = ctx.davidson(max_cycle=1)
+        assert st5["converged"] == 0 and st5["n_sigma"] == 1 and st5["iterations"] == 1
+        assert abs(np.linalg.norm(a5) - 1.0) < 1e-9
+    # leave the context holding the reference solution again
+    ctx.davidson()
+
+
+def run_full_parity(lib, norb, nelec, na, nb, seed, hf=False, with_rdm2=True, variants=True):
     h1, eri, sa, sb = make_problem(norb, nelec, na, nb, seed, hf)
     rng = np.random.default_rng(seed)
     with _capi.Context(h1, eri, lib=lib) as ctx:
@@ -88,4 +125,4 @@ def run_full_parity(lib, norb, nelec, na, nb, seed, hf=False, with_rdm2=True):
         assert (ctx.na, ctx.nb, ctx.nelec) == (len(sa), len(sb), tuple(nelec))
         check_link_tables(ctx, sa, sb, norb, h1, eri)
         H, S2 = check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng)
-        check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, with_rdm2=with_rdm2)
+        check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, with_rdm2=with_rdm2, variants=variants)

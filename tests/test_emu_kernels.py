@@ -20,15 +20,16 @@ from _parity import check_link_tables, check_operators, make_problem, run_full_p
     ],
 )
 def test_emu_full_parity(emu_lib, norb, nelec, na, nb, seed, hf):
-    run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf)
+    # the solver-variant sweep (restarts, long basis, ...) only on the smallest case: the emulator is slow
+    run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf, variants=(na * nb <= 40))
 
 
 def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
     # SQD_ELL_CAP=3 cuts the beta link lists into many overflow chunks (virtual rows): the partial sums
     # that travel through LDS must reproduce the same sigma / ground state
     monkeypatch.setenv("SQD_ELL_CAP", "3")
-    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
-    run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False)
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
+    run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False, variants=False)
 
 
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
@@ -36,9 +37,9 @@ def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,
     # the second ragged) with their own virtual-row ranges
     monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
-    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False)
+    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
-    run_full_parity(emu_lib, 9, (2, 4), 7, 100, 29, True)
+    run_full_parity(emu_lib, 9, (2, 4), 7, 100, 29, True, variants=False)
 
 
 def test_emu_h2_minimal(emu_lib):
