@@ -149,6 +149,7 @@ struct sqd_ctx {
   sqd::DevBuf items, multi, sig_partial;
   int64_t n_items = 0, n_multi = 0, n_slots = 0;
   int sig_T = 64, sig_R = 1, sig_K = 1, sig_nb_pad = 0;
+  int sig_kmax = 4;              // batch size limit chosen by the layout search in build_subspace
   size_t sig_shmem = 0;
   bool sig_lds_rows = true;      // C rows staged in LDS (false: rows too long, read from global/L2)
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)

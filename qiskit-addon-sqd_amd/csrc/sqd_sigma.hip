@@ -196,12 +196,17 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   const int64_t Bend = (B0 + g.chunk_cols < nb) ? B0 + g.chunk_cols : nb;
   const int vs0 = g.vs_chunk[chunk], vs1 = g.vs_chunk[chunk + 1];
   const int vd0 = g.vd_chunk[chunk], vd1 = g.vd_chunk[chunk + 1];
-  double* Crow = smem;                                          // [K][nb_pad]   (LDSROW only)
-  double* W2 = smem + (LDSROW ? (int64_t)g.K * g.nb_pad : 0);   // [K][2*nnorb]
+  // LDS plan (sized in build_sigma_work): [part_s | penw | region]; the region is K x (C row) then
+  // K x (integral row) for a batch, or ONE C row, ONE integral row and the doubles' partial sums for an
+  // own-row item -- the two uses overlap, so the allocation is their maximum, not their sum
   const int w2s = (nnorb + 1) & ~1;            // one integral row per staged link
-  double* part_s = W2 + (int64_t)g.K * w2s;  // [nvs_max] partial sums of the singles' virtual rows
-  double* part_d = part_s + g.nvs_max;       // [nvd_max] ... of the doubles' virtual rows
-  int* penw = reinterpret_cast<int*>(part_d + g.nvd_max);  // [K] S^2 partner widx of each staged link
+  const int nvs_pad = (g.nvs_max + 1) & ~1;
+  double* part_s = smem;                                    // [nvs_max] partial sums of the singles' virtual rows
+  int* penw = reinterpret_cast<int*>(smem + nvs_pad);       // [K <= 4] S^2 partner widx of each staged link
+  double* Crow = smem + nvs_pad + 2;                        // [K][nb_pad]   (LDSROW only)
+  const int64_t rows_staged = (it.type == 0) ? 1 : g.K;
+  double* W2 = Crow + (LDSROW ? rows_staged * g.nb_pad : 0);  // [rows_staged][w2s]
+  double* part_d = W2 + w2s;                                // [nvd_max] (own-row items) ... of the doubles' virtual rows
   const double* __restrict__ C = g.c;
   double acc[R];
 #pragma unroll

@@ -469,16 +469,22 @@ __global__ void k_merge_hs(int64_t n, const int64_t* __restrict__ s_ptr, const i
 //   type 2  a chunk of <= L further same-spin alpha links (unit-stride row AXPYs)
 // A row with a single item writes sigma directly; otherwise items write partial rows that
 // k_sigma_reduce adds in fixed order.
-static int build_sigma_work(sqd_ctx* c) {
-  const int64_t na = c->na, nb = c->nb;
-  // geometry: T threads cover the row in R strides; the beta virtual rows are spread over all T
-  // threads; K alpha links (source row + integral row each) are staged per batch within the LDS budget
-  const SpinTables& tb = c->sp[1];
-  const int64_t nvmax = tb.nv_s > tb.nv_d ? tb.nv_s : tb.nv_d;
+// Launch geometry and LDS plan of k_sigma for a given virtual-row layout.
+//   T threads cover the row in R strides; the beta virtual rows are spread over all T threads.
+//   LDS of one workgroup: [singles partials | penw | region], where the region holds K staged (C row +
+//   integral row) pairs for an alpha-single batch, or -- for an own-row item, which stages one pair -- that
+//   pair followed by the doubles' partial sums.  The two uses overlap: the allocation is the LARGER of them.
+//   wgs = workgroups resident per CU (LDS and the 32-wave limit): what the layout search maximises.
+struct SigmaPlan {
+  int T = 64, R = 1, K = 1, nb_pad = 0, wgs = 0;
+  size_t shmem = 0;
+};
+static SigmaPlan plan_sigma(const sqd_ctx* c, int64_t nb, const VRowsHost& vs, const VRowsHost& vd, int kmax) {
+  SigmaPlan p;
   // threads per workgroup (measured on MI355X, profiles/r01/sigma_geometry_sweep.txt): 512 up to
-  // nb = 2048 (two waves per SIMD leave room for 5 workgroups per CU), 1024 beyond; never more than
-  // the row or the virtual-row lists can occupy
-  int64_t want = nb > nvmax ? nb : nvmax;
+  // nb = 2048, 1024 beyond; never more than the row or the virtual-row lists can occupy
+  const int64_t nvmax = vs.nv > vd.nv ? vs.nv : vd.nv;
+  const int64_t want = nb > nvmax ? nb : nvmax;
   int T = (int)(((want + 63) / 64) * 64);
   const int tmax = (nb <= 2048) ? 512 : 1024;
   if (T > tmax) T = tmax;
@@ -487,43 +493,60 @@ static int build_sigma_work(sqd_ctx* c) {
     const int v = (std::atoi(env) / 64) * 64;
     if (v >= 64 && v <= 1024) T = v;
   }
-  const int nb_pad = (int)((nb + 1) & ~int64_t(1));
+  p.nb_pad = (int)((nb + 1) & ~int64_t(1));
   const size_t w2_bytes = (size_t)((c->nnorb + 1) & ~1) * 8;
-  const size_t row_bytes = (size_t)nb_pad * 8 + w2_bytes;  // one C row + one integral row
-  const size_t part_bytes = (size_t)(c->hv_s.nv_max + c->hv_d.nv_max) * 8 + 64;
+  const size_t row_bytes = (size_t)p.nb_pad * 8 + w2_bytes;  // one C row + one integral row
+  const size_t ps_bytes = (size_t)((vs.nv_max + 1) & ~int64_t(1)) * 8 + 16;  // singles partials + penw
+  const size_t pd_bytes = (size_t)vd.nv_max * 8;
   const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
-  int R, K;
+  auto plan_bytes = [&](int k) {
+    const size_t batch = (size_t)k * row_bytes, own = row_bytes + pd_bytes;
+    return ps_bytes + (batch > own ? batch : own) + 64;
+  };
   if (c->sig_lds_rows) {
-    R = (int)((nb + T - 1) / T);
-    size_t stage = 96 * 1024;
-    if (stage + part_bytes > budget) stage = budget - part_bytes;
-    K = (int)(stage / row_bytes);
-    if (K < 1) K = 1;
-    if (K > 4) K = 4;  // more links per batch lengthen the batch without saving launches (same sweep)
+    p.R = (int)((nb + T - 1) / T);
+    int K = kmax;  // more than 4 links per batch lengthen the batch without saving launches (geometry sweep)
+    while (K > 1 && ((size_t)K * row_bytes > 96 * 1024 || plan_bytes(K) > budget)) --K;
     if (const char* env = std::getenv("SQD_SIGMA_K")) {  // tuning hook
       const int v = std::atoi(env);
       if (v >= 1 && v <= K) K = v;
     }
-    c->sig_shmem = (size_t)K * row_bytes + part_bytes;
+    p.K = K;
+    p.shmem = plan_bytes(K);
   } else {
     // rows stay in global memory: one link per batch, workgroups of one column chunk
     T = (int)(c->sig_chunk < 1024 ? c->sig_chunk : 1024);
-    R = (int)((c->sig_chunk + T - 1) / T);
-    K = 1;
-    c->sig_shmem = w2_bytes + part_bytes;
+    p.R = (int)((c->sig_chunk + T - 1) / T);
+    p.K = 1;
+    p.shmem = ps_bytes + w2_bytes + pd_bytes + 64;
   }
-  if (R > 16) {
+  p.T = T;
+  const int by_lds = (int)((size_t)c->lds_bytes / p.shmem), by_waves = 32 / (T / 64);
+  p.wgs = by_lds < by_waves ? by_lds : by_waves;
+  return p;
+}
+
+static int build_sigma_work(sqd_ctx* c) {
+  const int64_t na = c->na, nb = c->nb;
+  const SigmaPlan plan = plan_sigma(c, nb, c->hv_s, c->hv_d, c->sig_kmax);
+  const int T = plan.T, R = plan.R, K = plan.K;
+  if (plan.shmem > (size_t)c->lds_bytes || R > 16) {
     set_error("beta string count " + std::to_string(nb) + " exceeds the sigma kernel's row geometry");
     return SQD_ERR_LIMIT;
   }
   c->sig_T = T;
   c->sig_R = R;
   c->sig_K = K;
-  c->sig_nb_pad = nb_pad;
+  c->sig_nb_pad = plan.nb_pad;
+  c->sig_shmem = plan.shmem;
   // same-spin links folded into the own-row item: sparse sets (few links per row) take all of them there
   // and need no partial rows / reduce launch; well-connected sets keep the own-row item short
   const int64_t hs_total = c->h_sptr[na] + c->h_dptr[na];
-  const int L0 = (hs_total <= 24 * na) ? 32 : 16, L = 32;
+  int L0 = (hs_total <= 24 * na) ? 32 : 16, L = 32;
+  if (const char* env = std::getenv("SQD_SIGMA_L")) {  // test hook: tiny chunks => many AXPY items per row
+    const int v = std::atoi(env);
+    if (v >= 1 && v <= 32) L0 = L = v;
+  }
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();
@@ -554,6 +577,12 @@ static int build_sigma_work(sqd_ctx* c) {
   c->n_items = (int64_t)items.size();
   c->n_multi = (int64_t)multi.size();
   c->n_slots = nslots;
+  if (std::getenv("SQD_DEBUG_GEOM"))
+    std::fprintf(stderr,
+                 "[sqd geom] na %lld nb %lld T %d R %d K %d lds_rows %d chunks %d cap %d nvs %lld nvd %lld shmem %zu items %zu "
+                 "multi %zu slots %d\n",
+                 (long long)na, (long long)nb, T, R, K, (int)c->sig_lds_rows, c->sig_nchunks, c->sp[1].cap,
+                 (long long)c->hv_s.nv_max, (long long)c->hv_d.nv_max, c->sig_shmem, items.size(), multi.size(), nslots);
   SQD_TRY(c->items.reserve(items.size() * sizeof(WorkItem)));
   SQD_TRY(c->multi.reserve((multi.size() + 1) * sizeof(MultiRow)));
   SQD_TRY(c->sig_partial.reserve((size_t)nslots * nb * 8 + 8));
@@ -836,6 +865,13 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->sig_lds_rows = lds_rows;
     c->sig_chunk = chunk_cols;
     c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
+    c->sig_kmax = 4;
+    // The kernel lives on resident waves: a single workgroup per CU (rows of ~2000 strings and more) is
+    // the one case where a smaller batch pays (HF-centred 2000 x 2000: 2.3 ms -> 1.5 ms per sigma with 3
+    // links per batch instead of 4).  Finer searches over cap / batch size to gain a third or fourth
+    // resident workgroup were measured too and are a wash (+-10 % either way, profiles/r01 notes).
+    if (lds_rows)
+      while (c->sig_kmax > 2 && plan_sigma(c, nb, vs, vd, c->sig_kmax).wgs < 2) --c->sig_kmax;
     t.cap = cap;
     t.nv_s = vs.nv;
     t.nv_d = vd.nv;

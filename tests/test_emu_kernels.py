@@ -32,6 +32,15 @@ def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
     run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False, variants=False)
 
 
+def test_emu_many_axpy_items(emu_lib, monkeypatch):
+    # SQD_SIGMA_L=2 cuts the same-spin alpha links into many 2-link AXPY items per row (partial rows + the
+    # fixed-order reduce with many slots per row)
+    monkeypatch.setenv("SQD_SIGMA_L", "2")
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    run_full_parity(emu_lib, 8, (4, 4), 9, 30, 5, False, variants=False)
+
+
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,

@@ -40,6 +40,13 @@ def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
 
 
+def test_many_axpy_items_forced(hip_lib, monkeypatch):
+    # many small AXPY items per row: partial rows + the fixed-order reduce with many slots per row
+    monkeypatch.setenv("SQD_SIGMA_L", "2")
+    run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
+    run_full_parity(hip_lib, 8, (4, 4), 70, 70, 17, False, variants=False)
+
+
 def test_global_row_fallback_forced(hip_lib, monkeypatch):
     # the path for rows that do not fit LDS, forced at a size the oracle can check (3 column chunks)
     monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
