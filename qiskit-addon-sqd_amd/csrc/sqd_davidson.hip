@@ -44,19 +44,6 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
     partial[(int64_t)blockIdx.x * NV + threadIdx.x] = block_sum_multi_get<NV>(red, threadIdx.x);
 }
 
-// out[v] = sum_b partial[b*width + v]
-// one workgroup per value v; fixed partition + fixed tree => bitwise reproducible
-__global__ void k_reduce_partials(const double* __restrict__ partial, int nblocks, int width, int nv,
-                                  double* __restrict__ out) {
-  __shared__ double red[16];
-  const int v = blockIdx.x;
-  double s = 0.0;
-  if (v < nv)
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[(int64_t)b * width + v];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0 && v < nv) out[v] = s;
-}
-
 struct Coef {
   double v[SQD_MAX_SPACE + 2];
 };
@@ -139,26 +126,6 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
   finish_and_post<MV + 2>(partial, width, nvec + 2, counter, dsums, mail, seq, red, rule);
 }
 
-// t <- scale * t - sum_v coef[v] X_v ;  partial[block] = |t|^2
-__global__ void k_orth(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef coef,
-                       double scale, double* __restrict__ t, double* __restrict__ partial) {
-  __shared__ double red[16];
-  double tt = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double s = scale * t[i];
-    for (int v = 0; v < nvec; ++v) s -= coef.v[v] * X[(int64_t)v * stride + i];
-    t[i] = s;
-    tt += s * s;
-  }
-  const double s = block_sum(tt, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-
-__global__ void k_scale(int64_t n, double a, double* __restrict__ x) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] *= a;
-}
-
 // per-block (min value, index) over hdiag; tril != 0 restricts to A >= B (pyscf _get_init_guess
 // when nelec_a == nelec_b and na == nb)
 __global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __restrict__ h,
@@ -178,23 +145,6 @@ __global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __r
     pmin[blockIdx.x] = best;
     pidx[blockIdx.x] = bi;
   }
-}
-
-// second stage (ONE workgroup): global argmin of the per-block candidates -> addr[0], on the device
-__global__ void k_argmin_final(const double* __restrict__ pmin, const int64_t* __restrict__ pidx, int nblocks,
-                               int64_t* __restrict__ addr) {
-  double best = 1e300;
-  int64_t bi = -1;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    const double v = pmin[b];
-    const int64_t i = pidx[b];
-    if (i >= 0 && (v < best || (v == best && i < bi) || bi < 0)) {
-      best = v;
-      bi = i;
-    }
-  }
-  block_argmin(best, bi);
-  if (threadIdx.x == 0) addr[0] = bi < 0 ? 0 : bi;
 }
 
 // pyscf get_init_guess: unit vector at addr, +1e-5 on the first and -1e-5 on the last element,
@@ -240,23 +190,6 @@ static inline unsigned red_blocks(int64_t n) {
 // Device scalar block: scal[0] = 1/|t'| (0 if linearly dependent), scal[1] = |t'|^2 of the last
 // orthogonalisation, scal[2..] = outputs of the latest reduction.
 constexpr int SCAL_RED = 2;
-
-// |t'|^2 from the per-block partials -> normalisation factor, kept on the device (no host round trip)
-__global__ void k_norm_to_scale(const double* __restrict__ partial, int nblocks, double lindep, double* __restrict__ scal) {
-  __shared__ double red[16];
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[b];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) {
-    scal[1] = s;
-    scal[0] = (s > lindep) ? 1.0 / sqrt(s) : 0.0;
-  }
-}
-__global__ void k_scale_dev(int64_t n, const double* __restrict__ scal, double* __restrict__ x) {
-  const double a = scal[0];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] *= a;
-}
 
 // Final stage of a reduction + hand-over to the host in ONE single-workgroup kernel: column sums of
 // the partial array (fixed order), written with scal[0..2) straight into the host-visible mailbox,

@@ -136,35 +136,6 @@ __device__ inline void fill_links_body(const uint64_t* __restrict__ strs, int64_
   }
 }
 
-// Exclusive scan of n int64 values by ONE workgroup; out has n+1 entries (out[n] = total).
-__global__ void k_exclusive_scan(const int64_t* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
-  __shared__ int64_t sums[1024];
-  const int T = blockDim.x, tid = threadIdx.x;
-  const int64_t chunk = (n + T - 1) / T;
-  const int64_t lo = (int64_t)tid * chunk;
-  const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += in[i];
-  sums[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t run = 0;
-    for (int t = 0; t < T; ++t) {
-      const int64_t v = sums[t];
-      sums[t] = run;
-      run += v;
-    }
-    out[n] = run;
-  }
-  __syncthreads();
-  int64_t run = sums[tid];
-  for (int64_t i = lo; i < hi; ++i) {
-    const int64_t v = in[i];
-    out[i] = run;
-    run += v;
-  }
-}
-
 // ------------------------------------------------------------------ link decoration
 // |I> = sign a+_cre a_des |J>;  value = sign * (h[cre,des] + sum_{k in J, k != des} (cre des|kk) - (cre k|k des))
 __device__ inline void decorate_singles_body(const uint64_t* __restrict__ strs, int64_t n_s,
