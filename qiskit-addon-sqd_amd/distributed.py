@@ -109,10 +109,12 @@ def solve_sci_batch_distributed(
         occ = mean_occ if occupancy_reduce == "mean" else (table[i, 1 : 1 + norb].copy(), table[i, 1 + norb :].copy())
         if i in local:
             r = local[i]
-            out.append(SCIResult(float(table[i, 0]), r.sci_state, occ, rdm1=r.rdm1, rdm2=r.rdm2))
+            raw = lambda name: object.__getattribute__(r, name)  # noqa: E731  (do not trigger lazy RDMs)
+            out.append(SCIResult(float(table[i, 0]), r.sci_state, occ, rdm1=raw("rdm1"), rdm2=raw("rdm2"),
+                                 _lazy_rdms=raw("_lazy_rdms")))
         elif i == best:
             state = SCIState(amps, np.asarray(sa), np.asarray(sb), norb=norb, nelec=tuple(int(x) for x in nelec))
-            out.append(SCIResult(float(table[i, 0]), state, occ))
+            out.append(SCIResult(float(table[i, 0]), state, occ, _lazy_rdms=True))
         else:
             out.append(SCIResult(float(table[i, 0]), None, occ))  # type: ignore[arg-type]
     return out

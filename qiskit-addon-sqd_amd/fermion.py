@@ -15,7 +15,7 @@ import threading
 import zlib
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Sequence
 
 import numpy as np
@@ -177,6 +177,19 @@ class SCIResult:
     rdm2: np.ndarray | None = None
     """Spin-summed 2-particle reduced density matrix."""
 
+    _lazy_rdms: bool = field(default=False, repr=False, compare=False)
+    """True: ``rdm1`` / ``rdm2`` are computed from ``sci_state`` on first access.  The SQD loop never reads
+    them (reference ``fermion.py:577-622`` uses energy, occupancies and the state), and the norb^4 ``rdm2``
+    costs more than the whole solve at the sizes of one subsample batch."""
+
+    def __getattribute__(self, name):
+        value = object.__getattribute__(self, name)
+        if value is None and name in ("rdm1", "rdm2") and object.__getattribute__(self, "_lazy_rdms"):
+            state = object.__getattribute__(self, "sci_state")
+            value = state.rdm(1 if name == "rdm1" else 2, spin_summed=True)
+            object.__setattr__(self, name, value)  # frozen dataclass: cache through object
+        return value
+
 
 # --------------------------------------------------------------------------- string formatting
 def bitstring_matrix_to_ci_strs(
@@ -307,7 +320,7 @@ def solve_sci(
     *,
     spin_sq: float | None = None,
     device: int = 0,
-    compute_rdms: bool = True,
+    compute_rdms: bool | str = "lazy",
     _slot: int = 0,
     **kwargs,
 ) -> SCIResult:
@@ -315,17 +328,20 @@ def solve_sci(
 
     As in the reference: ``norb`` is re-read from ``one_body_tensor``; the spin penalty uses pyscf's
     default strength 0.2 (``fix_spin_(myci, ss=spin_sq)``, :715); the energy is recomputed from the
-    returned state, not taken from the Davidson eigenvalue (:717-732); ``rdm1``/``rdm2`` are populated.
-    ``compute_rdms=False`` skips the norb^4 ``rdm2`` (then ``rdm1``/``rdm2`` are ``None``).
+    returned state, not taken from the Davidson eigenvalue (:717-732); ``rdm1``/``rdm2`` are available
+    on the result.  ``compute_rdms``: ``"lazy"`` (default) -- the energy is ``<c|H|c>`` from the fused
+    native call and ``rdm1``/``rdm2`` are built from the returned state when first read; ``True`` -- built
+    now and the energy contracted from them exactly as the reference does (:725-732); ``False`` -- ``None``.
     """
     one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
     norb, _ = one_body_tensor.shape
     ctx = _get_context(one_body_tensor, two_body_tensor, device, _slot)
     strs_a, strs_b = ci_strings
-    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not compute_rdms)
+    eager = compute_rdms is True
+    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not eager)
     if tuple(int(x) for x in nelec) != ctx.nelec:
         raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
-    if compute_rdms:
+    if eager:
         dm1a, dm1b = ctx.rdm1s()
         occupancies = (np.diagonal(dm1a).copy(), np.diagonal(dm1b).copy())
         dm1 = dm1a + dm1b
@@ -343,7 +359,8 @@ def solve_sci(
         norb=norb,
         nelec=tuple(int(x) for x in nelec),
     )
-    return SCIResult(energy, sci_state, orbital_occupancies=occupancies, rdm1=dm1, rdm2=dm2)
+    return SCIResult(energy, sci_state, orbital_occupancies=occupancies, rdm1=dm1, rdm2=dm2,
+                     _lazy_rdms=(compute_rdms == "lazy"))
 
 
 def solve_fermion(

@@ -100,6 +100,13 @@ def test_python_api_through_emulator(emu_backend):
     res = solve_sci((sa, sb), h1, eri, norb, nelec)
     assert isinstance(res, SCIResult) and abs(res.energy - e_ref) < 1e-8
     assert abs(np.trace(res.rdm1) - 5) < 1e-9 and res.rdm2.shape == (6,) * 4
+    # default: RDMs are built on first access; compute_rdms=True builds them in the call and contracts
+    # the energy from them exactly as the reference does -- same numbers either way
+    assert object.__getattribute__(solve_sci((sa, sb), h1, eri, norb, nelec), "rdm2") is None
+    eager = solve_sci((sa, sb), h1, eri, norb, nelec, compute_rdms=True)
+    assert object.__getattribute__(eager, "rdm2") is not None
+    assert abs(eager.energy - res.energy) < 1e-10
+    assert np.allclose(eager.rdm1, res.rdm1, atol=1e-12) and np.allclose(eager.rdm2, res.rdm2, atol=1e-12)
     assert np.allclose(res.sci_state.orbital_occupancies()[0], res.orbital_occupancies[0], atol=1e-12)
     with pytest.raises(ValueError, match="does not match"):
         solve_sci((sa, sb), h1, eri, norb, (2, 2))
