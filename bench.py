@@ -265,8 +265,11 @@ def extra_measurements(args, ctx):
     from qiskit_addon_sqd_amd import synthetic as S
 
     res = {}
-    for name, gen, n in (("hf_317", S.hf_centred_strings, 317), ("uniform_1000", S.uniform_strings, 1000),
-                         ("hf_1000", S.hf_centred_strings, 1000), ("uniform_4000", S.uniform_strings, 4000)):
+    # SURVEY 8(d) ladder D = 1e4 (100^2) .. 1e8 (10^4 x 10^4, 26 resident vectors of 0.8 GB), both generators
+    for name, gen, n in (("uniform_100", S.uniform_strings, 100), ("hf_100", S.hf_centred_strings, 100),
+                         ("hf_317", S.hf_centred_strings, 317), ("uniform_1000", S.uniform_strings, 1000),
+                         ("hf_1000", S.hf_centred_strings, 1000), ("uniform_4000", S.uniform_strings, 4000),
+                         ("uniform_10000", S.uniform_strings, 10000)):
         sa, sb = gen(args.norb, args.nelec, n, 11), gen(args.norb, args.nelec, n, 13)
         ctx.set_subspace(sa, sb)  # first call at a new size grows the arenas (hipMalloc): not timed
         ctx.davidson(fetch=False)
