@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Turns gpurun_out/<round>/ (written by profiles/collect.sh on the GPU box) into the tracked summaries under
+profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traffic from the PMC passes
+(FETCH_SIZE is doubled on gfx950, both counters are in KB -- MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
+os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
+
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*_probe.txt")) + [os.path.join(src, "gpu_tests.txt")]:
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, "final_" + os.path.basename(f)))
+for d in glob.glob(os.path.join(src, "prof_*")):
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, "final_" + os.path.basename(d)[5:] + "_kernel_stats.csv"))
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+for wl in ("uniform317", "hf317"):
+    out = {}
+    for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
+        acc = defaultdict(list)
+        for f in glob.glob(os.path.join(src, sub + wl, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        out[counter] = {k: {"dispatches": len(v), "avg_KB": sum(v) / len(v)} for k, v in acc.items()}
+    if out["FETCH_SIZE"]:
+        hbm = {}
+        for k, v in out["FETCH_SIZE"].items():
+            w = out["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
+            hbm[k] = {"dispatches": v["dispatches"], "hbm_bytes_per_launch": (2.0 * v["avg_KB"] + w["avg_KB"]) * 1024.0}
+        out["HBM_BYTES"] = hbm
+        json.dump(out, open(os.path.join(dst, "pmc", f"final_{wl}_pmc_summary.json"), "w"), indent=1)
+        top = sorted(hbm.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]
+        print(wl, [(k, round(v["hbm_bytes_per_launch"] / 1e6, 3), v["dispatches"]) for k, v in top])
+print("written to", dst)
