@@ -76,13 +76,14 @@ def pmc_traffic_bytes(args):
     """HBM bytes per k_sigma launch from the committed rocprofv3 PMC passes of THIS workload (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
     bench.py cannot collect counters itself.  None when no matching profile is committed."""
-    if (args.norb, args.nelec, args.na, args.nb, args.strings) != (30, 8, 317, 317, "uniform"):
+    if (args.norb, args.nelec, args.na, args.nb) != (30, 8, 317, 317):
         return None
-    f = ROOT / "profiles" / "r01" / "pmc" / "v3_uniform317_pmc_summary.json"
+    f = ROOT / "profiles" / "r01" / "pmc" / f"final_{args.strings}317_pmc_summary.json"
     try:
-        d = json.loads(f.read_text())
-        key = [k for k in d["FETCH_SIZE"] if "k_sigma<" in k][0]
-        return (2.0 * d["FETCH_SIZE"][key]["avg_KB"] + d["WRITE_SIZE"][key]["avg_KB"]) * 1024.0
+        d = json.loads(f.read_text())["HBM_BYTES"]
+        # the H-sigma instantiation is the one the Davidson launches (most dispatches); S^2 runs once per solve
+        key = max((k for k in d if "k_sigma<" in k), key=lambda k: d[k]["dispatches"])
+        return d[key]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
