@@ -105,9 +105,11 @@ typedef struct sqd_davidson_stats {
   double e_davidson;   /* eigenvalue of H + penalty (pyscf's discarded return value, without ecore) */
   double residual;     /* final |r| */
   double ms_total;     /* device time of the Davidson loop (HIP events on the context stream) */
-  double ms_sigma;     /* device time summed over the TIMED sigma launches (see time_sigma_every) */
+  double ms_sigma;     /* device time summed over the TIMED sigma applications (k_sigma + k_sigma_reduce;
+                          see time_sigma_every) */
   double ms_setup;     /* device time of the last sqd_set_subspace */
   int n_sigma_timed;   /* number of sigma launches bracketed by events in this run */
+  double ms_sigma_kernel; /* of which: the k_sigma launches alone (start event .. event after k_sigma) */
 } sqd_davidson_stats;
 
 void sqd_davidson_default_opts(sqd_davidson_opts* o);

@@ -176,6 +176,7 @@ struct sqd_ctx {
   // kernels run on the compute stream
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_sol = nullptr;
+  hipEvent_t ev_after_sigma_kernel = nullptr;  // if set: recorded once, right after the next k_sigma launch
   const int* sigma_stop = nullptr;  // device flag honoured by the sigma launches of a Davidson run, else null
   hipEvent_t ev_aux = nullptr;  // set_subspace: "CSR pointers are on the host" (later kernels keep running)
   double* h_amps = nullptr;

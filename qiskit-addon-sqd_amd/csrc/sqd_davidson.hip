@@ -550,7 +550,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   // every time_sigma_every-th sigma launch of this context is bracketed by events (stats->ms_sigma); an
   // event pair costs ~10 us of stream time, so this is sampling, and off unless asked for
   const int ev_every = o->time_sigma_every > 0 ? o->time_sigma_every : 0;
-  const int max_ev = ev_every ? (int)c->sig_ev.size() / 2 : 0;
+  const int max_ev = ev_every ? (int)c->sig_ev.size() / 3 : 0;
   bool first = true;
   // outcome of the outstanding residual hand-over: sets rnorm, conv, stop
   auto settle_residual = [&]() -> int {
@@ -584,10 +584,15 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     // sigma for the newest basis vector, and the new column of the projected matrix
     const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
     ++c->sigma_launches;
-    if (timed) SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nev], s));
-    SQD_TRY(apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift));
     if (timed) {
-      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[2 * nev + 1], s));
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev], s));
+      c->ev_after_sigma_kernel = c->sig_ev[3 * nev + 1];  // recorded by launch_sigma right after k_sigma
+    }
+    const int rc_h = apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift);
+    c->ev_after_sigma_kernel = nullptr;
+    SQD_TRY(rc_h);
+    if (timed) {
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev + 2], s));
       ++nev;
     }
     const long long seq_col = ++c->mail_seq;
@@ -695,7 +700,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     st->n_sigma = nsig;
     st->e_davidson = e;
     st->residual = rnorm;
-    st->ms_total = st->ms_sigma = st->ms_setup = 0.0;
+    st->ms_total = st->ms_sigma = st->ms_setup = st->ms_sigma_kernel = 0.0;
     st->n_sigma_timed = nev;
   }
   if (defer_sync) return SQD_OK;
@@ -714,13 +719,16 @@ int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st) {
   }
   if (st) {
     st->ms_total = ms;
-    double msig = 0.0;
+    double msig = 0.0, mker = 0.0;
     for (int i = 0; i < c->dav_nev; ++i) {
       float t = 0.f;
-      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[2 * i], c->sig_ev[2 * i + 1]));
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 2]));
       msig += t;
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 1]));
+      mker += t;
     }
     st->ms_sigma = msig;
+    st->ms_sigma_kernel = mker;
     st->ms_setup = c->ms_setup;
   }
   return SQD_OK;

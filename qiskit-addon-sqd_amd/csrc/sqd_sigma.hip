@@ -362,6 +362,10 @@ static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
   hipLaunchKernelGGL((k_sigma<R, SPIN, LDSROW>), dim3((unsigned)c->n_items, (unsigned)c->sig_nchunks), dim3(c->sig_T),
                      c->sig_shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
+  if (c->ev_after_sigma_kernel) {  // profiling: duration of k_sigma alone (the reduce follows)
+    SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+    c->ev_after_sigma_kernel = nullptr;
+  }
   return SQD_OK;
 }
 template <int R>

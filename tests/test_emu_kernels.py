@@ -21,7 +21,7 @@ from _parity import check_link_tables, check_operators, make_problem, run_full_p
 )
 def test_emu_full_parity(emu_lib, norb, nelec, na, nb, seed, hf):
     # the solver-variant sweep (restarts, long basis, ...) only on the smallest case: the emulator is slow
-    run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf, variants=(na * nb <= 40))
+    run_full_parity(emu_lib, norb, nelec, na, nb, seed, hf, variants=(na * nb <= 20))
 
 
 def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
