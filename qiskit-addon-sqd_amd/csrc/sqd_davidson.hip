@@ -96,8 +96,7 @@ template <int MV>
 __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
                                    int64_t stride, int nvec, const Coef coef, double e,
                                    const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
-                                   double* __restrict__ partial, int width, unsigned* counter,
-                                   double* __restrict__ dsums, double* mail, long long seq, const StopRule rule) {
+                                   double* __restrict__ partial, int width) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   double vals[MV + 2];
@@ -121,9 +120,9 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
       if (v < nvec) vals[2 + v] += xv[v] * t;
   }
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
+  // per-workgroup partials only: k_orth_dev (next in the stream) folds them
   if ((int)threadIdx.x < nvec + 2)
-    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 2>(red, threadIdx.x));
-  finish_and_post<MV + 2>(partial, width, nvec + 2, counter, dsums, mail, seq, red, rule);
+    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
 }
 
 // per-block (min value, index) over hdiag; tril != 0 restricts to A >= B (pyscf _get_init_guess
@@ -313,13 +312,38 @@ __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t str
 // result is normalised in the same pass; otherwise it is left with its true (small) norm.  Either way the
 // next k_dots_post measures |X_new|^2 and the host carries 1/sqrt of it as sv_new, so no separate
 // normalisation pass and no host decision is needed here.
+//
+// The residual kernel leaves only per-workgroup partials: EVERY workgroup here folds them itself (fixed
+// order, the same arithmetic everywhere => the same totals to the bit), which is cheaper than a finishing
+// step inside the residual kernel (arrival atomics + coherent re-read, ~8 us) and needs no extra launch.
+// Workgroup 0 posts the totals to the host mailbox and applies the stop rule for the kernels enqueued ahead;
+// every workgroup applies it to itself.
+template <int MV>
 __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef sv,
-                           const double* __restrict__ dsums, double* __restrict__ t, const int* stop) {
-  __shared__ double g[SQD_MAX_SPACE + 2];
+                           const double* __restrict__ partial, int nblocks, int width, double* __restrict__ t,
+                           double* mail, long long seq, const StopRule rule, const int* stop) {
+  __shared__ double red[16 * (MV + 2)];
+  __shared__ double tot[MV + 2];
+  __shared__ double g[MV + 2];
   __shared__ double s_scale;
+  __shared__ int s_stop;
   if (stop && *stop) return;
-  const double tt = dsums[1];
-  if ((int)threadIdx.x < nvec) g[threadIdx.x] = (tt > 0.0) ? sv.v[threadIdx.x] * dsums[2 + threadIdx.x] / sqrt(tt) : 0.0;
+  const int nv = nvec + 2;
+  {
+    double vals[MV + 2];
+#pragma unroll
+    for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+      for (int v = 0; v < MV + 2; ++v)
+        if (v < nv) vals[v] += partial[(int64_t)b * width + v];
+    }
+    block_sum_multi<MV + 2>(vals, nv, red);
+    if ((int)threadIdx.x < nv) tot[threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+  }
+  __syncthreads();
+  const double rr = tot[0], tt = tot[1];
+  if ((int)threadIdx.x < nvec) g[threadIdx.x] = (tt > 0.0) ? sv.v[threadIdx.x] * tot[2 + threadIdx.x] / sqrt(tt) : 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
     double c2 = 0.0;
@@ -327,8 +351,19 @@ __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stri
     const double inv = (1.0 - c2 > 1e-3) ? 1.0 / sqrt(1.0 - c2) : 1.0;
     s_scale = (tt > 0.0) ? inv / sqrt(tt) : 0.0;
     for (int v = 0; v < nvec; ++v) g[v] *= inv * sv.v[v];
+    s_stop = ((rule.de_small && rr < rule.tol2) || !(rr > rule.lindep) || !(tt > 0.0)) ? 1 : 0;
+  }
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < nv) mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = tot[threadIdx.x];
+    __threadfence_system();
   }
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (s_stop && rule.flag) *rule.flag = 1;
+    __threadfence_system();
+    *reinterpret_cast<volatile long long*>(mail) = seq;
+  }
+  if (s_stop) return;  // the correction is not needed (and may be 0/0)
   const double scale = s_scale;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = scale * t[i];
@@ -410,7 +445,7 @@ static int multi_dot(sqd_ctx* c, const double* X, int64_t stride, int nvec, cons
 }
 
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
-  SQD_TRY(c->partial.reserve((size_t)RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
   SQD_TRY(c->scal.reserve(1024));
   return multi_dot(c, x, 0, 1, y, out);
 }
@@ -482,7 +517,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->sol.reserve((size_t)D * 8));
-  SQD_TRY(c->partial.reserve((size_t)RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
   SQD_TRY(c->scal.reserve(1024));
   double* X = c->X.as<double>();
   double* AX = c->AX.as<double>();
@@ -506,7 +541,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   // factor is carried in sv like that of every later basis vector)
   double* scal = c->scal.as<double>();
   double* dsums_col = scal + 8;    // totals of the latest k_dots_post
-  double* dsums_res = scal + 48;   // totals of the latest k_residual_precond (consumed by k_orth_dev)
+
   unsigned* counter = reinterpret_cast<unsigned*>(scal + 104);
   int* stop_flag = reinterpret_cast<int*>(scal + 120);
   SQD_HIP_CHECK(hipMemsetAsync(counter, 0, 17 * sizeof(double), s));  // arrival counters and the stop flag
@@ -644,16 +679,19 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     seq_res = ++c->mail_seq;
     m_res = m;
     const StopRule rule{stop_flag, std::fabs(de) < tol ? 1 : 0, tol2, lindep};
-    if (max_space <= 12)
+    // (the two kernels use a partial buffer of their own: the next k_dots_post may already be enqueued)
+    double* part_res = c->partial.as<double>() + (size_t)RED_BLOCKS * width;
+    if (max_space <= 12) {
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m,
-                         raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, c->partial.as<double>(), width, counter,
-                         dsums_res, mail_res, seq_res, rule);
-    else
+                         raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, part_res, width);
+      hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv,
+                         (const double*)part_res, (int)gb, width, tnew, mail_res, seq_res, rule, (const int*)stop_flag);
+    } else {
       hipLaunchKernelGGL((k_residual_precond<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X,
-                         (const double*)AX, D, m, raw, e, (const double*)c->hdiag.as<double>(), pd, tnew,
-                         c->partial.as<double>(), width, counter, dsums_res, mail_res, seq_res, rule);
-    hipLaunchKernelGGL(k_orth_dev, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv, (const double*)dsums_res,
-                       tnew, (const int*)stop_flag);
+                         (const double*)AX, D, m, raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, part_res, width);
+      hipLaunchKernelGGL((k_orth_dev<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv,
+                         (const double*)part_res, (int)gb, width, tnew, mail_res, seq_res, rule, (const int*)stop_flag);
+    }
     SQD_HIP_CHECK(hipGetLastError());
     have_res = true;
     if (m + 1 > max_space) {
