@@ -168,6 +168,21 @@ int sqd_pauli_count(int device, const uint64_t* rows, int64_t d, int ngroups, co
 int sqd_pauli_fill(sqd_pauli_plan* plan, int64_t* indices, double* data, double* ms_kernels);
 int sqd_pauli_free(sqd_pauli_plan* plan);
 
+/* ---- host-side half of configuration recovery (no device work) -------------------------------------------
+ * Replaces the per-bitstring Python loop of reference configuration_recovery.py:230-304 (_bipartite_bitstring_
+ * correcting): every listed row of the bool sample matrix `bits` ([n_total][2*norb], left half = spin-down) is
+ * brought to Hamming weights (target_left, target_right) by flipping bits drawn without replacement with the
+ * occupancy-informed weights.  The draws REPLAY numpy's Generator.choice(candidates, size, replace=False, p=p)
+ * on a caller-supplied stream of uniform doubles (`uniforms`, from the same Generator), left half then right
+ * half, row after row; *n_used = doubles consumed, so that the caller can rewind the generator by the rest
+ * and a seeded run stays bit-identical to the reference's.  Returns SQD_ERR_STATE when a row's weights are
+ * ones numpy would raise on (the caller then takes the slow path to raise the same exception), SQD_ERR_LIMIT
+ * when the stream is too short. */
+int sqd_recover_rows(uint8_t* bits, int64_t n_total, int norb, const int64_t* rows, int64_t nrows,
+                     const double* up_left, const double* down_left, const double* up_right,
+                     const double* down_right, int target_left, int target_right, const double* uniforms,
+                     int64_t n_uniforms, int64_t* n_used);
+
 #ifdef __cplusplus
 }
 #endif

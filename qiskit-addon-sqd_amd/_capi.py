@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "sqd_pauli_count",
     "sqd_pauli_fill",
     "sqd_pauli_free",
+    "sqd_recover_rows",
 )
 
 
@@ -118,6 +119,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                     C.POINTER(_ctxp)]
     lib.sqd_pauli_fill.argtypes = [_ctxp, _i64p, _dp, _dp]
     lib.sqd_pauli_free.argtypes = [_ctxp]
+    lib.sqd_recover_rows.argtypes = [C.POINTER(C.c_uint8), C.c_int64, C.c_int, _i64p, C.c_int64, _dp, _dp, _dp, _dp,
+                                     C.c_int, C.c_int, _dp, C.c_int64, _i64p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("sqd_last_error", "sqd_davidson_default_opts"):

@@ -518,6 +518,14 @@ static int build_sigma_work(sqd_ctx* c) {
     const int v = std::atoi(env);
     if (v >= 1 && v <= 32) L0 = L = v;
   }
+  if (const char* env = std::getenv("SQD_SIGMA_LCHUNK")) {  // tuning hook: links per AXPY item
+    const int v = std::atoi(env);
+    if (v >= 1 && v <= 4096) L = v;
+  }
+  if (const char* env = std::getenv("SQD_SIGMA_L0")) {  // tuning hook: links folded into the own-row item
+    const int v = std::atoi(env);
+    if (v >= 0 && v <= 4096) L0 = v;
+  }
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();

@@ -127,3 +127,54 @@ def test_loop_argument_validation():
         diagonalize_fermionic_hamiltonian(h1, eri, bits, 2, 4, (2, 2), symmetrize_spin=True, max_dim=(2, 3))
     with pytest.raises(ValueError, match="did not contain any valid bitstrings"):
         diagonalize_fermionic_hamiltonian(h1, eri, bits, 2, 4, (2, 2), sci_solver=_oracle_solver([]))
+
+
+def test_recover_configurations_native_replay_matches_numpy_stream():
+    """The native row repair (csrc/sqd_recover.hip) replays numpy's Generator.choice(p=, replace=False): same
+    repaired rows, same merged probabilities, and the generator left at the same position as the per-row
+    Python path -- on noisy samples with several wrong bits per half, zero weights and duplicate rows."""
+    from qiskit_addon_sqd_amd import sampling
+
+    rng0 = np.random.default_rng(123)
+    norb, na, nb = 11, 4, 3
+    for trial in range(6):
+        n = 400
+        bits = np.zeros((n, 2 * norb), dtype=bool)
+        for i in range(n):
+            bits[i, rng0.choice(norb, nb, replace=False)] = True
+            bits[i, norb + rng0.choice(norb, na, replace=False)] = True
+        bits ^= rng0.random(bits.shape) < (0.05 + 0.05 * trial)
+        bits[::7] = bits[0]  # duplicates
+        probs = rng0.random(n)
+        probs /= probs.sum()
+        occ = (rng0.random(norb), rng0.random(norb))
+        if trial % 2:
+            occ[0][:3] = 0.0  # exact zeros / ones in the occupancies: zero flip weights
+            occ[1][-2:] = 1.0
+        g_fast, g_slow = np.random.default_rng(900 + trial), np.random.default_rng(900 + trial)
+        m_fast, p_fast = sampling.recover_configurations(bits, probs, occ, na, nb, g_fast)
+        orig = sampling._recover_rows_native
+        sampling._recover_rows_native = lambda *a, **k: False  # force the per-row numpy path
+        try:
+            m_slow, p_slow = sampling.recover_configurations(bits, probs, occ, na, nb, g_slow)
+        finally:
+            sampling._recover_rows_native = orig
+        assert np.array_equal(m_fast, m_slow) and np.array_equal(p_fast, p_slow)
+        assert g_fast.random() == g_slow.random()  # same stream position
+        assert (m_fast[:, :norb].sum(axis=1) == nb).all() and (m_fast[:, norb:].sum(axis=1) == na).all()
+    # a generator that cannot be rewound falls back to the per-row path
+    mt = np.random.Generator(np.random.MT19937(5))
+    m, p = sampling.recover_configurations(bits, probs, occ, na, nb, mt)
+    assert (m[:, norb:].sum(axis=1) == na).all()
+
+
+def test_unique_rows_matches_numpy_axis0():
+    from qiskit_addon_sqd_amd.sampling import _unique_rows
+
+    rng = np.random.default_rng(3)
+    for nbits in (1, 7, 8, 9, 60, 64, 65, 130):
+        b = rng.random((500, nbits)) < 0.5
+        b[::5] = b[1]
+        r0, c0 = np.unique(b, axis=0, return_counts=True)
+        r1, c1 = _unique_rows(b)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), nbits
