@@ -19,6 +19,9 @@ python bench_pauli.py > $OUT/bench_pauli.json 2>/dev/null
 python profiles/probes/_phase_probe.py > $OUT/phase_probe.txt 2>&1
 python profiles/probes/_rdm_probe.py > $OUT/rdm_probe.txt 2>&1
 python profiles/probes/_concurrency_probe.py > $OUT/concurrency_probe.txt 2>&1
+python profiles/probes/_loop_probe.py > $OUT/loop_probe.txt 2>&1
+CONC=4 python profiles/probes/_loop_probe.py >> $OUT/loop_probe.txt 2>&1
+python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel traces of the SAME commands as the bench lines
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_uniform317 -o p -- python $ROOT/bench.py --skip-cpu > /dev/null 2>&1
