@@ -116,6 +116,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->h_pinned) e = hipHostFree(c->h_pinned);
   if (c->h_mail) e = hipHostFree(c->h_mail);
   if (c->h_amps) e = hipHostFree(c->h_amps);
+  for (void* p : c->stage_blocks) e = hipHostFree(p);
   if (c->ev_sol) e = hipEventDestroy(c->ev_sol);
   if (c->ev_aux) e = hipEventDestroy(c->ev_aux);
   if (c->copy_stream) e = hipStreamDestroy(c->copy_stream);

@@ -139,9 +139,15 @@ struct sqd_ctx {
   sqd::DevBuf hdiag;        // f64[D]
   // sigma work list + launch geometry (fixed per subspace)
   sqd::DevBuf d_blob;               // packed capped-ELL descriptors (one upload); views in SpinTables
-  std::vector<char> h_blob;
+  // pinned host staging for the small uploads / downloads of set_subspace (a copy from pageable memory
+  // blocks the host for ~10 us each; from pinned memory it is an asynchronous enqueue).  Bump-allocated,
+  // reset at the start of every set_subspace once the previous one's copies have completed.
+  std::vector<void*> stage_blocks;
+  char* stage_cur = nullptr;
+  size_t stage_cap = 0, stage_off = 0, stage_total = 0;
+  bool stage_pending = false;
   sqd::DevBuf ptrs;                 // [s_ptr_a | d_ptr_a | s_ptr_b | d_ptr_b]; SpinTables::s_ptr/d_ptr are views
-  std::vector<int64_t> h_ptrs;      // host copy of the same
+  // (the host copy of the same lives in the pinned staging arena; h_sptr.. point into it)
   const int64_t *h_sptr = nullptr, *h_dptr = nullptr, *h_sptr_b = nullptr, *h_dptr_b = nullptr;
   std::vector<sqd::WorkItem> h_items;
   std::vector<sqd::MultiRow> h_multi;

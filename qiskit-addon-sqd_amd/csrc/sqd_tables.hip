@@ -63,6 +63,53 @@ void SpinTables::release() {
   for (DevBuf* b : all) b->release();
 }
 
+// ---- pinned staging arena (see sqd_ctx::stage_*)
+static int stage_reset(sqd_ctx* c) {
+  if (c->stage_pending) {  // copies of the previous set_subspace still read the arena
+    SQD_HIP_CHECK(hipEventSynchronize(c->ev[1]));
+    c->stage_pending = false;
+  }
+  if (c->stage_blocks.size() > 1) {  // grew last time: one block of the total size from now on
+    for (void* p : c->stage_blocks) SQD_HIP_CHECK(hipHostFree(p));
+    c->stage_blocks.clear();
+    c->stage_cur = nullptr;
+    c->stage_cap = 0;
+    void* p = nullptr;
+    SQD_HIP_CHECK(hipHostMalloc(&p, c->stage_total + (1 << 16), hipHostMallocDefault));
+    c->stage_blocks.push_back(p);
+    c->stage_cur = static_cast<char*>(p);
+    c->stage_cap = c->stage_total + (1 << 16);
+  }
+  c->stage_off = 0;
+  c->stage_total = 0;
+  return SQD_OK;
+}
+static int stage_alloc(sqd_ctx* c, size_t bytes, void** out) {
+  bytes = (bytes + 63) & ~size_t(63);
+  c->stage_total += bytes;
+  if (c->stage_off + bytes > c->stage_cap) {
+    const size_t want = bytes * 2 > (size_t(1) << 20) ? bytes * 2 : (size_t(1) << 20);
+    void* p = nullptr;
+    SQD_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    c->stage_blocks.push_back(p);
+    c->stage_cur = static_cast<char*>(p);
+    c->stage_cap = want;
+    c->stage_off = 0;
+  }
+  *out = c->stage_cur + c->stage_off;
+  c->stage_off += bytes;
+  return SQD_OK;
+}
+// host data -> pinned arena -> device, asynchronously on the context stream
+static int stage_upload(sqd_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return SQD_OK;
+  void* h = nullptr;
+  SQD_TRY(stage_alloc(c, bytes, &h));
+  std::memcpy(h, src, bytes);
+  SQD_HIP_CHECK(hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, c->stream));
+  return SQD_OK;
+}
+
 __device__ inline int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
 __device__ inline uint64_t below_mask(int p) { return (p >= 64) ? ~0ull : ((1ull << p) - 1ull); }
 
@@ -565,11 +612,8 @@ static int build_sigma_work(sqd_ctx* c) {
   SQD_TRY(c->items.reserve(items.size() * sizeof(WorkItem)));
   SQD_TRY(c->multi.reserve((multi.size() + 1) * sizeof(MultiRow)));
   SQD_TRY(c->sig_partial.reserve((size_t)nslots * nb * 8 + 8));
-  SQD_HIP_CHECK(hipMemcpyAsync(c->items.p, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
-                               c->stream));
-  if (!multi.empty())
-    SQD_HIP_CHECK(hipMemcpyAsync(c->multi.p, multi.data(), multi.size() * sizeof(MultiRow), hipMemcpyHostToDevice,
-                                 c->stream));
+  SQD_TRY(stage_upload(c, c->items.p, items.data(), items.size() * sizeof(WorkItem)));
+  SQD_TRY(stage_upload(c, c->multi.p, multi.data(), multi.size() * sizeof(MultiRow)));
   return SQD_OK;
 }
 
@@ -670,6 +714,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   SQD_TRY(validate_strings(sb, nb, c->norb, "Spin-down", &nocc[1]));
   const int norb = c->norb, nnorb = c->nnorb;
   hipStream_t st = c->stream;
+  SQD_TRY(stage_reset(c));
   SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
 
   const uint64_t* hs[2] = {sa, sb};
@@ -682,7 +727,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     t.nocc = nocc[s];
     t.n_slices = (t.n + 63) / 64;
     SQD_TRY(t.strs.reserve(t.n * 8));
-    SQD_HIP_CHECK(hipMemcpyAsync(t.strs.p, hs[s], t.n * 8, hipMemcpyHostToDevice, st));
+    SQD_TRY(stage_upload(c, t.strs.p, hs[s], (size_t)t.n * 8));
   }
   // pass 1: counts + CSR pointers for both spins, one host sync for the totals
   // all four CSR pointer arrays live in one device buffer so that ONE copy brings them (and with them
@@ -723,8 +768,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     hipLaunchKernelGGL(k_exclusive_scan4, dim3(4), dim3(256), 0, st, jobs);
     SQD_HIP_CHECK(hipGetLastError());
   }
-  c->h_ptrs.resize(nptr);
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_ptrs.data(), c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
+  void* h_ptrs = nullptr;  // pinned: the copy is asynchronous, the host waits on the event below
+  SQD_TRY(stage_alloc(c, (size_t)nptr * 8, &h_ptrs));
+  SQD_HIP_CHECK(hipMemcpyAsync(h_ptrs, c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipEventRecord(c->ev_aux, st));
   // everything that needs only the strings is queued BEHIND the copy and runs while the host waits for the
   // pointers and cuts the work lists: per-string energies, occupation tables, the diagonal
@@ -748,7 +794,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                      c->hdiag.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
   SQD_HIP_CHECK(hipEventSynchronize(c->ev_aux));
-  c->h_sptr = c->h_ptrs.data();
+  c->h_sptr = static_cast<const int64_t*>(h_ptrs);
   c->h_dptr = c->h_sptr + (na + 1);
   c->h_sptr_b = c->h_dptr + (na + 1);
   c->h_dptr_b = c->h_sptr_b + (nb + 1);
@@ -865,15 +911,16 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     };
     size_t blob = 0;
     for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);
-    c->h_blob.resize(blob + 16);
+    void* h_blob = nullptr;
+    SQD_TRY(stage_alloc(c, blob + 16, &h_blob));
     SQD_TRY(c->d_blob.reserve(blob + 16));
     size_t off = 0;
     for (const Up& u : ups) {
-      if (u.bytes) std::memcpy(c->h_blob.data() + off, u.src, u.bytes);
+      if (u.bytes) std::memcpy(static_cast<char*>(h_blob) + off, u.src, u.bytes);
       u.buf->set_view(static_cast<char*>(c->d_blob.p) + off);
       off += (u.bytes + 15) & ~size_t(15);
     }
-    if (blob) SQD_HIP_CHECK(hipMemcpyAsync(c->d_blob.p, c->h_blob.data(), blob, hipMemcpyHostToDevice, st));
+    if (blob) SQD_HIP_CHECK(hipMemcpyAsync(c->d_blob.p, h_blob, blob, hipMemcpyHostToDevice, st));
     SQD_TRY(t.es_rec.reserve((size_t)vs.total * sizeof(SRec) + 8));
     SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
     SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
@@ -899,6 +946,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   SQD_TRY(build_sigma_work(c));
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
   SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
+  c->stage_pending = true;
   c->ms_setup = -1.0;
   c->have_subspace = true;
   return SQD_OK;
