@@ -85,8 +85,10 @@ int sqd_contract_ss(sqd_ctx* ctx, const double* c, double* out);
 
 typedef struct sqd_davidson_opts {
   double tol;        /* pyscf conv_tol, default 1e-9 (SelectedCI) */
-  double tol_residual; /* |r| threshold; <= 0 selects sqrt(tol)/32 (pyscf: sqrt(tol); tighter here so that
-                          <c|H|c> of a penalty-shifted eigenvector is good to ~1e-7 Ha) */
+  double tol_residual; /* |r| threshold; <= 0 selects sqrt(tol)/32 (pyscf: sqrt(tol)).  Tighter here because the
+                          orbital occupancies, and with a spin penalty <c|H|c> itself, are FIRST order in the
+                          residual: 1e-6 instead of 1e-4, which keeps a seeded SQD run reproducible.  Pass
+                          sqrt(tol) for pyscf's rule (about a quarter fewer sigma builds). */
   double lindep;     /* 1e-14 */
   int max_cycle;     /* 100 */
   int max_space;     /* 12 */
