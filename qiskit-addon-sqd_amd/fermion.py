@@ -274,7 +274,7 @@ def solve_sci_batch(
     *,
     spin_sq: float | None = None,
     devices: Sequence[int] | None = None,
-    concurrency: int = 1,
+    concurrency: int | None = None,
     **kwargs,
 ) -> list[SCIResult]:
     """Diagonalize Hamiltonian in subspaces (reference ``fermion.py:643-681``).
@@ -283,9 +283,14 @@ def solve_sci_batch(
     ``devices=[0, 1, ...]`` batch ``i`` runs on ``devices[i % len(devices)]`` (one host thread and one
     context per device; ctypes releases the GIL during native calls).  ``concurrency=k`` runs ``k``
     solves at a time on each device (own context + HIP stream each): a 1e5-determinant solve is
-    latency-bound and leaves most of the GPU idle, so independent batches overlap well.
-    Default: device 0, one at a time.
+    latency-bound and leaves most of the GPU idle, so independent batches overlap well (measured: 16
+    HF-centred 317 x 317 batches 3.7 -> 1.8 ms per batch at k = 4).  Default (``None``): device 0, up to 4
+    batches in flight while every subspace stays below 4e6 determinants (26 resident vectors each), else one
+    at a time.  The results do not depend on the concurrency.
     """
+    if concurrency is None:
+        biggest = max((len(a) * len(b) for a, b in ci_strings), default=0)
+        concurrency = min(4, len(ci_strings)) if 0 < biggest <= 4_000_000 else 1
     if concurrency > 1:
         devices = [d for d in (devices or [0]) for _ in range(concurrency)]
     if not devices or len(devices) == 1 or len(ci_strings) <= 1:

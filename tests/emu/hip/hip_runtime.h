@@ -71,9 +71,13 @@ inline void* dyn_smem() {
 }
 inline Wave& my_wave() { return cur_block()->waves[tl().tid.x / 64]; }
 inline std::mutex& atomic_mu() { static std::mutex m; return m; }
+inline std::mutex& launch_mu() { static std::mutex m; return m; }
 
 template <class K, class... A>
 void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
+  // one kernel at a time: the current block and the `__shared__ static` variables are process-wide, and host
+  // threads (solve_sci_batch runs several contexts concurrently) may launch at the same moment
+  std::lock_guard<std::mutex> launch_guard(launch_mu());
   const int T = block.x;
   Block blk;
   blk.dyn.assign(shmem + 64, 0);
