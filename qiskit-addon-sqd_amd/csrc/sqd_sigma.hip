@@ -93,25 +93,39 @@ __device__ inline double axpy_chunk(const double* __restrict__ C, const uint32_t
 }
 
 // ---- one virtual row of a beta list against LDS-staged data.  Link records are fetched PF at a time
-// (independent coalesced loads in flight together), then consumed against LDS.
-// singles on the own row: sum (value + sign * W[widx]) * Crow[src]
+// (independent coalesced loads in flight together), then consumed against LDS.  The LDS phase is written
+// WITHOUT per-link predicates: links beyond the row's count get index 0 and weight 0, so that all PF gathers
+// of a round are issued back to back and waited for once (predicated per-link blocks make the compiler wait
+// for each pair of LDS reads separately -- measured as the pace of the whole kernel).
+// singles on the own row: sum (value + sign * W[pair]) * Crow[src]
 __device__ inline double vrow_singles_own(const SigmaArgs& g, int64_t v, const double* Crow, const double* W2) {
   const int64_t base = g.esb_sl[v >> 6] + (v & 63);
   const int cnt = g.vs_cnt[v];
-  constexpr int PF = 4;
+  constexpr int PF = 8;
   double a = 0.0;
   for (int k0 = 0; k0 < cnt; k0 += PF) {
     SRec recs[PF];
     double vals[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < PF; ++u) {
+      recs[u] = SRec{0u, 0u};
+      vals[u] = 0.0;
       if (k0 + u < cnt) {
         recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
         vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
       }
+    }
+    double w[PF], x[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (k0 + u < cnt) a += (vals[u] + srec_sign(recs[u].meta) * W2[srec_widx(recs[u].meta) >> 1]) * Crow[recs[u].src];
+    for (int u = 0; u < PF; ++u) {
+      w[u] = W2[srec_widx(recs[u].meta) >> 1];
+      x[u] = Crow[recs[u].src];
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const double sg = (k0 + u < cnt) ? srec_sign(recs[u].meta) : 0.0;
+      a += (vals[u] + sg * w[u]) * x[u];
+    }
   }
   return a;
 }
@@ -125,14 +139,19 @@ __device__ inline double vrow_doubles_own(const SigmaArgs& g, int64_t v, const d
     uint32_t srcs[PF];
     double vals[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < PF; ++u) {
+      srcs[u] = 0u;
+      vals[u] = 0.0;
       if (k0 + u < cnt) {
         srcs[u] = g.edb_src[base + (int64_t)(k0 + u) * 64];
         vals[u] = g.edb_val[base + (int64_t)(k0 + u) * 64];
       }
+    }
+    double x[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (k0 + u < cnt) a += vals[u] * Crow[srcs[u]];
+    for (int u = 0; u < PF; ++u) x[u] = Crow[srcs[u]];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) a += vals[u] * x[u];
   }
   return a;
 }
@@ -146,37 +165,63 @@ __device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B
   return a;
 }
 
-// singles against a batch of kb staged alpha links: sum sign * sum_j W[j][pair] * Crow[j][src].
+// singles against a batch of KT staged alpha links: sum sign * sum_j W[j][pair] * Crow[j][src].
+// KT is the batch capacity (compile-time: the j loop unrolls, all gathers of a link are in flight together);
+// slots beyond the batch's actual count hold zero rows (staged by the caller).
 // SPIN: the S^2 operator couples alpha link j (cre a, des b) to the one beta link with the same orbital
-// pair and the opposite direction (cre b, des a); penw[j] is that beta link's widx, pen the coefficient.
-template <bool SPIN>
-__device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const double* Crow, const double* W, int kb,
-                                            int ws, const int* penw, double pen) {
+// pair and the opposite direction (cre b, des a); penw[j] is that beta link's widx (-1 for an empty slot),
+// pen the coefficient.
+template <bool SPIN, int KT>
+__device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const double* Crow, const double* W, int ws,
+                                            const int* penw, double pen) {
   const int64_t base = g.esb_sl[v >> 6] + (v & 63);
   const int cnt = g.vs_cnt[v];
   constexpr int PF = 8;
+  int pw[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) pw[j] = SPIN ? penw[j] : -1;
   double a = 0.0;
   for (int k0 = 0; k0 < cnt; k0 += PF) {
     SRec recs[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < PF; ++u) {
+      recs[u] = SRec{0u, 0u};
       if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+    }
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (k0 + u < cnt) {
-        const int widx = (int)srec_widx(recs[u].meta);
-        const double* cr = Crow + recs[u].src;
-        const double* w = W + (widx >> 1);
-        double t = 0.0;
-        for (int j = 0; j < kb; ++j) {
-          double wj = w[(int64_t)j * ws];
-          if (SPIN) wj += (widx == penw[j]) ? pen : 0.0;
-          t += wj * cr[(int64_t)j * g.nb_pad];
-        }
-        a += srec_sign(recs[u].meta) * t;
+    for (int u = 0; u < PF; ++u) {
+      const int widx = (int)srec_widx(recs[u].meta);
+      const double* cr = Crow + recs[u].src;
+      const double* w = W + (widx >> 1);
+      double wj[KT], cj[KT];
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        wj[j] = w[(int64_t)j * ws];
+        cj[j] = cr[(int64_t)j * g.nb_pad];
       }
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        double wv = wj[j];
+        if (SPIN) wv += (widx == pw[j]) ? pen : 0.0;
+        t += wv * cj[j];
+      }
+      const double sg = (k0 + u < cnt) ? srec_sign(recs[u].meta) : 0.0;
+      a += sg * t;
+    }
   }
   return a;
+}
+// dispatch on the batch capacity of this launch (uniform)
+template <bool SPIN>
+__device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t v, const double* Crow, const double* W,
+                                              int ws, const int* penw, double pen) {
+  switch (K) {
+    case 1: return vrow_singles_batch<SPIN, 1>(g, v, Crow, W, ws, penw, pen);
+    case 2: return vrow_singles_batch<SPIN, 2>(g, v, Crow, W, ws, penw, pen);
+    case 3: return vrow_singles_batch<SPIN, 3>(g, v, Crow, W, ws, penw, pen);
+    default: return vrow_singles_batch<SPIN, 4>(g, v, Crow, W, ws, penw, pen);
+  }
 }
 
 // LDSROW: the C rows of an item are staged in LDS (the tuned path).  !LDSROW: rows too long for LDS are
@@ -282,13 +327,21 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       }
       for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
     }
+    // empty slots of a short batch: zero rows (the gather loop runs over the full batch capacity)
+    for (int j = kb; j < (LDSROW ? g.K : 1); ++j) {
+      if (tid == 0) penw[j] = -1;
+      double* cr = Crow + (int64_t)j * g.nb_pad;
+      double* w2 = W2 + (int64_t)j * w2s;
+      for (int64_t i = tid; i < nb; i += T) cr[i] = 0.0;
+      for (int i = tid; i < nnorb; i += T) w2[i] = 0.0;
+    }
     __syncthreads();
     if (LDSROW) {
       for (int v = vs0 + tid; v < vs1; v += T)
-        part_s[v - vs0] = vrow_singles_batch<SPIN>(g, v, Crow, W2, kb, w2s, penw, pen);
+        part_s[v - vs0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen);
     } else {
       for (int v = vs0 + tid; v < vs1; v += T)
-        part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN>(g, v, srow0, W2, 1, w2s, penw, pen);
+        part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN, 1>(g, v, srow0, W2, w2s, penw, pen);
     }
     __syncthreads();
 #pragma unroll
