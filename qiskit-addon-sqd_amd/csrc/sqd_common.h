@@ -160,6 +160,9 @@ struct sqd_ctx {
   bool sig_lds_rows = true;      // C rows staged in LDS (false: rows too long, read from global/L2)
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
+  // LDS capacity (in virtual rows) of the singles' / doubles' partial-sum arrays; a chunk with more
+  // virtual rows than that is walked in several passes over the same staged row
+  int64_t sig_ps = 0, sig_pd = 0;
   // Davidson workspace
   sqd::DevBuf X, AX;        // (max_space+1) * D each
   sqd::DevBuf sol;          // f64[D] resident solution

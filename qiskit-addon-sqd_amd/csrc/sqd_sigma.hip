@@ -52,7 +52,8 @@ struct SigmaArgs {
   const int32_t* vd_own;
   int nv_s, nv_d;
   // column chunks (gridDim.y): chunk k covers columns [k*chunk_cols, ...) and the virtual rows
-  // [v*_chunk[k], v*_chunk[k+1]); nvs_max / nvd_max = longest such range (LDS partial-sum arrays)
+  // [v*_chunk[k], v*_chunk[k+1]); nvs_max / nvd_max = capacity of the LDS partial-sum arrays: the longest
+  // such range, or less -- then the range is walked in passes of that many virtual rows
   const int32_t* vs_chunk;
   const int32_t* vd_chunk;
   int64_t chunk_cols;
@@ -157,12 +158,22 @@ __device__ inline double vrow_doubles_own(const SigmaArgs& g, int64_t v, const d
 }
 // string B's share of a list: its contiguous run of full rows, then its tail (fixed order)
 // (part[] holds the rows of one column chunk, whose first row is v0)
-__device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B, const double* part, int v0) {
-  const int f0 = own[3 * B] - v0, nfull = own[3 * B + 1], tail = own[3 * B + 2];
+// part[] holds the virtual rows [v0, v1) of this pass (all rows of the column chunk when one pass suffices;
+// full rows precede tails in the row order, so passes add a string's rows in the same fixed order)
+__device__ inline double own_rows_sum(const int32_t* __restrict__ own, int64_t B, const double* part, int v0, int v1) {
+  const int f0 = own[3 * B], nfull = own[3 * B + 1], tail = own[3 * B + 2];
+  const int x0 = f0 > v0 ? f0 : v0, x1 = (f0 + nfull < v1) ? f0 + nfull : v1;
   double a = 0.0;
-  for (int x = 0; x < nfull; ++x) a += part[f0 + x];
-  if (tail >= 0) a += part[tail - v0];
+  for (int x = x0; x < x1; ++x) a += part[x - v0];
+  if (tail >= v0 && tail < v1) a += part[tail - v0];
   return a;
+}
+
+// passes needed to walk ns singles' and nd doubles' virtual rows with LDS room for cs / cd partial sums
+__device__ inline int npasses(int ns, int cs, int nd, int cd) {
+  const int a = (ns + cs - 1) / (cs > 0 ? cs : 1), b = (nd + cd - 1) / (cd > 0 ? cd : 1);
+  const int n = a > b ? a : b;
+  return n > 1 ? n : 1;
 }
 
 // singles against a batch of KT staged alpha links: sum sign * sum_j W[j][pair] * Crow[j][src].
@@ -226,7 +237,9 @@ __device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t
 
 // LDSROW: the C rows of an item are staged in LDS (the tuned path).  !LDSROW: rows too long for LDS are
 // read in place (global memory / L2), one alpha link per batch; everything else is unchanged.
-template <int R, bool SPIN, bool LDSROW>
+// PASS: the beta lists outgrow the LDS partial-sum arrays and continue in extra passes (staged rows of ~10^4
+// strings); a separate instantiation so that the tuned single-pass kernels keep their register budget.
+template <int R, bool SPIN, bool LDSROW, bool PASS>
 __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)
   if (g.stop && *g.stop) return;  // uniform over the launch
@@ -273,14 +286,19 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         W2[i] = g.ja_row[A * nnorb + i];
       }
     __syncthreads();
-    // every virtual row of the beta lists, by whichever thread comes next; partial sums through LDS
+    // every virtual row of the beta lists, by whichever thread comes next; partial sums through LDS.
+    // One pass unless the lists outgrow the partial-sum arrays (long rows, see build_subspace).
+    // (the first nvs_max / nvd_max of them here; lists that outgrow the partial-sum arrays -- long rows, see
+    // build_subspace -- continue in the extra passes at the end of the kernel)
+    const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
+    const int d1 = (vd0 + g.nvd_max < vd1) ? vd0 + g.nvd_max : vd1;
     if (g.mode == 0) {
       if (LDSROW) {
-        for (int v = vs0 + tid; v < vs1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, Crow, W2);
-        for (int v = vd0 + tid; v < vd1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, Crow);
+        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, Crow, W2);
+        for (int v = vd0 + tid; v < d1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, Crow);
       } else {
-        for (int v = vs0 + tid; v < vs1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, crow0, W2);
-        for (int v = vd0 + tid; v < vd1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, crow0);
+        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, crow0, W2);
+        for (int v = vd0 + tid; v < d1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, crow0);
       }
     }
     __syncthreads();
@@ -298,8 +316,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
         double a = d * (LDSROW ? Crow[B] : crow0[B]);
         if (g.mode == 0) {
           // beta same-spin singles (value) + beta single x alpha occupation (W2 slot 0), beta doubles
-          a += own_rows_sum(g.vs_own, B, part_s, vs0);
-          a += own_rows_sum(g.vd_own, B, part_d, vd0);
+          a += own_rows_sum(g.vs_own, B, part_s, vs0, s1);
+          a += own_rows_sum(g.vd_own, B, part_d, vd0, d1);
           // first same-spin alpha links of this row: unit-stride row reads
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
         }
@@ -336,11 +354,12 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       for (int i = tid; i < nnorb; i += T) w2[i] = 0.0;
     }
     __syncthreads();
+    const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
     if (LDSROW) {
-      for (int v = vs0 + tid; v < vs1; v += T)
+      for (int v = vs0 + tid; v < s1; v += T)
         part_s[v - vs0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen);
     } else {
-      for (int v = vs0 + tid; v < vs1; v += T)
+      for (int v = vs0 + tid; v < s1; v += T)
         part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN, 1>(g, v, srow0, W2, w2s, penw, pen);
     }
     __syncthreads();
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
             a += g.jbT[(int64_t)pair * nb + B] * (LDSROW ? Crow[(int64_t)j * g.nb_pad + B] : sg0 * srow0[B]);
           }
         }
-        a += own_rows_sum(g.vs_own, B, part_s, vs0);
+        a += own_rows_sum(g.vs_own, B, part_s, vs0, s1);
         acc[r] = a;
       }
     }
@@ -376,6 +395,39 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   for (int r = 0; r < R; ++r) {
     const int64_t B = B0 + tid + (int64_t)r * T;
     if (B < Bend) __builtin_nontemporal_store(acc[r], &out[B]);
+  }
+  // ---- extra passes (staged rows of ~10^4 strings: one partial sum per virtual row does not fit beside
+  // the row).  The staged rows are still in LDS; every further pass evaluates the next nvs_max / nvd_max
+  // virtual rows and each thread adds its strings' share to the element it has just written (same thread,
+  // same address: program order).  Full rows precede tails in the row order and a string's full rows are
+  // contiguous, so the order of additions is fixed by the layout alone.
+  if (PASS && LDSROW && it.type != 2 && ((g.type_mask >> it.type) & 1)) {
+    const bool own = (it.type == 0);
+    const int npass = own ? (g.mode == 0 ? npasses(vs1 - vs0, g.nvs_max, vd1 - vd0, g.nvd_max) : 1)
+                          : npasses(vs1 - vs0, g.nvs_max, 0, 1);
+    const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+    for (int ps = 1; ps < npass; ++ps) {
+      const int s0 = vs0 + ps * g.nvs_max, s1 = (s0 + g.nvs_max < vs1) ? s0 + g.nvs_max : vs1;
+      const int d0 = vd0 + ps * g.nvd_max, d1 = (d0 + g.nvd_max < vd1) ? d0 + g.nvd_max : vd1;
+      __syncthreads();  // the previous pass's sums have been consumed
+      if (own) {
+        for (int v = s0 + tid; v < s1; v += T) part_s[v - s0] = vrow_singles_own(g, v, Crow, W2);
+        for (int v = d0 + tid; v < d1; v += T) part_d[v - d0] = vrow_doubles_own(g, v, Crow);
+      } else {
+        for (int v = s0 + tid; v < s1; v += T)
+          part_s[v - s0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen);
+      }
+      __syncthreads();
+#pragma nounroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t B = B0 + tid + (int64_t)r * T;
+        if (B < Bend) {
+          double t = own_rows_sum(g.vs_own, B, part_s, s0, s1);
+          if (own) t += own_rows_sum(g.vd_own, B, part_d, d0, d1);
+          out[B] += t;
+        }
+      }
+    }
   }
 }
 
@@ -406,13 +458,13 @@ __global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, doubl
     y[i] = a * x[i] + b * y[i];
 }
 
-template <int R, bool SPIN, bool LDSROW>
+template <int R, bool SPIN, bool LDSROW, bool PASS>
 static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
   if (c->sig_shmem > 64 * 1024) {
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN, LDSROW>),
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN, LDSROW, PASS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
   }
-  hipLaunchKernelGGL((k_sigma<R, SPIN, LDSROW>), dim3((unsigned)c->n_items, (unsigned)c->sig_nchunks), dim3(c->sig_T),
+  hipLaunchKernelGGL((k_sigma<R, SPIN, LDSROW, PASS>), dim3((unsigned)c->n_items, (unsigned)c->sig_nchunks), dim3(c->sig_T),
                      c->sig_shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   if (c->ev_after_sigma_kernel) {  // profiling: duration of k_sigma alone (the reduce follows)
@@ -423,12 +475,16 @@ static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
 }
 template <int R>
 static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
-  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true, true>(c, g) : launch_sigma_rs<R, false, true>(c, g);
+  const bool spin = (g.mode == 1 || g.spin);
+  if (c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max)  // multi-pass walk of the beta lists
+    return spin ? launch_sigma_rs<R, true, true, true>(c, g) : launch_sigma_rs<R, false, true, true>(c, g);
+  return spin ? launch_sigma_rs<R, true, true, false>(c, g) : launch_sigma_rs<R, false, true, false>(c, g);
 }
 // rows in global memory: R is 1 (test hook) or 4 (4096-column chunks of 1024 threads)
 template <int R>
 static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
-  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true, false>(c, g) : launch_sigma_rs<R, false, false>(c, g);
+  return (g.mode == 1 || g.spin) ? launch_sigma_rs<R, true, false, false>(c, g)
+                                 : launch_sigma_rs<R, false, false, false>(c, g);
 }
 
 int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift) {
@@ -481,8 +537,8 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.vs_chunk = b.vs_chunk.as<int32_t>();
   g.vd_chunk = b.vd_chunk.as<int32_t>();
   g.chunk_cols = c->sig_chunk;
-  g.nvs_max = (int)c->hv_s.nv_max;
-  g.nvd_max = (int)c->hv_d.nv_max;
+  g.nvs_max = (int)c->sig_ps;
+  g.nvd_max = (int)c->sig_pd;
   g.stop = c->sigma_stop;
 
   const int R = c->sig_R;

@@ -514,8 +514,8 @@ static SigmaPlan plan_sigma(const sqd_ctx* c, int64_t nb, const VRowsHost& vs, c
   p.nb_pad = (int)((nb + 1) & ~int64_t(1));
   const size_t w2_bytes = (size_t)((c->nnorb + 1) & ~1) * 8;
   const size_t row_bytes = (size_t)p.nb_pad * 8 + w2_bytes;  // one C row + one integral row
-  const size_t ps_bytes = (size_t)((vs.nv_max + 1) & ~int64_t(1)) * 8 + 16;  // singles partials + penw
-  const size_t pd_bytes = (size_t)vd.nv_max * 8;
+  const size_t ps_bytes = (size_t)((c->sig_ps + 1) & ~int64_t(1)) * 8 + 16;  // singles partials + penw
+  const size_t pd_bytes = (size_t)c->sig_pd * 8;
   const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
   auto plan_bytes = [&](int k) {
     const size_t batch = (size_t)k * row_bytes, own = row_bytes + pd_bytes;
@@ -605,10 +605,10 @@ static int build_sigma_work(sqd_ctx* c) {
   c->n_slots = nslots;
   if (std::getenv("SQD_DEBUG_GEOM"))
     std::fprintf(stderr,
-                 "[sqd geom] na %lld nb %lld T %d R %d K %d lds_rows %d chunks %d cap %d nvs %lld nvd %lld shmem %zu items %zu "
+                 "[sqd geom] na %lld nb %lld T %d R %d K %d lds_rows %d chunks %d cap %d nvs %lld/%lld nvd %lld/%lld shmem %zu items %zu "
                  "multi %zu slots %d\n",
                  (long long)na, (long long)nb, T, R, K, (int)c->sig_lds_rows, c->sig_nchunks, c->sp[1].cap,
-                 (long long)c->hv_s.nv_max, (long long)c->hv_d.nv_max, c->sig_shmem, items.size(), multi.size(), nslots);
+                 (long long)c->hv_s.nv_max, (long long)c->sig_ps, (long long)c->hv_d.nv_max, (long long)c->sig_pd, c->sig_shmem, items.size(), multi.size(), nslots);
   SQD_TRY(c->items.reserve(items.size() * sizeof(WorkItem)));
   SQD_TRY(c->multi.reserve((multi.size() + 1) * sizeof(MultiRow)));
   SQD_TRY(c->sig_partial.reserve((size_t)nslots * nb * 8 + 8));
@@ -868,6 +868,12 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       if (forced >= 64 && forced <= 1024) lds_rows = false;
       else forced = 0;
     }
+    int64_t forced_pass = 0;  // test hook: partial-sum capacity in virtual rows, forces the multi-pass walk
+    if (const char* env = std::getenv("SQD_SIGMA_PASS")) {
+      forced_pass = std::atoll(env);
+      if (forced_pass < 1 || !lds_rows) forced_pass = 0;
+    }
+    int64_t pass_s = 0, pass_d = 0;
     for (;;) {
       if (!lds_rows) chunk_cols = forced ? forced : 4096;
       const size_t target = lds_rows ? 40 * 1024 : 120 * 1024;
@@ -877,7 +883,28 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
         if ((size_t)(vs.nv_max + vd.nv_max) * 8 <= target || cap >= (1 << 20)) break;
       }
       const size_t part_bytes = (size_t)(vs.nv_max + vd.nv_max) * 8 + 64;
-      if (lds_rows && row_bytes + part_bytes > budget) {
+      pass_s = vs.nv_max;
+      pass_d = vd.nv_max;
+      if (lds_rows && (row_bytes + part_bytes > budget || forced_pass)) {
+        // The row fits but one partial sum per virtual row does not (at least one row per beta string with
+        // links: nb of ~8000 and more).  Keep the row in LDS -- a gather from LDS beats a gather from L2
+        // by far -- and walk the virtual rows in passes over a bounded partial-sum buffer.
+        size_t avail = (budget > row_bytes + 128) ? budget - row_bytes - 128 : 0;
+        if (std::getenv("SQD_SIGMA_NOPASS")) avail = 0;  // tuning hook: previous behaviour (global rows)
+        if (avail >= 24 * 1024 || forced_pass) {
+          cap = cap0 < 32 && !forced_pass ? 32 : cap0;  // moderate rows: balance without a row per 8 links
+          make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
+          make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
+          const int64_t entries = (int64_t)(avail / 8);
+          pass_s = forced_pass ? forced_pass : entries / 4;
+          if (pass_s > vs.nv_max) pass_s = vs.nv_max;
+          if (pass_s < 1) pass_s = 1;
+          pass_d = forced_pass ? forced_pass : entries - ((pass_s + 1) & ~int64_t(1));
+          if (!forced_pass && pass_d >= 1024) pass_d &= ~int64_t(1023);  // whole strides of the workgroup
+          if (pass_d > vd.nv_max) pass_d = vd.nv_max;
+          if (pass_d < 1) pass_d = 1;
+          break;
+        }
         lds_rows = false;
         continue;
       }
@@ -888,6 +915,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       break;
     }
     c->sig_lds_rows = lds_rows;
+    c->sig_ps = pass_s;
+    c->sig_pd = pass_d;
     c->sig_chunk = chunk_cols;
     c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
     c->sig_kmax = 4;

@@ -51,6 +51,20 @@ def test_emu_global_row_fallback(emu_lib, monkeypatch):
     run_full_parity(emu_lib, 9, (2, 4), 7, 100, 29, True, variants=False)
 
 
+def test_emu_multi_pass_partial_sums(emu_lib, monkeypatch):
+    # SQD_SIGMA_PASS=5 leaves LDS room for only 5 partial sums per list: the virtual rows of the staged
+    # row are walked in several passes (the layout of rows with ~10^4 strings), singles and doubles needing
+    # different numbers of passes
+    monkeypatch.setenv("SQD_SIGMA_PASS", "5")
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
+    # 420 / 840 virtual rows in passes of 40, two column strides per thread (64 threads: the emulator's
+    # barriers are OS-thread rendezvous)
+    monkeypatch.setenv("SQD_SIGMA_PASS", "40")
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    monkeypatch.setenv("SQD_SIGMA_T", "64")
+    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
+
+
 def test_emu_h2_minimal(emu_lib):
     # H2 / STO-3G textbook integrals: 2 electrons in 2 orbitals, 2x2 subspace
     h1 = np.diag([-1.2525, -0.4759])

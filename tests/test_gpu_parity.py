@@ -54,6 +54,14 @@ def test_global_row_fallback_forced(hip_lib, monkeypatch):
     run_full_parity(hip_lib, 12, (2, 6), 3, 924, 19, False)
 
 
+def test_multi_pass_partial_sums_forced(hip_lib, monkeypatch):
+    # LDS room for 48 partial sums per list: the staged row's virtual rows are walked in many passes
+    monkeypatch.setenv("SQD_SIGMA_PASS", "48")
+    run_full_parity(hip_lib, 10, (5, 5), 40, 150, 31, True)
+    monkeypatch.setenv("SQD_ELL_CAP", "3")
+    run_full_parity(hip_lib, 12, (2, 6), 3, 924, 19, False)
+
+
 def test_h2_sto3g(hip_lib):
     h1 = np.diag([-1.2525, -0.4759])
     eri = np.zeros((2, 2, 2, 2))
@@ -161,17 +169,20 @@ def test_n2_sigma_vs_sparse_oracle(hip_lib):
 
 
 @pytest.mark.parametrize("hf", [False, True])
-def test_long_rows_against_transposed_problem(hip_lib, hf):
+@pytest.mark.parametrize("nmany", [10000, 20000])
+def test_long_rows_against_transposed_problem(hip_lib, hf, nmany):
     """20 000 beta strings: a C row (160 KB) does not fit LDS, so sigma takes the global-row / column-chunk
-    path.  With spin-restricted integrals the problem is symmetric under alpha<->beta exchange (a global
-    sign on the basis), so sigma of the transposed problem -- 20 000 alpha strings x 6 beta strings, the
-    LDS-staged path -- must give the transposed result; contract_ss and the penalty form likewise."""
+    path; 10 000: the row (80 KB) is staged but one partial sum per virtual row is not, so the beta lists
+    are walked in passes.  With spin-restricted integrals the problem is symmetric under alpha<->beta
+    exchange (a global sign on the basis), so sigma of the transposed problem -- nmany alpha strings x 6
+    beta strings, the plain LDS-staged path -- must give the transposed result; contract_ss and the penalty
+    form likewise."""
     norb = 30
     h1, eri = O.synthetic_integrals(norb)
     gen = O.hf_centred_strings if hf else O.random_strings
-    few, many = gen(norb, 8, 6, 41), gen(norb, 8, 20000, 43)
+    few, many = gen(norb, 8, 6, 41), gen(norb, 8, nmany, 43)
     rng = np.random.default_rng(5)
-    x = rng.standard_normal((6, 20000))
+    x = rng.standard_normal((6, nmany))
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(few, many)
         s_long = ctx.sigma(x)
