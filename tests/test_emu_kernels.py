@@ -91,6 +91,29 @@ def test_emu_one_by_one(emu_lib):
         assert abs(ctx.energy() - O.make_hdiag(h1, eri, sa, sb, 5)[0, 0]) < 1e-12
 
 
+@pytest.mark.parametrize(
+    "norb,nelec,na,nb,seed",
+    [
+        (4, (2, 0), 4, 1, 1),   # no beta electrons: the beta string table is the single string 0
+        (4, (0, 2), 1, 5, 2),   # no alpha electrons
+        (3, (3, 3), 1, 1, 4),   # every orbital doubly occupied
+        (4, (4, 1), 1, 3, 5),   # full alpha shell, one beta electron
+        (6, (1, 0), 6, 1, 6),   # one electron in total
+    ],
+)
+def test_emu_empty_and_full_shells(emu_lib, norb, nelec, na, nb, seed):
+    h1, eri, sa, sb = make_problem(norb, nelec, na, nb, seed)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        ctx.davidson()
+        e, s2, (da, db) = ctx.energy(), ctx.spin_square(), ctx.rdm1s()
+    H = O.jw_project(O.jw_hamiltonian(h1, eri), sa, sb, norb)
+    assert abs(e - np.linalg.eigvalsh(H)[0]) < 1e-10
+    assert abs(np.trace(da) - nelec[0]) < 1e-10 and abs(np.trace(db) - nelec[1]) < 1e-10
+    sz = 0.5 * (nelec[0] - nelec[1])
+    assert s2 > sz * (sz + 1) - 1e-9
+
+
 def test_emu_ragged_widths(emu_lib):
     # nb not a multiple of 64 and > 64: exercises sliced-ELL slice boundaries and partial waves
     norb, nelec = 9, (2, 3)
