@@ -7,7 +7,7 @@ import pytest
 from oracle import sqd_oracle as O
 from qiskit_addon_sqd_amd import _capi
 
-from _parity import check_link_tables, check_operators, make_problem, run_full_parity
+from _parity import check_link_tables, check_operators, make_problem, run_full_parity, run_operator_parity
 
 
 @pytest.mark.parametrize(
@@ -29,7 +29,7 @@ def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
     # that travel through LDS must reproduce the same sigma / ground state
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
-    run_full_parity(emu_lib, 6, (2, 3), 9, 14, 5, False, variants=False)
+    run_operator_parity(emu_lib, 6, (2, 3), 9, 14, 5, False)
 
 
 def test_emu_many_axpy_items(emu_lib, monkeypatch):
@@ -38,7 +38,7 @@ def test_emu_many_axpy_items(emu_lib, monkeypatch):
     monkeypatch.setenv("SQD_SIGMA_L", "2")
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
-    run_full_parity(emu_lib, 8, (4, 4), 9, 30, 5, False, variants=False)
+    run_operator_parity(emu_lib, 8, (4, 4), 9, 30, 5, False)
 
 
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
@@ -48,7 +48,7 @@ def test_emu_global_row_fallback(emu_lib, monkeypatch):
     monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
     run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
-    run_full_parity(emu_lib, 9, (2, 4), 7, 100, 29, True, variants=False)
+    run_operator_parity(emu_lib, 9, (2, 4), 7, 100, 29, True)
 
 
 def test_emu_multi_pass_partial_sums(emu_lib, monkeypatch):
@@ -62,7 +62,7 @@ def test_emu_multi_pass_partial_sums(emu_lib, monkeypatch):
     monkeypatch.setenv("SQD_SIGMA_PASS", "40")
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     monkeypatch.setenv("SQD_SIGMA_T", "64")
-    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
+    run_operator_parity(emu_lib, 8, (3, 4), 12, 70, 23, False)
 
 
 def test_emu_h2_minimal(emu_lib):
