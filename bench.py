@@ -135,7 +135,9 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    # SQD_BENCH_FORCE_DIST=1 (under torchrun with one process): take the N > 1 code path on one GPU, to
+    # measure what the per-step exchange costs
+    if world > 1 or (os.environ.get("SQD_BENCH_FORCE_DIST") and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -149,16 +151,35 @@ def main():
     sa, sb = make_batch(args, 1000 + rank)
     ctx = _capi.Context(h1, eri, device=local_rank)
 
+    width = 1 + 2 * args.norb
+    if dist is not None:
+        # buffers of the per-step exchange, allocated once: device table, pinned host record / table
+        allrec = torch.zeros((world, width), device=dev, dtype=torch.float64)
+        h_rec = torch.zeros(width, dtype=torch.float64).pin_memory()
+        h_all = torch.zeros((world, width), dtype=torch.float64).pin_memory()
+        # solver and exchange share ONE stream (sqd_ctx_use_stream): waking a second hardware queue per step
+        # costs more than the collective itself (36 vs 77-110 us, profiles/probes/_exchange_probe.py)
+        xstream = torch.cuda.Stream(device=dev)
+        ctx.use_stream(xstream.cuda_stream)
+
     def exchange(e, oa, ob):
         if dist is None:
             return e, oa, ob
         # same exchange as qiskit_addon_sqd_amd.distributed: ONE all-reduce(sum) of a table whose rows are
-        # zero except the owner's record [E, occ_a, occ_b]  (61 doubles per batch at norb = 30)
-        allrec = torch.zeros((world, 1 + 2 * args.norb), device=dev, dtype=torch.float64)
-        allrec[rank] = torch.from_numpy(np.concatenate([[e], oa, ob])).to(dev)
-        dist.all_reduce(allrec, op=dist.ReduceOp.SUM)
-        best = int(torch.argmin(allrec[:, 0]).item())
-        row = allrec[best].cpu().numpy()
+        # zero except the owner's record [E, occ_a, occ_b]  (61 doubles per batch at norb = 30); one host
+        # synchronisation per step (after the table is back in pinned memory), argmin on the host
+        rec = h_rec.numpy()
+        rec[0] = e
+        rec[1 : 1 + args.norb] = oa
+        rec[1 + args.norb :] = ob
+        with torch.cuda.stream(xstream):
+            allrec.zero_()
+            allrec[rank].copy_(h_rec, non_blocking=True)
+            dist.all_reduce(allrec, op=dist.ReduceOp.SUM)
+            h_all.copy_(allrec, non_blocking=True)
+        xstream.synchronize()
+        table = h_all.numpy()
+        row = table[int(np.argmin(table[:, 0]))].copy()
         return row[0], row[1 : 1 + args.norb], row[1 + args.norb :]
 
     for _ in range(args.warmup):
@@ -179,9 +200,12 @@ def main():
     ms_dav = 0.0
     ms_setup = 0.0
     n_timed = 0
+    s_exchange = 0.0  # host time inside the per-step record exchange (N > 1 only)
     for _ in range(args.steps):
         e, oa, ob, s2, st, _ = one_step(ctx, sa, sb, args.spin_sq, args.time_sigma_every)
+        tx = time.perf_counter()
         e_best, _, _ = exchange(e, oa, ob)
+        s_exchange += time.perf_counter() - tx
         nsig += st["n_sigma"]
         n_timed += st["n_sigma_timed"]
         ms_sigma += st["ms_sigma_kernel"]
@@ -228,6 +252,7 @@ def main():
                 "parallelism": f"batch-per-gpu x{world}" + (" + all_reduce(E,occ)->argmin" if world > 1 else ""),
             },
             "wall_to_e0_ms": 1e3 * elapsed_max / args.steps,
+            "exchange_ms_per_step": 1e3 * s_exchange / args.steps,  # rank 0's host time in the all-reduce step
             "sigma_per_solve": nsig / args.steps,
             "davidson_ms_per_solve": ms_dav / args.steps,
             "tables_ms_per_solve": ms_setup / args.steps,

@@ -45,6 +45,14 @@ int sqd_device_count(int* count);
  * done inside kernel_fixed_space (reference fermion.py:713,721 / :803,810). */
 int sqd_ctx_create(int device, int norb, const double* h1, const double* eri, sqd_ctx** out);
 int sqd_ctx_destroy(sqd_ctx* ctx);
+/* Make the context enqueue all its work on a caller-owned HIP stream (a hipStream_t passed as void*, e.g.
+ * torch.cuda.Stream().cuda_stream) instead of the stream it created.  For callers with device work of
+ * their own per solve -- the RCCL exchange of the per-batch records [E, occ_a, occ_b] after the
+ * reference's batch loop (fermion.py:432, :577-605): on the solver's stream the exchange costs 36 us per
+ * step, on another hardware queue 77-110 us (profiles/probes/_exchange_probe.py).  The stream must
+ * outlive the context; call between solves (the previous stream is drained first).  No counterpart in
+ * the reference: pyscf is host code. */
+int sqd_ctx_use_stream(sqd_ctx* ctx, void* stream);
 
 /* Define the subspace.  strs_a / strs_b must be strictly ascending with a constant
  * popcount per spin (the post-condition of reference _check_ci_strs, fermion.py:1075-1097);

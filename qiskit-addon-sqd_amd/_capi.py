@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "sqd_device_count",
     "sqd_ctx_create",
     "sqd_ctx_destroy",
+    "sqd_ctx_use_stream",
     "sqd_set_subspace",
     "sqd_get_dims",
     "sqd_link_counts",
@@ -96,6 +97,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.sqd_ctx_create.argtypes = [C.c_int, C.c_int, _dp, _dp, C.POINTER(_ctxp)]
     lib.sqd_ctx_destroy.argtypes = [_ctxp]
+    lib.sqd_ctx_use_stream.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_set_subspace.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
@@ -198,6 +200,11 @@ class Context:
             if rc == -1:
                 raise ValueError(msg)
             raise SQDNativeError(f"libsqd_hip error {rc}: {msg}")
+
+    def use_stream(self, stream_handle: int):
+        """Enqueue all further work of this context on a caller-owned HIP stream (``hipStream_t`` as an integer,
+        e.g. ``torch.cuda.Stream().cuda_stream``); the stream must outlive the context."""
+        self._check(self._lib.sqd_ctx_use_stream(self._h, C.c_void_p(int(stream_handle))))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

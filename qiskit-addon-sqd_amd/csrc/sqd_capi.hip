@@ -98,6 +98,19 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
   return SQD_OK;
 }
 
+SQD_API int sqd_ctx_use_stream(sqd_ctx* c, void* stream) {
+  if (!c) {
+    set_error("sqd_ctx_use_stream: null context");
+    return SQD_ERR_INVALID;
+  }
+  SQD_HIP_CHECK(hipSetDevice(c->device));
+  if (c->stream) SQD_HIP_CHECK(hipStreamSynchronize(c->stream));  // nothing of ours is left in flight
+  if (c->stream && c->owns_stream) SQD_HIP_CHECK(hipStreamDestroy(c->stream));
+  c->stream = reinterpret_cast<hipStream_t>(stream);
+  c->owns_stream = false;
+  return SQD_OK;
+}
+
 SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (!c) return SQD_OK;
   hipError_t e = hipSetDevice(c->device);
@@ -120,7 +133,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->ev_sol) e = hipEventDestroy(c->ev_sol);
   if (c->ev_aux) e = hipEventDestroy(c->ev_aux);
   if (c->copy_stream) e = hipStreamDestroy(c->copy_stream);
-  if (c->stream) e = hipStreamDestroy(c->stream);
+  if (c->stream && c->owns_stream) e = hipStreamDestroy(c->stream);
   delete c;
   return SQD_OK;
 }

@@ -127,6 +127,7 @@ struct sqd_ctx {
   int num_cu = 256;
   int lds_bytes = 160 * 1024;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;  // false after sqd_ctx_use_stream: the caller's stream is never destroyed here
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sig_ev;  // (start, stop) pairs bracketing the sigma launches of a Davidson run
   // integrals
