@@ -143,6 +143,14 @@ def load_library() -> C.CDLL:
             f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). qiskit_addon_sqd_amd has no CPU fallback."
         )
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  A process that ends up with both
+    # loses the device in whichever initialises second ("no ROCm-capable device is detected"), so torch --
+    # this package's plumbing for streams and torch.distributed -- is imported first when it is installed:
+    # the library then binds to the runtime torch has already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch-free deployments use the system runtime alone
+        pass
     try:
         lib = C.CDLL(str(LIB_PATH), mode=os.RTLD_NOW | os.RTLD_LOCAL)
     except OSError as exc:  # pragma: no cover - depends on the box

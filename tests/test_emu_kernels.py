@@ -89,6 +89,10 @@ def test_emu_one_by_one(emu_lib):
         amps, st = ctx.davidson()
         assert st["converged"] == 1 and amps.shape == (1, 1) and abs(abs(amps[0, 0]) - 1) < 1e-12
         assert abs(ctx.energy() - O.make_hdiag(h1, eri, sa, sb, 5)[0, 0]) < 1e-12
+        ctx.use_stream(0)  # sqd_ctx_use_stream: adopt a caller-owned stream (the null stream here), solve again
+        ctx.set_subspace(sa, sb)
+        ctx.davidson()
+        assert abs(ctx.energy() - O.make_hdiag(h1, eri, sa, sb, 5)[0, 0]) < 1e-12
 
 
 @pytest.mark.parametrize(

@@ -283,3 +283,25 @@ def test_concurrent_batches_on_one_gpu(hip_lib):
         assert a.energy == b.energy
         assert np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
         assert np.array_equal(a.orbital_occupancies[0], b.orbital_occupancies[0])
+
+
+def test_context_on_caller_stream(hip_lib):
+    """sqd_ctx_use_stream: the same solve on a torch-owned stream gives the same bits (fixed-order reductions),
+    and the caller's stream survives the context."""
+    import torch
+
+    stream = torch.cuda.Stream()
+    h1, eri, sa, sb = make_problem(8, (4, 4), 30, 30, 3, True)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        a0, _ = ctx.davidson()
+        e0 = ctx.energy()
+        ctx.use_stream(stream.cuda_stream)
+        ctx.set_subspace(sa, sb)
+        a1, _ = ctx.davidson()
+        e1 = ctx.energy()
+    assert e0 == e1 and np.array_equal(a0, a1)
+    with torch.cuda.stream(stream):  # still usable after the context is gone
+        x = torch.ones(8, device="cuda").sum()
+    stream.synchronize()
+    assert float(x) == 8.0
