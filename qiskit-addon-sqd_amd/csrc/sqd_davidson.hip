@@ -26,6 +26,27 @@ constexpr int NV = 16;       // vectors per fused reduction launch
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_T = 512;    // 8 waves per workgroup: half as many partials to fold as with 256
 
+// ---- loads over "the first nvec of up to N vectors" WITHOUT a branch per vector.  Written as
+// `if (v < nvec) acc += X[v*stride+i] * y` the compiler emits, per vector, a scalar branch around
+// {global_load; s_waitcnt vmcnt(0); v_fmac}: nvec dependent memory round trips in sequence, which was the
+// whole duration of the Davidson BLAS-1 kernels (ISA + kernel trace: 9-21 us growing with the basis size).
+// Here every slot is loaded -- slots past nvec re-read vector 0 (an L1 hit on a line already requested) --
+// so all loads are in flight together, and the consumers select instead of branching.
+template <int N>
+__device__ inline void load_vectors(const double* __restrict__ X, int64_t stride, int nvec, int64_t i, double (&out)[N]) {
+#pragma unroll
+  for (int v = 0; v < N; ++v) out[v] = X[(int64_t)(v < nvec ? v : 0) * stride + i];
+}
+// the same for one row of a [blocks][width] partial-sum array (ordinary / device-coherent loads)
+template <int N, bool COHERENT>
+__device__ inline void load_partials(const double* partial, int64_t row_offset, int nv, double (&out)[N]) {
+#pragma unroll
+  for (int v = 0; v < N; ++v) {
+    const double* p = &partial[row_offset + (v < nv ? v : 0)];
+    out[v] = COHERENT ? coherent_load(p) : *p;
+  }
+}
+
 // partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
 __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
                        const double* __restrict__ y, double* __restrict__ partial) {
@@ -35,9 +56,10 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const double yv = y[i];
+    double xv[NV];
+    load_vectors<NV>(X, stride, nvec, i, xv);
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-      if (v < nvec) acc[v] += X[(int64_t)v * stride + i] * yv;
+    for (int v = 0; v < NV; ++v) acc[v] += (v < nvec) ? xv[v] * yv : 0.0;
   }
   block_sum_multi<NV>(acc, nvec, red);
   if ((int)threadIdx.x < nvec)
@@ -53,7 +75,13 @@ __global__ void k_lincomb(int64_t n, const double* __restrict__ X, int64_t strid
                           double* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = 0.0;
-    for (int v = 0; v < nvec; ++v) s += coef.v[v] * X[(int64_t)v * stride + i];
+    for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (v0 + u < nvec) ? coef.v[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+    }
     out[i] = s;
   }
 }
@@ -105,19 +133,28 @@ __global__ void k_residual_precond(int64_t n, const double* __restrict__ X, cons
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double r = 0.0;
     double xv[MV];
+    const double hd = hdiag[i];
+    // eight (X_v, AX_v) pairs requested per round, branch-free (see load_vectors); X_v is kept for the overlaps
 #pragma unroll
-    for (int v = 0; v < MV; ++v)
-      if (v < nvec) {
-        xv[v] = X[(int64_t)v * stride + i];
-        r += coef.v[v] * (AX[(int64_t)v * stride + i] - e * xv[v]);
-      }
-    const double t = r / (hdiag[i] + penalty_diag(pd, i) - e + 1e-4);
+    for (int v0 = 0; v0 < MV; v0 += 8) {
+      double a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < MV) {
+          const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : 0) * stride + i;
+          xv[v0 + u] = X[off];
+          a8[u] = AX[off];
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < MV) r += (v0 + u < nvec) ? coef.v[v0 + u] * (a8[u] - e * xv[v0 + u]) : 0.0;
+    }
+    const double t = r / (hd + penalty_diag(pd, i) - e + 1e-4);
     out[i] = t;
     vals[0] += r * r;
     vals[1] += t * t;
 #pragma unroll
-    for (int v = 0; v < MV; ++v)
-      if (v < nvec) vals[2 + v] += xv[v] * t;
+    for (int v = 0; v < MV; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
   }
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   // per-workgroup partials only: k_orth_dev (next in the stream) folds them
@@ -203,17 +240,18 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) vals[v] = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    double p[MAXV];
+    load_partials<MAXV, false>(partial, (int64_t)b * width, nv, p);
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v)
-      if (v < nv) vals[v] += partial[(int64_t)b * width + v];
+    for (int v = 0; v < MAXV; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
   }
   block_sum_multi<MAXV>(vals, nv, red);
-  if ((int)threadIdx.x < nv) mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = block_sum_multi_get<MAXV>(red, threadIdx.x);
+  if ((int)threadIdx.x < nv) mail_store(&mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x], block_sum_multi_get<MAXV>(red, threadIdx.x));
   if (threadIdx.x == 0) {
-    mail[MAIL_PAYLOAD + 0] = scal[0];
-    mail[MAIL_PAYLOAD + 1] = scal[1];
+    mail_store(&mail[MAIL_PAYLOAD + 0], scal[0]);
+    mail_store(&mail[MAIL_PAYLOAD + 1], scal[1]);
   }
-  __threadfence_system();
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();
@@ -257,21 +295,22 @@ __device__ inline void finish_and_post(const double* partial, int width, int nv,
 #pragma unroll
   for (int v = 0; v < N; ++v) vals[v] = 0.0;
   for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+    double p[N];
+    load_partials<N, true>(partial, (int64_t)b * width, nv, p);  // all requests in flight together
 #pragma unroll
-    for (int v = 0; v < N; ++v)
-      if (v < nv) vals[v] += coherent_load(&partial[(int64_t)b * width + v]);
+    for (int v = 0; v < N; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
   }
   block_sum_multi<N>(vals, nv, red);
   if ((int)threadIdx.x < nv) {
     const double s = block_sum_multi_get<N>(red, threadIdx.x);
     dsums[threadIdx.x] = s;
-    mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = s;
+    mail_store(&mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x], s);
   }
   if (rule.flag && threadIdx.x == 0) {
     const double s0 = block_sum_multi_get<N>(red, 0), s1 = block_sum_multi_get<N>(red, 1);
     if ((rule.de_small && s0 < rule.tol2) || !(s0 > rule.lindep) || !(s1 > 0.0)) *rule.flag = 1;
   }
-  __threadfence_system();
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();
@@ -291,13 +330,13 @@ __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t str
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const double yv = y[i];
+    double xv[MV];
+    load_vectors<MV>(X, stride, nvec, i, xv);
 #pragma unroll
-    for (int v = 0; v < MV; ++v)
-      if (v < nvec) {
-        const double xv = X[(int64_t)v * stride + i];
-        acc[1 + v] += xv * yv;
-        if (v == nvec - 1) acc[0] += xv * xv;
-      }
+    for (int v = 0; v < MV; ++v) {
+      acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
+      acc[0] += (v == nvec - 1) ? xv[v] * xv[v] : 0.0;
+    }
   }
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
   if ((int)threadIdx.x < nvec + 1)
@@ -334,9 +373,10 @@ __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stri
 #pragma unroll
     for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+      double p[MV + 2];
+      load_partials<MV + 2, false>(partial, (int64_t)b * width, nv, p);
 #pragma unroll
-      for (int v = 0; v < MV + 2; ++v)
-        if (v < nv) vals[v] += partial[(int64_t)b * width + v];
+      for (int v = 0; v < MV + 2; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
     }
     block_sum_multi<MV + 2>(vals, nv, red);
     if ((int)threadIdx.x < nv) tot[threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
@@ -354,8 +394,8 @@ __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stri
     s_stop = ((rule.de_small && rr < rule.tol2) || !(rr > rule.lindep) || !(tt > 0.0)) ? 1 : 0;
   }
   if (blockIdx.x == 0) {
-    if ((int)threadIdx.x < nv) mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x] = tot[threadIdx.x];
-    __threadfence_system();
+    if ((int)threadIdx.x < nv) mail_store(&mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x], tot[threadIdx.x]);
+    __builtin_amdgcn_s_waitcnt(0);
   }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -367,7 +407,13 @@ __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stri
   const double scale = s_scale;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = scale * t[i];
-    for (int v = 0; v < nvec; ++v) s -= g[v] * X[(int64_t)v * stride + i];
+    for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+    }
     t[i] = s;
   }
 }

@@ -54,6 +54,13 @@ __device__ inline void coherent_store(double* p, double v) {
 __device__ inline double coherent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Payload words of the host-visible mailbox (fine-grained pinned host memory): written through at system
+// scope.  Protocol of a post: every writing thread issues its stores and waits for them (s_waitcnt), the
+// workgroup meets at a barrier, then ONE thread fences at system scope and writes the sequence word.  (Fencing
+// in every thread -- eight waves each writing the L2 back -- is what this replaces.)
+__device__ inline void mail_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 }  // namespace sqd
 

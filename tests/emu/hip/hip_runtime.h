@@ -182,6 +182,7 @@ template <class T> inline T atomicExch(T* p, T v) {
   T old = *p; *p = v; return old;
 }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
 inline void __builtin_amdgcn_s_waitcnt(int) {}
