@@ -219,6 +219,11 @@ __global__ void k_init_guess(int64_t n, const double* __restrict__ pmin, const i
 static inline unsigned red_blocks(int64_t n) {
   int64_t b = (n + RED_T - 1) / RED_T;  // one element per thread while the grid lasts: latency, not bandwidth
   if (b > RED_BLOCKS) b = RED_BLOCKS;
+  static const int64_t cap = [] {  // tuning hook
+    const char* env = std::getenv("SQD_RED_BLOCKS");
+    return env ? (int64_t)std::atoi(env) : (int64_t)0;
+  }();
+  if (cap > 0 && b > cap) b = cap;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
