@@ -71,24 +71,42 @@ struct SigmaArgs {
   const int* stop;
 };
 
-// sum_l val[l] * C[src[l], B] over a chunk of same-spin links: the row reads are independent, so they
-// are issued PF at a time before any is consumed (memory-level parallelism instead of a load-use chain)
+// N consecutive same-spin links starting at l0: a += val[l] * C[src[l], B] in link order.  N is a compile-time
+// constant and nothing is predicated: the N (wave-uniform, scalar) record loads are issued together, then the
+// N row loads, then the multiply-adds.  With a test per link the compiler wrapped every link in its own block
+// {s_load src; wait; global_load; s_load val; wait} -- two scalar round trips per link in sequence (ISA).
+template <int N>
+__device__ inline double axpy_round(const double* __restrict__ C, const uint32_t* __restrict__ src,
+                                    const double* __restrict__ val, int64_t l0, int64_t nb, int64_t B, double a) {
+  double x[N], v[N];
+  uint32_t s[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    s[u] = src[l0 + u];
+    v[u] = val[l0 + u];
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) x[u] = C[(int64_t)s[u] * nb + B];
+#pragma unroll
+  for (int u = 0; u < N; ++u) a += v[u] * x[u];
+  return a;
+}
+// sum_l val[l] * C[src[l], B] over a chunk of same-spin links: whole rounds of 8, then the remainder as one
+// round of its exact size (no padded loads: at 10^4 x 10^4 the row reads are the bandwidth)
 __device__ inline double axpy_chunk(const double* __restrict__ C, const uint32_t* __restrict__ src,
                                     const double* __restrict__ val, int64_t begin, int count, int64_t nb, int64_t B) {
-  constexpr int PF = 8;
-  const int64_t end = begin + count;
   double a = 0.0;
-  for (int64_t l0 = begin; l0 < end; l0 += PF) {
-    double x[PF], v[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (l0 + u < end) {
-        v[u] = val[l0 + u];
-        x[u] = C[(int64_t)src[l0 + u] * nb + B];
-      }
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-      if (l0 + u < end) a += v[u] * x[u];
+  int64_t l = begin;
+  for (int k = 0; k + 8 <= count; k += 8, l += 8) a = axpy_round<8>(C, src, val, l, nb, B, a);
+  switch (count & 7) {
+    case 1: a = axpy_round<1>(C, src, val, l, nb, B, a); break;
+    case 2: a = axpy_round<2>(C, src, val, l, nb, B, a); break;
+    case 3: a = axpy_round<3>(C, src, val, l, nb, B, a); break;
+    case 4: a = axpy_round<4>(C, src, val, l, nb, B, a); break;
+    case 5: a = axpy_round<5>(C, src, val, l, nb, B, a); break;
+    case 6: a = axpy_round<6>(C, src, val, l, nb, B, a); break;
+    case 7: a = axpy_round<7>(C, src, val, l, nb, B, a); break;
+    default: break;
   }
   return a;
 }
@@ -331,27 +349,37 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
     const SRec rec0 = g.sa_rec[it.begin];
     const double* srow0 = C + (int64_t)rec0.src * nb;  // !LDSROW: the (unsigned) source row in place
     const double sg0 = srec_sign(rec0.meta);
-    for (int j = 0; j < kb; ++j) {
-      const SRec rec = g.sa_rec[it.begin + j];
-      const double sg = srec_sign(rec.meta);
-      const int widx = (int)srec_widx(rec.meta);
-      const int pair = widx >> 1;
-      if (tid == 0) penw[j] = widx ^ 1;  // same pair, opposite direction
-      double* w2 = W2 + (int64_t)j * w2s;
-      if (LDSROW) {
-        const double* __restrict__ src = C + (int64_t)rec.src * nb;
-        double* cr = Crow + (int64_t)j * g.nb_pad;
-        for (int64_t i = tid; i < nb; i += T) cr[i] = sg * src[i];
-      }
-      for (int i = tid; i < nnorb; i += T) w2[i] = (g.mode == 0) ? g.eri_pp[(int64_t)pair * nnorb + i] : 0.0;
+    // All KM records first, then the KM rows' loads together, then the LDS writes: with one block per link
+    // (record -> row -> LDS) the links of a batch were staged one memory round trip after another.  Slots
+    // past the batch's count re-read link 0 and are written as zero rows (the gather loop runs over the full
+    // batch capacity); only the kslots slots that exist in the LDS plan are written.
+    constexpr int KM = 4;
+    const int kslots = LDSROW ? g.K : 1;
+    SRec recs[KM];
+#pragma unroll
+    for (int j = 0; j < KM; ++j) recs[j] = g.sa_rec[it.begin + (j < kb ? j : 0)];
+    if (tid == 0) {
+#pragma unroll
+      for (int j = 0; j < KM; ++j)
+        if (j < kslots) penw[j] = (j < kb) ? ((int)srec_widx(recs[j].meta) ^ 1) : -1;  // same pair, opposite direction
     }
-    // empty slots of a short batch: zero rows (the gather loop runs over the full batch capacity)
-    for (int j = kb; j < (LDSROW ? g.K : 1); ++j) {
-      if (tid == 0) penw[j] = -1;
-      double* cr = Crow + (int64_t)j * g.nb_pad;
-      double* w2 = W2 + (int64_t)j * w2s;
-      for (int64_t i = tid; i < nb; i += T) cr[i] = 0.0;
-      for (int i = tid; i < nnorb; i += T) w2[i] = 0.0;
+    if (LDSROW) {
+      for (int64_t i = tid; i < nb; i += T) {
+        double t[KM];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) t[j] = C[(int64_t)recs[j].src * nb + i];
+#pragma unroll
+        for (int j = 0; j < KM; ++j)
+          if (j < kslots) Crow[(int64_t)j * g.nb_pad + i] = (j < kb) ? srec_sign(recs[j].meta) * t[j] : 0.0;
+      }
+    }
+    for (int i = tid; i < nnorb; i += T) {
+      double w[KM];
+#pragma unroll
+      for (int j = 0; j < KM; ++j) w[j] = g.eri_pp[(int64_t)(srec_widx(recs[j].meta) >> 1) * nnorb + i];
+#pragma unroll
+      for (int j = 0; j < KM; ++j)
+        if (j < kslots) W2[(int64_t)j * w2s + i] = (j < kb && g.mode == 0) ? w[j] : 0.0;
     }
     __syncthreads();
     const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
@@ -369,10 +397,12 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       if (B < Bend) {
         double a = 0.0;
         if (g.mode == 0) {
-          for (int j = 0; j < kb; ++j) {
-            const int pair = (int)(srec_widx(g.sa_rec[it.begin + j].meta) >> 1);
-            a += g.jbT[(int64_t)pair * nb + B] * (LDSROW ? Crow[(int64_t)j * g.nb_pad + B] : sg0 * srow0[B]);
-          }
+          double jb[KM];
+#pragma unroll
+          for (int j = 0; j < KM; ++j) jb[j] = g.jbT[(int64_t)(srec_widx(recs[j].meta) >> 1) * nb + B];
+#pragma unroll
+          for (int j = 0; j < KM; ++j)
+            if (j < kslots) a += (j < kb) ? jb[j] * (LDSROW ? Crow[(int64_t)j * g.nb_pad + B] : sg0 * srow0[B]) : 0.0;
         }
         a += own_rows_sum(g.vs_own, B, part_s, vs0, s1);
         acc[r] = a;
