@@ -20,7 +20,7 @@ python profiles/probes/_phase_probe.py > $OUT/phase_probe.txt 2>&1
 python profiles/probes/_rdm_probe.py > $OUT/rdm_probe.txt 2>&1
 python profiles/probes/_concurrency_probe.py > $OUT/concurrency_probe.txt 2>&1
 python profiles/probes/_loop_probe.py > $OUT/loop_probe.txt 2>&1
-CONC=4 python profiles/probes/_loop_probe.py >> $OUT/loop_probe.txt 2>&1
+CONC=6 python profiles/probes/_loop_probe.py >> $OUT/loop_probe.txt 2>&1
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel traces of the SAME commands as the bench lines
