@@ -609,11 +609,8 @@ static int build_sigma_work(sqd_ctx* c) {
                  "multi %zu slots %d\n",
                  (long long)na, (long long)nb, T, R, K, (int)c->sig_lds_rows, c->sig_nchunks, c->sp[1].cap,
                  (long long)c->hv_s.nv_max, (long long)c->sig_ps, (long long)c->hv_d.nv_max, (long long)c->sig_pd, c->sig_shmem, items.size(), multi.size(), nslots);
-  SQD_TRY(c->items.reserve(items.size() * sizeof(WorkItem)));
-  SQD_TRY(c->multi.reserve((multi.size() + 1) * sizeof(MultiRow)));
+  // (the lists travel to the device inside the descriptor blob of build_subspace: one copy, not three)
   SQD_TRY(c->sig_partial.reserve((size_t)nslots * nb * 8 + 8));
-  SQD_TRY(stage_upload(c, c->items.p, items.data(), items.size() * sizeof(WorkItem)));
-  SQD_TRY(stage_upload(c, c->multi.p, multi.data(), multi.size() * sizeof(MultiRow)));
   return SQD_OK;
 }
 
@@ -929,7 +926,14 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     t.cap = cap;
     t.nv_s = vs.nv;
     t.nv_d = vd.nv;
-    // all descriptors travel in ONE host blob / ONE copy; the per-array DevBufs are views into it
+    // the sigma work list is cut on the host from the same pointer arrays (no device dependency)
+    c->na = na;
+    c->nb = nb;
+    c->D = na * nb;
+    c->nelec[0] = nocc[0];
+    c->nelec[1] = nocc[1];
+    SQD_TRY(build_sigma_work(c));
+    // all descriptors and the work list travel in ONE host blob / ONE copy; the per-array DevBufs are views into it
     struct Up { DevBuf* buf; const void* src; size_t bytes; };
     const Up ups[] = {
         {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_own, vs.own.data(), vs.own.size() * 4},
@@ -937,6 +941,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
         {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_own, vd.own.data(), vd.own.size() * 4},
         {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
         {&t.vs_chunk, vs.chunk.data(), vs.chunk.size() * 4}, {&t.vd_chunk, vd.chunk.data(), vd.chunk.size() * 4},
+        {&c->items, c->h_items.data(), c->h_items.size() * sizeof(WorkItem)},
+        {&c->multi, c->h_multi.data(), c->h_multi.size() * sizeof(MultiRow)},
     };
     size_t blob = 0;
     for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);
@@ -966,13 +972,6 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                          (const double*)t.d_val.as<double>(), t.ed_src.as<uint32_t>(), t.ed_val.as<double>());
     SQD_HIP_CHECK(hipGetLastError());
   }
-  // diagonal
-  c->na = na;
-  c->nb = nb;
-  c->D = na * nb;
-  c->nelec[0] = nocc[0];
-  c->nelec[1] = nocc[1];
-  SQD_TRY(build_sigma_work(c));
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
   SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
   c->stage_pending = true;
