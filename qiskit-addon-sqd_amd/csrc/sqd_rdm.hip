@@ -33,9 +33,17 @@ __global__ void k_col_norms(const double* __restrict__ C, int64_t na, int64_t nb
   const int64_t B = (int64_t)blockIdx.x * 64 + col;
   double s = 0.0;
   if (B < nb)
-    for (int64_t a = rl; a < na; a += RL) {
-      const double v = C[a * nb + B];
-      s += v * v;
+    for (int64_t a0 = rl; a0 < na; a0 += (int64_t)RL * 8) {
+      // eight rows requested together (rows past the end re-read row a0 and are not added): as a plain loop
+      // this was one memory round trip per row, 12 us for 317 rows
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t a = a0 + (int64_t)u * RL;
+        v[u] = C[(a < na ? a : a0) * nb + B];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (a0 + (int64_t)u * RL < na) ? v[u] * v[u] : 0.0;
     }
   red[threadIdx.x] = s;
   __syncthreads();
