@@ -270,6 +270,7 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
 // reduction launch per hand-over, and the host is not needed between producer and consumer kernels.
 constexpr int MAIL_SLOT = 128;  // doubles per mailbox slot (slot 0: projected-matrix column, slot 1: residual)
 constexpr unsigned COUNT_GROUPS = 16;  // arrival counters: word 0 = groups done, words 1..16 = per group
+constexpr unsigned COUNT_STRIDE = 32;  // ... each in its own 128-byte line: atomics on one line serialise in one L2 channel
 template <int N>
 __device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
                                        double* __restrict__ dsums, double* mail, long long seq, double* red,
@@ -285,8 +286,8 @@ __device__ inline void finish_and_post(const double* partial, int width, int nv,
     int last = 0;
     const unsigned G = COUNT_GROUPS, grp = blockIdx.x % G;
     const unsigned gsize = (gridDim.x - grp + G - 1) / G, ngroups = gridDim.x < G ? gridDim.x : G;
-    if (atomicAdd(&counter[1 + grp], 1u) == gsize - 1) {
-      atomicExch(&counter[1 + grp], 0u);  // ready for the next fused reduction on this stream
+    if (atomicAdd(&counter[COUNT_STRIDE * (1 + grp)], 1u) == gsize - 1) {
+      atomicExch(&counter[COUNT_STRIDE * (1 + grp)], 0u);  // ready for the next fused reduction on this stream
       if (atomicAdd(&counter[0], 1u) == ngroups - 1) {
         atomicExch(&counter[0], 0u);
         last = 1;
@@ -497,7 +498,7 @@ static int multi_dot(sqd_ctx* c, const double* X, int64_t stride, int nvec, cons
 
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
   SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
-  SQD_TRY(c->scal.reserve(1024));
+  SQD_TRY(c->scal.reserve(8192));
   return multi_dot(c, x, 0, 1, y, out);
 }
 
@@ -574,7 +575,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->sol.reserve((size_t)D * 8));
   SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
-  SQD_TRY(c->scal.reserve(1024));
+  SQD_TRY(c->scal.reserve(8192));
   double* X = c->X.as<double>();
   double* AX = c->AX.as<double>();
   const unsigned gb = red_blocks(D);
@@ -598,9 +599,10 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   double* scal = c->scal.as<double>();
   double* dsums_col = scal + 8;    // totals of the latest k_dots_post
 
-  unsigned* counter = reinterpret_cast<unsigned*>(scal + 104);
-  int* stop_flag = reinterpret_cast<int*>(scal + 120);
-  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, 17 * sizeof(double), s));  // arrival counters and the stop flag
+  constexpr int COUNT_DOUBLES = (int)((COUNT_GROUPS + 1) * COUNT_STRIDE * sizeof(unsigned) / sizeof(double));
+  unsigned* counter = reinterpret_cast<unsigned*>(scal + 128);
+  int* stop_flag = reinterpret_cast<int*>(scal + 128 + COUNT_DOUBLES);
+  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, (COUNT_DOUBLES + 1) * sizeof(double), s));  // arrival counters and the stop flag
   const double tol2 = toloose * toloose;
   double* mail_col = c->d_mail;
   double* mail_res = c->d_mail + MAIL_SLOT;
