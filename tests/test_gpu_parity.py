@@ -154,6 +154,36 @@ def test_n2_headline_properties(hip_lib, hf):
         assert s2 > -1e-9
 
 
+def test_fes_size_properties(hip_lib):
+    """BASELINE config 4's size: 40 orbitals, 15 + 15 electrons, 707 x 707 = 499 849 determinants (HF-centred
+    strings).  Size-independent properties only: link tables bit-exact at full size, diagonal, hermiticity and
+    linearity of sigma, the variational bound, the eigen-residual, traces of the RDMs, energy from the RDMs."""
+    norb, nocc, n = 40, 15, 707
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, nocc, n, 5), O.hf_centred_strings(norb, nocc, n, 6)
+    rng = np.random.default_rng(3)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        check_link_tables(ctx, sa, sb, norb, h1, eri)
+        assert np.allclose(ctx.hdiag(), O.make_hdiag(h1, eri, sa, sb, norb), atol=1e-9)
+        x = rng.standard_normal((n, n)); y = rng.standard_normal((n, n))
+        sx, sy = ctx.sigma(x), ctx.sigma(y)
+        assert abs(np.vdot(y, sx) - np.vdot(x, sy)) < 1e-8 * abs(np.vdot(y, sx))
+        assert np.allclose(ctx.sigma(2.0 * x - 3.0 * y), 2.0 * sx - 3.0 * sy, atol=1e-8)
+        amps, st = ctx.davidson()
+        assert st["converged"] == 1
+        e = ctx.energy()
+        assert abs(e - st["e_davidson"]) < 1e-8
+        assert e <= ctx.hdiag().min() + 1e-9
+        assert np.linalg.norm(ctx.sigma(amps) - e * amps) < 1e-4
+        d1a, d1b = ctx.rdm1s()
+        assert abs(np.trace(d1a) - nocc) < 1e-9 and abs(np.trace(d1b) - nocc) < 1e-9
+        d2 = ctx.rdm2()
+        assert abs(O.energy_from_rdms(h1, eri, d1a + d1b, d2) - e) < 1e-8
+        assert abs(np.einsum("ppqq->", d2) - 30 * 29) < 1e-6
+        assert ctx.spin_square() > -1e-9
+
+
 def test_n2_sigma_vs_sparse_oracle(hip_lib):
     """sigma at N2 size against the scipy-sparse Slater-Condon oracle on a 60 x 50 sub-selection
     (D = 3000) drawn from the headline HF-centred string sets."""
