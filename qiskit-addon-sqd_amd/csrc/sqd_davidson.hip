@@ -590,6 +590,10 @@ static bool lowest_eig_rqi(int n, const double* A, const double* v_old, double e
     for (int i = 0; i < n; ++i) res += (y[i] - theta * x[i]) * (y[i] - theta * x[i]);
     if (std::sqrt(res) <= 8.0 * tiny) {
       if (!(theta <= e_old + 64.0 * tiny)) return false;  // not provably the lowest eigenvalue
+      // (a new vector that does not couple to the old Ritz vector leaves that pair an eigenpair of the grown
+      // matrix although its own diagonal may lie lower: the lowest eigenvalue is below every diagonal element)
+      for (int i = 0; i < n; ++i)
+        if (theta > A[i * n + i] + 64.0 * tiny) return false;
       *e_out = theta;
       for (int i = 0; i < n; ++i) v_out[i] = x[i];
       return true;
