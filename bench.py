@@ -161,6 +161,7 @@ def main():
         # costs more than the collective itself (36 vs 77-110 us, profiles/probes/_exchange_probe.py)
         xstream = torch.cuda.Stream(device=dev)
         ctx.use_stream(xstream.cuda_stream)
+        my_row, rec, table = allrec[rank], h_rec.numpy(), h_all.numpy()  # views, made once
 
     def exchange(e, oa, ob):
         if dist is None:
@@ -168,17 +169,15 @@ def main():
         # same exchange as qiskit_addon_sqd_amd.distributed: ONE all-reduce(sum) of a table whose rows are
         # zero except the owner's record [E, occ_a, occ_b]  (61 doubles per batch at norb = 30); one host
         # synchronisation per step (after the table is back in pinned memory), argmin on the host
-        rec = h_rec.numpy()
         rec[0] = e
         rec[1 : 1 + args.norb] = oa
         rec[1 + args.norb :] = ob
         with torch.cuda.stream(xstream):
             allrec.zero_()
-            allrec[rank].copy_(h_rec, non_blocking=True)
+            my_row.copy_(h_rec, non_blocking=True)
             dist.all_reduce(allrec, op=dist.ReduceOp.SUM)
             h_all.copy_(allrec, non_blocking=True)
         xstream.synchronize()
-        table = h_all.numpy()
         row = table[int(np.argmin(table[:, 0]))].copy()
         return row[0], row[1 : 1 + args.norb], row[1 + args.norb :]
 
