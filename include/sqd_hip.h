@@ -80,6 +80,12 @@ int sqd_double_links(sqd_ctx* ctx, int spin, int32_t* tgt, int32_t* src, int32_t
 /* hdiag[ia*nb+ib] = <ab|H|ab>.  Replaces pyscf SelectedCI.make_hdiag (kernel_fixed_space). */
 int sqd_hdiag(sqd_ctx* ctx, double* out);
 
+/* Davidson start vector used when ci0 == NULL: pyscf SelectedCI.get_init_guess -> direct_spin1._get_init_guess
+ * (inside kernel_fixed_space, reference fermion.py:721, :810): unit vector at the lowest diagonal element --
+ * searched over the lower triangle ia >= ib when nelec_a == nelec_b and na == nb -- with +1e-5 on the first and
+ * -1e-5 on the last element, normalised.  out: na*nb doubles. */
+int sqd_init_guess(sqd_ctx* ctx, double* out);
+
 /* sigma = P H P c  (+ penalty).  Replaces pyscf selected_ci.contract_2e
  * (SCIcontract_2e_aaaa x2, SCIcontract_2e_bbaa) and, when use_spin != 0, the fix_spin_ wrapper:
  *   use_spin = 0 : sigma = H c
@@ -152,6 +158,10 @@ int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
 int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
 int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);
 int sqd_rdm2(sqd_ctx* ctx, const double* amps, double* dm2);
+/* sqd_rdm2s: the spin-resolved pieces (dm2aa, dm2ab, dm2bb), dm2ab[p,q,r,s] = <p+_a r+_b s_b q_a> (pyscf
+ * make_rdm2s, reference fermion.py:124-125 -- SCIState.rdm(rank=2, spin_summed=False)); norb^4 doubles each.
+ * dm2 of sqd_rdm2 = dm2aa + dm2bb + dm2ab + dm2ab^T(2,3,0,1). */
+int sqd_rdm2s(sqd_ctx* ctx, const double* amps, double* dm2aa, double* dm2ab, double* dm2bb);
 
 /* Benchmark hooks: run `reps` sigma builds on the resident solution buffer and report the
  * average device time per launch of the dominant sigma kernel (HIP events on the context stream). */

@@ -147,7 +147,7 @@ def solve_fermion_ref(ci_strs, hcore, eri, tol=1e-9, max_cycle=100, max_space=12
     Davidson on the restated contract_2e, energy as <c|H|c>, occupancies.  Returns (e, amps, occ, n_sigma)."""
     sa, sb = O.check_ci_strs(ci_strs)
     prob = RefProblem(hcore, eri, sa, sb)
-    x0 = O.init_guess(prob.hdiag, prob.na, prob.nb)
+    x0 = O.init_guess(prob.hdiag, prob.na, prob.nb, prob.nelec)
     conv, e, x, nsig = O.davidson_pyscf(prob.contract_2e, x0, prob.hdiag, tol=tol, max_cycle=max_cycle,
                                         max_space=max_space)
     x = x / np.linalg.norm(x)

@@ -181,6 +181,28 @@ def jw_rdms(c: np.ndarray, strs_a, strs_b, norb: int):
     return dm1[0], dm1[1], dm2
 
 
+def jw_rdm2s(c: np.ndarray, strs_a, strs_b, norb: int):
+    """(dm2aa, dm2ab, dm2bb) by definition, pyscf ``make_rdm2s`` convention (reference ``fermion.py:124-125``):
+    dm2st[p,q,r,s] = <p+_s r+_t s_t q_s>; the spin-summed dm2 is dm2aa + dm2bb + dm2ab + dm2ab^T(2,3,0,1)."""
+    a = jw_annihilators(2 * norb)
+    ad = [x.T.tocsr() for x in a]
+    psi = np.zeros(1 << (2 * norb))
+    psi[jw_basis_indices(strs_a, strs_b, norb)] = np.asarray(c).ravel()
+    out = []
+    for s, t in ((0, 0), (0, norb), (norb, norb)):
+        dm2 = np.zeros((norb,) * 4)
+        for q in range(norb):
+            for sidx in range(norb):
+                v = a[t + sidx] @ (a[s + q] @ psi)
+                if not np.any(v):
+                    continue
+                for p in range(norb):
+                    for r in range(norb):
+                        dm2[p, q, r, sidx] = psi @ (ad[s + p] @ (ad[t + r] @ v))
+        out.append(dm2)
+    return tuple(out)
+
+
 # --------------------------------------------------------------------------
 # string-space links (canonical order: by target address, then source address)
 # --------------------------------------------------------------------------
@@ -363,6 +385,66 @@ def build_php(h1, eri, strs_a, strs_b, norb: int, sparse: bool = False):
     return H.tocsr() if sparse else np.asarray(H.todense())
 
 
+def sigma_string_space(h1, eri, strs_a, strs_b, c, norb: int) -> np.ndarray:
+    """sigma = (P H P) c at sizes where the D x D matrix of ``build_php`` cannot be formed (BASELINE's
+    317 x 317 and 707 x 707): the same decomposition, H = Ha (x) 1 + 1 (x) Hb + sum_{pq,rs} (pq|rs)
+    Ea_pq (x) Eb_rs, evaluated factor by factor on the amplitude matrix,
+        sigma = Ha C + C Hb^T + sum_rs [sum_pq (pq|rs) Ea_pq] C Eb_rs^T,
+    with dense same-spin matrices and one small dense product per beta orbital pair (r, s).  The E
+    operators include their diagonal (occupation) part, so nothing here uses the J-table / hdiag split of
+    the HIP kernels.  Checked against ``build_php`` (itself against the Jordan-Wigner brute force) in
+    tests/test_oracle.py."""
+    na, nb = len(strs_a), len(strs_b)
+    C = np.asarray(c, dtype=float).reshape(na, nb)
+    Ha = same_spin_hamiltonian(h1, eri, strs_a, norb)
+    Hb = same_spin_hamiltonian(h1, eri, strs_b, norb)
+    out = Ha @ C + C @ Hb.T
+
+    def all_links(strs):
+        """(tgt, src, p, q, sign) of every non-zero <tgt|E_pq|src>, the diagonal p = q included."""
+        sl = single_links(strs, norb)
+        occ = occupation_matrix(strs, norb)
+        I, k = np.nonzero(occ)
+        return (np.concatenate((sl["tgt"], I)), np.concatenate((sl["src"], I)), np.concatenate((sl["p"], k)),
+                np.concatenate((sl["q"], k)), np.concatenate((sl["sign"], np.ones(len(I), dtype=np.int64))))
+
+    ta, sa, pa, qa, ga = all_links(strs_a)
+    tb, sb, pb, qb, gb = all_links(strs_b)
+    key = pb * norb + qb
+    order = np.argsort(key, kind="stable")
+    bounds = np.flatnonzero(np.diff(key[order])) + 1
+    for idx in np.split(order, bounds):
+        r, s = int(pb[idx[0]]), int(qb[idx[0]])
+        Ga = np.zeros((na, na))
+        np.add.at(Ga, (ta, sa), ga * eri[pa, qa, r, s])
+        # for a fixed (r, s) every source string has at most one target: plain fancy-index accumulation
+        out[:, tb[idx]] += Ga @ (C[:, sb[idx]] * gb[idx])
+    return out
+
+
+class StringSpaceOperator:
+    """``sigma_string_space`` with the string-space pieces built once: v -> (P H P) v for the oracle's
+    Davidson at BASELINE sizes (flat vectors in, flat vectors out)."""
+
+    def __init__(self, h1, eri, strs_a, strs_b, norb: int):
+        self.args = (h1, eri, strs_a, strs_b)
+        self.norb = norb
+        self.shape = (len(strs_a), len(strs_b))
+
+    def __call__(self, v):
+        h1, eri, sa, sb = self.args
+        return sigma_string_space(h1, eri, sa, sb, np.asarray(v).reshape(self.shape), self.norb).ravel()
+
+
+def bitstring_matrix_from_strings(strs_a, strs_b, norb: int) -> np.ndarray:
+    """Bool sample matrix whose row i is |beta_i alpha_i> in the reference's layout (``fermion.py:1027-1035``:
+    left half = spin-down, right half = spin-up, column 0 = most significant bit).  len(strs_a) == len(strs_b)."""
+    a = _u64(strs_a)[:, None]
+    b = _u64(strs_b)[:, None]
+    shifts = np.arange(norb - 1, -1, -1, dtype=np.uint64)[None, :]
+    return np.concatenate((((b >> shifts) & np.uint64(1)).astype(bool), ((a >> shifts) & np.uint64(1)).astype(bool)), axis=1)
+
+
 def build_spin_square(strs_a, strs_b, norb: int, nelec, sparse: bool = False):
     """P S^2 P:  S^2 = Sz(Sz+1) + sum_p n_pb (1 - n_pa) - sum_{p!=q} Ea_qp (x) Eb_pq."""
     na, nb = len(strs_a), len(strs_b)
@@ -535,11 +617,22 @@ def davidson_pyscf(aop, x0, hdiag, tol=1e-9, lindep=1e-14, max_cycle=100, max_sp
     return conv, e, x, nsig
 
 
-def init_guess(hdiag: np.ndarray, na: int, nb: int) -> np.ndarray:
-    """pyscf ``get_init_guess`` for selected CI: unit vector at argmin(hdiag)
-    with +1e-5 / -1e-5 on the first/last element."""
+def init_guess(hdiag: np.ndarray, na: int, nb: int, nelec=None) -> np.ndarray:
+    """pyscf ``get_init_guess`` for selected CI: unit vector at the lowest diagonal element
+    with +1e-5 / -1e-5 on the first/last element.  pyscf ``direct_spin1._get_init_guess`` (reached through
+    ``SelectedCI.get_init_guess``) searches only the lower triangle ``A >= B`` (``lib.pack_tril``) when
+    ``neleca == nelecb and na == nb``, so that the start vector does not favour one of two spin-mirrored
+    determinants; pass ``nelec`` to apply that rule (ties go to the first element in row-major order, as
+    numpy's ``argpartition``/``argmin`` on the packed triangle do for a unique minimum)."""
+    h = np.asarray(hdiag, dtype=float).reshape(na, nb)
+    if nelec is not None and nelec[0] == nelec[1] and na == nb:
+        ia, ib = np.tril_indices(na)
+        k = int(np.argmin(h[ia, ib]))
+        addr = int(ia[k]) * nb + int(ib[k])
+    else:
+        addr = int(np.argmin(h))
     x = np.zeros(na * nb)
-    x[np.argmin(hdiag)] = 1.0
+    x[addr] = 1.0
     x[0] += 1e-5
     x[-1] -= 1e-5
     return x

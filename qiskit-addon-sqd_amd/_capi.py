@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "sqd_single_links",
     "sqd_double_links",
     "sqd_hdiag",
+    "sqd_init_guess",
     "sqd_sigma",
     "sqd_contract_ss",
     "sqd_davidson_default_opts",
@@ -40,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "sqd_spin_square",
     "sqd_rdm1s",
     "sqd_rdm2",
+    "sqd_rdm2s",
     "sqd_time_sigma",
     "sqd_sigma_bytes",
     "sqd_pauli_count",
@@ -104,6 +106,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_single_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp]
     lib.sqd_double_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _dp]
     lib.sqd_hdiag.argtypes = [_ctxp, _dp]
+    lib.sqd_init_guess.argtypes = [_ctxp, _dp]
     lib.sqd_sigma.argtypes = [_ctxp, _dp, _dp, C.c_int, C.c_double, C.c_double]
     lib.sqd_contract_ss.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_davidson_default_opts.argtypes = [C.POINTER(DavidsonOpts)]
@@ -115,6 +118,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
     lib.sqd_rdm2.argtypes = [_ctxp, _dp, _dp]
+    lib.sqd_rdm2s.argtypes = [_ctxp, _dp, _dp, _dp, _dp]
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
     lib.sqd_pauli_count.argtypes = [C.c_int, _u64p, C.c_int64, C.c_int, _u64p, _i64p, _u64p, _dp, _i64p, _i64p,
@@ -278,6 +282,12 @@ class Context:
         self._check(self._lib.sqd_hdiag(self._h, _ptr(out)))
         return out
 
+    def init_guess(self) -> np.ndarray:
+        """The Davidson start vector used when no ``ci0`` is given (pyscf ``get_init_guess``), normalised."""
+        out = np.empty((self.na, self.nb))
+        self._check(self._lib.sqd_init_guess(self._h, _ptr(out)))
+        return out
+
     # -- operators
     def sigma(self, c, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0) -> np.ndarray:
         c = _as_f64(c).reshape(self.na, self.nb)
@@ -377,6 +387,13 @@ class Context:
         out = np.empty((self.norb,) * 4)
         self._check(self._lib.sqd_rdm2(self._h, p, _ptr(out)))
         return out
+
+    def rdm2s(self, amps=None):
+        """(dm2aa, dm2ab, dm2bb), pyscf ``make_rdm2s`` convention."""
+        keep, p = self._state(amps)
+        out = [np.empty((self.norb,) * 4) for _ in range(3)]
+        self._check(self._lib.sqd_rdm2s(self._h, p, *[_ptr(o) for o in out]))
+        return tuple(out)
 
     # -- benchmark hooks
     def time_sigma(self, reps: int = 10, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0) -> float:

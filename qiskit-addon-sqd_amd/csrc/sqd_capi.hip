@@ -240,6 +240,17 @@ SQD_API int sqd_hdiag(sqd_ctx* c, double* out) {
   return SQD_OK;
 }
 
+SQD_API int sqd_init_guess(sqd_ctx* c, double* out) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!out) return SQD_ERR_INVALID;
+  SQD_TRY(c->io_out.reserve((size_t)c->D * 8));
+  SQD_TRY(enqueue_init_guess(c, c->io_out.as<double>()));
+  SQD_HIP_CHECK(hipMemcpyAsync(out, c->io_out.p, c->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return SQD_OK;
+}
+
 // stage a host vector into tmp slot (X buffer is not used so a Davidson state is not disturbed)
 static int upload_vec(sqd_ctx* c, const double* host, DevBuf& buf) {
   SQD_TRY(buf.reserve((size_t)c->D * 8));
@@ -434,6 +445,15 @@ SQD_API int sqd_rdm2(sqd_ctx* c, const double* amps, double* dm2) {
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
   return dev_rdm2(c, d, dm2);
+}
+
+SQD_API int sqd_rdm2s(sqd_ctx* c, const double* amps, double* dm2aa, double* dm2ab, double* dm2bb) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!dm2aa || !dm2ab || !dm2bb) return SQD_ERR_INVALID;
+  const double* d = nullptr;
+  SQD_TRY(state_ptr(c, amps, &d));
+  return dev_rdm2s(c, d, dm2aa, dm2ab, dm2bb);
 }
 
 SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double shift, double* ms_per_sigma) {

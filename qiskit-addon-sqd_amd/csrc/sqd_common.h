@@ -203,6 +203,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift);
 // blas-1 (sqd_davidson.hip)
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
+int enqueue_init_guess(sqd_ctx* c, double* d_x);  // pyscf get_init_guess into d_x (no synchronisation)
 // defer_sync: return with the solution still being formed on the stream; the caller synchronises and
 // then calls davidson_collect_timings (the non-timing fields of *st are final on return either way)
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
@@ -211,6 +212,7 @@ int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st);
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
 int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
+int dev_rdm2s(sqd_ctx* c, const double* d_c, double* dm2aa, double* dm2ab, double* dm2bb);
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c);   // kernels + result copy, no synchronisation
 void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised

@@ -639,6 +639,23 @@ static bool lowest_eig_rqi(int n, const double* A, const double* v_old, double e
   return false;
 }
 
+// pyscf get_init_guess (direct_spin1._get_init_guess): unit vector at the lowest diagonal element -- searched over
+// the lower triangle A >= B when nelec_a == nelec_b and na == nb -- plus the +-1e-5 noise, normalised
+int enqueue_init_guess(sqd_ctx* c, double* x) {
+  const int64_t D = c->D;
+  const unsigned gb = red_blocks(D);
+  SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  const int tril_only = (c->nelec[0] == c->nelec[1] && c->na == c->nb) ? 1 : 0;
+  double* pmin = c->partial.as<double>();
+  int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
+  hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, c->stream, D, c->nb, tril_only,
+                     (const double*)c->hdiag.as<double>(), pmin, pidx);
+  hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, c->stream, D, (const double*)pmin, (const int64_t*)pidx,
+                     (int)gb, x);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync) {
   if (!c->have_subspace) {
@@ -673,13 +690,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   if (ci0_host) {
     SQD_HIP_CHECK(hipMemcpyAsync(X, ci0_host, D * 8, hipMemcpyHostToDevice, s));
   } else {
-    const int tril_only = (c->nelec[0] == c->nelec[1] && c->na == c->nb) ? 1 : 0;
-    double* pmin = c->partial.as<double>();
-    int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
-    hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, s, D, c->nb, tril_only, (const double*)c->hdiag.as<double>(),
-                       pmin, pidx);
-    hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, s, D, (const double*)pmin, (const int64_t*)pidx, (int)gb, X);
-    SQD_HIP_CHECK(hipGetLastError());
+    SQD_TRY(enqueue_init_guess(c, X));
   }
   // (a user vector is not normalised on the device: the first fused reduction measures |X_0|^2 and the
   // factor is carried in sv like that of every later basis vector)

@@ -65,6 +65,36 @@ __device__ inline void mail_store(double* p, double v) {
 }  // namespace sqd
 
 namespace sqd {
+// ---- one-wavefront collectives (the small dense solves that run inside the LAST workgroup of a fused
+// reduction kernel).  All 64 lanes must call them.  wave_sync: LDS written by one lane is read by another.
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ inline double wave_sum(double v) {  // fixed tree => bitwise reproducible; result on every lane
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return __shfl(v, 0);
+}
+__device__ inline double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off);
+    v = o > v ? o : v;
+  }
+  return __shfl(v, 0);
+}
+// index of the largest value (ties to the lower index); lanes without a candidate pass a negative value
+__device__ inline int wave_argmax(double v, int idx) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ov = __shfl_down(v, off);
+    const int oi = __shfl_down(idx, off);
+    if (ov > v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+  return __shfl(idx, 0);
+}
+
 // (value, index) minimum over the workgroup, ties to the lower index; result valid on thread 0.
 // Lanes without a candidate pass index -1.
 __device__ inline void block_argmin(double& best, int64_t& bi) {

@@ -327,12 +327,16 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c) {
   return SQD_OK;
 }
 
-int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
+// dm2 pieces on the device.  resolved == false: spin-summed dm2 (pyscf make_rdm2) into out[0].
+// resolved == true: (dm2aa, dm2ab, dm2bb) (pyscf make_rdm2s; dm2ab[p,q,r,s] = <p+_a r+_b s_b q_a>) into out[0..2].
+static int rdm2_impl(sqd_ctx* c, const double* d_c, bool resolved, double* const* out) {
   const int norb = c->norb;
   const int64_t n2 = (int64_t)norb * norb, n4 = n2 * n2;
   hipStream_t st = c->stream;
-  // layout of scratch: dm2[n4] | G[n4] | per-spin { w[n] | dots_s[n_s] | dots_d[n_d] } | xlinks
-  int64_t need = 2 * n4;
+  // layout of scratch: same[2][n4] (the second only when resolved) | G[n4] | per-spin { w[n] | dots_s[n_s] |
+  // dots_d[n_d] } | xlinks
+  const int64_t nhead = resolved ? 3 * n4 : 2 * n4;
+  int64_t need = nhead;
   int64_t xl[2];
   for (int s = 0; s < 2; ++s) {
     need += c->sp[s].n + c->sp[s].n_s + c->sp[s].n_d;
@@ -341,10 +345,10 @@ int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
   const size_t xbytes = (size_t)(xl[0] + xl[1]) * sizeof(XLink);
   SQD_TRY(c->scratch.reserve((size_t)need * 8 + xbytes + 256));
   double* base = c->scratch.as<double>();
-  double* dm2 = base;
-  double* G = base + n4;
-  SQD_HIP_CHECK(hipMemsetAsync(dm2, 0, 2 * n4 * 8, st));
-  double* p = base + 2 * n4;
+  double* same[2] = {base, resolved ? base + n4 : base};
+  double* G = base + nhead - n4;
+  SQD_HIP_CHECK(hipMemsetAsync(base, 0, nhead * 8, st));
+  double* p = base + nhead;
   XLink* xlink[2];
   xlink[0] = reinterpret_cast<XLink*>(base + need);
   xlink[1] = xlink[0] + xl[0];
@@ -356,14 +360,14 @@ int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
     p += t.n + t.n_s + t.n_d;
     SQD_TRY(spin_link_dots(c, s, d_c, w, ds, dd));
     hipLaunchKernelGGL(k_rdm2_diag, dim3(nblk(n2, 64)), dim3(64), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
-                       (const double*)w, norb, dm2);
+                       (const double*)w, norb, same[s]);
     if (t.n_s > 0)
       hipLaunchKernelGGL(k_rdm2_singles, dim3(nblk(t.n_s, 256)), dim3(256), 0, st,
                          (const uint64_t*)t.strs.as<uint64_t>(), t.n_s, (const SRec*)t.s_rec.as<SRec>(),
-                         (const double*)ds, norb, dm2);
+                         (const double*)ds, norb, same[s]);
     if (t.n_d > 0)
       hipLaunchKernelGGL(k_rdm2_doubles, dim3(nblk(t.n_d, 256)), dim3(256), 0, st, t.n_d,
-                         (const uint32_t*)t.d_orb.as<uint32_t>(), (const double*)dd, norb, dm2);
+                         (const uint32_t*)t.d_orb.as<uint32_t>(), (const double*)dd, norb, same[s]);
     hipLaunchKernelGGL(k_xlinks, dim3(nblk(xl[s], 256)), dim3(256), 0, st, (const uint64_t*)t.strs.as<uint64_t>(), t.n,
                        t.nocc, t.n_s, (const uint32_t*)t.s_row.as<uint32_t>(), (const SRec*)t.s_rec.as<SRec>(),
                        xlink[s]);
@@ -374,11 +378,27 @@ int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
     hipLaunchKernelGGL(k_rdm2_ab, dim3(nblk(xl[1], 256), gy), dim3(256), 0, st, d_c, c->nb, xl[0], xl[1],
                        (const XLink*)xlink[0], (const XLink*)xlink[1], norb, G);
   }
-  hipLaunchKernelGGL(k_rdm2_symm_add, dim3(nblk(n4, 256)), dim3(256), 0, st, norb, (const double*)G, dm2);
-  SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipMemcpyAsync(dm2_host, dm2, n4 * 8, hipMemcpyDeviceToHost, st));
+  if (!resolved) {
+    hipLaunchKernelGGL(k_rdm2_symm_add, dim3(nblk(n4, 256)), dim3(256), 0, st, norb, (const double*)G, same[0]);
+    SQD_HIP_CHECK(hipGetLastError());
+    SQD_HIP_CHECK(hipMemcpyAsync(out[0], same[0], n4 * 8, hipMemcpyDeviceToHost, st));
+  } else {
+    SQD_HIP_CHECK(hipGetLastError());
+    SQD_HIP_CHECK(hipMemcpyAsync(out[0], same[0], n4 * 8, hipMemcpyDeviceToHost, st));
+    SQD_HIP_CHECK(hipMemcpyAsync(out[1], G, n4 * 8, hipMemcpyDeviceToHost, st));
+    SQD_HIP_CHECK(hipMemcpyAsync(out[2], same[1], n4 * 8, hipMemcpyDeviceToHost, st));
+  }
   SQD_HIP_CHECK(hipStreamSynchronize(st));
   return SQD_OK;
+}
+
+int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2_host) {
+  double* out[1] = {dm2_host};
+  return rdm2_impl(c, d_c, false, out);
+}
+int dev_rdm2s(sqd_ctx* c, const double* d_c, double* dm2aa, double* dm2ab, double* dm2bb) {
+  double* out[3] = {dm2aa, dm2ab, dm2bb};
+  return rdm2_impl(c, d_c, true, out);
 }
 
 }  // namespace sqd

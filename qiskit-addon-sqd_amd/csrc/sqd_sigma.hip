@@ -19,6 +19,7 @@
 // alpha single links it stages, coalesced, the K source rows C[A',:] and the K integral rows (pq|:)
 // into LDS, then every lane walks the sliced-ELL single-excitation list of its beta string and gathers
 // from LDS.  Global memory is only ever read with unit stride; all irregular accesses hit LDS.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -491,8 +492,14 @@ __global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, doubl
 template <int R, bool SPIN, bool LDSROW, bool PASS>
 static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
   if (c->sig_shmem > 64 * 1024) {
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN, LDSROW, PASS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
+    // once per (instantiation, device) and size step, not per launch
+    static std::atomic<size_t> granted[64];
+    const int dev = c->device & 63;
+    if (c->sig_shmem > granted[dev].load(std::memory_order_relaxed)) {
+      SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma<R, SPIN, LDSROW, PASS>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->sig_shmem));
+      granted[dev].store(c->sig_shmem, std::memory_order_relaxed);
+    }
   }
   hipLaunchKernelGGL((k_sigma<R, SPIN, LDSROW, PASS>), dim3((unsigned)c->n_items, (unsigned)c->sig_nchunks), dim3(c->sig_T),
                      c->sig_shmem, c->stream, g);
@@ -535,8 +542,11 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.nb_pad = c->sig_nb_pad;
   g.K = c->sig_K;
   g.mode = mode;
-  g.type_mask = 7;
-  if (const char* env = std::getenv("SQD_SIGMA_TYPES")) g.type_mask = std::atoi(env);
+  static const int type_mask = [] {  // profiling hook, read once per process
+    const char* env = std::getenv("SQD_SIGMA_TYPES");
+    return env ? std::atoi(env) : 7;
+  }();
+  g.type_mask = type_mask;
   g.spin = spin ? 1 : 0;
   g.ss = ss;
   g.shift = shift;

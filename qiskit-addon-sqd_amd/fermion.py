@@ -36,14 +36,43 @@ _CTX_CACHE: "OrderedDict[tuple, _capi.Context]" = OrderedDict()
 _CTX_CACHE_MAX = 16
 
 
+_HASH_LOCK = threading.Lock()
+_HASH_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of an integral array -> (array, full hash)
+
+
+def _full_hash(arr: np.ndarray) -> int:
+    """Hash of EVERY byte of an integral array, memoised by the array's identity (data pointer, size, strides, a
+    sampled CRC as a cheap guard against in-place edits).  The SQD loop passes the same tensor objects on every
+    call, so the full pass (xxh3, ~1 ms for norb = 30) is paid once per tensor, not once per solve; the memo
+    keeps a reference to the array so that its address cannot be recycled by another array while it is cached.
+    Two tensors that differ anywhere get different hashes, hence different contexts."""
+    a = np.asarray(arr)
+    if not a.flags.c_contiguous or a.dtype != np.float64:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 1024)
+    ident = (a.ctypes.data, a.size, zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes()))
+    with _HASH_LOCK:
+        hit = _HASH_MEMO.get(ident)
+        if hit is not None:
+            _HASH_MEMO.move_to_end(ident)
+            return hit[1]
+    try:
+        import xxhash
+
+        digest = xxhash.xxh3_64_intdigest(flat.data)
+    except ImportError:  # pragma: no cover - xxhash ships with this image
+        digest = zlib.crc32(flat.data) | (zlib.adler32(flat.data) << 32)
+    with _HASH_LOCK:
+        _HASH_MEMO[ident] = (a, digest)
+        while len(_HASH_MEMO) > 64:
+            _HASH_MEMO.popitem(last=False)
+    return digest
+
+
 def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
-    # fingerprint, not a full hash: every entry of hcore plus ~8k strided entries of eri (the loop calls
-    # this once per solve; a full pass over norb^4 doubles would cost more than a small solve)
     h = np.ascontiguousarray(hcore, dtype=np.float64)
-    e = np.asarray(eri).reshape(-1)
-    step = max(1, e.size // 8192)
-    sample = np.ascontiguousarray(e[::step], dtype=np.float64)
-    return (device, h.shape[0], e.size, zlib.crc32(h.tobytes()), zlib.crc32(sample.tobytes()))
+    return (device, h.shape[0], int(np.asarray(eri).size), zlib.crc32(h.tobytes()), _full_hash(eri))
 
 
 def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int = 0) -> _capi.Context:
@@ -140,10 +169,8 @@ class SCIState:
         if rank == 2:
             if spin_summed:
                 return self._ctx().rdm2(self.amplitudes)
-            raise NotImplementedError(
-                "Spin-resolved rank-2 reduced density matrices are not provided by this build; "
-                "use spin_summed=True."
-            )
+            # pyscf make_rdm2s: (dm2aa, dm2ab, dm2bb), returned as a tuple exactly as the reference does
+            return self._ctx().rdm2s(self.amplitudes)
         raise NotImplementedError(
             f"Computing the rank {rank} reduced density matrix is currently not supported."
         )

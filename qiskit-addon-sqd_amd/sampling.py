@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Sequence
 
+import warnings
+
 import numpy as np
 
 
@@ -180,10 +182,17 @@ def recover_configurations(
     (reference ``configuration_recovery.py:59-128``).  Bit ``i`` (< norb) is the spin-down partner of
     bit ``i + norb``; ``avg_occupancies = (occ_a, occ_b)`` indexed by orbital (LSB = rightmost bit)."""
     rng = np.random.default_rng(rand_seed)
-    if num_elec_a < 0 or num_elec_b < 0:
-        raise ValueError("The numbers of electrons must be specified as non-negative integers.")
     bitstring_matrix = np.asarray(bitstring_matrix, dtype=bool)
     norb = bitstring_matrix.shape[1] // 2
+    if len(np.array(avg_occupancies).shape) == 1:  # deprecated flat layout (configuration_recovery.py:100-108)
+        warnings.warn(
+            "Passing avg_occupancies as a 1D array is deprecated. Pass a length-2 tuple containing the spin-up and spin-down occupancies respectively.",
+            DeprecationWarning,
+            stacklevel=2,
+        )
+        avg_occupancies = (np.flip(avg_occupancies[norb:]), np.flip(avg_occupancies[:norb]))
+    if num_elec_a < 0 or num_elec_b < 0:
+        raise ValueError("The numbers of electrons must be specified as non-negative integers.")
     # column c of the left half is beta orbital norb-1-c; of the right half alpha orbital norb-1-c
     occs = np.flip(np.asarray(avg_occupancies)).flatten()
     occ_left, occ_right = occs[:norb], occs[norb:]

@@ -70,6 +70,31 @@ def _carryover(result: SCIResult, threshold: float, symmetrize_spin: bool):
     return _by_descending_count(keep_a, wa), _by_descending_count(keep_b, wb)
 
 
+# ---- SPMD plumbing (reference ``processes.py:100-134``: ``is_control_process`` / pickle ``broadcast`` over MPI;
+# here the process group is torch.distributed's -- "nccl" = RCCL on MI355X, "gloo" on CPU)
+def _process_group():
+    try:
+        import torch.distributed as dist
+    except ImportError:  # pragma: no cover - torch is part of the image
+        return None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def _is_control_process(dist) -> bool:
+    return dist is None or dist.get_rank() == 0
+
+
+def _broadcast(dist, obj):
+    """Pickle broadcast from the control process (rank 0); a pass-through outside distributed mode."""
+    if dist is None:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def diagonalize_fermionic_hamiltonian(
     one_body_tensor: np.ndarray,
     two_body_tensor: np.ndarray,
@@ -116,8 +141,20 @@ def diagonalize_fermionic_hamiltonian(
         include_a = include_b = include_configurations
     include_a, include_b = np.unique(include_a), np.unique(include_b)
 
-    rng = np.random.default_rng(seed)
-    solver = sci_solver if sci_solver is not None else solve_sci_batch
+    # Distributed (SPMD) mode, as in the reference (``fermion.py:410-451``): the control process (rank 0) owns the
+    # random stream and everything that has no distributed implementation -- building the batches of CI strings,
+    # picking the winner, convergence, carry-over -- and broadcasts the CI strings before and the iteration state
+    # after the one collective step, ``sci_solver``.  The other ranks never draw random numbers, so ``seed=None``
+    # is safe.  With a process group initialised the default solver is the batch-sharded collective one.
+    dist = _process_group()
+    control = _is_control_process(dist)
+    rng = np.random.default_rng(seed) if control else None
+    if sci_solver is not None:
+        solver = sci_solver
+    elif dist is not None:
+        from .distributed import solve_sci_batch_distributed as solver
+    else:
+        solver = solve_sci_batch
     raw_bitstrings, raw_probs = bit_array_to_arrays(bit_array)
 
     occupancies = initial_occupancies
@@ -126,42 +163,49 @@ def diagonalize_fermionic_hamiltonian(
     carry_a = carry_b = np.array([], dtype=np.int64)
 
     for _ in range(max_iterations):
-        # ---- configurations for this iteration
-        if occupancies is None:
-            bitstrings, probs = postselect_by_hamming_right_and_left(
-                raw_bitstrings, raw_probs, hamming_right=n_alpha, hamming_left=n_beta
-            )
-            if not bitstrings.size:
-                raise ValueError(
-                    "The input bit array did not contain any valid bitstrings. "
-                    "Either pass a bit array that contains at least one valid bitstring "
-                    "(with the correct right and left Hamming weights), or specify a value for initial_occupancies."
+        # ---- configurations for this iteration (control process only)
+        ci_strings = None
+        if control:
+            if occupancies is None:
+                bitstrings, probs = postselect_by_hamming_right_and_left(
+                    raw_bitstrings, raw_probs, hamming_right=n_alpha, hamming_left=n_beta
                 )
-        else:
-            bitstrings, probs = recover_configurations(raw_bitstrings, raw_probs, occupancies, n_alpha, n_beta, rand_seed=rng)
-        batches = subsample(bitstrings, probs, samples_per_batch=samples_per_batch, num_batches=num_batches, rand_seed=rng)
-        ci_strings = [
-            _batch_strings(b, norb, symmetrize_spin, include_a, include_b, carry_a, carry_b, max_dim_a, max_dim_b)
-            for b in batches
-        ]
+                if not bitstrings.size:
+                    raise ValueError(
+                        "The input bit array did not contain any valid bitstrings. "
+                        "Either pass a bit array that contains at least one valid bitstring "
+                        "(with the correct right and left Hamming weights), or specify a value for initial_occupancies."
+                    )
+            else:
+                bitstrings, probs = recover_configurations(raw_bitstrings, raw_probs, occupancies, n_alpha, n_beta, rand_seed=rng)
+            batches = subsample(bitstrings, probs, samples_per_batch=samples_per_batch, num_batches=num_batches, rand_seed=rng)
+            ci_strings = [
+                _batch_strings(b, norb, symmetrize_spin, include_a, include_b, carry_a, carry_b, max_dim_a, max_dim_b)
+                for b in batches
+            ]
+        ci_strings = _broadcast(dist, ci_strings)
 
-        # ---- the seam (reference fermion.py:432)
+        # ---- the seam (reference fermion.py:432): the only collective step
         results = solver(ci_strings, one_body_tensor, two_body_tensor, norb, nelec)
-        if callback is not None:
+        if callback is not None and control:
             callback(results)
 
-        # ---- bookkeeping
-        winner = min(results, key=lambda r: r.energy)
-        if best is None or winner.energy < best.energy:
-            best = winner
-        if (
-            current is not None
-            and abs(current.energy - winner.energy) < energy_tol
-            and np.linalg.norm(np.ravel(occupancies) - np.ravel(winner.orbital_occupancies), ord=np.inf) < occupancies_tol
-        ):
+        # ---- bookkeeping (control process), then the iteration state to every rank (reference :436-451)
+        state = None
+        if control:
+            winner = min(results, key=lambda r: r.energy)
+            new_best = winner if best is None or winner.energy < best.energy else best
+            converged = (
+                current is not None
+                and abs(current.energy - winner.energy) < energy_tol
+                and np.linalg.norm(np.ravel(occupancies) - np.ravel(winner.orbital_occupancies), ord=np.inf) < occupancies_tol
+            )
+            carry = (carry_a, carry_b) if converged else _carryover(winner, carryover_threshold, symmetrize_spin)
+            state = (new_best, winner, bool(converged), carry)
+        best, winner, converged, (carry_a, carry_b) = _broadcast(dist, state)
+        if converged:
             break
         current = winner
         occupancies = winner.orbital_occupancies
-        carry_a, carry_b = _carryover(winner, carryover_threshold, symmetrize_spin)
 
     return best

@@ -55,6 +55,9 @@ def check_operators(ctx, h1, eri, sa, sb, norb, nelec, rng, tol=1e-11):
 
 
 def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=True, variants=True):
+    # the start vector is pyscf's get_init_guess (lower-triangle rule included), normalised
+    x0 = O.init_guess(np.diag(H), len(sa), len(sb), nelec=ctx.nelec)
+    assert np.allclose(ctx.init_guess().ravel(), x0 / np.linalg.norm(x0), rtol=0, atol=1e-15)
     amps, st = ctx.davidson()
     w, v = np.linalg.eigh(H)
     assert st["converged"] == 1
@@ -78,6 +81,11 @@ def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=
         assert abs(e_rdm - ctx.energy()) < 1e-10
         n = np.trace(d1a) + np.trace(d1b)
         assert abs(np.einsum("ppqq->", d2) - n * (n - 1)) < 1e-9
+        aa, ab, bb = ctx.rdm2s()  # pyscf make_rdm2s pieces (SCIState.rdm(2, spin_summed=False))
+        assert np.allclose(aa + bb + ab + ab.transpose(2, 3, 0, 1), d2, atol=1e-12)
+        if norb <= 7:
+            for got, ref in zip((aa, ab, bb), O.jw_rdm2s(amps, sa, sb, norb)):
+                assert np.allclose(got, ref, atol=1e-12)
     if variants:
         check_solver_variants(ctx, w, v, amps, st, e_tol)
     return amps, st

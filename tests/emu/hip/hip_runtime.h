@@ -186,6 +186,8 @@ template <class T> inline T atomicExch(T* p, T v) {
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __builtin_amdgcn_wave_barrier() { emu::my_wave().bar->arrive_and_wait(); }
 template <class T> inline T atomicMax(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());
   T old = *p; if (v > old) *p = v; return old;

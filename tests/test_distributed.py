@@ -23,7 +23,7 @@ def test_shard_indices():
     assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
 
 
-def test_two_rank_gloo_batch_sharding(emu_lib):
+def _run_two_ranks(worker: str):
     from conftest import EMU_LIB
 
     port = _free_port()
@@ -31,9 +31,19 @@ def test_two_rank_gloo_batch_sharding(emu_lib):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SQD_EMU_LIB=str(EMU_LIB), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "_dist_worker.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
         assert f"rank {rank} ok" in out
+
+
+def test_two_rank_gloo_batch_sharding(emu_lib):
+    _run_two_ranks("_dist_worker.py")
+
+
+def test_two_rank_gloo_whole_loop_unseeded(emu_lib):
+    """The package's own SQD loop in SPMD mode with ``seed=None``: CI strings prepared on rank 0 and broadcast, the
+    collective solver in the middle, the iteration state broadcast back (reference fermion.py:421-451)."""
+    _run_two_ranks("_dist_loop_worker.py")

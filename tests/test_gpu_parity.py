@@ -134,7 +134,6 @@ def test_n2_headline_properties(hip_lib, hf):
         sx, sy = ctx.sigma(x), ctx.sigma(y)
         assert abs(np.vdot(y, sx) - np.vdot(x, sy)) < 1e-8 * abs(np.vdot(y, sx))
         assert np.allclose(ctx.sigma(2.0 * x - 3.0 * y), 2.0 * sx - 3.0 * sy, atol=1e-9)
-        # sigma against an independent sparse build of P H P on a random sub-block of rows
         amps, st = ctx.davidson()
         assert st["converged"] == 1
         e = ctx.energy()
@@ -152,6 +151,133 @@ def test_n2_headline_properties(hip_lib, hf):
         assert abs(np.einsum("ppqq->", d2) - 16 * 15) < 1e-7
         s2 = ctx.spin_square()
         assert s2 > -1e-9
+
+
+def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8):
+    """sigma, hdiag, E0, occupancies and the state itself at a BASELINE size against the oracles:
+    O1s = string-space evaluation of the decomposition that ``build_php`` forms densely (numpy, independent of
+    the J-table / hdiag split of the kernels), O2 = the C restatement of pyscf's contract_2e.  Tolerances:
+    sigma / hdiag 1e-11 * max|hdiag| absolute (observed ~1e-13); E0 1e-8 Ha (north_star bar 1e-6 Ha)."""
+    from oracle import sci_ref as R
+
+    h1, eri = O.synthetic_integrals(norb)
+    gen = O.hf_centred_strings if hf else O.random_strings
+    sa, sb = gen(norb, nocc, n, seeds[0]), gen(norb, nocc, n, seeds[1])
+    x = np.random.default_rng(7).standard_normal((n, n))
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        hd = ctx.hdiag()
+        s_gpu = ctx.sigma(x)
+        x0 = ctx.init_guess()
+        amps, st = ctx.davidson()
+        e, s2, occ_a, occ_b = ctx.observables()
+    scale = np.abs(hd).max()
+    assert np.allclose(hd, O.make_hdiag(h1, eri, sa, sb, norb), rtol=0, atol=1e-11 * scale)
+    assert np.abs(s_gpu - O.sigma_string_space(h1, eri, sa, sb, x, norb)).max() < 1e-11 * scale
+    if with_o2:
+        prob = R.RefProblem(h1, eri, sa, sb)
+        assert np.abs(s_gpu.ravel() - prob.contract_2e(x)).max() < 1e-11 * scale
+        assert np.allclose(hd.ravel(), prob.hdiag, rtol=0, atol=1e-11 * scale)
+    # start vector = pyscf get_init_guess
+    g = O.init_guess(hd.ravel(), n, n, nelec=(nocc, nocc))
+    assert np.allclose(x0.ravel(), g / np.linalg.norm(g), rtol=0, atol=1e-15)
+    # ground state: the oracle's Davidson (pyscf control flow, tightened so that its own residual is below the
+    # comparison tolerances) on the string-space operator
+    op = O.StringSpaceOperator(h1, eri, sa, sb, norb)
+    conv, e_ref, x_ref, _ = O.davidson_pyscf(op, g, hd.ravel(), tol=1e-13, max_cycle=200)
+    assert conv and st["converged"] == 1
+    x_ref = x_ref / np.linalg.norm(x_ref)
+    assert abs(e - e_ref) < e_tol and abs(st["e_davidson"] - e_ref) < e_tol
+    assert abs(abs(np.vdot(amps.ravel(), x_ref)) - 1.0) < 1e-9
+    r1a, r1b = O.make_rdm1s(x_ref.reshape(n, n), sa, sb, norb)
+    assert np.allclose(occ_a, np.diag(r1a), atol=5e-6) and np.allclose(occ_b, np.diag(r1b), atol=5e-6)
+    return e, e_ref
+
+
+@pytest.mark.parametrize("hf", [False, True])
+def test_n2_full_size_against_oracles(hip_lib, hf):
+    """BASELINE headline size, N2 (16e,30o) 317 x 317 = 100 489 determinants, both string generators: the full
+    sigma vector against O1s and O2, E0 / occupancies / state against the oracle's own Davidson."""
+    _full_size_checks(hip_lib, 30, 8, 317, hf, (1, 2), with_o2=True)
+
+
+@pytest.mark.parametrize("hf", [False, True])
+def test_fes_full_size_against_oracle(hip_lib, hf):
+    """BASELINE config 4's size, (30e,40o) 707 x 707 = 499 849 determinants: full sigma, E0, occupancies against
+    O1s (O2's dense formulation needs 1.3e14 flop per sigma at this size -- minutes -- and is left out)."""
+    _full_size_checks(hip_lib, 40, 15, 707, hf, (5, 6), with_o2=False)
+
+
+def test_n2_uniform_solve_vs_reference_flow(hip_lib):
+    """The whole reference orchestration (O2: check strings -> pyscf-flow Davidson on the restated contract_2e
+    -> <c|H|c>, occupancies; ``oracle/sci_ref.py: solve_fermion_ref`` follows fermion.py:745-845) at the headline
+    size, fed with a BOOL bitstring matrix as the reference's users do (fermion.py:788-795)."""
+    from oracle import sci_ref as R
+    from qiskit_addon_sqd_amd.fermion import bitstring_matrix_to_ci_strs, solve_fermion
+
+    norb, nelec, h1, eri, sa, sb = _n2_problem(317, False)
+    mat = O.bitstring_matrix_from_strings(sa, sb, norb)   # 317 samples |b_i a_i>
+    assert mat.dtype == bool and mat.shape == (317, 60)
+    ci = bitstring_matrix_to_ci_strs(mat, open_shell=True)
+    assert np.array_equal(ci[0], sa) and np.array_equal(ci[1], sb)
+    e, state, occ, s2 = solve_fermion(mat, h1, eri, open_shell=True)
+    e_ref, amps_ref, occ_ref, _ = R.solve_fermion_ref(O.bitstring_matrix_to_ci_strs(mat, open_shell=True), h1, eri,
+                                                      tol=1e-12)
+    assert abs(e - e_ref) < 1e-8
+    assert abs(abs(np.vdot(state.amplitudes, amps_ref)) - 1.0) < 1e-8
+    assert np.allclose(occ[0], occ_ref[0], atol=5e-6) and np.allclose(occ[1], occ_ref[1], atol=5e-6)
+    # closed shell: both spins get the union (fermion.py:1032-1033)
+    e2, state2, _, _ = solve_fermion(mat[:40], h1, eri, open_shell=False)
+    u = np.union1d(sa[:40], sb[:40])
+    assert np.array_equal(state2.ci_strs_a, u) and np.array_equal(state2.ci_strs_b, u)
+    assert state2.amplitudes.shape == (len(u), len(u))
+
+
+def test_config3_eight_batches_one_gpu(hip_lib):
+    """BASELINE config 3 on one GPU: 8 independent 317 x 317 subsample batches of the N2-sized problem through
+    (i) ``solve_sci_batch`` with batches in flight concurrently and (ii) the collective ``solve_sci_batch_distributed``
+    on an RCCL ("nccl") process group of world size 1 -- all-reduce of the (E, occ) records and winner broadcast
+    included -- against the one-at-a-time run, bit for bit."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from qiskit_addon_sqd_amd.distributed import solve_sci_batch_distributed
+    from qiskit_addon_sqd_amd.fermion import solve_sci_batch
+
+    norb, nelec = 30, (8, 8)
+    h1, eri = O.synthetic_integrals(norb)
+    batches = [(O.random_strings(norb, 8, 317, 100 + i), O.random_strings(norb, 8, 317, 200 + i)) for i in range(7)]
+    batches.append((O.hf_centred_strings(norb, 8, 317, 1), O.hf_centred_strings(norb, 8, 317, 2)))
+    serial = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False, concurrency=1)
+    par = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        coll = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False)
+        mean = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False, occupancy_reduce="mean")
+    finally:
+        dist.destroy_process_group()
+    best = int(np.argmin([r.energy for r in serial]))
+    assert best == 7  # the HF-centred batch contains the aufbau determinant
+    for i, (s0, p, c) in enumerate(zip(serial, par, coll)):
+        for r in (p, c):
+            assert r.energy == s0.energy, i
+            assert np.array_equal(r.orbital_occupancies[0], s0.orbital_occupancies[0])
+            assert np.array_equal(r.orbital_occupancies[1], s0.orbital_occupancies[1])
+            assert np.array_equal(r.sci_state.amplitudes, s0.sci_state.amplitudes)
+    mean_a = np.mean([s0.orbital_occupancies[0] for s0 in serial], axis=0)
+    assert all(np.allclose(r.orbital_occupancies[0], mean_a, atol=1e-13) for r in mean)
+    # one oracle anchor for the batch set: the winner's energy
+    op = O.StringSpaceOperator(h1, eri, batches[7][0], batches[7][1], norb)
+    hd = O.make_hdiag(h1, eri, batches[7][0], batches[7][1], norb).ravel()
+    conv, e_ref, _, _ = O.davidson_pyscf(op, O.init_guess(hd, 317, 317, nelec), hd, tol=1e-12, max_cycle=200)
+    assert conv and abs(serial[7].energy - e_ref) < 1e-8
 
 
 def test_fes_size_properties(hip_lib):

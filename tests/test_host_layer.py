@@ -116,3 +116,36 @@ def test_python_api_through_emulator(emu_backend):
         solve_fermion((sa, sb), h1, eri, bogus_kwarg=1)
     out = solve_sci_batch([(sa, sb), (sa[:5], sb[:4])], h1, eri, norb, nelec, compute_rdms=False)
     assert len(out) == 2 and out[0].rdm2 is None and out[0].energy <= out[1].energy + 1e-9
+
+
+def test_fcidump_round_trip(tmp_path):
+    """The benchmark's "synthetic FCIDUMP" really goes through the file format: 8-fold unique
+    entries written with 17 significant digits, expanded again on reading -- bit-for-bit."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    for norb, nelec in ((2, 2), (7, 6)):
+        h1, eri = S.synthetic_integrals(norb)
+        path = tmp_path / f"fcidump_{norb}"
+        S.write_fcidump(path, h1, eri, nelec, ms2=0, ecore=0.7137)
+        h1r, erir, ne, ms2, ecore = S.read_fcidump(path)
+        assert (ne, ms2, ecore) == (nelec, 0, 0.7137)
+        assert np.array_equal(h1r, h1) and np.array_equal(erir, eri)
+    head = (tmp_path / "fcidump_7").read_text().splitlines()[0]
+    assert "NORB=7" in head and "NELEC=6" in head
+
+
+def test_recover_configurations_deprecated_flat_occupancies():
+    """reference configuration_recovery.py:100-108: a flat occupancy array [b_{N-1}..b_0, a_{N-1}..a_0] is still
+    accepted (with a DeprecationWarning) and means the same as the (occ_a, occ_b) tuple."""
+    from qiskit_addon_sqd_amd.sampling import recover_configurations
+
+    rng = np.random.default_rng(3)
+    norb = 4
+    mat = rng.random((30, 2 * norb)) < 0.5
+    probs = np.full(30, 1 / 30)
+    occ_a, occ_b = rng.random(norb), rng.random(norb)
+    ref_m, ref_p = recover_configurations(mat, probs, (occ_a, occ_b), 2, 2, rand_seed=11)
+    flat = np.concatenate((np.flip(occ_b), np.flip(occ_a)))
+    with pytest.warns(DeprecationWarning):
+        m, p = recover_configurations(mat, probs, flat, 2, 2, rand_seed=11)
+    assert np.array_equal(m, ref_m) and np.array_equal(p, ref_p)

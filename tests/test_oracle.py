@@ -73,6 +73,11 @@ def test_slater_condon_matches_jordan_wigner(norb, nelec, na, nb, seed):
     assert np.allclose(d1a, r1a, atol=1e-12) and np.allclose(d1b, r1b, atol=1e-12)
     assert np.allclose(d2, O.make_rdm2(c, sa, sb, norb), atol=1e-12)
     assert abs(O.energy_from_rdms(h1, eri, d1a + d1b, d2) - w[0]) < 1e-10
+    aa, ab, bb = O.jw_rdm2s(c, sa, sb, norb)
+    assert np.allclose(aa + bb + ab + ab.transpose(2, 3, 0, 1), d2, atol=1e-12)
+    # the string-space sigma used at BASELINE sizes, against the dense matrix it factorises
+    x = np.random.default_rng(seed).standard_normal((na, nb))
+    assert np.allclose(O.sigma_string_space(h1, eri, sa, sb, x, norb).ravel(), Hbf @ x.ravel(), atol=1e-12)
 
 
 def test_spin_complete_space_has_spin_eigenvalues():
@@ -119,3 +124,27 @@ def test_c_restatement_matches_numpy_oracle(norb, nelec, na, nb, seed):
     assert abs(e - np.linalg.eigvalsh(H)[0]) < 1e-7
     r1a, r1b = O.make_rdm1s(amps, sa, sb, norb)
     assert np.allclose(occ[0], np.diag(r1a), atol=1e-12) and np.allclose(occ[1], np.diag(r1b), atol=1e-12)
+
+
+@pytest.mark.parametrize("norb,nelec,na,nb,seed,hf", [(10, (5, 5), 40, 37, 11, True), (12, (4, 6), 30, 70, 13, False)])
+def test_string_space_sigma_matches_dense_and_c_restatement(norb, nelec, na, nb, seed, hf):
+    """O1s (sigma_string_space) == dense P H P == O2 (pyscf's gather/dgemm/scatter restatement)."""
+    from oracle import sci_ref as R
+
+    h1, eri = O.synthetic_integrals(norb, seed=seed)
+    gen = O.hf_centred_strings if hf else O.random_strings
+    sa, sb = gen(norb, nelec[0], na, seed + 1), gen(norb, nelec[1], nb, seed + 2)
+    x = np.random.default_rng(seed).standard_normal((na, nb))
+    ref = O.build_php(h1, eri, sa, sb, norb) @ x.ravel()
+    assert np.allclose(O.sigma_string_space(h1, eri, sa, sb, x, norb).ravel(), ref, atol=1e-11)
+    assert np.allclose(R.RefProblem(h1, eri, sa, sb).contract_2e(x), ref, atol=1e-11)
+
+
+def test_init_guess_lower_triangle_rule():
+    """pyscf direct_spin1._get_init_guess: the minimum is searched over A >= B when the spin sectors match."""
+    h = np.array([[3.0, 1.0, 5.0], [2.0, 4.0, 6.0], [7.0, 8.0, 9.0]])  # global minimum at (0, 1), upper triangle
+    x = O.init_guess(h.ravel(), 3, 3, nelec=(2, 2))
+    assert np.argmax(x) == 1 * 3 + 0          # lowest element of the lower triangle: (1, 0) = 2.0
+    x = O.init_guess(h.ravel(), 3, 3, nelec=(2, 1))
+    assert np.argmax(x) == 0 * 3 + 1          # different sectors: the global minimum
+    assert x[0] == 1e-5 and x[-1] == -1e-5
