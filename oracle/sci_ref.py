@@ -61,6 +61,10 @@ def load(use_blas: bool = True):
         if fn:
             lib.ref_set_dgemm(fn)
             lib._blas_keepalive = blas
+    # physical cores, capped at 64: the OpenBLAS bundled with numpy/scipy keeps per-thread metadata for 64
+    # callers and crashes (SIGSEGV) when dgemm is entered from more OpenMP threads than that -- which a
+    # 256-thread GPU host does by default
+    lib.ref_set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
     _lib = lib
     return lib
 

@@ -316,6 +316,7 @@ class Context:
         fetch: bool = True,
         time_sigma_every: int = 0,
         observables: bool = False,
+        spin_square: bool = True,
     ):
         """Ground state of the projected Hamiltonian.  Returns (amps, stats); with ``observables=True`` the
         fused native call ``sqd_solve`` is used and (amps, stats, (energy, spin_square, occ_a, occ_b)) is
@@ -335,14 +336,16 @@ class Context:
             ci0 = _as_f64(ci0).reshape(self.na, self.nb)
             ci0p = _ptr(ci0)
         if observables:
+            # spin_square=False: <S^2> is not asked for (the sci_solver seam never reads it); without a spin
+            # penalty no sigma build at all then follows the Davidson
             e, s2 = C.c_double(), C.c_double()
             occ_a, occ_b = np.empty(self.norb), np.empty(self.norb)
             self._check(
                 self._lib.sqd_solve(self._h, C.byref(opts), ci0p, _ptr(amps) if fetch else None, C.byref(stats),
-                                    C.byref(e), C.byref(s2), _ptr(occ_a), _ptr(occ_b))
+                                    C.byref(e), C.byref(s2) if spin_square else None, _ptr(occ_a), _ptr(occ_b))
             )
             return (amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_},
-                    (e.value, s2.value, occ_a, occ_b))
+                    (e.value, s2.value if spin_square else None, occ_a, occ_b))
         self._check(
             self._lib.sqd_davidson(self._h, C.byref(opts), ci0p, _ptr(amps) if fetch else None, C.byref(stats))
         )

@@ -354,7 +354,7 @@ SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s
   NEED_SUBSPACE(c);
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
-  std::vector<double> out(3 + 2 * c->norb);
+  std::vector<double> out(4 + 2 * c->norb);
   SQD_TRY(dev_observables(c, d, out.data()));
   if (!(out[2] > 0.0)) {
     set_error("state has zero norm");
@@ -371,6 +371,13 @@ SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s
 
 // One call for the whole of solve_fermion's device work: Davidson, then the observables' kernels on the
 // compute stream WHILE the amplitudes travel to the host on the copy stream; one synchronisation.
+//
+// Energy: the reference recomputes <c|H|c> from the returned state because pyscf's eigenvalue includes the spin
+// penalty (fermion.py:717-732, :825-827).  The Ritz value IS the Rayleigh quotient of the returned vector with
+// the operator that was iterated (every A X_v in the basis is an exact sigma build), so
+//     <c|H|c> = e_davidson - shift * <penalty>,   <penalty> = <S^2> - ss   or   <(S^2 - ss)^2> = |S^2 c - ss c|^2,
+// both available from the one S^2 c that <S^2> needs anyway: no extra H sigma build.  Without a penalty and with
+// s2 == NULL (the sci_solver seam never reads <S^2>, fermion.py:684-742) no sigma build follows the Davidson at all.
 SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* ci0, double* amps,
                       sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b) {
   CTX_ENTER(c);
@@ -381,7 +388,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     set_error("bad Davidson options");
     return SQD_ERR_INVALID;
   }
-  SQD_TRY(run_davidson(c, &o, ci0, stats, /*defer_sync=*/true));
+  SQD_TRY(run_davidson(c, &o, ci0, nullptr, /*defer_sync=*/true));
   const size_t bytes = (size_t)c->D * 8;
   // small states go through a pinned staging buffer (a truly asynchronous copy); large ones straight to
   // the caller's memory
@@ -400,24 +407,37 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
       SQD_HIP_CHECK(hipMemcpyAsync(c->h_amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
     }
   }
-  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>()));
+  int form = o.use_spin;
+  if (form == 3) {
+    const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    form = (o.ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+  }
+  const bool need_s2 = (s2 != nullptr) || form != 0;
+  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2));
   if (amps && !staged)
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
   if (amps) SQD_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
   if (staged) std::memcpy(amps, c->h_amps, bytes);
   SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-  SQD_TRY(davidson_collect_timings(c, stats));
-  std::vector<double> out(3 + 2 * c->norb);
+  sqd_davidson_stats local;
+  sqd_davidson_stats* stp = stats ? stats : &local;
+  SQD_TRY(davidson_collect(c, stp));
+  std::vector<double> out(4 + 2 * c->norb);
   dev_observables_collect(c, out.data());
-  if (!(out[2] > 0.0)) {
+  const double cc = out[2];
+  if (!(cc > 0.0)) {
     set_error("state has zero norm");
     return SQD_ERR_INVALID;
   }
-  if (e) *e = out[0] / out[2];
-  if (s2) *s2 = out[1] / out[2];
+  const double ct = out[1] / cc, tt = out[3 + 2 * c->norb] / cc;
+  double penalty = 0.0;
+  if (form == 1) penalty = ct - o.ss;
+  else if (form == 2) penalty = tt - 2.0 * o.ss * ct + o.ss * o.ss;
+  if (e) *e = stp->e_davidson - (form ? o.shift * penalty : 0.0);
+  if (s2) *s2 = ct;
   for (int p = 0; p < c->norb; ++p) {
-    if (occ_a) occ_a[p] = out[3 + p] / out[2];
-    if (occ_b) occ_b[p] = out[3 + c->norb + p] / out[2];
+    if (occ_a) occ_a[p] = out[3 + p] / cc;
+    if (occ_b) occ_b[p] = out[3 + c->norb + p] / cc;
   }
   return SQD_OK;
 }

@@ -188,6 +188,8 @@ struct sqd_ctx {
   hipEvent_t ev_sol = nullptr;
   hipEvent_t ev_after_sigma_kernel = nullptr;  // if set: recorded once, right after the next k_sigma launch
   const int* sigma_stop = nullptr;  // device flag honoured by the sigma launches of a Davidson run, else null
+  const int* sigma_index = nullptr; // device word naming the basis vector a Davidson sigma works on (1-based), else null
+  std::vector<int> dav_ev_iter;     // iteration index of each timed sigma launch of the latest run
   hipEvent_t ev_aux = nullptr;  // set_subspace: "CSR pointers are on the host" (later kernels keep running)
   double* h_amps = nullptr;
   size_t h_amps_cap = 0;
@@ -199,21 +201,32 @@ namespace sqd {
 int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri);
 int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb);
 // sigma (sqd_sigma.hip).  mode 0: H (+ shift*(S^2-ss) if spin) ; mode 1: pure S^2
-int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift);
-int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift);
+// in_stride / out_stride != 0 (inside a Davidson run): the vector is chosen on the device through
+// sqd_ctx::sigma_index, input d_c + (*index - 1) * in_stride, output d_sigma + (*index - 1) * out_stride
+int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                 int64_t in_stride = 0, int64_t out_stride = 0);
+int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride = 0,
+            int64_t out_stride = 0);
 // blas-1 (sqd_davidson.hip)
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
 int enqueue_init_guess(sqd_ctx* c, double* d_x);  // pyscf get_init_guess into d_x (no synchronisation)
 // defer_sync: return with the solution still being formed on the stream; the caller synchronises and
-// then calls davidson_collect_timings (the non-timing fields of *st are final on return either way)
+// then calls davidson_collect, which fills *st (outcome + event timings)
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync = false);
-int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st);
+int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st);
+// arrival counters shared by the fused ("last workgroup finishes") reductions of a context's stream.  They reset
+// themselves after every use; a Davidson run also zeroes them, so a kernel aborted mid-way cannot poison later ones.
+int reserve_counters(sqd_ctx* c);
+unsigned* counter_ptr(sqd_ctx* c);
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
 int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
 int dev_rdm2s(sqd_ctx* c, const double* d_c, double* dm2aa, double* dm2ab, double* dm2bb);
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
-int dev_observables_enqueue(sqd_ctx* c, const double* d_c);   // kernels + result copy, no synchronisation
+// kernels only, no synchronisation.  with_h: <c|H|c> by a sigma build (else out[0] = 0); with_s2: S^2 c is built and
+// <c|S^2|c>, |S^2 c|^2 reduced (else 0).  Results land in host-visible memory, read by dev_observables_collect:
+// out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true);
 void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised
 }  // namespace sqd

@@ -1,4 +1,4 @@
-// Device-resident single-root Davidson for P (H + penalty) P.
+// Device-resident, device-CONTROLLED single-root Davidson for P (H + penalty) P.
 //
 // Replaces pyscf kernel_fixed_space -> FCISolver.eig -> lib.davidson1 (numpy BLAS-1 on the host)
 // as called from qiskit_addon_sqd/fermion.py:721-723 and :810-818.  Control flow and constants
@@ -8,10 +8,16 @@
 // vector away and spends a sigma build on the Ritz vector; here the basis collapses to
 // {Ritz vector, correction} and A*Ritz is formed by linear combination, saving that sigma build.
 //
-// All vectors (basis X, A X, hdiag) stay in HBM; only the (m x m) projected matrix and a handful of
-// norms cross to the host per iteration.  BLAS-1 work is fused: one pass builds residual +
-// preconditioned correction + its overlaps with the basis; reductions are fixed-order (bitwise
-// reproducible run to run).
+// Round-2 structure: the host no longer takes part in an iteration.  Everything an iteration decides --
+// the projected matrix, its lowest eigenpair (warm-started Rayleigh-quotient iteration or Jacobi, by ONE
+// wavefront inside the last workgroup of the reduction that produced the new column), the Ritz
+// coefficients, the restart, the stop rule -- lives in a small state block in device memory (DavState).
+// An iteration is four launches whose arguments never change,
+//     k_sigma(X[m-1] -> AX[m-1])  ->  k_dots_eig  ->  k_residual_precond  ->  k_orth_dev,
+// every kernel reads "which vector / how many / whether to stop" from the state block, so the host just
+// keeps one iteration enqueued ahead of the one it has seen finish (a small progress record in host-
+// visible memory) and no launch ever waits for the host.  Reductions are fixed-order => bitwise
+// reproducible run to run.
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -22,7 +28,7 @@
 
 namespace sqd {
 
-constexpr int NV = 16;       // vectors per fused reduction launch
+constexpr int NV = 16;       // vectors per fused reduction launch (stand-alone dots)
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_T = 512;    // 8 waves per workgroup: half as many partials to fold as with 256
 
@@ -66,28 +72,6 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
     partial[(int64_t)blockIdx.x * NV + threadIdx.x] = block_sum_multi_get<NV>(red, threadIdx.x);
 }
 
-struct Coef {
-  double v[SQD_MAX_SPACE + 2];
-};
-
-// out = sum_{v<nvec} coef[v] * X[v]
-__global__ void k_lincomb(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef coef,
-                          double* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
-      double x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (v0 + u < nvec) ? coef.v[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
-    }
-    out[i] = s;
-  }
-}
-
-// r = sum_v coef[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to `out`.
-// partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]
 // Diagonal of the spin penalty for the preconditioner (pyscf leaves hdiag un-shifted, which makes
 // the (S^2-ss)^2 form crawl; the operator is unchanged, only the preconditioner is better):
 //   form 1: shift (d - ss);  form 2: shift ((d - ss)^2 + n_flip),  d = sz(sz+1) + |B\A|, n_flip = |B\A||A\B|
@@ -107,60 +91,33 @@ __device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
   return p.shift * (d * d + nba * (double)__popcll(A & ~B));
 }
 
-// When the residual totals say the solve is over -- (|dE| < tol and |r|^2 < tol2) or a vanishing residual /
-// correction -- the device raises *flag itself, so that work the host enqueued ahead (next sigma, ...) returns
-// at once.  The host applies the SAME comparisons to the same numbers.  flag == nullptr: no rule.
-struct StopRule {
-  int* flag;
-  int de_small;
-  double tol2, lindep;
-};
-template <int N>
-__device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
-                                       double* __restrict__ dsums, double* mail, long long seq, double* red,
-                                       const StopRule rule);
+// ------------------------------------------------------------------ the state block
+constexpr int MAXB = SQD_MAX_SPACE + 1;  // most basis vectors a run can hold (max_space + the fresh correction)
 
-template <int MV>
-__global__ void k_residual_precond(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
-                                   int64_t stride, int nvec, const Coef coef, double e,
-                                   const double* __restrict__ hdiag, const PenaltyDiag pd, double* __restrict__ out,
-                                   double* __restrict__ partial, int width) {
-  // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
-  __shared__ double red[16 * (MV + 2)];
-  double vals[MV + 2];
-#pragma unroll
-  for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double r = 0.0;
-    double xv[MV];
-    const double hd = hdiag[i];
-    // eight (X_v, AX_v) pairs requested per round, branch-free (see load_vectors); X_v is kept for the overlaps
-#pragma unroll
-    for (int v0 = 0; v0 < MV; v0 += 8) {
-      double a8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (v0 + u < MV) {
-          const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : 0) * stride + i;
-          xv[v0 + u] = X[off];
-          a8[u] = AX[off];
-        }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (v0 + u < MV) r += (v0 + u < nvec) ? coef.v[v0 + u] * (a8[u] - e * xv[v0 + u]) : 0.0;
-    }
-    const double t = r / (hd + penalty_diag(pd, i) - e + 1e-4);
-    out[i] = t;
-    vals[0] += r * r;
-    vals[1] += t * t;
-#pragma unroll
-    for (int v = 0; v < MV; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
-  }
-  block_sum_multi<MV + 2>(vals, nvec + 2, red);
-  // per-workgroup partials only: k_orth_dev (next in the stream) folds them
-  if ((int)threadIdx.x < nvec + 2)
-    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
-}
+struct DavState {
+  int m_next;    // size of the basis whose newest vector X[m_next-1] is next to get its sigma (read by k_sigma, k_dots_eig)
+  int m_cur;     // size of the basis of the CURRENT projected problem (written by k_dots_eig; read by residual / orth)
+  int it;        // projected problems solved so far
+  int nsig;      // sigma builds that entered the projected matrix
+  int stop;      // the solve is over: every kernel enqueued behind this returns at once
+  int conv;      // ... and converged
+  int first;     // no projected problem solved yet (dE of the first one is the eigenvalue itself)
+  int m_eig;     // size of the last projected problem solved (-1: none, e.g. right after a restart)
+  int restart;   // the current iteration collapses the basis to {Ritz vector, correction}
+  int err;       // 1: the start vector has zero norm
+  int sol_m;     // the solution is sum_{v < sol_m} sol_coef[v] X_v
+  int pad;
+  double e, de, rnorm2;
+  double sv[MAXB + 1];        // 1 / |X_v| (basis vector v is sv_v X_v: vectors are never normalised by a pass)
+  double coef[MAXB + 1];      // Ritz coefficients on the orthonormal basis
+  double raw[MAXB + 1];       // ... on the stored vectors (coef * sv)
+  double sol_coef[MAXB + 1];  // normalised raw coefficients of the solution
+  double heff[MAXB * MAXB];   // projected matrix, row stride MAXB
+};
+struct DavParams {  // constants of one run
+  double tol, tol2, lindep;
+  int max_space;
+};
 
 // per-block (min value, index) over hdiag; tril != 0 restricts to A >= B (pyscf _get_init_guess
 // when nelec_a == nelec_b and na == nb)
@@ -183,13 +140,43 @@ __global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __r
   }
 }
 
+// start of a run: state block and arrival counters (workgroup 0; the kernels that use them come later in the stream)
+__device__ inline void dav_state_init(DavState* st, unsigned* counter) {
+  for (int i = threadIdx.x; i < COUNT_WORDS; i += blockDim.x) counter[i] = 0u;
+  for (int i = threadIdx.x; i < MAXB * MAXB; i += blockDim.x) st->heff[i] = 0.0;
+  for (int i = threadIdx.x; i <= MAXB; i += blockDim.x) {
+    st->sv[i] = (i == 0) ? 1.0 : 0.0;
+    st->coef[i] = (i == 0) ? 1.0 : 0.0;
+    st->raw[i] = (i == 0) ? 1.0 : 0.0;
+    st->sol_coef[i] = (i == 0) ? 1.0 : 0.0;
+  }
+  if (threadIdx.x == 0) {
+    st->m_next = 1;
+    st->m_cur = 1;
+    st->it = 0;
+    st->nsig = 0;
+    st->stop = 0;
+    st->conv = 0;
+    st->first = 1;
+    st->m_eig = -1;
+    st->restart = 0;
+    st->err = 0;
+    st->sol_m = 1;
+    st->e = 0.0;
+    st->de = 0.0;
+    st->rnorm2 = 0.0;
+  }
+}
+__global__ void k_dav_init(DavState* st, unsigned* counter) { dav_state_init(st, counter); }
+
 // pyscf get_init_guess: unit vector at addr, +1e-5 on the first and -1e-5 on the last element,
 // normalised here with the closed-form norm (no reduction, no host round trip)
 // (every workgroup repeats the final stage of the argmin over the <= RED_BLOCKS per-block candidates
 // instead of a separate single-workgroup launch)
 __global__ void k_init_guess(int64_t n, const double* __restrict__ pmin, const int64_t* __restrict__ pidx, int nblocks,
-                             double* __restrict__ x) {
+                             double* __restrict__ x, DavState* st, unsigned* counter) {
   __shared__ long long s_addr;
+  if (st && blockIdx.x == 0) dav_state_init(st, counter);
   {
     double best = 1e300;
     int64_t bi = -1;
@@ -232,11 +219,12 @@ static inline unsigned red_blocks(int64_t n) {
 // orthogonalisation, scal[2..] = outputs of the latest reduction.
 constexpr int SCAL_RED = 2;
 
-// Final stage of a reduction + hand-over to the host in ONE single-workgroup kernel: column sums of
-// the partial array (fixed order), written with scal[0..2) straight into the host-visible mailbox,
-// then a system-scope fence and the sequence word.  The host spins on that word (bounded) -- no copy
-// engine, no stream synchronisation on the critical path.
+// Final stage of a stand-alone reduction + hand-over to the host in ONE single-workgroup kernel: column sums
+// of the partial array (fixed order), written straight into the host-visible mailbox, then a system-scope
+// fence and the sequence word.  The host spins on that word (bounded) -- no copy engine, no stream
+// synchronisation on the critical path.
 constexpr int MAIL_PAYLOAD = 8;  // doubles; mail[0] is the sequence word
+constexpr int MAIL_SLOT = 128;   // doubles per mailbox slot: 0 stand-alone reductions, 1 Davidson progress, 2 Davidson result
 template <int MAXV>
 __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks, int width, int nv,
                                  const double* __restrict__ scal, double* __restrict__ mail, long long seq) {
@@ -264,73 +252,250 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
   }
 }
 
-// ---- fused reductions for the Davidson loop: the workgroup that arrives LAST folds the per-block
-// partials (fixed order => bitwise reproducible), leaves the totals on the device (dsums, for the
-// kernels that follow in the stream) and posts them to a host-visible mailbox.  No single-workgroup
-// reduction launch per hand-over, and the host is not needed between producer and consumer kernels.
-constexpr int MAIL_SLOT = 128;  // doubles per mailbox slot (slot 0: projected-matrix column, slot 1: residual)
-constexpr unsigned COUNT_GROUPS = 16;  // arrival counters: word 0 = groups done, words 1..16 = per group
-constexpr unsigned COUNT_STRIDE = 32;  // ... each in its own 128-byte line: atomics on one line serialise in one L2 channel
-template <int N>
-__device__ inline void finish_and_post(const double* partial, int width, int nv, unsigned* counter,
-                                       double* __restrict__ dsums, double* mail, long long seq, double* red,
-                                       const StopRule rule) {
-  __shared__ int s_last;
-  // the callers wrote their partials with coherent_store: once those stores have completed (waitcnt) the
-  // workgroup may be counted; no L2-wide fence (see sqd_device.h)
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // two-level arrival count (COUNT_GROUPS group words + a top word): device-scope atomics on ONE word
-    // serialise at ~50 ns each, which for a few hundred workgroups costs more than the reduction itself
-    int last = 0;
-    const unsigned G = COUNT_GROUPS, grp = blockIdx.x % G;
-    const unsigned gsize = (gridDim.x - grp + G - 1) / G, ngroups = gridDim.x < G ? gridDim.x : G;
-    if (atomicAdd(&counter[COUNT_STRIDE * (1 + grp)], 1u) == gsize - 1) {
-      atomicExch(&counter[COUNT_STRIDE * (1 + grp)], 0u);  // ready for the next fused reduction on this stream
-      if (atomicAdd(&counter[0], 1u) == ngroups - 1) {
-        atomicExch(&counter[0], 0u);
-        last = 1;
-      }
+// ------------------------------------------------------------------ the projected eigenproblem, on ONE wavefront
+// Lane i owns row i of the small matrices (n <= MAXB <= 64); all 64 lanes execute every collective.
+//
+// Lowest eigenpair after the basis grew by ONE vector, by Rayleigh-quotient iteration from the previous Ritz
+// vector padded with a zero (a start whose residual is already small).  The previous matrix is the leading
+// principal block of this one, so by Cauchy interlacing  l1(new) <= l1(old) <= l2(new): an eigenvalue found at or
+// below the old Ritz value IS the lowest one -- that test, plus a residual at rounding level, is the acceptance
+// rule; anything else returns false and the caller runs the Jacobi solver.
+// A, M: n x n with row stride ld (LDS); x, y: length-n work vectors (LDS).  v_io: previous Ritz vector in, new out.
+__device__ inline bool wave_lowest_eig_rqi(int n, int ld, const double* A, double* M, double* x, double* y, double* v_io,
+                                           double e_old, double* e_out) {
+  const int lane = threadIdx.x & 63;
+  const bool act = lane < n;
+  double xi = (act && lane < n - 1) ? v_io[lane] : 0.0;
+  double rowabs = 0.0;
+  if (act)
+    for (int j = 0; j < n; ++j) rowabs += fabs(A[lane * ld + j]);
+  const double nrm = wave_sum(xi * xi), anorm = wave_max(act ? rowabs : 0.0);
+  if (!(nrm > 0.0) || !(anorm > 0.0)) return false;
+  xi *= 1.0 / sqrt(nrm);
+  const double tiny = 2.3e-16 * anorm;
+  auto rayleigh = [&](double xl) {  // x <- xl (all lanes), y <- A x, returns x.Ax
+    wave_sync();
+    if (act) x[lane] = xl;
+    wave_sync();
+    double r = 0.0;
+    if (act)
+      for (int j = 0; j < n; ++j) r += A[lane * ld + j] * x[j];
+    if (act) y[lane] = r;
+    return wave_sum(act ? xl * r : 0.0);
+  };
+  double theta = rayleigh(xi);
+  for (int it = 0; it < 6; ++it) {
+    const double yi = act ? y[lane] : 0.0;
+    const double res = wave_sum(act ? (yi - theta * xi) * (yi - theta * xi) : 0.0);
+    if (sqrt(res) <= 8.0 * tiny) {
+      if (!(theta <= e_old + 64.0 * tiny)) return false;  // not provably the lowest eigenvalue
+      // (a new vector that does not couple to the old Ritz vector leaves that pair an eigenpair of the grown
+      // matrix although its own diagonal may lie lower: the lowest eigenvalue is below every diagonal element)
+      const double above = wave_max(act ? theta - A[lane * ld + lane] : -1.0);
+      if (above > 64.0 * tiny) return false;
+      *e_out = theta;
+      wave_sync();
+      if (act) v_io[lane] = xi;
+      wave_sync();
+      return true;
     }
-    s_last = last;
+    // y = (A - theta I)^-1 x   (Gaussian elimination, partial pivoting; a vanishing pivot is what converges it)
+    wave_sync();
+    if (act) {
+      for (int j = 0; j < n; ++j) M[lane * ld + j] = A[lane * ld + j] - (j == lane ? theta : 0.0);
+      y[lane] = xi;
+    }
+    wave_sync();
+    for (int k = 0; k < n; ++k) {
+      const int p = wave_argmax((act && lane >= k) ? fabs(M[lane * ld + k]) : -1.0, lane);
+      if (p != k) {
+        wave_sync();
+        if (act) {
+          const double a = M[k * ld + lane], b = M[p * ld + lane];
+          M[k * ld + lane] = b;
+          M[p * ld + lane] = a;
+        }
+        if (lane == 0) {
+          const double a = y[k];
+          y[k] = y[p];
+          y[p] = a;
+        }
+      }
+      wave_sync();
+      if (lane == 0 && fabs(M[k * ld + k]) < tiny) M[k * ld + k] = (M[k * ld + k] < 0.0) ? -tiny : tiny;
+      wave_sync();
+      if (act && lane > k) {
+        const double f = M[lane * ld + k] / M[k * ld + k];
+        if (f != 0.0) {
+          for (int j = k + 1; j < n; ++j) M[lane * ld + j] -= f * M[k * ld + j];
+          y[lane] -= f * y[k];
+        }
+      }
+      wave_sync();
+    }
+    if (lane == 0)
+      for (int i = n - 1; i >= 0; --i) {
+        double r = y[i];
+        for (int j = i + 1; j < n; ++j) r -= M[i * ld + j] * y[j];
+        y[i] = r / M[i * ld + i];
+      }
+    wave_sync();
+    const double yl = act ? y[lane] : 0.0;
+    const double yn = wave_sum(yl * yl), dot = wave_sum(yl * xi);
+    if (!(yn > 0.0) || !(yn < 1e300)) return false;
+    const double sc = ((dot < 0.0) ? -1.0 : 1.0) / sqrt(yn);  // keep the orientation of the previous Ritz vector
+    xi = yl * sc;
+    theta = rayleigh(xi);
   }
-  __syncthreads();
-  if (!s_last) return;
-  double vals[N];
-#pragma unroll
-  for (int v = 0; v < N; ++v) vals[v] = 0.0;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
-    double p[N];
-    load_partials<N, true>(partial, (int64_t)b * width, nv, p);  // all requests in flight together
-#pragma unroll
-    for (int v = 0; v < N; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
+  return false;
+}
+
+// cyclic Jacobi for a small symmetric matrix (destroyed); lowest eigenvalue returned, its eigenvector in v_out.
+// Lane k owns element k of the row / column being rotated.
+__device__ inline double wave_lowest_eig_jacobi(int n, int ld, double* A, double* V, double* v_out) {
+  const int lane = threadIdx.x & 63;
+  const bool act = lane < n;
+  if (act)
+    for (int j = 0; j < n; ++j) V[lane * ld + j] = (lane == j) ? 1.0 : 0.0;
+  wave_sync();
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    if (act) {
+      dia = A[lane * ld + lane] * A[lane * ld + lane];
+      for (int j = lane + 1; j < n; ++j) off += A[lane * ld + j] * A[lane * ld + j];
+    }
+    off = wave_sum(off);
+    dia = wave_sum(dia);
+    // converged to working precision (quadratic convergence: one more sweep would change nothing)
+    if (off <= 1e-32 * dia || off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p * ld + q], app = A[p * ld + p], aqq = A[q * ld + q];
+        wave_sync();
+        if (apq == 0.0) continue;  // uniform over the wave
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        if (act) {
+          const double akp = A[lane * ld + p], akq = A[lane * ld + q];
+          A[lane * ld + p] = cs * akp - sn * akq;
+          A[lane * ld + q] = sn * akp + cs * akq;
+        }
+        wave_sync();
+        if (act) {
+          const double apk = A[p * ld + lane], aqk = A[q * ld + lane];
+          A[p * ld + lane] = cs * apk - sn * aqk;
+          A[q * ld + lane] = sn * apk + cs * aqk;
+          const double vkp = V[lane * ld + p], vkq = V[lane * ld + q];
+          V[lane * ld + p] = cs * vkp - sn * vkq;
+          V[lane * ld + q] = sn * vkp + cs * vkq;
+        }
+        wave_sync();
+      }
   }
-  block_sum_multi<N>(vals, nv, red);
-  if ((int)threadIdx.x < nv) {
-    const double s = block_sum_multi_get<N>(red, threadIdx.x);
-    dsums[threadIdx.x] = s;
-    mail_store(&mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x], s);
+  // lowest diagonal element (ties to the lower index)
+  const int idx = wave_argmax(act ? -A[lane * ld + lane] : -1e300, lane);
+  const double w0 = A[idx * ld + idx];
+  wave_sync();
+  if (act) v_out[lane] = V[lane * ld + idx];
+  wave_sync();
+  return w0;
+}
+
+// One wavefront of the LAST workgroup of k_dots_eig: the new column of the projected matrix from the folded
+// dot products, the linear-dependence test, the lowest eigenpair, the Ritz coefficients, the restart decision.
+// tot[0] = |X_{m-1}|^2, tot[1+v] = X_v . A X_{m-1}.
+template <int MV>
+__device__ inline void wave_eig_step(DavState* st, const double* tot, const DavParams prm, double* sA, double* sM,
+                                     double* sx, double* sy, double* sv_eig) {
+  const int lane = threadIdx.x & 63;
+  const int m = st->m_next;
+  constexpr int LD = MV;
+  if (st->restart) {  // the previous iteration collapsed the basis: X0 = Ritz vector (unit norm), A X0 by combination
+    wave_sync();
+    for (int i = lane; i < MAXB * MAXB; i += 64) st->heff[i] = 0.0;
+    wave_sync();
+    if (lane == 0) {
+      st->heff[0] = st->e;
+      st->sv[0] = 1.0;
+      st->restart = 0;
+      st->m_eig = -1;
+    }
+    wave_sync();
   }
-  if (rule.flag && threadIdx.x == 0) {
-    const double s0 = block_sum_multi_get<N>(red, 0), s1 = block_sum_multi_get<N>(red, 1);
-    if ((rule.de_small && s0 < rule.tol2) || !(s0 > rule.lindep) || !(s1 > 0.0)) *rule.flag = 1;
+  const double nrm2 = tot[0];
+  if (st->it == 0 && !(nrm2 > 0.0)) {
+    if (lane == 0) {
+      st->err = 1;
+      st->stop = 1;
+    }
+    return;
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence_system();
-    *reinterpret_cast<volatile long long*>(mail) = seq;
+  if (!(nrm2 > prm.lindep)) {
+    // the last correction vector was linearly dependent on the basis: stop with the Ritz vector of the
+    // previous projected problem (pyscf: 'Linear dependency in trial subspace'); this sigma is not counted
+    if (lane == 0) {
+      st->conv = (st->rnorm2 < prm.tol2) ? 1 : 0;
+      st->stop = 1;
+    }
+    return;
+  }
+  const double svm = 1.0 / sqrt(nrm2);
+  if (lane < m) {
+    const double h = tot[1 + lane] * ((lane == m - 1) ? svm : st->sv[lane]) * svm;
+    st->heff[lane * MAXB + (m - 1)] = h;
+    st->heff[(m - 1) * MAXB + lane] = h;
+  }
+  wave_sync();
+  if (lane < m)
+    for (int j = 0; j < m; ++j) sA[lane * LD + j] = st->heff[lane * MAXB + j];
+  // previous Ritz vector (coefficients of the last projected problem) as the warm start
+  if (lane < m) sv_eig[lane] = (lane < m - 1) ? st->coef[lane] : 0.0;
+  wave_sync();
+  double e_new = 0.0;
+  bool warm = false;
+  if (m == st->m_eig + 1 && !st->first && m >= 2) warm = wave_lowest_eig_rqi(m, LD, sA, sM, sx, sy, sv_eig, st->e, &e_new);
+  if (!warm) e_new = wave_lowest_eig_jacobi(m, LD, sA, sM, sv_eig);  // (sA is rebuilt from heff every iteration)
+  // the Ritz coefficients of this projected problem
+  const double ci = (lane < m) ? sv_eig[lane] : 0.0;
+  const double cn = wave_sum(ci * ci);
+  const double svi = (lane < m) ? ((lane == m - 1) ? svm : st->sv[lane]) : 0.0;
+  wave_sync();
+  if (lane < m) {
+    st->coef[lane] = ci;
+    st->raw[lane] = ci * svi;
+    st->sol_coef[lane] = (cn > 0.0 ? ci / sqrt(cn) : ci) * svi;
+    if (lane == m - 1) st->sv[lane] = svm;
+  }
+  if (lane == 0) {
+    const double elast = st->e;
+    st->e = e_new;
+    st->de = st->first ? e_new : e_new - elast;
+    st->first = 0;
+    st->m_eig = m;
+    st->m_cur = m;
+    st->sol_m = m;
+    st->nsig += 1;
+    st->it += 1;
+    const int restart = (m + 1 > prm.max_space) ? 1 : 0;
+    st->restart = restart;
+    st->m_next = restart ? 2 : m + 1;
   }
 }
 
-// sums[0] = |X_{nvec-1}|^2, sums[1+v] = X_v . y  (v < nvec <= MV); y = A X_{nvec-1} in the Davidson loop
+// sums[0] = |X_{m-1}|^2, sums[1+v] = X_v . y  (v < m <= MV), y = A X_{m-1}, m = st->m_next; the workgroup that
+// arrives LAST folds the per-block partials (fixed order) and one of its wavefronts solves the projected problem.
 template <int MV>
-__global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t stride, int nvec,
-                            const double* __restrict__ y, double* __restrict__ partial, int width, unsigned* counter,
-                            double* __restrict__ dsums, double* mail, long long seq, const int* stop) {
+__global__ void k_dots_eig(int64_t n, const double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+                           double* __restrict__ partial, int width, unsigned* counter, DavState* st,
+                           const DavParams prm) {
   __shared__ double red[16 * (MV + 1)];
-  if (stop && *stop) return;  // enqueued ahead of a residual that ended the solve: nobody waits for this
+  __shared__ double tot[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sx[MV + 1], sy[MV + 1], sv_eig[MV + 1];
+  if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
+                         // kernel before every workgroup has arrived)
+  const int nvec = st->m_next;
+  const double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
   double acc[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
@@ -347,32 +512,119 @@ __global__ void k_dots_post(int64_t n, const double* __restrict__ X, int64_t str
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
   if ((int)threadIdx.x < nvec + 1)
     coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
-  finish_and_post<MV + 1>(partial, width, nvec + 1, counter, dsums, mail, seq, red, StopRule{nullptr, 0, 0.0, 0.0});
+  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+  double vals[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) vals[v] = 0.0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+    double p[MV + 1];
+    load_partials<MV + 1, true>(partial, (int64_t)b * width, nvec + 1, p);  // all requests in flight together
+#pragma unroll
+    for (int v = 0; v < MV + 1; ++v) vals[v] += (v < nvec + 1) ? p[v] : 0.0;
+  }
+  block_sum_multi<MV + 1>(vals, nvec + 1, red);
+  if ((int)threadIdx.x < nvec + 1) tot[threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  wave_eig_step<MV>(st, tot, prm, sA, sM, sx, sy, sv_eig);
+}
+
+// r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
+// partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]; k_orth_dev (next in the stream) folds them.
+template <int MV>
+__global__ void k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+                                   const DavState* __restrict__ st, const double* __restrict__ hdiag,
+                                   const PenaltyDiag pd, double* __restrict__ partial, int width) {
+  // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
+  __shared__ double red[16 * (MV + 2)];
+  __shared__ double s_raw[MV];
+  if (st->stop) return;
+  const int nvec = st->m_cur;
+  const double e = st->e;
+  if ((int)threadIdx.x < MV) s_raw[threadIdx.x] = ((int)threadIdx.x < nvec) ? st->raw[threadIdx.x] : 0.0;
+  __syncthreads();
+  double* __restrict__ out = X + (int64_t)nvec * stride;
+  double vals[MV + 2];
+#pragma unroll
+  for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double r = 0.0;
+    double xv[MV];
+    const double hd = hdiag[i];
+    // eight (X_v, AX_v) pairs requested per round, branch-free (see load_vectors); X_v is kept for the overlaps
+#pragma unroll
+    for (int v0 = 0; v0 < MV; v0 += 8) {
+      double a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < MV) {
+          const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : 0) * stride + i;
+          xv[v0 + u] = X[off];
+          a8[u] = AX[off];
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < MV) r += (v0 + u < nvec) ? s_raw[v0 + u] * (a8[u] - e * xv[v0 + u]) : 0.0;
+    }
+    const double t = r / (hd + penalty_diag(pd, i) - e + 1e-4);
+    out[i] = t;
+    vals[0] += r * r;
+    vals[1] += t * t;
+#pragma unroll
+    for (int v = 0; v < MV; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
+  }
+  block_sum_multi<MV + 2>(vals, nvec + 2, red);
+  if ((int)threadIdx.x < nvec + 2)
+    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+}
+
+// progress record of one iteration in host-visible memory: {sequence word | it, stop, e, de, |r|^2, m}
+__device__ inline void post_progress(double* mail, long long seq, const DavState* st, int stop, double rr) {
+  mail_store(&mail[MAIL_PAYLOAD + 0], (double)st->it);
+  mail_store(&mail[MAIL_PAYLOAD + 1], (double)stop);
+  mail_store(&mail[MAIL_PAYLOAD + 2], st->e);
+  mail_store(&mail[MAIL_PAYLOAD + 3], st->de);
+  mail_store(&mail[MAIL_PAYLOAD + 4], rr);
+  mail_store(&mail[MAIL_PAYLOAD + 5], (double)st->m_cur);
+  __builtin_amdgcn_s_waitcnt(0);
+  __threadfence_system();
+  *reinterpret_cast<volatile long long*>(mail) = seq;
 }
 
 // t <- scale * t - sum_v g_v X_v with everything derived on the device from the residual kernel's totals
-// (dsums = {|r|^2, |t|^2, X_v . t}) and the per-vector normalisation factors sv (basis vector v is
+// (tot = {|r|^2, |t|^2, X_v . t}) and the per-vector normalisation factors sv (basis vector v is
 // sv_v * X_v): g'_v = sv_v (X_v . t) / |t|, c2 = sum g'_v^2.  The basis is orthonormal, so
 // |t/|t| - sum g'_v sv_v X_v|^2 = 1 - c2 is known before the vector is formed: when 1 - c2 > 1e-3 the
 // result is normalised in the same pass; otherwise it is left with its true (small) norm.  Either way the
-// next k_dots_post measures |X_new|^2 and the host carries 1/sqrt of it as sv_new, so no separate
-// normalisation pass and no host decision is needed here.
+// next k_dots_eig measures |X_new|^2 and carries 1/sqrt of it as sv_new, so no separate normalisation pass.
 //
 // The residual kernel leaves only per-workgroup partials: EVERY workgroup here folds them itself (fixed
 // order, the same arithmetic everywhere => the same totals to the bit), which is cheaper than a finishing
 // step inside the residual kernel (arrival atomics + coherent re-read, ~8 us) and needs no extra launch.
-// Workgroup 0 posts the totals to the host mailbox and applies the stop rule for the kernels enqueued ahead;
-// every workgroup applies it to itself.
+// Every workgroup applies the stop rule to itself; workgroup 0 records it in the state block (for the kernels
+// enqueued behind) and posts the iteration's progress record to the host.
+// When the iteration is a restart (basis full), the same pass collapses the basis: X0 <- Ritz vector,
+// AX0 <- A * Ritz (linear combinations, element by element in place), X1 <- the correction.
 template <int MV>
-__global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, const Coef sv,
-                           const double* __restrict__ partial, int nblocks, int width, double* __restrict__ t,
-                           double* mail, long long seq, const StopRule rule, const int* stop) {
+__global__ void k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
+                           const DavParams prm, const double* __restrict__ partial, int nblocks, int width,
+                           double* mail, long long seq) {
   __shared__ double red[16 * (MV + 2)];
   __shared__ double tot[MV + 2];
   __shared__ double g[MV + 2];
+  __shared__ double s_raw[MV];
   __shared__ double s_scale;
-  __shared__ int s_stop;
-  if (stop && *stop) return;
+  __shared__ int s_stop, s_was_stopped;
+  // (workgroup 0 raises st->stop further down while other workgroups may still be starting: the flag is
+  // sampled once per workgroup so that all its threads take the same path)
+  if (threadIdx.x == 0) s_was_stopped = st->stop;
+  __syncthreads();
+  if (s_was_stopped) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) post_progress(mail, seq, st, 1, st->rnorm2);
+    return;
+  }
+  const int nvec = st->m_cur;
+  const int restart = st->restart;
   const int nv = nvec + 2;
   {
     double vals[MV + 2];
@@ -389,48 +641,105 @@ __global__ void k_orth_dev(int64_t n, const double* __restrict__ X, int64_t stri
   }
   __syncthreads();
   const double rr = tot[0], tt = tot[1];
-  if ((int)threadIdx.x < nvec) g[threadIdx.x] = (tt > 0.0) ? sv.v[threadIdx.x] * tot[2 + threadIdx.x] / sqrt(tt) : 0.0;
+  if ((int)threadIdx.x < MV) {
+    const int v = threadIdx.x;
+    g[v] = (v < nvec && tt > 0.0) ? st->sv[v] * tot[2 + v] / sqrt(tt) : 0.0;
+    s_raw[v] = (v < nvec) ? st->raw[v] : 0.0;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     double c2 = 0.0;
     for (int v = 0; v < nvec; ++v) c2 += g[v] * g[v];
     const double inv = (1.0 - c2 > 1e-3) ? 1.0 / sqrt(1.0 - c2) : 1.0;
     s_scale = (tt > 0.0) ? inv / sqrt(tt) : 0.0;
-    for (int v = 0; v < nvec; ++v) g[v] *= inv * sv.v[v];
-    s_stop = ((rule.de_small && rr < rule.tol2) || !(rr > rule.lindep) || !(tt > 0.0)) ? 1 : 0;
-  }
-  if (blockIdx.x == 0) {
-    if ((int)threadIdx.x < nv) mail_store(&mail[MAIL_PAYLOAD + SCAL_RED + threadIdx.x], tot[threadIdx.x]);
-    __builtin_amdgcn_s_waitcnt(0);
+    for (int v = 0; v < nvec; ++v) g[v] *= inv * st->sv[v];
+    const int de_small = fabs(st->de) < prm.tol;
+    s_stop = ((de_small && rr < prm.tol2) || !(rr > prm.lindep) || !(tt > 0.0)) ? 1 : 0;
+    if (blockIdx.x == 0) {
+      st->rnorm2 = rr;
+      if (s_stop) {
+        st->conv = (rr < prm.tol2) ? 1 : 0;
+        st->stop = 1;
+      } else if (restart) {
+        // from here on the solution is X0 alone (the collapse below), should the run end before the next
+        // projected problem is solved
+        st->sol_coef[0] = 1.0;
+        st->sol_m = 1;
+      }
+      post_progress(mail, seq, st, s_stop, rr);
+    }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (s_stop && rule.flag) *rule.flag = 1;
-    __threadfence_system();
-    *reinterpret_cast<volatile long long*>(mail) = seq;
-  }
   if (s_stop) return;  // the correction is not needed (and may be 0/0)
   const double scale = s_scale;
+  double* __restrict__ t = X + (int64_t)nvec * stride;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = scale * t[i];
+    double x0 = 0.0, ax0 = 0.0;
     for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
+      double x[8], a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i;
+        x[u] = X[off];
+        a[u] = restart ? AX[off] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u < nvec ? v0 + u : v0;
+        const double on = (v0 + u < nvec) ? 1.0 : 0.0;
+        s -= on * g[v] * x[u];
+        x0 += on * s_raw[v] * x[u];
+        ax0 += on * s_raw[v] * a[u];
+      }
+    }
+    if (restart) {
+      X[i] = x0;
+      AX[i] = ax0;
+      X[stride + i] = s;
+    } else {
+      t[i] = s;
+    }
+  }
+}
+
+// the solution: sum_{v < sol_m} sol_coef[v] X_v (unit norm: orthonormal basis, unit Ritz coefficients), and the
+// run's outcome for the host (read after the stream has been synchronised)
+__global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
+                           double* __restrict__ out, double* res) {
+  __shared__ double s_c[MAXB + 1];
+  const int nvec = st->sol_m;
+  if ((int)threadIdx.x <= MAXB) s_c[threadIdx.x] = ((int)threadIdx.x < nvec) ? st->sol_coef[threadIdx.x] : 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    mail_store(&res[0], (double)st->conv);
+    mail_store(&res[1], (double)st->it);
+    mail_store(&res[2], (double)st->nsig);
+    mail_store(&res[3], st->e);
+    mail_store(&res[4], st->rnorm2);
+    mail_store(&res[5], (double)st->err);
+    mail_store(&res[6], (double)st->stop);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int v0 = 0; v0 < nvec; v0 += 8) {
       double x[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+      for (int u = 0; u < 8; ++u) s += (v0 + u < nvec) ? s_c[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
     }
-    t[i] = s;
+    out[i] = s;
   }
 }
 
-// host side of finish_and_post: wait for sequence word `seq` in mailbox slot `slot`, read nv totals
-static int wait_mail(sqd_ctx* c, int slot, long long seq, int nv, double* sums) {
+// host side of a mailbox post: wait for sequence word `seq` in mailbox slot `slot`
+static int wait_mail(sqd_ctx* c, int slot, long long seq) {
   const double* mail = c->h_mail + (size_t)slot * MAIL_SLOT;
   volatile const long long* flag = reinterpret_cast<volatile const long long*>(mail);
   bool seen = false;
   for (long spin = 0; spin < 20000000L; ++spin) {
-    if (*flag == seq) {
+    if (*flag >= seq) {  // sequence numbers only grow on a context: a later post implies this one
       seen = true;
       break;
     }
@@ -438,13 +747,12 @@ static int wait_mail(sqd_ctx* c, int slot, long long seq, int nv, double* sums) 
   }
   if (!seen) {  // fall back to a plain synchronisation (also surfaces asynchronous kernel errors)
     SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*flag != seq) {
+    if (*flag < seq) {
       set_error("device mailbox was not written");
       return SQD_ERR_HIP;
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (int v = 0; v < nv; ++v) sums[v] = mail[MAIL_PAYLOAD + SCAL_RED + v];
   return SQD_OK;
 }
 
@@ -459,23 +767,7 @@ static int fetch_sums(sqd_ctx* c, int nblocks, int width, int nv, double* sums) 
                        (const double*)c->partial.as<double>(), nblocks, width, nv, (const double*)c->scal.as<double>(),
                        c->d_mail, seq);
   SQD_HIP_CHECK(hipGetLastError());
-  volatile long long* flag = reinterpret_cast<volatile long long*>(c->h_mail);
-  bool seen = false;
-  for (long spin = 0; spin < 20000000L; ++spin) {
-    if (*flag == seq) {
-      seen = true;
-      break;
-    }
-    __builtin_ia32_pause();
-  }
-  if (!seen) {  // fall back to a plain synchronisation (also surfaces asynchronous kernel errors)
-    SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*flag != seq) {
-      set_error("device mailbox was not written");
-      return SQD_ERR_HIP;
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
+  SQD_TRY(wait_mail(c, 0, seq));
   c->h_pinned[0] = c->h_mail[MAIL_PAYLOAD + 0];
   c->h_pinned[1] = c->h_mail[MAIL_PAYLOAD + 1];
   for (int v = 0; v < nv; ++v) sums[v] = c->h_mail[MAIL_PAYLOAD + SCAL_RED + v];
@@ -496,165 +788,44 @@ static int multi_dot(sqd_ctx* c, const double* X, int64_t stride, int nvec, cons
   return SQD_OK;
 }
 
-int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
+static int reserve_reduction_buffers(sqd_ctx* c) {
   SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
-  SQD_TRY(c->scal.reserve(8192));
+  // scal: [0..128) scalars of stand-alone reductions | arrival counters | DavState
+  const void* before = c->scal.p;
+  const size_t bytes = (size_t)128 * 8 + COUNT_WORDS * sizeof(unsigned) + sizeof(DavState) + 256;
+  SQD_TRY(c->scal.reserve(bytes));
+  if (c->scal.p != before)  // fresh allocation: the self-resetting arrival counters start from zero
+    SQD_HIP_CHECK(hipMemsetAsync(c->scal.p, 0, bytes, c->stream));
+  return SQD_OK;
+}
+unsigned* counter_ptr(sqd_ctx* c) { return reinterpret_cast<unsigned*>(c->scal.as<double>() + 128); }
+int reserve_counters(sqd_ctx* c) { return reserve_reduction_buffers(c); }
+static DavState* state_ptr_dev(sqd_ctx* c) {
+  return reinterpret_cast<DavState*>(reinterpret_cast<char*>(counter_ptr(c)) + COUNT_WORDS * sizeof(unsigned));
+}
+
+int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
+  SQD_TRY(reserve_reduction_buffers(c));
   return multi_dot(c, x, 0, 1, y, out);
-}
-
-// cyclic Jacobi for a small symmetric matrix; eigenvalues ascending in w, eigenvectors in columns of V
-static void jacobi_eigh(int n, const double* Ain, double* w, double* V) {
-  std::vector<double> A(Ain, Ain + n * n);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 100; ++sweep) {
-    double off = 0.0, dia = 0.0;
-    for (int i = 0; i < n; ++i) {
-      dia += A[i * n + i] * A[i * n + i];
-      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
-    }
-    // converged to working precision (quadratic convergence: one more sweep would change nothing)
-    if (off <= 1e-32 * dia || off < 1e-300) break;
-    for (int p = 0; p < n; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < n; ++k) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = cs * akp - sn * akq;
-          A[k * n + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = cs * apk - sn * aqk;
-          A[q * n + k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = cs * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
-  std::vector<int> order(n);
-  for (int i = 0; i < n; ++i) order[i] = i;
-  for (int i = 0; i < n; ++i)
-    for (int j = i + 1; j < n; ++j)
-      if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]]) std::swap(order[i], order[j]);
-  std::vector<double> Vs(n * n);
-  for (int j = 0; j < n; ++j) {
-    w[j] = A[order[j] * n + order[j]];
-    for (int k = 0; k < n; ++k) Vs[k * n + j] = V[k * n + order[j]];
-  }
-  std::memcpy(V, Vs.data(), sizeof(double) * n * n);
-}
-
-// Lowest eigenpair of the projected matrix after the basis grew by ONE vector, by Rayleigh-quotient iteration
-// from the previous Ritz vector padded with a zero (a start whose residual is already small).  The previous
-// matrix is the leading principal block of this one, so by Cauchy interlacing  l1(new) <= l1(old) <= l2(new):
-// an eigenvalue found at or below the old Ritz value IS the lowest one -- that test, plus a residual at
-// rounding level, is the acceptance rule; anything else returns false and the caller runs the Jacobi solver.
-// Cost ~2 LU factorisations of an m x m matrix (1 us at m = 12) instead of 13 us of cold Jacobi sweeps.
-static bool lowest_eig_rqi(int n, const double* A, const double* v_old, double e_old, double* e_out, double* v_out) {
-  if (n < 2 || n > SQD_MAX_SPACE + 1) return false;
-  double x[SQD_MAX_SPACE + 2], y[SQD_MAX_SPACE + 2], M[(SQD_MAX_SPACE + 1) * (SQD_MAX_SPACE + 1)];
-  double nrm = 0.0, anorm = 0.0;
-  for (int i = 0; i < n; ++i) {
-    x[i] = (i < n - 1) ? v_old[i] : 0.0;
-    nrm += x[i] * x[i];
-    double r = 0.0;
-    for (int j = 0; j < n; ++j) r += std::fabs(A[i * n + j]);
-    anorm = r > anorm ? r : anorm;
-  }
-  if (!(nrm > 0.0) || !(anorm > 0.0)) return false;
-  nrm = 1.0 / std::sqrt(nrm);
-  for (int i = 0; i < n; ++i) x[i] *= nrm;
-  auto rayleigh = [&](const double* v, double* Av) {
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) {
-      double r = 0.0;
-      for (int j = 0; j < n; ++j) r += A[i * n + j] * v[j];
-      Av[i] = r;
-      t += v[i] * r;
-    }
-    return t;
-  };
-  double theta = rayleigh(x, y);
-  const double tiny = 2.3e-16 * anorm;
-  for (int it = 0; it < 6; ++it) {
-    // residual of the current pair
-    double res = 0.0;
-    for (int i = 0; i < n; ++i) res += (y[i] - theta * x[i]) * (y[i] - theta * x[i]);
-    if (std::sqrt(res) <= 8.0 * tiny) {
-      if (!(theta <= e_old + 64.0 * tiny)) return false;  // not provably the lowest eigenvalue
-      // (a new vector that does not couple to the old Ritz vector leaves that pair an eigenpair of the grown
-      // matrix although its own diagonal may lie lower: the lowest eigenvalue is below every diagonal element)
-      for (int i = 0; i < n; ++i)
-        if (theta > A[i * n + i] + 64.0 * tiny) return false;
-      *e_out = theta;
-      for (int i = 0; i < n; ++i) v_out[i] = x[i];
-      return true;
-    }
-    // y = (A - theta I)^-1 x   (Gaussian elimination, partial pivoting; a vanishing pivot is what converges it)
-    for (int i = 0; i < n * n; ++i) M[i] = A[i];
-    for (int i = 0; i < n; ++i) {
-      M[i * n + i] -= theta;
-      y[i] = x[i];
-    }
-    for (int k = 0; k < n; ++k) {
-      int p = k;
-      for (int i = k + 1; i < n; ++i)
-        if (std::fabs(M[i * n + k]) > std::fabs(M[p * n + k])) p = i;
-      if (p != k) {
-        for (int j = 0; j < n; ++j) std::swap(M[k * n + j], M[p * n + j]);
-        std::swap(y[k], y[p]);
-      }
-      if (std::fabs(M[k * n + k]) < tiny) M[k * n + k] = (M[k * n + k] < 0.0) ? -tiny : tiny;
-      const double inv = 1.0 / M[k * n + k];
-      for (int i = k + 1; i < n; ++i) {
-        const double f = M[i * n + k] * inv;
-        if (f == 0.0) continue;
-        for (int j = k + 1; j < n; ++j) M[i * n + j] -= f * M[k * n + j];
-        y[i] -= f * y[k];
-      }
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double r = y[i];
-      for (int j = i + 1; j < n; ++j) r -= M[i * n + j] * y[j];
-      y[i] = r / M[i * n + i];
-    }
-    double yn = 0.0, dot = 0.0;
-    for (int i = 0; i < n; ++i) {
-      yn += y[i] * y[i];
-      dot += y[i] * x[i];
-    }
-    if (!(yn > 0.0) || !std::isfinite(yn)) return false;
-    yn = ((dot < 0.0) ? -1.0 : 1.0) / std::sqrt(yn);  // keep the orientation of the previous Ritz vector
-    for (int i = 0; i < n; ++i) x[i] = y[i] * yn;
-    theta = rayleigh(x, y);
-  }
-  return false;
 }
 
 // pyscf get_init_guess (direct_spin1._get_init_guess): unit vector at the lowest diagonal element -- searched over
 // the lower triangle A >= B when nelec_a == nelec_b and na == nb -- plus the +-1e-5 noise, normalised
-int enqueue_init_guess(sqd_ctx* c, double* x) {
+static int enqueue_init_guess_impl(sqd_ctx* c, double* x, DavState* st, unsigned* counter) {
   const int64_t D = c->D;
   const unsigned gb = red_blocks(D);
-  SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
+  SQD_TRY(reserve_reduction_buffers(c));
   const int tril_only = (c->nelec[0] == c->nelec[1] && c->na == c->nb) ? 1 : 0;
   double* pmin = c->partial.as<double>();
   int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
   hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, c->stream, D, c->nb, tril_only,
                      (const double*)c->hdiag.as<double>(), pmin, pidx);
   hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, c->stream, D, (const double*)pmin, (const int64_t*)pidx,
-                     (int)gb, x);
+                     (int)gb, x, st, counter);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }
+int enqueue_init_guess(sqd_ctx* c, double* x) { return enqueue_init_guess_impl(c, x, nullptr, nullptr); }
 
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync) {
@@ -666,7 +837,6 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   int max_space = o->max_space;
   if (max_space < 2) max_space = 2;
   if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
-  const double tol = o->tol, lindep = o->lindep;
   // residual threshold: sqrt(tol)/32 by default (pyscf: sqrt(tol)).  Energies would be fine with pyscf's
   // value (second order in the residual without a penalty), but the orbital occupancies that steer the next
   // configuration-recovery round are FIRST order in it: 1e-4 with pyscf's threshold, 1e-6 with this one, and
@@ -678,36 +848,35 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->sol.reserve((size_t)D * 8));
-  SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
-  SQD_TRY(c->scal.reserve(8192));
+  SQD_TRY(reserve_reduction_buffers(c));
   double* X = c->X.as<double>();
   double* AX = c->AX.as<double>();
   const unsigned gb = red_blocks(D);
   const int width = SQD_MAX_SPACE + 4;
+  unsigned* counter = counter_ptr(c);
+  DavState* dst = state_ptr_dev(c);
 
   SQD_HIP_CHECK(hipEventRecord(c->ev[2], s));
-  // ---- initial vector
-  if (ci0_host) {
-    SQD_HIP_CHECK(hipMemcpyAsync(X, ci0_host, D * 8, hipMemcpyHostToDevice, s));
-  } else {
-    SQD_TRY(enqueue_init_guess(c, X));
-  }
+  // ---- initial vector + state block
   // (a user vector is not normalised on the device: the first fused reduction measures |X_0|^2 and the
   // factor is carried in sv like that of every later basis vector)
-  double* scal = c->scal.as<double>();
-  double* dsums_col = scal + 8;    // totals of the latest k_dots_post
+  if (ci0_host) {
+    SQD_HIP_CHECK(hipMemcpyAsync(X, ci0_host, D * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_dav_init, dim3(1), dim3(256), 0, s, dst, counter);
+    SQD_HIP_CHECK(hipGetLastError());
+  } else {
+    SQD_TRY(enqueue_init_guess_impl(c, X, dst, counter));
+  }
 
-  constexpr int COUNT_DOUBLES = (int)((COUNT_GROUPS + 1) * COUNT_STRIDE * sizeof(unsigned) / sizeof(double));
-  unsigned* counter = reinterpret_cast<unsigned*>(scal + 128);
-  int* stop_flag = reinterpret_cast<int*>(scal + 128 + COUNT_DOUBLES);
-  SQD_HIP_CHECK(hipMemsetAsync(counter, 0, (COUNT_DOUBLES + 1) * sizeof(double), s));  // arrival counters and the stop flag
-  const double tol2 = toloose * toloose;
-  double* mail_col = c->d_mail;
-  double* mail_res = c->d_mail + MAIL_SLOT;
-
+  DavParams prm;
+  prm.tol = o->tol;
+  prm.tol2 = toloose * toloose;
+  prm.lindep = o->lindep;
+  prm.max_space = max_space;
   PenaltyDiag pd;
   {
     int form = o->use_spin;
+    // pyscf SpinPenaltyFCISolver.contract_2e chooses the form with sz = |neleca - nelecb| / 2
     const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
     if (form == 3) form = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
     const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
@@ -719,206 +888,102 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     pd.sb = c->sp[1].strs.as<uint64_t>();
     pd.nb = c->nb;
   }
-  std::vector<double> heff((size_t)nvecs * nvecs, 0.0), sub, w(nvecs), V((size_t)nvecs * nvecs);
-  std::vector<double> sums(width);
-  std::vector<double> v_eig(nvecs + 1, 0.0), v_new(nvecs + 1, 0.0);  // lowest Ritz vector of the last projected problem
-  int m_eig = -1;                                                     // ... and that problem's size
-  static const bool use_rqi = std::getenv("SQD_EIG_JACOBI") == nullptr;  // A/B hook: always the Jacobi solver
-  // Pipelined loop.  Per iteration the stream holds
-  //   sigma(X_new) -> k_dots_post [mailbox 0] -> (host: small eigenproblem) -> k_residual_precond [mailbox 1]
-  //   -> k_orth_dev -> (restart kernels)
-  // and the host enqueues the NEXT sigma + k_dots_post before it looks at mailbox 1: the residual norm only
-  // decides whether to stop, so the decision overlaps with the next sigma, and the one sigma in flight when
-  // the solve converges is discarded (never counted).  One host stall per iteration instead of two.
-  // Basis vector v is sv_v * X_v (sv_v = 1/|X_v|, measured by k_dots_post): normalisation never costs a pass.
-  Coef coef, raw, sv;
-  int m = 1;  // basis size; X[m-1] is the newest vector, its sigma not yet built
-  int mc = 1; // number of basis vectors the current Ritz coefficients refer to
-  coef.v[0] = 1.0;
-  sv.v[0] = 1.0;
-  double e = 0.0, elast = 0.0, rnorm = 0.0, de = 0.0;
-  bool conv = false, have_res = false, stop = false;
-  long long seq_res = 0;
-  int m_res = 0;  // basis size of the residual kernel whose mailbox is outstanding
-  int nsig = 0, nev = 0, it = 0;
+  double* mail_prog = c->d_mail + MAIL_SLOT;
+  const double* h_prog = c->h_mail + MAIL_SLOT;
+  double* part_res = c->partial.as<double>() + (size_t)RED_BLOCKS * width;  // residual / orth: a buffer of their own
+
   // every time_sigma_every-th sigma launch of this context is bracketed by events (stats->ms_sigma); an
   // event pair costs ~10 us of stream time, so this is sampling, and off unless asked for
   const int ev_every = o->time_sigma_every > 0 ? o->time_sigma_every : 0;
   const int max_ev = ev_every ? (int)c->sig_ev.size() / 3 : 0;
-  bool first = true;
-  // outcome of the outstanding residual hand-over: sets rnorm, conv, stop
-  auto settle_residual = [&]() -> int {
-    have_res = false;
-    SQD_TRY(wait_mail(c, 1, seq_res, m_res + 2, sums.data()));
-    rnorm = std::sqrt(sums[0]);
-    if (o->verbose)
-      std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", it - 1, m_res, e, de, rnorm);
-    // (the same comparisons, on the same numbers, as StopRule on the device)
-    if (std::fabs(de) < tol && sums[0] < tol2) {
-      conv = true;
-      stop = true;
-    } else if (!(sums[0] > lindep) || !(sums[1] > 0.0)) {
-      conv = sums[0] < tol2;
-      stop = true;
+  int nev = 0;
+  c->dav_ev_iter.clear();
+
+  // sigma reads "which vector" from the state block: X[m_next - 1] -> AX[m_next - 1]
+  struct IndexGuard {
+    sqd_ctx* c;
+    ~IndexGuard() {
+      c->sigma_stop = nullptr;
+      c->sigma_index = nullptr;
     }
+  } guard{c};
+  c->sigma_stop = &dst->stop;
+  c->sigma_index = &dst->m_next;
+
+  // Host loop: iteration j is enqueued as soon as the progress record of iteration j - 1 - AHEAD has been seen
+  // without a stop.  AHEAD = 1 keeps one whole iteration queued behind the running one, so no launch waits for
+  // the host; when the solve stops, at most AHEAD + 1 iterations of early-exit kernels are wasted.
+  const int ahead = o->verbose ? 0 : 1;
+  long long seq_of[4] = {0, 0, 0, 0};  // sequence numbers of the latest iterations enqueued (ring)
+  bool stopped = false;
+  int enq = 0;
+  auto settle = [&](int j) -> int {  // wait for iteration j's progress record
+    SQD_TRY(wait_mail(c, 1, seq_of[j & 3]));
+    if (h_prog[MAIL_PAYLOAD + 1] != 0.0) stopped = true;
+    if (o->verbose)
+      std::fprintf(stderr, "[sqd davidson] it %d space %d e %.12f de %.3e |r| %.3e\n", (int)h_prog[MAIL_PAYLOAD + 0] - 1,
+                   (int)h_prog[MAIL_PAYLOAD + 5], h_prog[MAIL_PAYLOAD + 2], h_prog[MAIL_PAYLOAD + 3],
+                   std::sqrt(h_prog[MAIL_PAYLOAD + 4]));
     return SQD_OK;
   };
-  c->sigma_stop = stop_flag;
-  struct StopGuard {  // the flag is only meaningful inside this run
-    sqd_ctx* c;
-    ~StopGuard() { c->sigma_stop = nullptr; }
-  } stop_guard{c};
-  for (it = 0; it < o->max_cycle; ++it) {
-    // |dE| >= tol rules convergence out before the residual is known: only then is the next sigma enqueued
-    // ahead of the residual hand-over (nothing is wasted except on a linear-dependence stop)
-    if (have_res && std::fabs(de) < tol) {
-      SQD_TRY(settle_residual());
-      if (stop) break;
-    }
-    // sigma for the newest basis vector, and the new column of the projected matrix
+  while (!stopped && enq < o->max_cycle) {
     const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
     ++c->sigma_launches;
     if (timed) {
       SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev], s));
       c->ev_after_sigma_kernel = c->sig_ev[3 * nev + 1];  // recorded by launch_sigma right after k_sigma
     }
-    const int rc_h = apply_h(c, X + (int64_t)(m - 1) * D, AX + (int64_t)(m - 1) * D, o->use_spin, o->ss, o->shift);
+    const int rc_h = apply_h(c, X, AX, o->use_spin, o->ss, o->shift, D, D);
     c->ev_after_sigma_kernel = nullptr;
     SQD_TRY(rc_h);
     if (timed) {
       SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev + 2], s));
+      c->dav_ev_iter.push_back(enq);
       ++nev;
     }
-    const long long seq_col = ++c->mail_seq;
-    if (max_space <= 12)
-      hipLaunchKernelGGL((k_dots_post<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
-                         (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
-                         mail_col, seq_col, (const int*)stop_flag);
-    else
-      hipLaunchKernelGGL((k_dots_post<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m,
-                         (const double*)(AX + (int64_t)(m - 1) * D), c->partial.as<double>(), width, counter, dsums_col,
-                         mail_col, seq_col, (const int*)stop_flag);
-    SQD_HIP_CHECK(hipGetLastError());
-    if (have_res) {
-      SQD_TRY(settle_residual());
-      if (stop) break;  // the sigma just enqueued is discarded
-    }
-    ++nsig;
-    SQD_TRY(wait_mail(c, 0, seq_col, m + 1, sums.data()));
-    const double nrm2 = sums[0];
-    if (it == 0 && !(nrm2 > 0.0)) {
-      set_error("initial vector has zero norm");
-      return SQD_ERR_INVALID;
-    }
-    if (!(nrm2 > lindep)) {
-      // the last correction vector was linearly dependent on the basis: stop with the Ritz vector of the
-      // previous projected problem (pyscf: 'Linear dependency in trial subspace')
-      conv = rnorm < toloose;
-      --nsig;
-      break;
-    }
-    sv.v[m - 1] = 1.0 / std::sqrt(nrm2);
-    for (int i = 0; i < m; ++i)
-      heff[(size_t)i * nvecs + (m - 1)] = heff[(size_t)(m - 1) * nvecs + i] = sums[1 + i] * sv.v[i] * sv.v[m - 1];
-    sub.assign((size_t)m * m, 0.0);
-    for (int i = 0; i < m; ++i)
-      for (int j = 0; j < m; ++j) sub[(size_t)i * m + j] = heff[(size_t)i * nvecs + j];
-    // (grown by one vector since the last projected problem: try the warm-started solver first)
-    bool warm = false;
-    if (use_rqi && m == m_eig + 1 && !first) {
-      double e_new = 0.0;
-      warm = lowest_eig_rqi(m, sub.data(), v_eig.data(), e, &e_new, v_new.data());
-      if (warm) {
-        w[0] = e_new;
-        for (int i = 0; i < m; ++i) V[(size_t)i * m + 0] = v_new[i];
-      }
-    }
-    if (!warm) jacobi_eigh(m, sub.data(), w.data(), V.data());
-    m_eig = m;
-    for (int i = 0; i < m; ++i) v_eig[i] = V[(size_t)i * m + 0];
-    elast = e;
-    e = w[0];
-    de = first ? e : e - elast;
-    first = false;
-    for (int i = 0; i < m; ++i) {
-      coef.v[i] = V[(size_t)i * m + 0];
-      raw.v[i] = coef.v[i] * sv.v[i];  // coefficients on the stored (un-normalised) vectors
-    }
-    mc = m;
-    // residual, preconditioned correction (into X[m]) and its overlaps; then orthogonalisation on the device
-    double* tnew = X + (int64_t)m * D;
-    seq_res = ++c->mail_seq;
-    m_res = m;
-    const StopRule rule{stop_flag, std::fabs(de) < tol ? 1 : 0, tol2, lindep};
-    // (the two kernels use a partial buffer of their own: the next k_dots_post may already be enqueued)
-    double* part_res = c->partial.as<double>() + (size_t)RED_BLOCKS * width;
+    const long long seq = ++c->mail_seq;
+    seq_of[enq & 3] = seq;
     if (max_space <= 12) {
-      hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D, m,
-                         raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, part_res, width);
-      hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv,
-                         (const double*)part_res, (int)gb, width, tnew, mail_res, seq_res, rule, (const int*)stop_flag);
+      hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D,
+                         c->partial.as<double>(), width, counter, dst, prm);
+      hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
+                         (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
+      hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,
+                         (int)gb, width, mail_prog, seq);
     } else {
-      hipLaunchKernelGGL((k_residual_precond<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X,
-                         (const double*)AX, D, m, raw, e, (const double*)c->hdiag.as<double>(), pd, tnew, part_res, width);
-      hipLaunchKernelGGL((k_orth_dev<SQD_MAX_SPACE + 1>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, sv,
-                         (const double*)part_res, (int)gb, width, tnew, mail_res, seq_res, rule, (const int*)stop_flag);
+      hipLaunchKernelGGL((k_dots_eig<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D,
+                         c->partial.as<double>(), width, counter, dst, prm);
+      hipLaunchKernelGGL((k_residual_precond<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
+                         (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
+      hipLaunchKernelGGL((k_orth_dev<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,
+                         (int)gb, width, mail_prog, seq);
     }
     SQD_HIP_CHECK(hipGetLastError());
-    have_res = true;
-    if (m + 1 > max_space) {
-      // collapse: X0 <- Ritz vector, AX0 <- A*Ritz (linear combination), X1 <- correction
-      double* x0 = c->sol.as<double>();
-      SQD_TRY(c->tmp1.reserve((size_t)D * 8));
-      double* ax0 = c->tmp1.as<double>();
-      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, m, raw, x0);
-      hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)AX, D, m, raw, ax0);
-      SQD_HIP_CHECK(hipMemcpyAsync(X + D, tnew, D * 8, hipMemcpyDeviceToDevice, s));
-      SQD_HIP_CHECK(hipMemcpyAsync(X, x0, D * 8, hipMemcpyDeviceToDevice, s));
-      SQD_HIP_CHECK(hipMemcpyAsync(AX, ax0, D * 8, hipMemcpyDeviceToDevice, s));
-      std::fill(heff.begin(), heff.end(), 0.0);
-      heff[0] = e;
-      m = 2;
-      coef.v[0] = 1.0;  // the Ritz vector is now X0
-      coef.v[1] = 0.0;
-      sv.v[0] = 1.0;
-      mc = 1;
-    } else {
-      ++m;
-    }
+    ++enq;
+    if (enq - 1 - ahead >= 0) SQD_TRY(settle(enq - 1 - ahead));
   }
-  if (have_res) SQD_TRY(settle_residual());  // cycle limit reached: the last residual still decides `converged`
-  // solution = Ritz vector of the last projected problem, normalised
-  {
-    const int mm = mc;
-    double* x0 = c->sol.as<double>();
-    // the basis is orthonormal and the Ritz coefficients have unit norm, so the combination is normalised to
-    // rounding (the observables divide by <c|c> anyway); no extra reduction + host round trip
-    double cn = 0.0;
-    for (int i = 0; i < mm; ++i) cn += coef.v[i] * coef.v[i];
-    Coef cf = coef;
-    for (int i = 0; i < mm; ++i) cf.v[i] = (cn > 0.0 ? coef.v[i] / std::sqrt(cn) : coef.v[i]) * sv.v[i];
-    hipLaunchKernelGGL(k_lincomb, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, mm, cf, x0);
-    SQD_HIP_CHECK(hipGetLastError());
-  }
+  // solution = Ritz vector of the last projected problem, normalised; the run's outcome to mailbox slot 2
+  hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
+                     c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
+  SQD_HIP_CHECK(hipGetLastError());
   SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
   c->have_solution = true;
   c->dav_nev = nev;
-  if (st) {
-    st->converged = conv ? 1 : 0;
-    st->iterations = it;
-    st->n_sigma = nsig;
-    st->e_davidson = e;
-    st->residual = rnorm;
-    st->ms_total = st->ms_sigma = st->ms_setup = st->ms_sigma_kernel = 0.0;
-    st->n_sigma_timed = nev;
-  }
+  if (st) std::memset(st, 0, sizeof(*st));
   if (defer_sync) return SQD_OK;
   SQD_HIP_CHECK(hipStreamSynchronize(s));
-  return davidson_collect_timings(c, st);
+  return davidson_collect(c, st);
 }
 
-// event timings of the latest run (the stream must have been synchronised since)
-int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st) {
+// outcome and event timings of the latest run (the stream must have been synchronised since)
+int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st) {
+  const double* res = c->h_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const int iterations = (int)res[1];
+  if (res[5] != 0.0) {
+    set_error("initial vector has zero norm");
+    return SQD_ERR_INVALID;
+  }
   float ms = 0.f;
   SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
   if (c->ms_setup < 0.0) {
@@ -927,17 +992,26 @@ int davidson_collect_timings(sqd_ctx* c, sqd_davidson_stats* st) {
     c->ms_setup = tms;
   }
   if (st) {
+    st->converged = (int)res[0];
+    st->iterations = iterations;
+    st->n_sigma = (int)res[2];
+    st->e_davidson = res[3];
+    st->residual = std::sqrt(res[4] > 0.0 ? res[4] : 0.0);
     st->ms_total = ms;
     double msig = 0.0, mker = 0.0;
+    int counted = 0;
     for (int i = 0; i < c->dav_nev; ++i) {
+      if (c->dav_ev_iter[i] >= iterations) continue;  // enqueued ahead of the stop: that launch returned at once
       float t = 0.f;
       SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 2]));
       msig += t;
       SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 1]));
       mker += t;
+      ++counted;
     }
     st->ms_sigma = msig;
     st->ms_sigma_kernel = mker;
+    st->n_sigma_timed = counted;
     st->ms_setup = c->ms_setup;
   }
   return SQD_OK;

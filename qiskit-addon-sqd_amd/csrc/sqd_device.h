@@ -54,6 +54,36 @@ __device__ inline void coherent_store(double* p, double v) {
 __device__ inline double coherent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// "The workgroup that arrives last finishes the job": two-level arrival count (COUNT_GROUPS group words + a top
+// word, each in its own 128-byte line -- device-scope atomics on ONE word serialise at ~50 ns each, and atomics on
+// one line serialise in one L2 channel).  Call with every thread of the workgroup AFTER its hand-over data has
+// been written with coherent_store (the waitcnt below completes those stores; no L2-wide fence); returns true in
+// every thread of the one workgroup that arrived last, which then reads the others' data with coherent_load.
+// The counters reset themselves, so one zeroed block of COUNT_WORDS words serves every fused reduction on a stream.
+constexpr unsigned COUNT_GROUPS = 16;
+constexpr unsigned COUNT_STRIDE = 32;
+constexpr int COUNT_WORDS = (int)((COUNT_GROUPS + 1) * COUNT_STRIDE);
+__device__ inline bool arrive_last(unsigned* counter, unsigned block, unsigned nblocks) {
+  __shared__ int s_last;
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int last = 0;
+    const unsigned G = COUNT_GROUPS, grp = block % G;
+    const unsigned gsize = (nblocks - grp + G - 1) / G, ngroups = nblocks < G ? nblocks : G;
+    if (atomicAdd(&counter[COUNT_STRIDE * (1 + grp)], 1u) == gsize - 1) {
+      atomicExch(&counter[COUNT_STRIDE * (1 + grp)], 0u);
+      if (atomicAdd(&counter[0], 1u) == ngroups - 1) {
+        atomicExch(&counter[0], 0u);
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
 // Payload words of the host-visible mailbox (fine-grained pinned host memory): written through at system
 // scope.  Protocol of a post: every writing thread issues its stores and waits for them (s_waitcnt), the
 // workgroup meets at a barrier, then ONE thread fences at system scope and writes the sequence word.  (Fencing

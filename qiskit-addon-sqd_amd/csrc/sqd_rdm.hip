@@ -97,35 +97,6 @@ __global__ void k_occupancy(const uint64_t* __restrict__ strs, int64_t n, const 
   if (threadIdx.x == 0) out[(int64_t)p * stride] = s;
 }
 
-// partial[block*3 + {0,1,2}] = (a.c, b.c, c.c)
-__global__ void k_expect3(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
-                          const double* __restrict__ cv, double* __restrict__ partial) {
-  __shared__ double red[16];
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double x = cv[i];
-    s0 += a[i] * x;
-    s1 += b[i] * x;
-    s2 += x * x;
-  }
-  s0 = block_sum(s0, red);
-  s1 = block_sum(s1, red);
-  s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    partial[blockIdx.x * 3 + 0] = s0;
-    partial[blockIdx.x * 3 + 1] = s1;
-    partial[blockIdx.x * 3 + 2] = s2;
-  }
-}
-// out[v] = sum_b partial[b*3+v], one workgroup per v
-__global__ void k_reduce3(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
-  __shared__ double red[16];
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[b * 3 + blockIdx.x];
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = s;
-}
-
 __global__ void k_rdm1_singles(int64_t nl, const SRec* __restrict__ rec, const double* __restrict__ dots, int norb,
                                double* __restrict__ dm1) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,9 +255,132 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
   return SQD_OK;
 }
 
-// One call, one host synchronisation: out = { <c|H|c>, <c|S^2|c>, <c|c>, occ_a[norb], occ_b[norb] }
-// (occupancies un-normalised).  This is everything solve_fermion needs after the Davidson
-// (reference fermion.py:820-830) without building the off-diagonal RDM elements.
+// ---- everything solve_fermion derives from the state after the Davidson (reference fermion.py:820-830) in ONE
+// launch: the dot products c.(Hc), c.(S^2 c), c.c, |S^2 c|^2 and both spins' orbital occupancies (the diagonals of
+// pyscf make_rdm1s).  Two kinds of workgroup in the same grid:
+//   row role    (blockIdx.x <  nrb): one wavefront per alpha string A -- w_a[A] = sum_B C[A,B]^2 and the dot products
+//                over its row; the workgroup adds its rows' weights into a partial occ_a[p] (fixed order);
+//   column role (blockIdx.x >= nrb): 64 beta strings x 8 row lanes -- w_b[B] = sum_A C[A,B]^2 (eight rows in flight
+//                per lane), then a partial occ_b[p] over its 64 strings.
+// The workgroup that arrives last folds the partial records in block order (bitwise reproducible) and writes the
+// result straight into host-visible memory: no reduce launches, no copy.
+constexpr int OBS_W = 4 + SQD_MAX_NORB;  // partial record: 4 dot products + one occupancy per orbital
+constexpr int OBS_ROWS = 8;              // alpha strings per row-role workgroup (512 threads)
+__global__ void k_observables(const double* __restrict__ C, const double* __restrict__ T1, const double* __restrict__ T2,
+                              int64_t na, int64_t nb, const uint64_t* __restrict__ strs_a,
+                              const uint64_t* __restrict__ strs_b, int norb, unsigned nrb, double* partial,
+                              unsigned* counter, double* out) {
+  __shared__ double red[1024];
+  __shared__ double wrow[64];
+  __shared__ double dots[OBS_ROWS][4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* rec = partial + (int64_t)blockIdx.x * OBS_W;
+  if (blockIdx.x < nrb) {
+    const int64_t A = (int64_t)blockIdx.x * OBS_ROWS + wv;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (A < na) {
+      for (int64_t b = lane; b < nb; b += 64) {
+        const double v = C[A * nb + b];
+        const double h = T1 ? T1[A * nb + b] : 0.0, t = T2 ? T2[A * nb + b] : 0.0;
+        s[0] += h * v;
+        s[1] += t * v;
+        s[2] += v * v;
+        s[3] += t * t;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dots[wv][k] = s[k];
+      wrow[wv] = s[2];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 4) {
+      double t = 0.0;
+      for (int w = 0; w < OBS_ROWS; ++w) t += dots[w][threadIdx.x];
+      coherent_store(&rec[threadIdx.x], t);
+    } else if ((int)threadIdx.x < 4 + norb) {
+      const int p = threadIdx.x - 4;
+      double t = 0.0;
+      for (int w = 0; w < OBS_ROWS; ++w) {
+        const int64_t Aw = (int64_t)blockIdx.x * OBS_ROWS + w;
+        if (Aw < na && ((strs_a[Aw] >> p) & 1ull)) t += wrow[w];
+      }
+      coherent_store(&rec[4 + p], t);
+    }
+  } else {
+    const int col = lane, rl = wv, RL = blockDim.x >> 6;
+    const int64_t B = (int64_t)(blockIdx.x - nrb) * 64 + col;
+    double s = 0.0;
+    if (B < nb)
+      for (int64_t a0 = rl; a0 < na; a0 += (int64_t)RL * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t a = a0 + (int64_t)u * RL;
+          v[u] = C[(a < na ? a : a0) * nb + B];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (a0 + (int64_t)u * RL < na) ? v[u] * v[u] : 0.0;
+      }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < RL; ++r) s += red[r * 64 + col];
+      wrow[col] = (B < nb) ? s : 0.0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 4) {
+      coherent_store(&rec[threadIdx.x], 0.0);
+    } else if ((int)threadIdx.x < 4 + norb) {
+      const int p = threadIdx.x - 4;
+      double t = 0.0;
+      for (int j = 0; j < 64; ++j) {
+        const int64_t Bj = (int64_t)(blockIdx.x - nrb) * 64 + j;
+        if (Bj < nb && ((strs_b[Bj] >> p) & 1ull)) t += wrow[j];
+      }
+      coherent_store(&rec[4 + p], t);
+    }
+  }
+  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+  // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
+  const int nres = 3 + 2 * norb + 1;
+  for (int r = threadIdx.x; r < nres; r += blockDim.x) {
+    int field;
+    unsigned b0, b1;
+    if (r < 3) {
+      field = r;
+      b0 = 0;
+      b1 = nrb;
+    } else if (r < 3 + norb) {
+      field = 4 + (r - 3);
+      b0 = 0;
+      b1 = nrb;
+    } else if (r < 3 + 2 * norb) {
+      field = 4 + (r - 3 - norb);
+      b0 = nrb;
+      b1 = gridDim.x;
+    } else {
+      field = 3;
+      b0 = 0;
+      b1 = nrb;
+    }
+    double t = 0.0;
+    for (unsigned b = b0; b < b1; b += 8) {  // eight partial records in flight per round, added in block order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = coherent_load(&partial[(int64_t)(b + u < b1 ? b + u : b) * OBS_W + field]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += (b + u < b1) ? v[u] : 0.0;
+    }
+    mail_store(&out[r], t);
+  }
+}
+
+constexpr int OBS_MAIL = 3 * 128;  // doubles into the host-visible mailbox (slots 0..2 belong to the Davidson)
+
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
   SQD_TRY(dev_observables_enqueue(c, d_c));
   SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -294,36 +388,31 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
   return SQD_OK;
 }
 void dev_observables_collect(sqd_ctx* c, double* out_host) {
-  const int nres = 3 + 2 * c->norb;
-  for (int i = 0; i < nres; ++i) out_host[i] = c->h_pinned[i];
+  const int nres = 3 + 2 * c->norb + 1;
+  for (int i = 0; i < nres; ++i) out_host[i] = c->h_mail[OBS_MAIL + i];
 }
-int dev_observables_enqueue(sqd_ctx* c, const double* d_c) {
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2) {
   const int norb = c->norb;
   hipStream_t st = c->stream;
   const int64_t D = c->D;
-  SQD_TRY(c->tmp1.reserve((size_t)D * 8));
-  SQD_TRY(c->tmp2.reserve((size_t)D * 8));
-  const int nres = 3 + 2 * norb;
-  SQD_TRY(c->scratch.reserve((size_t)(c->na + c->nb + nres + 3 * 512) * 8 + 64));
-  double* wa = c->scratch.as<double>();
-  double* wb = wa + c->na;
-  double* res = wb + c->nb;
-  double* part = res + nres;
-  SQD_TRY(launch_sigma(c, d_c, c->tmp1.as<double>(), 0, false, 0.0, 0.0));
-  SQD_TRY(launch_sigma(c, d_c, c->tmp2.as<double>(), 1, false, 0.0, 0.0));
-  int nblk3 = (int)((D + 255) / 256);
-  if (nblk3 > 512) nblk3 = 512;
-  hipLaunchKernelGGL(k_expect3, dim3(nblk3), dim3(256), 0, st, D, (const double*)c->tmp1.as<double>(),
-                     (const double*)c->tmp2.as<double>(), d_c, part);
-  hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(128), 0, st, (const double*)part, nblk3, res);
-  hipLaunchKernelGGL(k_row_norms, dim3(nblk(c->na, 4)), dim3(256), 0, st, d_c, c->na, c->nb, wa);
-  hipLaunchKernelGGL(k_col_norms, dim3(nblk(c->nb, 64)), dim3(512), 0, st, d_c, c->na, c->nb, wb);
-  hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)c->sp[0].strs.as<uint64_t>(), c->na,
-                     (const double*)wa, 1, res + 3);
-  hipLaunchKernelGGL(k_occupancy, dim3(norb), dim3(256), 0, st, (const uint64_t*)c->sp[1].strs.as<uint64_t>(), c->nb,
-                     (const double*)wb, 1, res + 3 + norb);
+  const double *t1 = nullptr, *t2 = nullptr;
+  if (with_h) {
+    SQD_TRY(c->tmp1.reserve((size_t)D * 8));
+    SQD_TRY(launch_sigma(c, d_c, c->tmp1.as<double>(), 0, false, 0.0, 0.0));
+    t1 = c->tmp1.as<double>();
+  }
+  if (with_s2) {
+    SQD_TRY(c->tmp2.reserve((size_t)D * 8));
+    SQD_TRY(launch_sigma(c, d_c, c->tmp2.as<double>(), 1, false, 0.0, 0.0));
+    t2 = c->tmp2.as<double>();
+  }
+  const unsigned nrb = (unsigned)((c->na + OBS_ROWS - 1) / OBS_ROWS), ncb = (unsigned)((c->nb + 63) / 64);
+  SQD_TRY(c->scratch.reserve((size_t)(nrb + ncb) * OBS_W * 8 + 64));
+  SQD_TRY(reserve_counters(c));
+  hipLaunchKernelGGL(k_observables, dim3(nrb + ncb), dim3(512), 0, st, d_c, t1, t2, c->na, c->nb,
+                     (const uint64_t*)c->sp[0].strs.as<uint64_t>(), (const uint64_t*)c->sp[1].strs.as<uint64_t>(), norb,
+                     nrb, c->scratch.as<double>(), counter_ptr(c), c->d_mail + OBS_MAIL);
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipMemcpyAsync(c->h_pinned, res, nres * 8, hipMemcpyDeviceToHost, st));
   return SQD_OK;
 }
 

@@ -67,9 +67,13 @@ struct SigmaArgs {
   const double* edb_val;
   const double* jbT;
   const double* eri_pp;
-  // Davidson enqueues the next sigma before the host has seen the residual; when the device finds the
-  // solve finished it raises this flag and the launch returns at once (nullptr: unconditional)
+  // Davidson enqueues whole iterations ahead of the host; when the device finds the solve finished it raises this
+  // flag and the launch returns at once (nullptr: unconditional)
   const int* stop;
+  // device-controlled Davidson: the vector to work on is chosen on the device.  With vec_index != nullptr the
+  // input is c + (*vec_index - 1) * c_stride and the output sigma + (*vec_index - 1) * s_stride.
+  const int* vec_index;
+  int64_t c_stride, s_stride;
 };
 
 // N consecutive same-spin links starting at l0: a += val[l] * C[src[l], B] in link order.  N is a compile-time
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   const int64_t rows_staged = (it.type == 0) ? 1 : g.K;
   double* W2 = Crow + (LDSROW ? rows_staged * g.nb_pad : 0);  // [rows_staged][w2s]
   double* part_d = W2 + w2s;                                // [nvd_max] (own-row items) ... of the doubles' virtual rows
-  const double* __restrict__ C = g.c;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  double* __restrict__ sigma_out = g.sigma + vsel * g.s_stride;
   double acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       }
     }
   }
-  double* __restrict__ out = (it.slot < 0) ? (g.sigma + A * nb) : (g.partial + (int64_t)it.slot * nb);
+  double* __restrict__ out = (it.slot < 0) ? (sigma_out + A * nb) : (g.partial + (int64_t)it.slot * nb);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t B = B0 + tid + (int64_t)r * T;
@@ -466,9 +472,10 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
 __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
-                               double* __restrict__ sigma, const int* stop) {
+                               double* __restrict__ sigma, const int* stop, const int* vec_index, int64_t s_stride) {
   __shared__ double red[1024];
   if (stop && *stop) return;
+  if (vec_index) sigma += (int64_t)(*vec_index - 1) * s_stride;
   const MultiRow mr = rows[blockIdx.x];
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6, SL = blockDim.x >> 6;
   const int64_t B = (int64_t)blockIdx.y * 64 + col;
@@ -483,8 +490,14 @@ __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* 
   }
 }
 
-// y = a*x + b*y
-__global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+// y = a*x + b*y   (x / y optionally selected on the device like the sigma vectors: stride 0 = not indexed)
+__global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y,
+                        const int* stop, const int* vec_index, int64_t x_stride, int64_t y_stride) {
+  if (stop && *stop) return;
+  if (vec_index) {
+    x += (int64_t)(*vec_index - 1) * x_stride;
+    y += (int64_t)(*vec_index - 1) * y_stride;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + b * y[i];
 }
@@ -524,7 +537,8 @@ static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
                                  : launch_sigma_rs<R, false, false, false>(c, g);
 }
 
-int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift) {
+int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                 int64_t in_stride, int64_t out_stride) {
   if (!c->have_subspace) {
     set_error("no subspace set");
     return SQD_ERR_STATE;
@@ -580,6 +594,10 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.nvs_max = (int)c->sig_ps;
   g.nvd_max = (int)c->sig_pd;
   g.stop = c->sigma_stop;
+  const bool indexed = c->sigma_index && (in_stride || out_stride);
+  g.vec_index = indexed ? c->sigma_index : nullptr;
+  g.c_stride = in_stride;
+  g.s_stride = out_stride;
 
   const int R = c->sig_R;
   int rc;
@@ -593,19 +611,21 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (c->n_multi > 0) {
     hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
-                       d_sigma, g.stop);
+                       d_sigma, g.stop, g.vec_index, out_stride);
     SQD_HIP_CHECK(hipGetLastError());
   }
   return SQD_OK;
 }
 
-int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift) {
+int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride,
+            int64_t out_stride) {
   if (use_spin == 3) {
+    // pyscf SpinPenaltyFCISolver.contract_2e: sz = |neleca - nelecb| / 2 decides between the two penalty forms
     const double sz = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
     use_spin = (ss < sz * (sz + 1.0) + 0.1) ? 1 : 2;
   }
-  if (use_spin == 0) return launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0);
-  if (use_spin == 1) return launch_sigma(c, d_c, d_sigma, 0, true, ss, shift);
+  if (use_spin == 0) return launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0, in_stride, out_stride);
+  if (use_spin == 1) return launch_sigma(c, d_c, d_sigma, 0, true, ss, shift, in_stride, out_stride);
   if (use_spin != 2) {
     set_error("use_spin must be 0..3");
     return SQD_ERR_INVALID;
@@ -617,12 +637,17 @@ int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double
   double* t1 = c->tmp1.as<double>();
   double* t2 = c->tmp2.as<double>();
   const unsigned nb_ = (unsigned)((D + 255) / 256 > 2048 ? 2048 : (D + 255) / 256);
-  SQD_TRY(launch_sigma(c, d_c, t1, 1, false, 0.0, 0.0));                            // t1 = S^2 c
-  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, d_c, 1.0, t1);  // t1 -= ss c
-  SQD_TRY(launch_sigma(c, t1, t2, 1, false, 0.0, 0.0));                              // t2 = S^2 t1
-  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, (const double*)t1, 1.0, t2);  // t2 -= ss t1
-  SQD_TRY(launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0));                        // sigma = H c
-  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, shift, (const double*)t2, 1.0, d_sigma);
+  const int* stop = c->sigma_stop;
+  const int* idx = (c->sigma_index && (in_stride || out_stride)) ? c->sigma_index : nullptr;
+  SQD_TRY(launch_sigma(c, d_c, t1, 1, false, 0.0, 0.0, in_stride, 0));                          // t1 = S^2 c
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, d_c, 1.0, t1, stop, idx, in_stride,
+                     (int64_t)0);                                                                  // t1 -= ss c
+  SQD_TRY(launch_sigma(c, t1, t2, 1, false, 0.0, 0.0, 0, 0));                                    // t2 = S^2 t1
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, -ss, (const double*)t1, 1.0, t2, stop,
+                     (const int*)nullptr, (int64_t)0, (int64_t)0);                                 // t2 -= ss t1
+  SQD_TRY(launch_sigma(c, d_c, d_sigma, 0, false, 0.0, 0.0, in_stride, out_stride));             // sigma = H c
+  hipLaunchKernelGGL(k_axpby, dim3(nb_), dim3(256), 0, c->stream, D, shift, (const double*)t2, 1.0, d_sigma, stop, idx,
+                     (int64_t)0, out_stride);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }

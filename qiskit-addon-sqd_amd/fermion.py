@@ -280,15 +280,36 @@ def _davidson_kwargs(kwargs: dict) -> dict:
     return out
 
 
-def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True):
+_TLS = threading.local()
+_PROFILE = {"time_sigma_every": 0}
+
+
+def set_profiling(time_sigma_every: int = 0) -> None:
+    """Benchmark hook: bracket every k-th sigma launch of the solves that follow with HIP events (0 = off); the
+    sums appear in ``last_solve_stats()`` (``ms_sigma_kernel``, ``n_sigma_timed``)."""
+    _PROFILE["time_sigma_every"] = int(time_sigma_every)
+
+
+def last_solve_stats() -> dict | None:
+    """Davidson statistics (``n_sigma``, ``iterations``, ``converged``, device times ...) of the latest solve made
+    on the calling thread -- what pyscf would report through its verbose log."""
+    return getattr(_TLS, "stats", None)
+
+
+def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True, spin_square=True):
     """Shared core: tables -> Davidson (-> energy, <S^2>, occupancies in the same native call), all on the
     device.  Returns (amps, stats, obs) with obs = (energy, spin_square, occ_a, occ_b) or None."""
     ctx.set_subspace(ci_strs[0], ci_strs[1])
     dk = _davidson_kwargs(kwargs)
     ci0 = dk.pop("ci0", None)
+    if _PROFILE["time_sigma_every"]:
+        dk["time_sigma_every"] = _PROFILE["time_sigma_every"]
     if observables:
-        return ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, observables=True, **dk)
+        out = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, observables=True, spin_square=spin_square, **dk)
+        _TLS.stats = out[1]
+        return out
     amps, stats = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, **dk)
+    _TLS.stats = stats
     return amps, stats, None
 
 
@@ -372,7 +393,7 @@ def solve_sci(
     ctx = _get_context(one_body_tensor, two_body_tensor, device, _slot)
     strs_a, strs_b = ci_strings
     eager = compute_rdms is True
-    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not eager)
+    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not eager, spin_square=False)
     if tuple(int(x) for x in nelec) != ctx.nelec:
         raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
     if eager:
