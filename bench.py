@@ -6,17 +6,21 @@ launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --
 rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric "Davidson sigma-vectors/sec & wall-clock to E0, N2 (16e,30o) 1e5 dets"):
-synthetic N2-sized FCIDUMP integrals (norb = 30, nelec = (8, 8)), particle-conserving random
-bitstrings, na = nb = 317 strings per spin (D = 100 489 determinants), ONE independent subspace
-(subsample batch) per GPU -- weak scaling, batches differ by seed.
+synthetic N2-sized FCIDUMP integrals (norb = 30, nelec = (8, 8); written to and read back from a FCIDUMP file
+before the timed region), particle-conserving random bitstrings, na = nb = 317 strings per spin
+(D = 100 489 determinants), ONE independent subspace (subsample batch) per GPU -- weak scaling, batches differ
+by seed.
 
-A *step* is one complete native ``solve_fermion`` on one batch: CI-string link tables + hdiag built on
-the device from the string lists, Davidson to pyscf's default tolerance (tol 1e-9) from pyscf's
-initial guess, then <c|H|c>, orbital occupancies (rdm1 diagonals), <S^2>, and the amplitude matrix
-returned to the host.  Integrals are resident in HBM (context created before the timed region).
-For N > 1 every step ends with the path's only exchange: one all-reduce of the (E, occ_a, occ_b)
-records over RCCL and an argmin (reference semantics, fermion.py:577).  ``value`` = sigma-vectors built by all ranks /
-max-over-ranks wall time of the K steps.
+A *step* is one call of the PRODUCT's public entry point on one batch per GPU:
+  N = 1: ``qiskit_addon_sqd_amd.fermion.solve_fermion((strs_a, strs_b), hcore, eri)`` -- string checks, CI-string
+         link tables + hdiag built on the device, Davidson to pyscf's default tolerance (tol 1e-9) from pyscf's initial
+         guess, then <c|H|c>, <S^2>, orbital occupancies, and the amplitude matrix returned to the host as an
+         ``SCIState``: everything the reference's ``solve_fermion`` returns, Python layer included;
+  N > 1: ``qiskit_addon_sqd_amd.distributed.solve_sci_batch_distributed(batches, ...)`` with N batches -- rank r solves
+         batch r, then the path's only exchange: ONE all-reduce of the (E, occ_a, occ_b) records over RCCL, argmin
+         (reference semantics, fermion.py:577) and the broadcast of the winner's amplitudes.  Nothing is omitted.
+Integrals are resident in HBM (the context is created in the warm-up).  ``value`` = sigma-vectors built by all ranks /
+max-over-ranks wall time of the K steps.  ``native_ms_per_step`` (N = 1) times the same solve through the C ABI alone.
 """
 from __future__ import annotations
 
@@ -24,6 +28,7 @@ import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -33,6 +38,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PROFILE_ROUND = "r02"
 
 
 def parse_args():
@@ -48,57 +54,74 @@ def parse_args():
                    help="uniform = random particle-conserving bitstrings (BASELINE config); hf = HF-centred")
     p.add_argument("--spin-sq", type=float, default=None)
     p.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--skip-secondary", action="store_true", help="skip the secondary entries (HF-centred 317^2, 1e4 x 1e4 sigma)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0)
-    p.add_argument("--extra", action="store_true", help="also measure the HF-centred variant and a D ladder")
+    p.add_argument("--extra", action="store_true", help="also measure a D ladder")
     p.add_argument("--time-sigma-every", type=int, default=8,
                    help="bracket every k-th sigma launch of the timed region with HIP events (roofline leg); an "
                         "event pair costs ~10 us of stream time, hence sampling")
     return p.parse_args()
 
 
-def make_batch(args, seed):
+def make_batch(args, seed, strings=None):
     from qiskit_addon_sqd_amd import synthetic as S
 
-    gen = S.uniform_strings if args.strings == "uniform" else S.hf_centred_strings
+    gen = S.uniform_strings if (strings or args.strings) == "uniform" else S.hf_centred_strings
     return gen(args.norb, args.nelec, args.na, seed), gen(args.norb, args.nelec, args.nb, seed + 7919)
 
 
-def one_step(ctx, sa, sb, spin_sq, time_every=0):
-    """Native body of solve_fermion (qiskit_addon_sqd_amd/fermion.py) on a resident Hamiltonian."""
-    ctx.set_subspace(sa, sb)
-    amps, st, (e, s2, occ_a, occ_b) = ctx.davidson(spin_sq=spin_sq, shift=0.1, time_sigma_every=time_every,
-                                                   observables=True)
-    return e, occ_a, occ_b, s2, st, amps
+def integrals_through_fcidump(args, rank):
+    """The synthetic Hamiltonian really travels through the FCIDUMP format: written, read back,
+    compared bit for bit -- outside the timed region."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    h1, eri = S.synthetic_integrals(args.norb)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = Path(tmp) / f"FCIDUMP_{args.norb}_{rank}"
+        S.write_fcidump(path, h1, eri, nelec=2 * args.nelec, ms2=0)
+        h1r, erir, nelec, _, _ = S.read_fcidump(path)
+    assert nelec == 2 * args.nelec and np.array_equal(h1r, h1) and np.array_equal(erir, eri)
+    return h1r, erir
 
 
-def pmc_traffic_bytes(args):
-    """HBM bytes per k_sigma launch from the committed rocprofv3 PMC passes of THIS workload (separate
+def pmc_traffic(args):
+    """HBM bytes per k_sigma launch from the COMMITTED rocprofv3 PMC passes of this workload (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
-    bench.py cannot collect counters itself.  None when no matching profile is committed."""
+    bench.py cannot collect counters itself.  (None, source) when no matching profile is committed."""
     if (args.norb, args.nelec, args.na, args.nb) != (30, 8, 317, 317):
-        return None
-    f = ROOT / "profiles" / "r01" / "pmc" / f"final_{args.strings}317_pmc_summary.json"
-    try:
-        d = json.loads(f.read_text())["HBM_BYTES"]
-        # the H-sigma instantiation is the one the Davidson launches (most dispatches); S^2 runs once per solve
-        key = max((k for k in d if "k_sigma<" in k), key=lambda k: d[k]["dispatches"])
-        return d[key]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+        return None, None
+    for rnd in (PROFILE_ROUND, "r01"):
+        f = ROOT / "profiles" / rnd / "pmc" / f"final_{args.strings}317_pmc_summary.json"
+        try:
+            d = json.loads(f.read_text())["HBM_BYTES"]
+            # the H-sigma instantiation is the one the Davidson launches (most dispatches); S^2 runs once per solve
+            key = max((k for k in d if "k_sigma<" in k), key=lambda k: d[k]["dispatches"])
+            return d[key]["hbm_bytes_per_launch"], f"committed profile {f.relative_to(ROOT)} (not measured in this run)"
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(args, h1, eri, sa, sb, n_sigma_gpu):
-    """Reference-algorithm port (oracle O2: pyscf's dense gather/dgemm/scatter formulation, OpenMP over
-    strings + sequential OpenBLAS dgemm) on this box's host cores; bounded sample of the same workload."""
+    """The reference's CPU path on this box's host cores, bounded sample of the same workload.  Preferred: pyscf itself
+    (``kernel_fixed_space`` as the reference calls it, fermion.py:810-818) when it is importable on the box; otherwise
+    oracle O2, the C restatement of pyscf's dense gather/dgemm/scatter formulation (OpenMP over strings + sequential
+    OpenBLAS dgemm)."""
+    pyscf_note = "pyscf not importable on this box"
+    try:
+        return cpu_baseline_pyscf(args, h1, eri, sa, sb)
+    except ImportError:
+        pass
+    except Exception as exc:  # pyscf present but the call failed: say so and fall back to the port
+        pyscf_note = f"pyscf call failed: {exc!r}"
     from oracle import sci_ref as R
 
     lib = R.load()
     # physical cores, capped at 64: the OpenBLAS bundled with numpy/scipy keeps per-thread metadata for
     # 64 callers and crashes beyond that when dgemm is entered from more OpenMP threads
     threads = args.cpu_threads or max(1, min(64, (os.cpu_count() or 2) // 2))
-    if hasattr(lib, "ref_set_threads"):
-        lib.ref_set_threads(threads)
+    lib.ref_set_threads(threads)
     threads = R.num_threads()
     t0 = time.perf_counter()
     prob = R.RefProblem(h1, eri, sa, sb)
@@ -123,7 +146,64 @@ def cpu_baseline(args, h1, eri, sa, sb, n_sigma_gpu):
         "sample": (f"{n + 1} sigma builds of the same {prob.na}x{prob.nb} subspace (pyscf dense formulation, "
                    f"{prob.dense_flops_per_sigma():.2e} flop each, {R.blas_name()}); tables+hdiag {t_setup:.2f} s"),
         "s_per_sigma": per_sigma,
+        # the CPU's OWN Davidson is not run to the end: this multiplies its per-sigma time by the GPU's sigma count
         "est_wall_to_e0_s": t_setup + per_sigma * n_sigma_gpu,
+        "est_note": "estimate: CPU per-sigma time x the GPU run's sigma count (the CPU Davidson itself is not run)",
+        "pyscf": pyscf_note,
+    }
+
+
+def cpu_baseline_pyscf(args, h1, eri, sa, sb):
+    """pyscf itself on the host cores, called exactly as the reference does (fermion.py:803-818); raises ImportError
+    when pyscf is absent -- it is absent from the build container, so this leg is opportunistic."""
+    import pyscf
+    from pyscf import fci, lib
+
+    norb, nelec = args.norb, (args.nelec, args.nelec)
+    myci = fci.selected_ci.SelectedCI()
+    count = [0]
+    inner = myci.contract_2e
+
+    def counted(*a, **k):
+        count[0] += 1
+        return inner(*a, **k)
+
+    myci.contract_2e = counted
+    t0 = time.perf_counter()
+    e, _civec = fci.selected_ci.kernel_fixed_space(myci, h1, eri, norb, nelec, ci_strs=(np.asarray(sa), np.asarray(sb)))
+    wall = time.perf_counter() - t0
+    return {"value": count[0] / wall if count[0] else None, "unit": "sigma-vectors/s", "cores": int(lib.num_threads()),
+            "kind": "reference", "sample": f"pyscf {pyscf.__version__} kernel_fixed_space to convergence on the same "
+            f"{len(sa)}x{len(sb)} subspace: {count[0]} contract_2e calls in {wall:.2f} s",
+            "wall_to_e0_s": wall, "energy": float(e)}
+
+
+def oracle_energy_check(args, h1, eri, sa, sb, e_gpu):
+    """E0 of the benchmarked subspace from the oracle's own Davidson on the string-space operator (outside the
+    timed region; tests/test_gpu_parity.py holds the full comparison)."""
+    from oracle import sqd_oracle as O
+
+    op = O.StringSpaceOperator(h1, eri, sa, sb, args.norb)
+    hd = O.make_hdiag(h1, eri, sa, sb, args.norb).ravel()
+    conv, e_ref, _, nsig = O.davidson_pyscf(op, O.init_guess(hd, len(sa), len(sb), (args.nelec, args.nelec)), hd,
+                                            tol=1e-11, max_cycle=200)
+    return {"oracle_energy": float(e_ref), "abs_diff_ha": abs(float(e_ref) - e_gpu), "oracle_converged": bool(conv),
+            "oracle_sigma_builds": int(nsig), "oracle": "O1s string-space sigma + pyscf-flow Davidson (numpy)"}
+
+
+def roofline_entry(ctx, t_kernel_ms, t_apply_ms, n_timed, traffic=None, source=None):
+    b_alg = ctx.sigma_bytes()
+    b_need = ctx.sigma_bytes_needed()
+    ach = b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": "sqd::k_sigma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+        "bytes_per_launch": b_alg, "bytes_needed": b_need,
+        "frac_on_bytes_needed": (b_need / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_kernel_ms > 0 else 0.0,
+        "avg_launch_ms": t_kernel_ms, "sigma_application_ms": t_apply_ms, "timed_launches": n_timed,
+        "note": "bytes_per_launch = SURVEY 8d B_sigma = 16 D + 8 links + 8 (nnorb_s^2 + nnorb_a^2); bytes_needed = what this "
+                "formulation must read and write once (vectors, hdiag, the link records and the integral / J rows it "
+                "touches).  The working set is cache resident at D <= 1e7, so HBM traffic is far below peak by construction",
     }
 
 
@@ -144,46 +224,26 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    from qiskit_addon_sqd_amd import _capi
-    from qiskit_addon_sqd_amd import synthetic as S
+    from qiskit_addon_sqd_amd import fermion as F
+    from qiskit_addon_sqd_amd.distributed import solve_sci_batch_distributed
 
-    h1, eri = S.synthetic_integrals(args.norb)
-    sa, sb = make_batch(args, 1000 + rank)
-    ctx = _capi.Context(h1, eri, device=local_rank)
+    h1, eri = integrals_through_fcidump(args, rank)
+    batches = [make_batch(args, 1000 + r) for r in range(world)]
+    sa, sb = batches[rank]
+    nelec = (args.nelec, args.nelec)
 
-    width = 1 + 2 * args.norb
-    if dist is not None:
-        # buffers of the per-step exchange, allocated once: device table, pinned host record / table
-        allrec = torch.zeros((world, width), device=dev, dtype=torch.float64)
-        h_rec = torch.zeros(width, dtype=torch.float64).pin_memory()
-        h_all = torch.zeros((world, width), dtype=torch.float64).pin_memory()
-        # solver and exchange share ONE stream (sqd_ctx_use_stream): waking a second hardware queue per step
-        # costs more than the collective itself (36 vs 77-110 us, profiles/probes/_exchange_probe.py)
-        xstream = torch.cuda.Stream(device=dev)
-        ctx.use_stream(xstream.cuda_stream)
-        my_row, rec, table = allrec[rank], h_rec.numpy(), h_all.numpy()  # views, made once
-
-    def exchange(e, oa, ob):
+    def one_step():
+        """One call of the product's public API; returns (energy, Davidson statistics of this rank's solve)."""
         if dist is None:
-            return e, oa, ob
-        # same exchange as qiskit_addon_sqd_amd.distributed: ONE all-reduce(sum) of a table whose rows are
-        # zero except the owner's record [E, occ_a, occ_b]  (61 doubles per batch at norb = 30); one host
-        # synchronisation per step (after the table is back in pinned memory), argmin on the host
-        rec[0] = e
-        rec[1 : 1 + args.norb] = oa
-        rec[1 + args.norb :] = ob
-        with torch.cuda.stream(xstream):
-            allrec.zero_()
-            my_row.copy_(h_rec, non_blocking=True)
-            dist.all_reduce(allrec, op=dist.ReduceOp.SUM)
-            h_all.copy_(allrec, non_blocking=True)
-        xstream.synchronize()
-        row = table[int(np.argmin(table[:, 0]))].copy()
-        return row[0], row[1 : 1 + args.norb], row[1 + args.norb :]
+            e, _state, _occ, _s2 = F.solve_fermion((sa, sb), h1, eri, spin_sq=args.spin_sq, device=local_rank)
+        else:
+            res = solve_sci_batch_distributed(batches, h1, eri, args.norb, nelec, spin_sq=args.spin_sq,
+                                              device=local_rank, compute_rdms=False)
+            e = min(r.energy for r in res)
+        return e, F.last_solve_stats()
 
     for _ in range(args.warmup):
-        e, oa, ob, s2, st, _ = one_step(ctx, sa, sb, args.spin_sq)
-        exchange(e, oa, ob)
+        e, st = one_step()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -191,20 +251,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    F.set_profiling(time_sigma_every=args.time_sigma_every)
     sync()
     t0 = time.perf_counter()
     nsig = 0
-    ms_sigma = 0.0  # k_sigma launches alone (event before .. event right after the kernel)
-    ms_apply = 0.0  # whole sigma applications (k_sigma + k_sigma_reduce)
-    ms_dav = 0.0
-    ms_setup = 0.0
+    ms_sigma = ms_apply = ms_dav = ms_setup = 0.0
     n_timed = 0
-    s_exchange = 0.0  # host time inside the per-step record exchange (N > 1 only)
     for _ in range(args.steps):
-        e, oa, ob, s2, st, _ = one_step(ctx, sa, sb, args.spin_sq, args.time_sigma_every)
-        tx = time.perf_counter()
-        e_best, _, _ = exchange(e, oa, ob)
-        s_exchange += time.perf_counter() - tx
+        e, st = one_step()
         nsig += st["n_sigma"]
         n_timed += st["n_sigma_timed"]
         ms_sigma += st["ms_sigma_kernel"]
@@ -213,6 +267,7 @@ def main():
         ms_setup += st["ms_setup"]
     sync()
     elapsed = time.perf_counter() - t0
+    F.set_profiling(0)
 
     tot = torch.tensor([float(nsig), elapsed], device=dev, dtype=torch.float64)
     if dist is not None:
@@ -224,13 +279,14 @@ def main():
         nsig_all, elapsed_max = float(nsig), elapsed
 
     if rank == 0:
-        bytes_sigma = ctx.sigma_bytes()
+        ctx = F._get_context(h1, eri, local_rank)  # the context the timed solves used (cache hit)
         t_sigma_ms = ms_sigma / max(n_timed, 1)
-        achieved = bytes_sigma / (t_sigma_ms * 1e-3) / 1e9 if t_sigma_ms > 0 else 0.0
         ns_a, nd_a = ctx.link_counts(0)
         ns_b, nd_b = ctx.link_counts(1)
+        traffic, source = pmc_traffic(args)
         out = {
-            "metric": "Davidson sigma-vectors/sec (complete solve_fermion: tables + Davidson to tol 1e-9 + observables)",
+            "metric": "Davidson sigma-vectors/sec (complete solve_fermion through the Python API: string checks + tables + "
+                      "Davidson to tol 1e-9 + observables + SCIState)",
             "value": nsig_all / elapsed_max,
             "unit": "sigma-vectors/s",
             "n_gpus": world,
@@ -248,48 +304,96 @@ def main():
                              f"determinants, 1 subsample batch per GPU"),
                 "norb": args.norb, "nelec": [args.nelec, args.nelec], "na": args.na, "nb": args.nb,
                 "strings": args.strings, "spin_sq": args.spin_sq,
-                "parallelism": f"batch-per-gpu x{world}" + (" + all_reduce(E,occ)->argmin" if world > 1 else ""),
+                "entry_point": ("qiskit_addon_sqd_amd.fermion.solve_fermion" if dist is None else
+                                "qiskit_addon_sqd_amd.distributed.solve_sci_batch_distributed"),
+                "parallelism": f"batch-per-gpu x{world}" + (" + all_reduce(E,occ)->argmin + winner broadcast" if world > 1 else ""),
             },
             "wall_to_e0_ms": 1e3 * elapsed_max / args.steps,
-            "exchange_ms_per_step": 1e3 * s_exchange / args.steps,  # rank 0's host time in the all-reduce step
             "sigma_per_solve": nsig / args.steps,
             "davidson_ms_per_solve": ms_dav / args.steps,
             "tables_ms_per_solve": ms_setup / args.steps,
             "energy": float(e), "converged": int(st["converged"]), "residual": float(st["residual"]),
             "links": {"alpha_single": ns_a, "alpha_double": nd_a, "beta_single": ns_b, "beta_double": nd_b},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "sqd::k_sigma",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(args),
-                "bytes_per_launch": bytes_sigma,
-                "avg_launch_ms": t_sigma_ms,  # k_sigma alone, as in the committed rocprofv3 --stats summary
-                "sigma_application_ms": ms_apply / max(n_timed, 1),  # incl. k_sigma_reduce (fixed-order row sums)
-                "timed_launches": n_timed,  # every --time-sigma-every-th sigma of the timed region (HIP events)
-                "note": "algorithmic bytes = 16 D + 8 links + 8 (nnorb_s^2 + nnorb_a^2) (SURVEY 8d); working set is "
-                        "cache resident at this D, so HBM traffic is far below peak by construction",
-            },
+            "roofline": roofline_entry(ctx, t_sigma_ms, ms_apply / max(n_timed, 1), n_timed, traffic, source),
         }
+        if world == 1:
+            out["native_ms_per_step"] = native_step_ms(ctx, sa, sb, args)
+            try:
+                out["energy_check"] = oracle_energy_check(args, h1, eri, sa, sb, float(e))
+            except Exception as exc:  # never take the GPU number down
+                out["energy_check"] = {"error": repr(exc)}
         if world == 1 and not args.skip_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, h1, eri, sa, sb, nsig / args.steps)
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "sigma-vectors/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
+        if world == 1 and not args.skip_secondary:
+            out["secondary"] = secondary_entries(args, h1, eri, local_rank)
         if args.extra and world == 1:
             out["extra"] = extra_measurements(args, ctx)
         print(json.dumps(out), flush=True)
-    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def native_step_ms(ctx, sa, sb, args, steps=20):
+    """The same solve through the C ABI alone (sqd_solve_strings), Python layer excluded."""
+    for _ in range(3):
+        ctx.solve(sa, sb, spin_sq=args.spin_sq, shift=0.1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.solve(sa, sb, spin_sq=args.spin_sq, shift=0.1)
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def secondary_entries(args, h1, eri, device):
+    """Named secondary lines of every N = 1 run (not the headline): the HF-centred variant of the headline size -- the
+    workload that actually exercises the coupling enumeration -- and one sigma launch at the only HBM-relevant size,
+    uniform 1e4 x 1e4 (D = 1e8, 0.8 GB per vector)."""
+    from qiskit_addon_sqd_amd import fermion as F
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    res = {}
+    if (args.norb, args.nelec) != (30, 8):
+        return res
+    ctx = F._get_context(h1, eri, device)
+    # --- HF-centred 317 x 317 through the Python API
+    sa, sb = S.hf_centred_strings(30, 8, 317, 1001), S.hf_centred_strings(30, 8, 317, 1001 + 7919)
+    for _ in range(2):
+        F.solve_fermion((sa, sb), h1, eri, device=device)
+    F.set_profiling(4)
+    steps, nsig, ms_k, ms_a, nt, ms_dav = 10, 0, 0.0, 0.0, 0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e, *_ = F.solve_fermion((sa, sb), h1, eri, device=device)
+        st = F.last_solve_stats()
+        nsig += st["n_sigma"]; ms_k += st["ms_sigma_kernel"]; ms_a += st["ms_sigma"]; nt += st["n_sigma_timed"]
+        ms_dav += st["ms_total"]
+    dt = time.perf_counter() - t0
+    F.set_profiling(0)
+    res["hf_centred_317x317"] = {
+        "ms_per_solve": 1e3 * dt / steps, "sigma_per_solve": nsig / steps, "sigma_vectors_per_s": nsig / dt,
+        "us_per_davidson_iteration": 1e3 * ms_dav / max(nsig, 1), "energy": float(e),
+        "roofline": roofline_entry(ctx, ms_k / max(nt, 1), ms_a / max(nt, 1), nt),
+    }
+    # --- one sigma at uniform 1e4 x 1e4
+    try:
+        n = 10000
+        sa, sb = S.uniform_strings(30, 8, n, 11), S.uniform_strings(30, 8, n, 13)
+        ctx.set_subspace(sa, sb)
+        t_sig = ctx.time_sigma(5)
+        res["sigma_uniform_1e4x1e4"] = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
+                                        "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
+        ctx.set_subspace(sa[:16], sb[:16])  # release nothing, but leave a small subspace behind
+    except Exception as exc:
+        res["sigma_uniform_1e4x1e4"] = {"error": repr(exc)}
+    return res
+
+
 def extra_measurements(args, ctx):
-    """Secondary numbers (not the headline): HF-centred strings at the same size and a D ladder."""
+    """Secondary numbers (not the headline): a D ladder, both generators."""
     from qiskit_addon_sqd_amd import synthetic as S
 
     res = {}

@@ -154,6 +154,12 @@ int sqd_observables(sqd_ctx* ctx, const double* amps, double* e, double* s2, dou
  * Any of amps / stats / e / s2 / occ_a / occ_b may be NULL. */
 int sqd_solve(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, double* amps,
               sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b);
+/* sqd_solve_strings = sqd_set_subspace + sqd_solve in one call (one crossing of the ctypes boundary per solve): what
+ * reference solve_fermion does from the checked CI strings to its return value (fermion.py:797-830) and solve_sci
+ * per batch (fermion.py:713-742).  amps: na*nb doubles.  nelec_a / nelec_b (may be NULL) receive the popcounts. */
+int sqd_solve_strings(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb,
+                      const sqd_davidson_opts* opts, const double* ci0, double* amps, sqd_davidson_stats* stats,
+                      double* e, double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b);
 int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
 int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
 int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);
@@ -168,6 +174,10 @@ int sqd_rdm2s(sqd_ctx* ctx, const double* amps, double* dm2aa, double* dm2ab, do
 int sqd_time_sigma(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift, double* ms_per_sigma);
 /* Populated-link count and algorithmic bytes of one sigma (SURVEY 8d formula) for the current subspace. */
 int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
+/* Bytes this build's formulation has to move once per sigma (vectors + hdiag + the link records at their stored
+ * width + the integral / J rows the populated links touch): the honest denominator beside SURVEY 8d's B_sigma, which
+ * charges the whole packed integral tables whether or not a string set has the links that read them. */
+int sqd_sigma_bytes_needed(sqd_ctx* ctx, double* bytes);
 
 /* ---- qubit / Pauli path (reference qiskit_addon_sqd/qubit.py) -----------------
  * Projection of sum_t c_t P_t onto the subspace spanned by the computational basis states `rows`

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = (
     "sqd_davidson",
     "sqd_observables",
     "sqd_solve",
+    "sqd_solve_strings",
     "sqd_energy",
     "sqd_spin_square",
     "sqd_rdm1s",
@@ -44,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "sqd_rdm2s",
     "sqd_time_sigma",
     "sqd_sigma_bytes",
+    "sqd_sigma_bytes_needed",
     "sqd_pauli_count",
     "sqd_pauli_fill",
     "sqd_pauli_free",
@@ -114,6 +116,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_davidson.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats)]
     lib.sqd_observables.argtypes = [_ctxp, _dp, _dp, _dp, _dp, _dp]
     lib.sqd_solve.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats), _dp, _dp, _dp, _dp]
+    lib.sqd_solve_strings.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64, C.POINTER(DavidsonOpts), _dp, _dp,
+                                      C.POINTER(DavidsonStats), _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
@@ -121,6 +125,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_rdm2s.argtypes = [_ctxp, _dp, _dp, _dp, _dp]
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
+    lib.sqd_sigma_bytes_needed.argtypes = [_ctxp, _dp]
     lib.sqd_pauli_count.argtypes = [C.c_int, _u64p, C.c_int64, C.c_int, _u64p, _i64p, _u64p, _dp, _i64p, _i64p,
                                     C.POINTER(_ctxp)]
     lib.sqd_pauli_fill.argtypes = [_ctxp, _i64p, _dp, _dp]
@@ -177,6 +182,8 @@ def _ptr(a: np.ndarray, typ=_dp):
 def strings_to_u64(strs) -> np.ndarray:
     """CI strings (int64 / uint64 / python ints) -> contiguous uint64 array (bit pattern preserved)."""
     arr = np.asarray(strs)
+    if arr.dtype == np.int64 and arr.flags.c_contiguous and (arr.size == 0 or (arr[0] >= 0 and arr[-1] >= 0 and arr.min() >= 0)):
+        return arr.view(np.uint64)  # same bits, no copy
     if arr.dtype == object:
         arr = np.array([int(x) for x in arr], dtype=np.uint64)
     elif arr.dtype != np.uint64:
@@ -351,6 +358,40 @@ class Context:
         )
         return amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_}
 
+    def solve(self, strs_a, strs_b, ci0=None, *, tol: float = 1e-9, tol_residual: float | None = None,
+              lindep: float = 1e-14, max_cycle: int = 100, max_space: int = 12, spin_sq: float | None = None,
+              shift: float = 0.2, verbose: int = 0, time_sigma_every: int = 0, spin_square: bool = True):
+        """``set_subspace`` + ``davidson(observables=True)`` in one native call (``sqd_solve_strings``).
+        Returns (amps, stats, (energy, spin_square | None, occ_a, occ_b))."""
+        a = strings_to_u64(strs_a)
+        b = strings_to_u64(strs_b)
+        opts = DavidsonOpts()
+        self._lib.sqd_davidson_default_opts(C.byref(opts))
+        opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
+        opts.verbose = int(verbose)
+        opts.time_sigma_every = int(time_sigma_every)
+        opts.tol_residual = float(tol_residual) if tol_residual else 0.0
+        if spin_sq is not None:
+            opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
+        stats = DavidsonStats()
+        amps = np.empty((a.size, b.size))
+        ci0p = None
+        if ci0 is not None:
+            ci0 = _as_f64(ci0).reshape(a.size, b.size)
+            ci0p = _ptr(ci0)
+        e, s2 = C.c_double(), C.c_double()
+        ea, eb = C.c_int(), C.c_int()
+        occ_a, occ_b = np.empty(self.norb), np.empty(self.norb)
+        self._check(
+            self._lib.sqd_solve_strings(self._h, _ptr(a, _u64p), a.size, _ptr(b, _u64p), b.size, C.byref(opts), ci0p,
+                                        _ptr(amps), C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,
+                                        _ptr(occ_a), _ptr(occ_b), C.byref(ea), C.byref(eb))
+        )
+        self.na, self.nb = int(a.size), int(b.size)
+        self.nelec = (int(ea.value), int(eb.value))
+        return (amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_},
+                (e.value, s2.value if spin_square else None, occ_a, occ_b))
+
     # -- observables (amps=None -> resident Davidson solution)
     def _state(self, amps):
         if amps is None:
@@ -408,3 +449,9 @@ class Context:
         out = C.c_double()
         self._check(self._lib.sqd_sigma_bytes(self._h, C.byref(out)))
         return float(out.value)
+
+    def sigma_bytes_needed(self) -> float:
+        out = C.c_double()
+        self._check(self._lib.sqd_sigma_bytes_needed(self._h, C.byref(out)))
+        return float(out.value)
+

@@ -118,7 +118,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->stream) e = hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
-                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob};
+                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();
@@ -442,6 +442,19 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   return SQD_OK;
 }
 
+// sqd_set_subspace + sqd_solve in ONE crossing of the boundary: the body of reference solve_fermion / solve_sci from
+// the formatted CI strings to the returned tuple (fermion.py:797-830, :713-742).  Between two native calls the
+// Python side spends ~20 us (ctypes marshalling, the dims query), a tenth of a whole headline-size solve.
+SQD_API int sqd_solve_strings(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb,
+                              const sqd_davidson_opts* opts, const double* ci0, double* amps, sqd_davidson_stats* stats,
+                              double* e, double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b) {
+  CTX_ENTER(c);
+  SQD_TRY(build_subspace(c, strs_a, na, strs_b, nb));
+  if (nelec_a) *nelec_a = c->nelec[0];
+  if (nelec_b) *nelec_b = c->nelec[1];
+  return sqd_solve(c, opts, ci0, amps, stats, e, s2, occ_a, occ_b);
+}
+
 SQD_API int sqd_energy(sqd_ctx* c, const double* amps, double* e) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
@@ -513,3 +526,20 @@ SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
   *bytes = 16.0 * D + 8.0 * links + 8.0 * (ns * ns + nas * nas);
   return SQD_OK;
 }
+
+SQD_API int sqd_sigma_bytes_needed(sqd_ctx* c, double* bytes) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!bytes) return SQD_ERR_INVALID;
+  // what THIS formulation must move once per sigma (every object at its stored width, each counted once):
+  // c, sigma, hdiag; the beta link records (singles 16 B, doubles 12 B) and the alpha ones (merged list 12 B +
+  // 8 B per single); one packed integral row and one J_beta row per distinct orbital pair among the alpha
+  // singles (at most min(links, nnorb)); the J_alpha row of every alpha string
+  const double D = (double)c->D, nn = (double)c->nnorb;
+  const double nsa = (double)c->sp[0].n_s, nda = (double)c->sp[0].n_d, nsb = (double)c->sp[1].n_s, ndb = (double)c->sp[1].n_d;
+  const double pairs = nsa < nn ? nsa : nn;
+  *bytes = 24.0 * D + 16.0 * nsb + 12.0 * ndb + 12.0 * (nsa + nda) + 8.0 * nsa + pairs * 8.0 * (nn + (double)c->nb) +
+           (nsb > 0 ? 8.0 * nn * (double)c->na : 0.0);
+  return SQD_OK;
+}
+

@@ -138,6 +138,8 @@ struct sqd_ctx {
   int nelec[2] = {0, 0};
   sqd::SpinTables sp[2];
   sqd::DevBuf hdiag;        // f64[D]
+  sqd::DevBuf strs2;        // u64[na + nb]: both string lists (SpinTables::strs are views)
+  sqd::DevBuf guess_min;    // per alpha row: lowest diagonal element f64[na] and its flat index i64[na] (init guess)
   // sigma work list + launch geometry (fixed per subspace)
   sqd::DevBuf d_blob;               // packed capped-ELL descriptors (one upload); views in SpinTables
   // pinned host staging for the small uploads / downloads of set_subspace (a copy from pageable memory

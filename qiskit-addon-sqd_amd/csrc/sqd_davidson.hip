@@ -119,27 +119,6 @@ struct DavParams {  // constants of one run
   int max_space;
 };
 
-// per-block (min value, index) over hdiag; tril != 0 restricts to A >= B (pyscf _get_init_guess
-// when nelec_a == nelec_b and na == nb)
-__global__ void k_argmin(int64_t n, int64_t nb, int tril_only, const double* __restrict__ h,
-                         double* __restrict__ pmin, int64_t* __restrict__ pidx) {
-  double best = 1e300;
-  int64_t bi = -1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (tril_only && (i / nb) < (i % nb)) continue;
-    const double v = h[i];
-    if (v < best || (v == best && i < bi)) {
-      best = v;
-      bi = i;
-    }
-  }
-  block_argmin(best, bi);
-  if (threadIdx.x == 0) {
-    pmin[blockIdx.x] = best;
-    pidx[blockIdx.x] = bi;
-  }
-}
-
 // start of a run: state block and arrival counters (workgroup 0; the kernels that use them come later in the stream)
 __device__ inline void dav_state_init(DavState* st, unsigned* counter) {
   for (int i = threadIdx.x; i < COUNT_WORDS; i += blockDim.x) counter[i] = 0u;
@@ -253,99 +232,100 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
 }
 
 // ------------------------------------------------------------------ the projected eigenproblem, on ONE wavefront
-// Lane i owns row i of the small matrices (n <= MAXB <= 64); all 64 lanes execute every collective.
+// Lane i owns row i of the small matrix (n <= MV <= 64), IN REGISTERS; a row or an element of another lane is
+// fetched with v_readlane (wave_bcast with a compile-time lane), never through LDS: the first version of this
+// routine kept the matrices in LDS and cost 10-25 us per iteration in dependent LDS round trips (kernel trace,
+// profiles/r02), more than the host round trip it replaced.  All 64 lanes execute every collective.
 //
 // Lowest eigenpair after the basis grew by ONE vector, by Rayleigh-quotient iteration from the previous Ritz
 // vector padded with a zero (a start whose residual is already small).  The previous matrix is the leading
 // principal block of this one, so by Cauchy interlacing  l1(new) <= l1(old) <= l2(new): an eigenvalue found at or
 // below the old Ritz value IS the lowest one -- that test, plus a residual at rounding level, is the acceptance
-// rule; anything else returns false and the caller runs the Jacobi solver.
-// A, M: n x n with row stride ld (LDS); x, y: length-n work vectors (LDS).  v_io: previous Ritz vector in, new out.
-__device__ inline bool wave_lowest_eig_rqi(int n, int ld, const double* A, double* M, double* x, double* y, double* v_io,
-                                           double e_old, double* e_out) {
+// rule; anything else returns false and the caller runs the Jacobi solver.  The shifted solves use elimination in
+// the natural order (no pivot search: 2 n^2 fewer lane reads per solve).  A - theta I has at most one direction
+// of the wrong sign here and the vanishing pivot is the mechanism of inverse iteration; should a solve go wrong
+// all the same, the acceptance rule rejects the result and the Jacobi fallback takes over -- speed, never
+// correctness, is what the missing pivoting can cost.
+// a[j] = A[lane][j]; xi: previous Ritz vector component of this lane in, new one out.
+template <int MV>
+__device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double& xi_io, double e_old, double* e_out) {
   const int lane = threadIdx.x & 63;
   const bool act = lane < n;
-  double xi = (act && lane < n - 1) ? v_io[lane] : 0.0;
+  double xi = (act && lane < n - 1) ? xi_io : 0.0;
   double rowabs = 0.0;
-  if (act)
-    for (int j = 0; j < n; ++j) rowabs += fabs(A[lane * ld + j]);
+#pragma unroll
+  for (int j = 0; j < MV; ++j) rowabs += (j < n) ? fabs(a[j]) : 0.0;
   const double nrm = wave_sum(xi * xi), anorm = wave_max(act ? rowabs : 0.0);
   if (!(nrm > 0.0) || !(anorm > 0.0)) return false;
   xi *= 1.0 / sqrt(nrm);
   const double tiny = 2.3e-16 * anorm;
-  auto rayleigh = [&](double xl) {  // x <- xl (all lanes), y <- A x, returns x.Ax
-    wave_sync();
-    if (act) x[lane] = xl;
-    wave_sync();
+  auto matvec = [&](double xl) {  // (A x)_lane
     double r = 0.0;
-    if (act)
-      for (int j = 0; j < n; ++j) r += A[lane * ld + j] * x[j];
-    if (act) y[lane] = r;
-    return wave_sum(act ? xl * r : 0.0);
+#pragma unroll
+    for (int j = 0; j < MV; ++j)
+      if (j < n) r += a[j] * wave_bcast(xl, j);
+    return act ? r : 0.0;
   };
-  double theta = rayleigh(xi);
+  double yi = matvec(xi);
+  double theta = wave_sum(xi * yi);
   for (int it = 0; it < 6; ++it) {
-    const double yi = act ? y[lane] : 0.0;
     const double res = wave_sum(act ? (yi - theta * xi) * (yi - theta * xi) : 0.0);
     if (sqrt(res) <= 8.0 * tiny) {
       if (!(theta <= e_old + 64.0 * tiny)) return false;  // not provably the lowest eigenvalue
       // (a new vector that does not couple to the old Ritz vector leaves that pair an eigenpair of the grown
       // matrix although its own diagonal may lie lower: the lowest eigenvalue is below every diagonal element)
-      const double above = wave_max(act ? theta - A[lane * ld + lane] : -1.0);
+      double dg = 0.0;
+#pragma unroll
+      for (int j = 0; j < MV; ++j) dg = (j == lane) ? a[j] : dg;
+      const double above = wave_max(act ? theta - dg : -1.0);
       if (above > 64.0 * tiny) return false;
       *e_out = theta;
-      wave_sync();
-      if (act) v_io[lane] = xi;
-      wave_sync();
+      xi_io = xi;
       return true;
     }
-    // y = (A - theta I)^-1 x   (Gaussian elimination, partial pivoting; a vanishing pivot is what converges it)
-    wave_sync();
-    if (act) {
-      for (int j = 0; j < n; ++j) M[lane * ld + j] = A[lane * ld + j] - (j == lane ? theta : 0.0);
-      y[lane] = xi;
+    // z = (A - theta I)^-1 x: elimination in the natural order, row k owned by lane k
+    double m[MV];
+#pragma unroll
+    for (int j = 0; j < MV; ++j) m[j] = a[j] - ((j == lane) ? theta : 0.0);
+    double z = xi;
+#pragma unroll
+    for (int k = 0; k < MV; ++k)
+      if (k < n - 1) {
+        double pk = wave_bcast(m[k], k);
+        if (fabs(pk) < tiny) {
+          pk = (pk < 0.0) ? -tiny : tiny;
+          if (lane == k) m[k] = pk;
+        }
+        const double f = (act && lane > k) ? m[k] / pk : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < MV; ++j)
+          if (j < n) m[j] -= f * wave_bcast(m[j], k);
+        z -= f * wave_bcast(z, k);
+      }
+    // back substitution: sol[k] on every lane
+    double sol[MV];
+#pragma unroll
+    for (int k = MV - 1; k >= 0; --k) {
+      sol[k] = 0.0;
+      if (k < n) {
+        double r = z;
+#pragma unroll
+        for (int j = k + 1; j < MV; ++j)
+          if (j < n) r -= m[j] * sol[j];
+        double pk = m[k];
+        if (k == n - 1 && fabs(pk) < tiny) pk = (pk < 0.0) ? -tiny : tiny;  // the pivot that vanishes at convergence
+        sol[k] = wave_bcast(r / pk, k);
+      }
     }
-    wave_sync();
-    for (int k = 0; k < n; ++k) {
-      const int p = wave_argmax((act && lane >= k) ? fabs(M[lane * ld + k]) : -1.0, lane);
-      if (p != k) {
-        wave_sync();
-        if (act) {
-          const double a = M[k * ld + lane], b = M[p * ld + lane];
-          M[k * ld + lane] = b;
-          M[p * ld + lane] = a;
-        }
-        if (lane == 0) {
-          const double a = y[k];
-          y[k] = y[p];
-          y[p] = a;
-        }
-      }
-      wave_sync();
-      if (lane == 0 && fabs(M[k * ld + k]) < tiny) M[k * ld + k] = (M[k * ld + k] < 0.0) ? -tiny : tiny;
-      wave_sync();
-      if (act && lane > k) {
-        const double f = M[lane * ld + k] / M[k * ld + k];
-        if (f != 0.0) {
-          for (int j = k + 1; j < n; ++j) M[lane * ld + j] -= f * M[k * ld + j];
-          y[lane] -= f * y[k];
-        }
-      }
-      wave_sync();
-    }
-    if (lane == 0)
-      for (int i = n - 1; i >= 0; --i) {
-        double r = y[i];
-        for (int j = i + 1; j < n; ++j) r -= M[i * ld + j] * y[j];
-        y[i] = r / M[i * ld + i];
-      }
-    wave_sync();
-    const double yl = act ? y[lane] : 0.0;
+    double yl = 0.0;
+#pragma unroll
+    for (int k = 0; k < MV; ++k) yl = (k == lane && k < n) ? sol[k] : yl;
     const double yn = wave_sum(yl * yl), dot = wave_sum(yl * xi);
     if (!(yn > 0.0) || !(yn < 1e300)) return false;
     const double sc = ((dot < 0.0) ? -1.0 : 1.0) / sqrt(yn);  // keep the orientation of the previous Ritz vector
     xi = yl * sc;
-    theta = rayleigh(xi);
+    yi = matvec(xi);
+    theta = wave_sum(xi * yi);
   }
   return false;
 }
@@ -407,7 +387,7 @@ __device__ inline double wave_lowest_eig_jacobi(int n, int ld, double* A, double
 // tot[0] = |X_{m-1}|^2, tot[1+v] = X_v . A X_{m-1}.
 template <int MV>
 __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavParams prm, double* sA, double* sM,
-                                     double* sx, double* sy, double* sv_eig) {
+                                     double* sv_eig) {
   const int lane = threadIdx.x & 63;
   const int m = st->m_next;
   constexpr int LD = MV;
@@ -441,25 +421,71 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
     return;
   }
   const double svm = 1.0 / sqrt(nrm2);
-  if (lane < m) {
-    const double h = tot[1 + lane] * ((lane == m - 1) ? svm : st->sv[lane]) * svm;
-    st->heff[lane * MAXB + (m - 1)] = h;
-    st->heff[(m - 1) * MAXB + lane] = h;
-  }
-  wave_sync();
-  if (lane < m)
-    for (int j = 0; j < m; ++j) sA[lane * LD + j] = st->heff[lane * MAXB + j];
-  // previous Ritz vector (coefficients of the last projected problem) as the warm start
-  if (lane < m) sv_eig[lane] = (lane < m - 1) ? st->coef[lane] : 0.0;
-  wave_sync();
-  double e_new = 0.0;
-  bool warm = false;
-  if (m == st->m_eig + 1 && !st->first && m >= 2) warm = wave_lowest_eig_rqi(m, LD, sA, sM, sx, sy, sv_eig, st->e, &e_new);
-  if (!warm) e_new = wave_lowest_eig_jacobi(m, LD, sA, sM, sv_eig);  // (sA is rebuilt from heff every iteration)
-  // the Ritz coefficients of this projected problem
-  const double ci = (lane < m) ? sv_eig[lane] : 0.0;
-  const double cn = wave_sum(ci * ci);
   const double svi = (lane < m) ? ((lane == m - 1) ? svm : st->sv[lane]) : 0.0;
+  // row `lane` of the projected matrix in registers: the old block from the state, the new row / column from tot
+  double a[MV];
+#pragma unroll
+  for (int j = 0; j < MV; ++j) {
+    double v = 0.0;
+    if (lane < m && j < m) {
+      if (lane == m - 1) v = tot[1 + j] * ((j == m - 1) ? svm : st->sv[j]) * svm;
+      else if (j == m - 1) v = tot[1 + lane] * svi * svm;
+      else v = st->heff[lane * MAXB + j];
+    }
+    a[j] = v;
+  }
+  if (lane < m) {
+    st->heff[lane * MAXB + (m - 1)] = tot[1 + lane] * svi * svm;
+    st->heff[(m - 1) * MAXB + lane] = tot[1 + lane] * svi * svm;
+  }
+  double e_new = 0.0;
+  double ci = 0.0;  // this lane's component of the lowest eigenvector
+  bool done = false;
+  if (m == 1) {
+    e_new = wave_bcast(a[0], 0);
+    ci = (lane == 0) ? 1.0 : 0.0;
+    done = true;
+  } else if (m == 2) {
+    // symmetric 2 x 2 in closed form: lowest eigenvalue and its eigenvector
+    const double p = wave_bcast(a[0], 0), q = wave_bcast(a[1], 0), r = wave_bcast(a[1], 1);
+    const double hd = 0.5 * (p - r), rad = sqrt(hd * hd + q * q);
+    e_new = 0.5 * (p + r) - rad;
+    // (A - e) v = 0: v = (q, e - p) or (e - r, q); take the better conditioned one
+    double v0, v1;
+    if (fabs(e_new - p) > fabs(e_new - r)) {
+      v0 = q;
+      v1 = e_new - p;
+    } else {
+      v0 = e_new - r;
+      v1 = q;
+    }
+    double nn = sqrt(v0 * v0 + v1 * v1);
+    if (!(nn > 0.0)) {  // diagonal matrix with equal entries
+      v0 = (p <= r) ? 1.0 : 0.0;
+      v1 = 1.0 - v0;
+      nn = 1.0;
+    }
+    const double sgn = (v0 < 0.0) ? -1.0 : 1.0;  // orientation: positive weight on the older vector
+    ci = (lane == 0) ? sgn * v0 / nn : ((lane == 1) ? sgn * v1 / nn : 0.0);
+    done = true;
+  } else if (m == st->m_eig + 1 && !st->first) {
+    ci = (lane < m - 1) ? st->coef[lane] : 0.0;  // previous Ritz vector as the warm start
+    done = wave_lowest_eig_rqi<MV>(m, a, ci, st->e, &e_new);
+    if (!done) ci = 0.0;
+  }
+  if (!done) {  // fallback: cyclic Jacobi on an LDS copy
+    wave_sync();
+    if (lane < m) {
+#pragma unroll
+      for (int j = 0; j < MV; ++j)
+        if (j < m) sA[lane * LD + j] = a[j];
+    }
+    wave_sync();
+    e_new = wave_lowest_eig_jacobi(m, LD, sA, sM, sv_eig);
+    ci = (lane < m) ? sv_eig[lane] : 0.0;
+  }
+  // the Ritz coefficients of this projected problem
+  const double cn = wave_sum(ci * ci);
   wave_sync();
   if (lane < m) {
     st->coef[lane] = ci;
@@ -491,7 +517,7 @@ __global__ void k_dots_eig(int64_t n, const double* __restrict__ X, const double
                            const DavParams prm) {
   __shared__ double red[16 * (MV + 1)];
   __shared__ double tot[MV + 1];
-  __shared__ double sA[MV * MV], sM[MV * MV], sx[MV + 1], sy[MV + 1], sv_eig[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
   if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
                          // kernel before every workgroup has arrived)
   const int nvec = st->m_next;
@@ -526,7 +552,7 @@ __global__ void k_dots_eig(int64_t n, const double* __restrict__ X, const double
   if ((int)threadIdx.x < nvec + 1) tot[threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
   __syncthreads();
   if (threadIdx.x >= 64) return;
-  wave_eig_step<MV>(st, tot, prm, sA, sM, sx, sy, sv_eig);
+  wave_eig_step<MV>(st, tot, prm, sA, sM, sv_eig);
 }
 
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
@@ -673,16 +699,31 @@ __global__ void k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict
   if (s_stop) return;  // the correction is not needed (and may be 0/0)
   const double scale = s_scale;
   double* __restrict__ t = X + (int64_t)nvec * stride;
+  if (!restart) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      double s = scale * t[i];
+      for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+      }
+      t[i] = s;
+    }
+    return;
+  }
+  // restart: the same pass also forms the Ritz vector and A * Ritz, in place, element by element
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = scale * t[i];
     double x0 = 0.0, ax0 = 0.0;
-    for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
+    for (int v0 = 0; v0 < nvec; v0 += 8) {
       double x[8], a[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i;
         x[u] = X[off];
-        a[u] = restart ? AX[off] : 0.0;
+        a[u] = AX[off];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -693,13 +734,9 @@ __global__ void k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict
         ax0 += on * s_raw[v] * a[u];
       }
     }
-    if (restart) {
-      X[i] = x0;
-      AX[i] = ax0;
-      X[stride + i] = s;
-    } else {
-      t[i] = s;
-    }
+    X[i] = x0;
+    AX[i] = ax0;
+    X[stride + i] = s;
   }
 }
 
@@ -815,13 +852,11 @@ static int enqueue_init_guess_impl(sqd_ctx* c, double* x, DavState* st, unsigned
   const int64_t D = c->D;
   const unsigned gb = red_blocks(D);
   SQD_TRY(reserve_reduction_buffers(c));
-  const int tril_only = (c->nelec[0] == c->nelec[1] && c->na == c->nb) ? 1 : 0;
-  double* pmin = c->partial.as<double>();
-  int64_t* pidx = reinterpret_cast<int64_t*>(pmin + RED_BLOCKS);
-  hipLaunchKernelGGL(k_argmin, dim3(gb), dim3(RED_T), 0, c->stream, D, c->nb, tril_only,
-                     (const double*)c->hdiag.as<double>(), pmin, pidx);
-  hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, c->stream, D, (const double*)pmin, (const int64_t*)pidx,
-                     (int)gb, x, st, counter);
+  // the per-row minima of the diagonal (lower triangle only when pyscf's rule says so) were left by set_subspace
+  // (k_tables_diag); every workgroup of k_init_guess finishes the argmin over them itself
+  const double* pmin = c->guess_min.as<double>();
+  const int64_t* pidx = reinterpret_cast<const int64_t*>(pmin + c->na);
+  hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, c->stream, D, pmin, pidx, (int)c->na, x, st, counter);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }

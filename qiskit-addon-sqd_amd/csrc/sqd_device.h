@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace sqd {
 
 // Sum over the workgroup; result valid on thread 0.  `red` = >= 16 doubles of LDS.
@@ -84,6 +86,12 @@ __device__ inline bool arrive_last(unsigned* counter, unsigned block, unsigned n
   return s_last != 0;
 }
 
+__device__ inline void coherent_store_i64(int64_t* p, int64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int64_t coherent_load_i64(const int64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // Payload words of the host-visible mailbox (fine-grained pinned host memory): written through at system
 // scope.  Protocol of a post: every writing thread issues its stores and waits for them (s_waitcnt), the
 // workgroup meets at a barrier, then ONE thread fences at system scope and writes the sequence word.  (Fencing
@@ -111,6 +119,16 @@ __device__ inline double wave_max(double v) {
     v = o > v ? o : v;
   }
   return __shfl(v, 0);
+}
+// value of lane `src` (uniform over the wave) on every lane: v_readlane_b32 x2, no LDS crossbar
+__device__ inline double wave_bcast(double v, int src) {
+  int w[2];
+  __builtin_memcpy(w, &v, 8);
+  w[0] = __builtin_amdgcn_readlane(w[0], src);
+  w[1] = __builtin_amdgcn_readlane(w[1], src);
+  double r;
+  __builtin_memcpy(&r, w, 8);
+  return r;
 }
 // index of the largest value (ties to the lower index); lanes without a candidate pass a negative value
 __device__ inline int wave_argmax(double v, int idx) {

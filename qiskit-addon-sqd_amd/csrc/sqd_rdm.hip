@@ -345,9 +345,14 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
     }
   }
   if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
-  // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
+  // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}.  J threads share one result: thread (r, j) adds the
+  // partial records b0 + j, b0 + j + J, ... (eight write-through loads in flight per round -- one thread per result
+  // walked the records in ~2 us rounds, 10 us for 45 workgroups), the J sub-sums are added in order j = 0..J-1.
   const int nres = 3 + 2 * norb + 1;
-  for (int r = threadIdx.x; r < nres; r += blockDim.x) {
+  const int J = (int)blockDim.x / nres < 8 ? (int)blockDim.x / nres : 8;
+  const int r = threadIdx.x / J, j = threadIdx.x % J;
+  double t = 0.0;
+  if (r < nres) {
     int field;
     unsigned b0, b1;
     if (r < 3) {
@@ -367,14 +372,18 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
       b0 = 0;
       b1 = nrb;
     }
-    double t = 0.0;
-    for (unsigned b = b0; b < b1; b += 8) {  // eight partial records in flight per round, added in block order
+    for (unsigned b = b0 + j; b < b1; b += 8 * J) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = coherent_load(&partial[(int64_t)(b + u < b1 ? b + u : b) * OBS_W + field]);
+      for (int u = 0; u < 8; ++u) v[u] = coherent_load(&partial[(int64_t)(b + u * J < b1 ? b + u * J : b) * OBS_W + field]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t += (b + u < b1) ? v[u] : 0.0;
+      for (int u = 0; u < 8; ++u) t += (b + u * J < b1) ? v[u] : 0.0;
     }
+  }
+  red[threadIdx.x] = t;
+  __syncthreads();
+  if (r < nres && j == 0) {
+    for (int k = 1; k < J; ++k) t += red[threadIdx.x + k];
     mail_store(&out[r], t);
   }
 }

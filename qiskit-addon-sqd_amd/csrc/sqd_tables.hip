@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "sqd_common.h"
+#include "sqd_device.h"
 
 namespace sqd {
 
@@ -130,122 +131,6 @@ __global__ void k_pack_eri(const double* __restrict__ eri4, int norb, int nnorb,
   if (p == s && q == r) km[p * norb + q] = v;
 }
 
-// ------------------------------------------------------------------ pair enumeration
-// One wavefront per target string I.  pc = popcount(I ^ J): 2 -> single, 4 -> double.
-__device__ inline void count_links_body(const uint64_t* __restrict__ strs, int64_t n, int64_t* __restrict__ cnt_s,
-                                        int64_t* __restrict__ cnt_d) {
-  const int lane = threadIdx.x & 63;
-  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (I >= n) return;  // whole wave leaves together
-  const uint64_t sI = strs[I];
-  int64_t cs = 0, cd = 0;
-  for (int64_t j0 = 0; j0 < n; j0 += 64) {
-    const int64_t J = j0 + lane;
-    int pc = 0;
-    if (J < n) pc = __popcll(sI ^ strs[J]);
-    cs += __popcll(__ballot(pc == 2));
-    cd += __popcll(__ballot(pc == 4));
-  }
-  if (lane == 0) {
-    cnt_s[I] = cs;
-    cnt_d[I] = cd;
-  }
-}
-
-__device__ inline void fill_links_body(const uint64_t* __restrict__ strs, int64_t n, const int64_t* __restrict__ s_ptr,
-                                       const int64_t* __restrict__ d_ptr, SRec* __restrict__ s_rec,
-                                       uint32_t* __restrict__ s_row, uint32_t* __restrict__ d_src,
-                                       uint32_t* __restrict__ d_row) {
-  const int lane = threadIdx.x & 63;
-  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (I >= n) return;
-  const uint64_t sI = strs[I];
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int64_t ps = s_ptr[I], pd = d_ptr[I];
-  for (int64_t j0 = 0; j0 < n; j0 += 64) {
-    const int64_t J = j0 + lane;
-    int pc = 0;
-    if (J < n) pc = __popcll(sI ^ strs[J]);
-    const unsigned long long ms = __ballot(pc == 2);
-    const unsigned long long md = __ballot(pc == 4);
-    if (pc == 2) {
-      const int64_t pos = ps + __popcll(ms & lt);
-      s_rec[pos].src = (uint32_t)J;
-      s_row[pos] = (uint32_t)I;
-    }
-    if (pc == 4) {
-      const int64_t pos = pd + __popcll(md & lt);
-      d_src[pos] = (uint32_t)J;
-      d_row[pos] = (uint32_t)I;
-    }
-    ps += __popcll(ms);
-    pd += __popcll(md);
-  }
-}
-
-// ------------------------------------------------------------------ link decoration
-// |I> = sign a+_cre a_des |J>;  value = sign * (h[cre,des] + sum_{k in J, k != des} (cre des|kk) - (cre k|k des))
-__device__ inline void decorate_singles_body(const uint64_t* __restrict__ strs, int64_t n_s,
-                                             const uint32_t* __restrict__ s_row, SRec* __restrict__ s_rec,
-                                             double* __restrict__ s_val, const double* __restrict__ h1,
-                                             const double* __restrict__ eri4, int norb) {
-  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= n_s) return;
-  const uint64_t I = strs[s_row[l]];
-  const uint32_t src = s_rec[l].src;
-  const uint64_t J = strs[src];
-  const uint64_t x = I ^ J;
-  const int a = ctz64(x & I);  // created
-  const int b = ctz64(x & J);  // annihilated
-  const int lo = a < b ? a : b, hi = a < b ? b : a;
-  const uint64_t between = below_mask(hi) & ~below_mask(lo + 1);
-  const int neg = __popcll(J & between) & 1;
-  const int64_t n1 = norb, n2 = n1 * norb, n3 = n2 * norb;
-  double v = h1[a * norb + b];
-  uint64_t occ = J & ~(1ull << b);
-  while (occ) {
-    const int k = ctz64(occ);
-    occ &= occ - 1;
-    v += eri4[a * n3 + b * n2 + k * n1 + k] - eri4[a * n3 + k * n2 + k * n1 + b];
-  }
-  s_val[l] = neg ? -v : v;
-  const uint32_t widx = 2u * tril(a, b) + (a > b ? 1u : 0u);
-  s_rec[l].meta = widx | ((uint32_t)a << 13) | ((uint32_t)b << 19) | ((uint32_t)neg << 31);
-}
-
-// |I> = sign a+_p a+_r a_s a_q |J>, p>r, q>s;  value = sign * ((pq|rs) - (ps|rq))
-__device__ inline void decorate_doubles_body(const uint64_t* __restrict__ strs, int64_t n_d,
-                                             const uint32_t* __restrict__ d_row, const uint32_t* __restrict__ d_src,
-                                             uint32_t* __restrict__ d_orb, double* __restrict__ d_val,
-                                             const double* __restrict__ eri4, int norb) {
-  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= n_d) return;
-  const uint64_t I = strs[d_row[l]];
-  const uint64_t J = strs[d_src[l]];
-  const uint64_t x = I ^ J;
-  uint64_t cre = x & I, des = x & J;
-  const int r = ctz64(cre);
-  cre &= cre - 1;
-  const int p = ctz64(cre);
-  const int s = ctz64(des);
-  des &= des - 1;
-  const int q = ctz64(des);
-  // apply a_q, a_s, a+_r, a+_p in that order, collecting parities
-  uint64_t st = J;
-  int par = __popcll(st & below_mask(q));
-  st ^= 1ull << q;
-  par += __popcll(st & below_mask(s));
-  st ^= 1ull << s;
-  par += __popcll(st & below_mask(r));
-  st |= 1ull << r;
-  par += __popcll(st & below_mask(p));
-  const int neg = par & 1;
-  const int64_t n1 = norb, n2 = n1 * norb, n3 = n2 * norb;
-  const double v = eri4[p * n3 + q * n2 + r * n1 + s] - eri4[p * n3 + s * n2 + r * n1 + q];
-  d_val[l] = neg ? -v : v;
-  d_orb[l] = (uint32_t)p | ((uint32_t)r << 6) | ((uint32_t)q << 12) | ((uint32_t)s << 18) | ((uint32_t)neg << 31);
-}
-
 // ------------------------------------------------------------------ per-string tables
 // e_str[I] = sum_{i in I} h_ii + 1/2 sum_{i,j in I} (J_ij - K_ij)
 __device__ inline void string_energy_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ h1,
@@ -297,8 +182,17 @@ __device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n,
   out[idx] = v;
 }
 
-// ---- both spins in one launch (gridDim.y = 2): at the sizes of one subsample batch these kernels run a few
-// microseconds each, less than it costs the host to enqueue one, so halving the launches is what counts
+// ---- set_subspace is FOUR launches (round 1: nine).  At the sizes of one subsample batch every one of these
+// kernels runs 3-6 us, less than it costs the host to enqueue it, so the work is grouped by dependency level and the
+// jobs of one level share a launch through blockIdx.y:
+//   A  k_tables_count : link counts of both spins, per-string mean-field energies of both spins; the workgroup that
+//                       arrives last turns the counts into the four CSR pointer arrays (exclusive scans)
+//      -> one D2H copy of the pointers (the host cuts the sigma work list and the capped-ELL descriptors from them)
+//   B  k_tables_diag  : J tables of both spins, the diagonal (+ per-row minima for pyscf's init guess); needs only
+//                       the strings and the energies, so it runs while the host waits for the copy and cuts the lists
+//   C  k_tables_fill  : link enumeration into the CSR arrays, each link decorated (orbitals, sign, pair index,
+//                       integral value) by the lane that found it
+//   D  k_tables_ell   : merged same-spin CSR (alpha) + the capped sliced-ELL copies (beta)
 struct SpinLinkArgs {
   const uint64_t* strs;
   int64_t n, n_s, n_d;
@@ -314,48 +208,200 @@ struct SpinLinkArgs {
 struct SpinLinkArgs2 {
   SpinLinkArgs a[2];
 };
-__global__ void k_count_links2(const SpinLinkArgs2 p) {
-  const SpinLinkArgs& a = p.a[blockIdx.y];
-  count_links_body(a.strs, a.n, a.cnt_s, a.cnt_d);
-}
-__global__ void k_fill_links2(const SpinLinkArgs2 p) {
-  const SpinLinkArgs& a = p.a[blockIdx.y];
-  fill_links_body(a.strs, a.n, a.s_ptr, a.d_ptr, a.s_rec, a.s_row, a.d_src, a.d_row);
-}
-// singles and doubles of both spins: blockIdx.y = 2 * spin + (0 singles | 1 doubles)
-__global__ void k_decorate_links2(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ eri4,
-                                  int norb) {
-  const SpinLinkArgs& a = p.a[blockIdx.y >> 1];
-  if ((blockIdx.y & 1) == 0)
-    decorate_singles_body(a.strs, a.n_s, a.s_row, a.s_rec, a.s_val, h1, eri4, norb);
-  else
-    decorate_doubles_body(a.strs, a.n_d, a.d_row, a.d_src, a.d_orb, a.d_val, eri4, norb);
-}
-// per-string energies (blockIdx.y = spin) and occupation tables (blockIdx.y = 2 + spin)
-__global__ void k_string_tables2(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ jm,
-                                 const double* __restrict__ km, const double* __restrict__ eri_pp, int norb, int nnorb) {
-  const SpinLinkArgs& a = p.a[blockIdx.y & 1];
-  if (blockIdx.y < 2)
-    string_energy_body(a.strs, a.n, h1, jm, km, norb, a.e_str);
-  else
-    jtable_body(a.strs, a.n, eri_pp, nnorb, a.transposed, a.jtab);
+
+// four independent exclusive scans by ONE workgroup (the last one of k_tables_count), one after the other
+struct ScanJobs {
+  const int64_t* in[4];
+  int64_t* out[4];
+  int64_t n[4];
+};
+__device__ inline void block_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t n, int64_t* sums) {
+  const int T = blockDim.x, tid = threadIdx.x;
+  const int64_t chunk = (n + T - 1) / T;
+  const int64_t lo = (int64_t)tid * chunk;
+  const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += coherent_load_i64(&in[i]);
+  __syncthreads();  // (sums is reused from job to job)
+  sums[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t run = 0;
+    for (int t = 0; t < T; ++t) {
+      const int64_t v = sums[t];
+      sums[t] = run;
+      run += v;
+    }
+    out[n] = run;
+  }
+  __syncthreads();
+  int64_t run = sums[tid];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t v = coherent_load_i64(&in[i]);
+    out[i] = run;
+    run += v;
+  }
 }
 
-// hdiag[A,B] = e_a[A] + e_b[B] + sum_{i in A} JT_b[tril(i,i)][B]
-__global__ void k_hdiag(const uint64_t* __restrict__ strs_a, const double* __restrict__ e_a,
-                        const double* __restrict__ e_b, const double* __restrict__ jT_b, int64_t na, int64_t nb,
-                        double* __restrict__ hdiag) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= na * nb) return;
-  const int64_t A = idx / nb, B = idx - A * nb;
-  uint64_t occ = strs_a[A];
-  double v = e_a[A] + e_b[B];
-  while (occ) {
-    const int i = ctz64(occ);
-    occ &= occ - 1;
-    v += jT_b[((int64_t)i * (i + 1) / 2 + i) * nb + B];
+// A: blockIdx.y = spin (link counts) | 2 + spin (string energies)
+__global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ jm,
+                               const double* __restrict__ km, int norb, const ScanJobs jobs, unsigned* counter) {
+  __shared__ int64_t sums[1024];
+  if (blockIdx.y >= 2) {
+    const SpinLinkArgs& a = p.a[blockIdx.y & 1];
+    string_energy_body(a.strs, a.n, h1, jm, km, norb, a.e_str);
+    return;
   }
-  hdiag[A * nb + B] = v;
+  {
+    const SpinLinkArgs& a = p.a[blockIdx.y];
+    // one wavefront per target string I.  pc = popcount(I ^ J): 2 -> single, 4 -> double.
+    const int lane = threadIdx.x & 63;
+    const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (I < a.n) {
+      const uint64_t sI = a.strs[I];
+      int64_t cs = 0, cd = 0;
+      for (int64_t j0 = 0; j0 < a.n; j0 += 64) {
+        const int64_t J = j0 + lane;
+        int pc = 0;
+        if (J < a.n) pc = __popcll(sI ^ a.strs[J]);
+        cs += __popcll(__ballot(pc == 2));
+        cd += __popcll(__ballot(pc == 4));
+      }
+      if (lane == 0) {
+        coherent_store_i64(&a.cnt_s[I], cs);
+        coherent_store_i64(&a.cnt_d[I], cd);
+      }
+    }
+  }
+  if (!arrive_last(counter, blockIdx.y * gridDim.x + blockIdx.x, 2 * gridDim.x)) return;
+  for (int j = 0; j < 4; ++j) block_exclusive_scan(jobs.in[j], jobs.out[j], jobs.n[j], sums);
+}
+
+// B: blockIdx.y = 0 alpha J table | 1 beta J table (transposed) | 2 the diagonal, one alpha string per workgroup:
+//   hdiag[A,B] = e_a[A] + e_b[B] + sum_{k in B} v_A[k],  v_A[k] = sum_{i in A} (ii|kk)   (pyscf make_hdiag)
+// and the row's lowest element (over B <= A when tril_only: pyscf's init-guess rule for equal spin sectors)
+__global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ jm, const double* __restrict__ eri_pp,
+                              int norb, int nnorb, int64_t na, int64_t nb, int tril_only, double* __restrict__ hdiag,
+                              double* __restrict__ pmin, int64_t* __restrict__ pidx) {
+  __shared__ double v[SQD_MAX_NORB];
+  if (blockIdx.y < 2) {
+    const SpinLinkArgs& a = p.a[blockIdx.y];
+    jtable_body(a.strs, a.n, eri_pp, nnorb, a.transposed, a.jtab);
+    return;
+  }
+  for (int64_t A = blockIdx.x; A < na; A += gridDim.x) {
+    const uint64_t sA = p.a[0].strs[A];
+    __syncthreads();
+    if ((int)threadIdx.x < norb) {
+      uint64_t occ = sA;
+      double t = 0.0;
+      while (occ) {
+        const int i = ctz64(occ);
+        occ &= occ - 1;
+        t += jm[i * norb + threadIdx.x];
+      }
+      v[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const double ea = p.a[0].e_str[A];
+    double best = 1e300;
+    int64_t bi = -1;
+    for (int64_t B = threadIdx.x; B < nb; B += blockDim.x) {
+      uint64_t occ = p.a[1].strs[B];
+      double t = ea + p.a[1].e_str[B];
+      while (occ) {
+        const int k = ctz64(occ);
+        occ &= occ - 1;
+        t += v[k];
+      }
+      hdiag[A * nb + B] = t;
+      if (!(tril_only && A < B) && (t < best || bi < 0)) {  // B ascends: the first minimum wins
+        best = t;
+        bi = A * nb + B;
+      }
+    }
+    block_argmin(best, bi);
+    if (threadIdx.x == 0) {
+      pmin[A] = best;
+      pidx[A] = bi;
+    }
+  }
+}
+
+// C: one wavefront per target string (blockIdx.y = spin): enumerate, compact with ballot + prefix popcount, and let
+// the lane that found a link decorate it
+__global__ void k_tables_fill(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ eri4,
+                              int norb) {
+  const SpinLinkArgs& a = p.a[blockIdx.y];
+  const uint64_t* __restrict__ strs = a.strs;
+  const int64_t n = a.n;
+  const int lane = threadIdx.x & 63;
+  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (I >= n) return;
+  const uint64_t sI = strs[I];
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t n1 = norb, n2 = n1 * norb, n3 = n2 * norb;
+  int64_t ps = a.s_ptr[I], pd = a.d_ptr[I];
+  for (int64_t j0 = 0; j0 < n; j0 += 64) {
+    const int64_t J = j0 + lane;
+    uint64_t sJ = 0;
+    int pc = 0;
+    if (J < n) {
+      sJ = strs[J];
+      pc = __popcll(sI ^ sJ);
+    }
+    const unsigned long long ms = __ballot(pc == 2);
+    const unsigned long long md = __ballot(pc == 4);
+    if (pc == 2) {
+      // |I> = sign a+_cre a_des |J>;  value = sign * (h[cre,des] + sum_{k in J, k != des} (cre des|kk) - (cre k|k des))
+      const int64_t pos = ps + __popcll(ms & lt);
+      const uint64_t x = sI ^ sJ;
+      const int ca = ctz64(x & sI), cb = ctz64(x & sJ);
+      const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+      const uint64_t between = below_mask(hi) & ~below_mask(lo + 1);
+      const int neg = __popcll(sJ & between) & 1;
+      double val = h1[ca * norb + cb];
+      uint64_t occ = sJ & ~(1ull << cb);
+      while (occ) {
+        const int k = ctz64(occ);
+        occ &= occ - 1;
+        val += eri4[ca * n3 + cb * n2 + k * n1 + k] - eri4[ca * n3 + k * n2 + k * n1 + cb];
+      }
+      const uint32_t widx = 2u * tril(ca, cb) + (ca > cb ? 1u : 0u);
+      a.s_rec[pos] = SRec{(uint32_t)J, widx | ((uint32_t)ca << 13) | ((uint32_t)cb << 19) | ((uint32_t)neg << 31)};
+      a.s_row[pos] = (uint32_t)I;
+      a.s_val[pos] = neg ? -val : val;
+    }
+    if (pc == 4) {
+      // |I> = sign a+_p a+_r a_s a_q |J>, p>r, q>s;  value = sign * ((pq|rs) - (ps|rq))
+      const int64_t pos = pd + __popcll(md & lt);
+      const uint64_t x = sI ^ sJ;
+      uint64_t cre = x & sI, des = x & sJ;
+      const int r = ctz64(cre);
+      cre &= cre - 1;
+      const int pp = ctz64(cre);
+      const int s = ctz64(des);
+      des &= des - 1;
+      const int q = ctz64(des);
+      // apply a_q, a_s, a+_r, a+_p in that order, collecting parities
+      uint64_t st = sJ;
+      int par = __popcll(st & below_mask(q));
+      st ^= 1ull << q;
+      par += __popcll(st & below_mask(s));
+      st ^= 1ull << s;
+      par += __popcll(st & below_mask(r));
+      st |= 1ull << r;
+      par += __popcll(st & below_mask(pp));
+      const int neg = par & 1;
+      const double val = eri4[pp * n3 + q * n2 + r * n1 + s] - eri4[pp * n3 + s * n2 + r * n1 + q];
+      a.d_src[pos] = (uint32_t)J;
+      a.d_row[pos] = (uint32_t)I;
+      a.d_val[pos] = neg ? -val : val;
+      a.d_orb[pos] = (uint32_t)pp | ((uint32_t)r << 6) | ((uint32_t)q << 12) | ((uint32_t)s << 18) | ((uint32_t)neg << 31);
+    }
+    ps += __popcll(ms);
+    pd += __popcll(md);
+  }
 }
 
 // ------------------------------------------------------------------ capped sliced ELL (column role)
@@ -368,32 +414,70 @@ __global__ void k_hdiag(const uint64_t* __restrict__ strs_a, const double* __res
 // sliced ELL over the ordered rows: entry (k, lane) of slice b at sl[b] + 64 k + lane.  Descriptors
 // are computed on the host from the CSR pointers (they arrive with the one synchronisation of
 // set_subspace); the fill runs on the device.
-__global__ void k_fill_vell_singles(int64_t nv, const int32_t* __restrict__ vcnt, const int64_t* __restrict__ vstart,
-                                    const int64_t* __restrict__ sl, const SRec* __restrict__ rec,
-                                    const double* __restrict__ val, SRec* __restrict__ erec,
-                                    double* __restrict__ eval) {
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nv) return;
-  const int64_t base = sl[v >> 6] + (v & 63);
-  const int64_t p0 = vstart[v];
-  const int cnt = vcnt[v];
-  for (int k = 0; k < cnt; ++k) {
-    erec[base + (int64_t)k * 64] = rec[p0 + k];
-    eval[base + (int64_t)k * 64] = val[p0 + k];
+struct EllArgs {
+  // merged same-spin CSR of the row role (alpha): row i = its single links (value incl. sign) then its double links
+  int64_t n_a;
+  const int64_t *sa_ptr, *da_ptr;
+  const SRec* sa_rec;
+  const double* sa_val;
+  const uint32_t* da_src;
+  const double* da_val;
+  int64_t* hs_ptr;
+  uint32_t* hs_src;
+  double* hs_val;
+  // capped sliced-ELL copies of the column role (beta)
+  int64_t nv_s, nv_d;
+  const int32_t *vs_cnt, *vd_cnt;
+  const int64_t *vs_start, *vd_start, *es_sl, *ed_sl;
+  const SRec* sb_rec;
+  const double* sb_val;
+  const uint32_t* db_src;
+  const double* db_val;
+  SRec* es_rec;
+  double* es_val;
+  uint32_t* ed_src;
+  double* ed_val;
+};
+// D: blockIdx.y = 0 merged alpha CSR (one wavefront per row: rows of the Hartree-Fock neighbourhood hold hundreds
+// of links) | 1 beta singles' ELL (thread per virtual row) | 2 beta doubles' ELL
+__global__ void k_tables_ell(const EllArgs g) {
+  if (blockIdx.y == 0) {
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i > g.n_a) return;
+    const int64_t o = g.sa_ptr[i] + g.da_ptr[i];
+    if (lane == 0) g.hs_ptr[i] = o;
+    if (i == g.n_a) return;
+    const int64_t s0 = g.sa_ptr[i], ns = g.sa_ptr[i + 1] - s0, d0 = g.da_ptr[i], nd = g.da_ptr[i + 1] - d0;
+    for (int64_t k = lane; k < ns; k += 64) {
+      g.hs_src[o + k] = g.sa_rec[s0 + k].src;
+      g.hs_val[o + k] = g.sa_val[s0 + k];
+    }
+    for (int64_t k = lane; k < nd; k += 64) {
+      g.hs_src[o + ns + k] = g.da_src[d0 + k];
+      g.hs_val[o + ns + k] = g.da_val[d0 + k];
+    }
+    return;
   }
-}
-__global__ void k_fill_vell_doubles(int64_t nv, const int32_t* __restrict__ vcnt, const int64_t* __restrict__ vstart,
-                                    const int64_t* __restrict__ sl, const uint32_t* __restrict__ src,
-                                    const double* __restrict__ val, uint32_t* __restrict__ esrc,
-                                    double* __restrict__ eval) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nv) return;
-  const int64_t base = sl[v >> 6] + (v & 63);
-  const int64_t p0 = vstart[v];
-  const int cnt = vcnt[v];
-  for (int k = 0; k < cnt; ++k) {
-    esrc[base + (int64_t)k * 64] = src[p0 + k];
-    eval[base + (int64_t)k * 64] = val[p0 + k];
+  if (blockIdx.y == 1) {
+    if (v >= g.nv_s) return;
+    const int64_t base = g.es_sl[v >> 6] + (v & 63);
+    const int64_t p0 = g.vs_start[v];
+    const int cnt = g.vs_cnt[v];
+    for (int k = 0; k < cnt; ++k) {
+      g.es_rec[base + (int64_t)k * 64] = g.sb_rec[p0 + k];
+      g.es_val[base + (int64_t)k * 64] = g.sb_val[p0 + k];
+    }
+  } else {
+    if (v >= g.nv_d) return;
+    const int64_t base = g.ed_sl[v >> 6] + (v & 63);
+    const int64_t p0 = g.vd_start[v];
+    const int cnt = g.vd_cnt[v];
+    for (int k = 0; k < cnt; ++k) {
+      g.ed_src[base + (int64_t)k * 64] = g.db_src[p0 + k];
+      g.ed_val[base + (int64_t)k * 64] = g.db_val[p0 + k];
+    }
   }
 }
 
@@ -454,29 +538,6 @@ static void make_vrows(const int64_t* ptr, int64_t n, int cap, int64_t chunk_col
     out.sl[b + 1] = out.sl[b] + 64 * (int64_t)w;
   }
   out.total = out.sl[nsl];
-}
-
-// merged same-spin CSR: row i = its single links (value incl. sign) followed by its double links
-__global__ void k_merge_hs(int64_t n, const int64_t* __restrict__ s_ptr, const int64_t* __restrict__ d_ptr,
-                           const SRec* __restrict__ s_rec, const double* __restrict__ s_val,
-                           const uint32_t* __restrict__ d_src, const double* __restrict__ d_val,
-                           int64_t* __restrict__ hs_ptr, uint32_t* __restrict__ hs_src, double* __restrict__ hs_val) {
-  // one wavefront per row (rows of the Hartree-Fock neighbourhood hold hundreds of links)
-  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i > n) return;
-  const int64_t o = s_ptr[i] + d_ptr[i];
-  if (lane == 0) hs_ptr[i] = o;
-  if (i == n) return;
-  const int64_t s0 = s_ptr[i], ns = s_ptr[i + 1] - s0, d0 = d_ptr[i], nd = d_ptr[i + 1] - d0;
-  for (int64_t k = lane; k < ns; k += 64) {
-    hs_src[o + k] = s_rec[s0 + k].src;
-    hs_val[o + k] = s_val[s0 + k];
-  }
-  for (int64_t k = lane; k < nd; k += 64) {
-    hs_src[o + ns + k] = d_src[d0 + k];
-    hs_val[o + ns + k] = d_val[d0 + k];
-  }
 }
 
 // ------------------------------------------------------------------ sigma work list (host)
@@ -666,43 +727,6 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
   return SQD_OK;
 }
 
-// four independent exclusive scans in one launch (one workgroup each)
-struct ScanJobs {
-  const int64_t* in[4];
-  int64_t* out[4];
-  int64_t n[4];
-};
-__global__ void k_exclusive_scan4(const ScanJobs jobs) {
-  __shared__ int64_t sums[1024];
-  const int64_t* __restrict__ in = jobs.in[blockIdx.x];
-  int64_t* __restrict__ out = jobs.out[blockIdx.x];
-  const int64_t n = jobs.n[blockIdx.x];
-  const int T = blockDim.x, tid = threadIdx.x;
-  const int64_t chunk = (n + T - 1) / T;
-  const int64_t lo = (int64_t)tid * chunk;
-  const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += in[i];
-  sums[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t run = 0;
-    for (int t = 0; t < T; ++t) {
-      const int64_t v = sums[t];
-      sums[t] = run;
-      run += v;
-    }
-    out[n] = run;
-  }
-  __syncthreads();
-  int64_t run = sums[tid];
-  for (int64_t i = lo; i < hi; ++i) {
-    const int64_t v = in[i];
-    out[i] = run;
-    run += v;
-  }
-}
-
 int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb) {
   c->have_subspace = false;
   c->have_solution = false;
@@ -714,20 +738,29 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   SQD_TRY(stage_reset(c));
   SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
 
-  const uint64_t* hs[2] = {sa, sb};
   const int64_t ns[2] = {na, nb};
   int64_t maxn = na > nb ? na : nb;
   SQD_TRY(c->scratch.reserve((size_t)(4 * maxn + 4 * (maxn / 64 + 2) + 64) * 8));
+  SQD_TRY(reserve_counters(c));
+  // both string lists in one device buffer: one staged upload
+  SQD_TRY(c->strs2.reserve((size_t)(na + nb) * 8));
+  {
+    void* h = nullptr;
+    SQD_TRY(stage_alloc(c, (size_t)(na + nb) * 8, &h));
+    std::memcpy(h, sa, (size_t)na * 8);
+    std::memcpy(static_cast<char*>(h) + (size_t)na * 8, sb, (size_t)nb * 8);
+    SQD_HIP_CHECK(hipMemcpyAsync(c->strs2.p, h, (size_t)(na + nb) * 8, hipMemcpyHostToDevice, st));
+  }
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     t.n = ns[s];
     t.nocc = nocc[s];
     t.n_slices = (t.n + 63) / 64;
-    SQD_TRY(t.strs.reserve(t.n * 8));
-    SQD_TRY(stage_upload(c, t.strs.p, hs[s], (size_t)t.n * 8));
+    t.strs.set_view(c->strs2.as<uint64_t>() + (s ? na : 0));
+    SQD_TRY(t.e_str.reserve(t.n * 8));
   }
-  // pass 1: counts + CSR pointers for both spins, one host sync for the totals
-  // all four CSR pointer arrays live in one device buffer so that ONE copy brings them (and with them
+  // launch A: counts + CSR pointers for both spins (+ per-string energies), one host sync for the totals.
+  // All four CSR pointer arrays live in one device buffer so that ONE copy brings them (and with them
   // every total the host needs) back: the sigma work list (alpha) and the capped-ELL geometry (beta)
   // are cut on the host from these pointers
   const int64_t nptr = 2 * (na + 1) + 2 * (nb + 1);
@@ -754,7 +787,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       la.a[s].cnt_d = cnt_d;
       la.a[s].s_ptr = t.s_ptr.as<int64_t>();
       la.a[s].d_ptr = t.d_ptr.as<int64_t>();
-      if (s == 1) hipLaunchKernelGGL(k_count_links2, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la);
+      la.a[s].e_str = t.e_str.as<double>();
       jobs.in[2 * s] = cnt_s;
       jobs.out[2 * s] = t.s_ptr.as<int64_t>();
       jobs.n[2 * s] = t.n;
@@ -762,33 +795,33 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
       jobs.n[2 * s + 1] = t.n;
     }
-    hipLaunchKernelGGL(k_exclusive_scan4, dim3(4), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(k_tables_count, dim3(nblk(maxn, 4), 4), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
+                       (const double*)c->jm.as<double>(), (const double*)c->km.as<double>(), norb, jobs, counter_ptr(c));
     SQD_HIP_CHECK(hipGetLastError());
   }
   void* h_ptrs = nullptr;  // pinned: the copy is asynchronous, the host waits on the event below
   SQD_TRY(stage_alloc(c, (size_t)nptr * 8, &h_ptrs));
   SQD_HIP_CHECK(hipMemcpyAsync(h_ptrs, c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipEventRecord(c->ev_aux, st));
-  // everything that needs only the strings is queued BEHIND the copy and runs while the host waits for the
-  // pointers and cuts the work lists: per-string energies, occupation tables, the diagonal
+  // launch B -- everything else that needs only the strings -- is queued BEHIND the copy and runs while the
+  // host waits for the pointers and cuts the work lists: occupation (J) tables, the diagonal, the row minima
   SQD_TRY(c->hdiag.reserve((size_t)na * nb * 8));
+  SQD_TRY(c->guess_min.reserve((size_t)na * 16));
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
-    SQD_TRY(t.e_str.reserve(t.n * 8));
     DevBuf& jt = (s == 0) ? t.jrow : t.jT;  // alpha: J[I][pair] (row role); beta: transposed (column role)
     SQD_TRY(jt.reserve(t.n * nnorb * 8));
-    la.a[s].e_str = t.e_str.as<double>();
     la.a[s].jtab = jt.as<double>();
     la.a[s].transposed = s;
   }
   {
-    const unsigned gx_e = nblk(maxn, 4), gx_j = nblk(maxn * nnorb, 256);
-    hipLaunchKernelGGL(k_string_tables2, dim3(gx_e > gx_j ? gx_e : gx_j, 4), dim3(256), 0, st, la, c->h1.as<double>(),
-                       c->jm.as<double>(), c->km.as<double>(), c->eri_pp.as<double>(), norb, nnorb);
+    const int64_t gx_j = (int64_t)nblk(maxn * nnorb, 256), gx_h = na < 65535 ? na : 65535;
+    const int tril_only = (nocc[0] == nocc[1] && na == nb) ? 1 : 0;
+    double* pmin = c->guess_min.as<double>();
+    hipLaunchKernelGGL(k_tables_diag, dim3((unsigned)(gx_j > gx_h ? gx_j : gx_h), 3), dim3(256), 0, st, la,
+                       (const double*)c->jm.as<double>(), (const double*)c->eri_pp.as<double>(), norb, nnorb, na, nb,
+                       tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + na));
   }
-  hipLaunchKernelGGL(k_hdiag, dim3(nblk(na * nb, 256)), dim3(256), 0, st, c->sp[0].strs.as<uint64_t>(),
-                     c->sp[0].e_str.as<double>(), c->sp[1].e_str.as<double>(), c->sp[1].jT.as<double>(), na, nb,
-                     c->hdiag.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
   SQD_HIP_CHECK(hipEventSynchronize(c->ev_aux));
   c->h_sptr = static_cast<const int64_t*>(h_ptrs);
@@ -796,7 +829,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   c->h_sptr_b = c->h_dptr + (na + 1);
   c->h_dptr_b = c->h_sptr_b + (nb + 1);
   const int64_t tot[4] = {c->h_sptr[na], c->h_dptr[na], c->h_sptr_b[nb], c->h_dptr_b[nb]};
-  // pass 2: fill + decorate
+  // launch C: fill + decorate
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     t.n_s = tot[2 * s];
@@ -822,23 +855,16 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     int64_t maxl = 0;
     for (int64_t v : tot) maxl = v > maxl ? v : maxl;
     if (maxl > 0) {
-      hipLaunchKernelGGL(k_fill_links2, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la);
-      hipLaunchKernelGGL(k_decorate_links2, dim3(nblk(maxl, 256), 4), dim3(256), 0, st, la, c->h1.as<double>(),
-                         c->eri4.as<double>(), norb);
+      hipLaunchKernelGGL(k_tables_fill, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
+                         (const double*)c->eri4.as<double>(), norb);
+      SQD_HIP_CHECK(hipGetLastError());
     }
   }
-  for (int s = 0; s < 2; ++s) {
-    SpinTables& t = c->sp[s];
-    if (s == 0) {
-      // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY work items
-      SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
-      SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
-      SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
-      hipLaunchKernelGGL(k_merge_hs, dim3(nblk(t.n + 1, 4)), dim3(256), 0, st, t.n, t.s_ptr.as<int64_t>(),
-                         t.d_ptr.as<int64_t>(), t.s_rec.as<SRec>(), t.s_val.as<double>(), t.d_src.as<uint32_t>(),
-                         t.d_val.as<double>(), t.hs_ptr.as<int64_t>(), t.hs_src.as<uint32_t>(), t.hs_val.as<double>());
-    }
-    SQD_HIP_CHECK(hipGetLastError());
+  {
+    SpinTables& t = c->sp[0];  // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY items
+    SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
+    SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
+    SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
   }
   // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
   {
@@ -960,16 +986,41 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
     SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
     SQD_TRY(t.ed_val.reserve((size_t)vd.total * 8 + 8));
-    if (t.n_s > 0)
-      hipLaunchKernelGGL(k_fill_vell_singles, dim3(nblk(vs.nv, 256)), dim3(256), 0, st, vs.nv,
-                         (const int32_t*)t.vs_cnt.as<int32_t>(), (const int64_t*)t.vs_start.as<int64_t>(),
-                         (const int64_t*)t.es_sl.as<int64_t>(), (const SRec*)t.s_rec.as<SRec>(),
-                         (const double*)t.s_val.as<double>(), t.es_rec.as<SRec>(), t.es_val.as<double>());
-    if (t.n_d > 0)
-      hipLaunchKernelGGL(k_fill_vell_doubles, dim3(nblk(vd.nv, 256)), dim3(256), 0, st, vd.nv,
-                         (const int32_t*)t.vd_cnt.as<int32_t>(), (const int64_t*)t.vd_start.as<int64_t>(),
-                         (const int64_t*)t.ed_sl.as<int64_t>(), (const uint32_t*)t.d_src.as<uint32_t>(),
-                         (const double*)t.d_val.as<double>(), t.ed_src.as<uint32_t>(), t.ed_val.as<double>());
+    {
+      // launch D: merged alpha CSR + both capped-ELL copies
+      const SpinTables& ta = c->sp[0];
+      EllArgs g;
+      g.n_a = ta.n;
+      g.sa_ptr = ta.s_ptr.as<int64_t>();
+      g.da_ptr = ta.d_ptr.as<int64_t>();
+      g.sa_rec = ta.s_rec.as<SRec>();
+      g.sa_val = ta.s_val.as<double>();
+      g.da_src = ta.d_src.as<uint32_t>();
+      g.da_val = ta.d_val.as<double>();
+      g.hs_ptr = ta.hs_ptr.as<int64_t>();
+      g.hs_src = ta.hs_src.as<uint32_t>();
+      g.hs_val = ta.hs_val.as<double>();
+      g.nv_s = t.n_s > 0 ? vs.nv : 0;
+      g.nv_d = t.n_d > 0 ? vd.nv : 0;
+      g.vs_cnt = t.vs_cnt.as<int32_t>();
+      g.vd_cnt = t.vd_cnt.as<int32_t>();
+      g.vs_start = t.vs_start.as<int64_t>();
+      g.vd_start = t.vd_start.as<int64_t>();
+      g.es_sl = t.es_sl.as<int64_t>();
+      g.ed_sl = t.ed_sl.as<int64_t>();
+      g.sb_rec = t.s_rec.as<SRec>();
+      g.sb_val = t.s_val.as<double>();
+      g.db_src = t.d_src.as<uint32_t>();
+      g.db_val = t.d_val.as<double>();
+      g.es_rec = t.es_rec.as<SRec>();
+      g.es_val = t.es_val.as<double>();
+      g.ed_src = t.ed_src.as<uint32_t>();
+      g.ed_val = t.ed_val.as<double>();
+      const unsigned gx_m = nblk(ta.n + 1, 4), gx_s = nblk(g.nv_s, 256), gx_d = nblk(g.nv_d, 256);
+      unsigned gx = gx_m > gx_s ? gx_m : gx_s;
+      gx = gx > gx_d ? gx : gx_d;
+      hipLaunchKernelGGL(k_tables_ell, dim3(gx, 3), dim3(256), 0, st, g);
+    }
     SQD_HIP_CHECK(hipGetLastError());
   }
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily

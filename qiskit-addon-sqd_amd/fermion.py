@@ -41,8 +41,8 @@ _HASH_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of an integr
 
 
 def _full_hash(arr: np.ndarray) -> int:
-    """Hash of EVERY byte of an integral array, memoised by the array's identity (data pointer, size, strides, a
-    sampled CRC as a cheap guard against in-place edits).  The SQD loop passes the same tensor objects on every
+    """Hash of EVERY byte of an integral array, memoised by the array's identity (data pointer, size, a 64-value
+    strided sample as a cheap guard against in-place edits).  The SQD loop passes the same tensor objects on every
     call, so the full pass (xxh3, ~1 ms for norb = 30) is paid once per tensor, not once per solve; the memo
     keeps a reference to the array so that its address cannot be recycled by another array while it is cached.
     Two tensors that differ anywhere get different hashes, hence different contexts."""
@@ -50,12 +50,10 @@ def _full_hash(arr: np.ndarray) -> int:
     if not a.flags.c_contiguous or a.dtype != np.float64:
         a = np.ascontiguousarray(a, dtype=np.float64)
     flat = a.reshape(-1)
-    step = max(1, flat.size // 1024)
-    ident = (a.ctypes.data, a.size, zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes()))
+    ident = (a.__array_interface__["data"][0], a.size, flat[:: max(1, flat.size // 64)].tobytes())
     with _HASH_LOCK:
         hit = _HASH_MEMO.get(ident)
         if hit is not None:
-            _HASH_MEMO.move_to_end(ident)
             return hit[1]
     try:
         import xxhash
@@ -71,8 +69,7 @@ def _full_hash(arr: np.ndarray) -> int:
 
 
 def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
-    h = np.ascontiguousarray(hcore, dtype=np.float64)
-    return (device, h.shape[0], int(np.asarray(eri).size), zlib.crc32(h.tobytes()), _full_hash(eri))
+    return (device, int(np.asarray(hcore).shape[0]), int(np.asarray(eri).size), _full_hash(hcore), _full_hash(eri))
 
 
 def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int = 0) -> _capi.Context:
@@ -242,10 +239,22 @@ def _popcounts(strs) -> np.ndarray:
     return np.bitwise_count(arr.astype(np.uint64)).astype(np.int64)
 
 
+def _sorted_unique_int(a) -> bool:
+    a = np.asarray(a)
+    return a.ndim == 1 and a.dtype.kind in "iu" and a.size > 0 and bool((a[1:] > a[:-1]).all()) and a[0] >= 0
+
+
 def _check_ci_strs(ci_strs: tuple[np.ndarray, np.ndarray]) -> tuple[np.ndarray, np.ndarray]:
     """Make sure the hamming weight is consistent in all determinants (``fermion.py:1075-1097``;
     same error text, vectorised popcount instead of a Python loop over every string)."""
     addr_up, addr_dn = ci_strs
+    if _sorted_unique_int(addr_up) and _sorted_unique_int(addr_dn):
+        # already what np.sort(np.unique(.)) would return: only the Hamming weights remain to be checked
+        up, dn = np.asarray(addr_up), np.asarray(addr_dn)
+        hu, hd = np.bitwise_count(up.view(np.uint64) if up.dtype == np.int64 else up.astype(np.uint64)), \
+            np.bitwise_count(dn.view(np.uint64) if dn.dtype == np.int64 else dn.astype(np.uint64))
+        if (hu == hu[0]).all() and (hd == hd[0]).all():
+            return up, dn
     for name, addr in (("Spin-up", addr_up), ("Spin-down", addr_dn)):
         ham = _popcounts(addr)
         bad = np.nonzero(ham != ham[0])[0]
@@ -299,15 +308,15 @@ def last_solve_stats() -> dict | None:
 def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True, spin_square=True):
     """Shared core: tables -> Davidson (-> energy, <S^2>, occupancies in the same native call), all on the
     device.  Returns (amps, stats, obs) with obs = (energy, spin_square, occ_a, occ_b) or None."""
-    ctx.set_subspace(ci_strs[0], ci_strs[1])
     dk = _davidson_kwargs(kwargs)
     ci0 = dk.pop("ci0", None)
     if _PROFILE["time_sigma_every"]:
         dk["time_sigma_every"] = _PROFILE["time_sigma_every"]
-    if observables:
-        out = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, observables=True, spin_square=spin_square, **dk)
+    if observables:  # tables + Davidson + observables: one native call
+        out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square, **dk)
         _TLS.stats = out[1]
         return out
+    ctx.set_subspace(ci_strs[0], ci_strs[1])
     amps, stats = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, **dk)
     _TLS.stats = stats
     return amps, stats, None
