@@ -18,6 +18,7 @@
  */
 #ifndef SQD_HIP_H
 #define SQD_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -39,6 +40,12 @@ typedef struct sqd_ctx sqd_ctx;
 int sqd_abi_version(void);
 const char* sqd_last_error(void);
 int sqd_device_count(int* count);
+
+/* Page-locked host memory for result buffers (hipHostMalloc / hipHostFree).  An `amps` buffer obtained here is
+ * filled by the DMA engine directly (sqd_solve, sqd_solve_strings); any other pointer goes through an internal pinned
+ * staging buffer and a host copy.  No counterpart in the reference (pyscf returns numpy arrays it allocates itself). */
+int sqd_host_alloc(size_t bytes, void** out);
+int sqd_host_free(void* p);
 
 /* Create a solver context on `device` holding the Hamiltonian integrals.
  * Replaces: pyscf SelectedCI() construction + direct_spin1.absorb_h1e + ao2mo.restore

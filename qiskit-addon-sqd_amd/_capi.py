@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -21,6 +22,8 @@ EXPORTED_SYMBOLS = (
     "sqd_abi_version",
     "sqd_last_error",
     "sqd_device_count",
+    "sqd_host_alloc",
+    "sqd_host_free",
     "sqd_ctx_create",
     "sqd_ctx_destroy",
     "sqd_ctx_use_stream",
@@ -99,6 +102,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_abi_version.restype = C.c_int
     lib.sqd_last_error.restype = C.c_char_p
     lib.sqd_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.sqd_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.sqd_host_free.argtypes = [C.c_void_p]
     lib.sqd_ctx_create.argtypes = [C.c_int, C.c_int, _dp, _dp, C.POINTER(_ctxp)]
     lib.sqd_ctx_destroy.argtypes = [_ctxp]
     lib.sqd_ctx_use_stream.argtypes = [_ctxp, C.c_void_p]
@@ -166,6 +171,54 @@ def load_library() -> C.CDLL:
         raise SQDNativeError(f"failed to load {LIB_PATH}: {exc}") from exc
     _LIB = bind(lib)
     return _LIB
+
+
+class _PinnedPool:
+    """Result arrays backed by page-locked host memory (``sqd_host_alloc``), recycled when the numpy array that wraps a
+    block is garbage collected.  The DMA engine writes the amplitudes of a solve straight into such an array; an
+    ordinary ``np.empty`` of 0.8 MB costs a staging copy plus a fresh mmap with ~200 first-touch page faults per solve."""
+
+    def __init__(self):
+        import threading
+
+        self._lock = threading.Lock()
+        self._free: dict[int, list[int]] = {}
+
+    def empty(self, shape) -> np.ndarray:
+        n = int(np.prod(shape))
+        nbytes = max(8 * n, 8)
+        size = 1 << max(12, (nbytes - 1).bit_length())  # power-of-two size classes
+        with self._lock:
+            blocks = self._free.get(size)
+            ptr = blocks.pop() if blocks else None
+        if ptr is None:
+            out = C.c_void_p()
+            rc = load_library().sqd_host_alloc(size, C.byref(out))
+            if rc != 0 or not out.value:
+                return np.empty(shape)  # page-locked memory exhausted: a plain array still works (staged copy)
+            ptr = out.value
+        buf = (C.c_double * n).from_address(ptr)
+        fin = weakref.finalize(buf, self._release, ptr, size)
+        fin.atexit = False  # at interpreter exit the process' memory goes away anyway; no HIP calls during teardown
+        return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+
+    def _release(self, ptr, size):
+        with self._lock:
+            blocks = self._free.setdefault(size, [])
+            if len(blocks) < 64:  # keep up to 64 blocks of a size class for reuse
+                blocks.append(ptr)
+                return
+        lib = _LIB
+        if lib is not None:
+            lib.sqd_host_free(C.c_void_p(ptr))
+
+
+_PINNED = _PinnedPool()
+
+
+def pinned_empty(shape) -> np.ndarray:
+    """Uninitialised float64 array in page-locked host memory (falls back to ``np.empty``)."""
+    return _PINNED.empty(shape)
 
 
 def _as_f64(a, shape=None) -> np.ndarray:
@@ -337,7 +390,7 @@ class Context:
         if spin_sq is not None:
             opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
         stats = DavidsonStats()
-        amps = np.empty((self.na, self.nb)) if fetch else None
+        amps = pinned_empty((self.na, self.nb)) if fetch else None
         ci0p = None
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(self.na, self.nb)
@@ -374,7 +427,7 @@ class Context:
         if spin_sq is not None:
             opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
         stats = DavidsonStats()
-        amps = np.empty((a.size, b.size))
+        amps = pinned_empty((a.size, b.size))
         ci0p = None
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(a.size, b.size)

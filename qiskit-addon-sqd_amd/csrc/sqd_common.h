@@ -28,6 +28,17 @@ void set_error(const std::string& msg);
     if (_rc != SQD_OK) return _rc; \
   } while (0)
 
+// ---- host waits.  hipStreamSynchronize / hipEventSynchronize go to sleep on an interrupt inside the runtime; on this
+// stack about one wait in a thousand then wakes up ~50 ms late (profiles/r02/jitter_probe.txt: two of 200 identical
+// 0.3 ms solves took 54 ms; round 1 saw the same "40-60 ms stall, cause not found" in its concurrency probe).  The
+// solves here are sub-millisecond, so the host polls instead (hipStreamQuery / hipEventQuery never block) and only
+// falls back to the blocking call after two seconds.
+int spin_stream_sync(hipStream_t s);
+// wait until a device-written sequence word in host-visible memory reaches `seq` (falls back to a stream sync)
+int spin_wait_word(const void* word, long long seq, hipStream_t s);
+int spin_event_sync(hipEvent_t e);
+#define SQD_STREAM_SYNC(s) SQD_TRY(sqd::spin_stream_sync(s))
+
 // ---- grow-only device buffer (arena semantics: reused across set_subspace calls) ----
 struct DevBuf {
   void* p = nullptr;
@@ -148,8 +159,14 @@ struct sqd_ctx {
   std::vector<void*> stage_blocks;
   char* stage_cur = nullptr;
   size_t stage_cap = 0, stage_off = 0, stage_total = 0;
-  bool stage_pending = false;
+  bool stage_pending = false;   // uploads of the last set_subspace may still read the arena (cleared by any full sync)
+  bool want_timing = false;     // record the set_subspace / Davidson timing events (costs stream bubbles: off unless asked)
   sqd::DevBuf ptrs;                 // [s_ptr_a | d_ptr_a | s_ptr_b | d_ptr_b]; SpinTables::s_ptr/d_ptr are views
+  // host-visible (mapped, coherent) twin of `ptrs`: the scan writes every pointer to both, so the host reads them
+  // without a copy command or an event; grow-only
+  int64_t* h_ptrs_map = nullptr;
+  int64_t* d_ptrs_map = nullptr;
+  size_t ptrs_map_cap = 0;
   // (the host copy of the same lives in the pinned staging arena; h_sptr.. point into it)
   const int64_t *h_sptr = nullptr, *h_dptr = nullptr, *h_sptr_b = nullptr, *h_dptr_b = nullptr;
   std::vector<sqd::WorkItem> h_items;
@@ -195,6 +212,7 @@ struct sqd_ctx {
   hipEvent_t ev_aux = nullptr;  // set_subspace: "CSR pointers are on the host" (later kernels keep running)
   double* h_amps = nullptr;
   size_t h_amps_cap = 0;
+  bool dav_timed = false;  // the latest Davidson run recorded its start / end events
   int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)
 };
 

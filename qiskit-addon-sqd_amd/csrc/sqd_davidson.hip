@@ -772,25 +772,7 @@ __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stri
 
 // host side of a mailbox post: wait for sequence word `seq` in mailbox slot `slot`
 static int wait_mail(sqd_ctx* c, int slot, long long seq) {
-  const double* mail = c->h_mail + (size_t)slot * MAIL_SLOT;
-  volatile const long long* flag = reinterpret_cast<volatile const long long*>(mail);
-  bool seen = false;
-  for (long spin = 0; spin < 20000000L; ++spin) {
-    if (*flag >= seq) {  // sequence numbers only grow on a context: a later post implies this one
-      seen = true;
-      break;
-    }
-    __builtin_ia32_pause();
-  }
-  if (!seen) {  // fall back to a plain synchronisation (also surfaces asynchronous kernel errors)
-    SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*flag < seq) {
-      set_error("device mailbox was not written");
-      return SQD_ERR_HIP;
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  return SQD_OK;
+  return spin_wait_word(c->h_mail + (size_t)slot * MAIL_SLOT, seq, c->stream);
 }
 
 // sums[0..nv) = column sums of the device partial array; c->h_pinned[0..2) = scal[0..2).
@@ -891,7 +873,8 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   unsigned* counter = counter_ptr(c);
   DavState* dst = state_ptr_dev(c);
 
-  SQD_HIP_CHECK(hipEventRecord(c->ev[2], s));
+  const bool timing = c->want_timing;
+  if (timing) SQD_HIP_CHECK(hipEventRecord(c->ev[2], s));
   // ---- initial vector + state block
   // (a user vector is not normalised on the device: the first fused reduction measures |X_0|^2 and the
   // factor is carried in sv like that of every later basis vector)
@@ -1001,12 +984,13 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
                      c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
+  if (timing) SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
+  c->dav_timed = timing;
   c->have_solution = true;
   c->dav_nev = nev;
   if (st) std::memset(st, 0, sizeof(*st));
   if (defer_sync) return SQD_OK;
-  SQD_HIP_CHECK(hipStreamSynchronize(s));
+  SQD_STREAM_SYNC(s);
   return davidson_collect(c, st);
 }
 
@@ -1020,7 +1004,7 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st) {
     return SQD_ERR_INVALID;
   }
   float ms = 0.f;
-  SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+  if (c->dav_timed) SQD_HIP_CHECK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
   if (c->ms_setup < 0.0) {
     float tms = 0.f;
     SQD_HIP_CHECK(hipEventElapsedTime(&tms, c->ev[0], c->ev[1]));

@@ -251,7 +251,7 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
   }
   SQD_HIP_CHECK(hipMemcpyAsync(dm1a, dm, n2 * 8, hipMemcpyDeviceToHost, st));
   SQD_HIP_CHECK(hipMemcpyAsync(dm1b, dm + n2, n2 * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  SQD_STREAM_SYNC(st);
   return SQD_OK;
 }
 
@@ -392,7 +392,7 @@ constexpr int OBS_MAIL = 3 * 128;  // doubles into the host-visible mailbox (slo
 
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
   SQD_TRY(dev_observables_enqueue(c, d_c));
-  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  SQD_STREAM_SYNC(c->stream);
   dev_observables_collect(c, out_host);
   return SQD_OK;
 }
@@ -486,7 +486,7 @@ static int rdm2_impl(sqd_ctx* c, const double* d_c, bool resolved, double* const
     SQD_HIP_CHECK(hipMemcpyAsync(out[1], G, n4 * 8, hipMemcpyDeviceToHost, st));
     SQD_HIP_CHECK(hipMemcpyAsync(out[2], same[1], n4 * 8, hipMemcpyDeviceToHost, st));
   }
-  SQD_HIP_CHECK(hipStreamSynchronize(st));
+  SQD_STREAM_SYNC(st);
   return SQD_OK;
 }
 

@@ -66,8 +66,8 @@ void SpinTables::release() {
 
 // ---- pinned staging arena (see sqd_ctx::stage_*)
 static int stage_reset(sqd_ctx* c) {
-  if (c->stage_pending) {  // copies of the previous set_subspace still read the arena
-    SQD_HIP_CHECK(hipEventSynchronize(c->ev[1]));
+  if (c->stage_pending) {  // copies of the previous set_subspace may still read the arena (no full sync since)
+    SQD_STREAM_SYNC(c->stream);
     c->stage_pending = false;
   }
   if (c->stage_blocks.size() > 1) {  // grew last time: one block of the total size from now on
@@ -209,44 +209,48 @@ struct SpinLinkArgs2 {
   SpinLinkArgs a[2];
 };
 
-// four independent exclusive scans by ONE workgroup (the last one of k_tables_count), one after the other
+// four independent exclusive scans by the LAST workgroup of k_tables_count, one wavefront each (256 threads = 4
+// wavefronts; the first version ran them one after the other through a serial LDS prefix: 15 us).  Every pointer is
+// written twice: to the device array the later kernels read and to its host-visible twin, so that the host -- which
+// cuts the sigma work list and the ELL descriptors from them -- needs no copy command and no event.
 struct ScanJobs {
   const int64_t* in[4];
   int64_t* out[4];
+  int64_t* host[4];
   int64_t n[4];
+  long long* seq_word;  // host-visible: written last
+  long long seq;
 };
-__device__ inline void block_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t n, int64_t* sums) {
-  const int T = blockDim.x, tid = threadIdx.x;
-  const int64_t chunk = (n + T - 1) / T;
-  const int64_t lo = (int64_t)tid * chunk;
+__device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t* host, int64_t n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (n + 63) / 64;
+  const int64_t lo = (int64_t)lane * chunk;
   const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
   int64_t s = 0;
   for (int64_t i = lo; i < hi; ++i) s += coherent_load_i64(&in[i]);
-  __syncthreads();  // (sums is reused from job to job)
-  sums[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t run = 0;
-    for (int t = 0; t < T; ++t) {
-      const int64_t v = sums[t];
-      sums[t] = run;
-      run += v;
-    }
-    out[n] = run;
+  // inclusive prefix over the lanes (Hillis-Steele on shuffles), then exclusive
+  int64_t incl = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t o = (int64_t)__shfl((long long)incl, lane - off >= 0 ? lane - off : lane);
+    if (lane >= off) incl += o;
   }
-  __syncthreads();
-  int64_t run = sums[tid];
+  int64_t run = incl - s;
+  const int64_t total = (int64_t)__shfl((long long)incl, 63);
   for (int64_t i = lo; i < hi; ++i) {
     const int64_t v = coherent_load_i64(&in[i]);
     out[i] = run;
+    __hip_atomic_store(&host[i], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     run += v;
+  }
+  if (lane == 0) {
+    out[n] = total;
+    __hip_atomic_store(&host[n], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // A: blockIdx.y = spin (link counts) | 2 + spin (string energies)
 __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ jm,
                                const double* __restrict__ km, int norb, const ScanJobs jobs, unsigned* counter) {
-  __shared__ int64_t sums[1024];
   if (blockIdx.y >= 2) {
     const SpinLinkArgs& a = p.a[blockIdx.y & 1];
     string_energy_body(a.strs, a.n, h1, jm, km, norb, a.e_str);
@@ -274,7 +278,16 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
     }
   }
   if (!arrive_last(counter, blockIdx.y * gridDim.x + blockIdx.x, 2 * gridDim.x)) return;
-  for (int j = 0; j < 4; ++j) block_exclusive_scan(jobs.in[j], jobs.out[j], jobs.n[j], sums);
+  {
+    const int j = threadIdx.x >> 6;  // blockDim.x == 256: one wavefront per scan
+    wave_exclusive_scan(jobs.in[j], jobs.out[j], jobs.host[j], jobs.n[j]);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *reinterpret_cast<volatile long long*>(jobs.seq_word) = jobs.seq;
+  }
 }
 
 // B: blockIdx.y = 0 alpha J table | 1 beta J table (transposed) | 2 the diagonal, one alpha string per workgroup:
@@ -693,7 +706,7 @@ int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri) {
   hipLaunchKernelGGL(k_pack_eri, dim3(nblk(n4, 256)), dim3(256), 0, c->stream, c->eri4.as<double>(), norb, nnorb,
                      c->eri_pp.as<double>(), c->jm.as<double>(), c->km.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipStreamSynchronize(c->stream));
+  SQD_STREAM_SYNC(c->stream);
   return SQD_OK;
 }
 
@@ -736,7 +749,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   const int norb = c->norb, nnorb = c->nnorb;
   hipStream_t st = c->stream;
   SQD_TRY(stage_reset(c));
-  SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
+  if (c->want_timing) SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
 
   const int64_t ns[2] = {na, nb};
   int64_t maxn = na > nb ? na : nb;
@@ -765,6 +778,16 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   // are cut on the host from these pointers
   const int64_t nptr = 2 * (na + 1) + 2 * (nb + 1);
   SQD_TRY(c->ptrs.reserve((size_t)nptr * 8));
+  if (c->ptrs_map_cap < (size_t)nptr) {  // host-visible twin of the pointer block (grow-only)
+    if (c->h_ptrs_map) SQD_HIP_CHECK(hipHostFree(c->h_ptrs_map));
+    c->h_ptrs_map = nullptr;
+    c->ptrs_map_cap = 0;
+    const size_t want = (size_t)nptr + (size_t)nptr / 4 + 64;
+    SQD_HIP_CHECK(hipHostMalloc((void**)&c->h_ptrs_map, want * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    SQD_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_ptrs_map, c->h_ptrs_map, 0));
+    c->ptrs_map_cap = want;
+  }
+  long long seq_ptrs = 0;
   {
     int64_t* base = c->ptrs.as<int64_t>();
     c->sp[0].s_ptr.set_view(base);
@@ -790,19 +813,20 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       la.a[s].e_str = t.e_str.as<double>();
       jobs.in[2 * s] = cnt_s;
       jobs.out[2 * s] = t.s_ptr.as<int64_t>();
+      jobs.host[2 * s] = c->d_ptrs_map + (jobs.out[2 * s] - c->ptrs.as<int64_t>());
       jobs.n[2 * s] = t.n;
       jobs.in[2 * s + 1] = cnt_d;
       jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
+      jobs.host[2 * s + 1] = c->d_ptrs_map + (jobs.out[2 * s + 1] - c->ptrs.as<int64_t>());
       jobs.n[2 * s + 1] = t.n;
     }
+    jobs.seq = ++c->mail_seq;
+    jobs.seq_word = reinterpret_cast<long long*>(c->d_mail + 3 * 128 + 256);  // its own word of the mailbox page
+    seq_ptrs = jobs.seq;
     hipLaunchKernelGGL(k_tables_count, dim3(nblk(maxn, 4), 4), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
                        (const double*)c->jm.as<double>(), (const double*)c->km.as<double>(), norb, jobs, counter_ptr(c));
     SQD_HIP_CHECK(hipGetLastError());
   }
-  void* h_ptrs = nullptr;  // pinned: the copy is asynchronous, the host waits on the event below
-  SQD_TRY(stage_alloc(c, (size_t)nptr * 8, &h_ptrs));
-  SQD_HIP_CHECK(hipMemcpyAsync(h_ptrs, c->ptrs.p, (size_t)nptr * 8, hipMemcpyDeviceToHost, st));
-  SQD_HIP_CHECK(hipEventRecord(c->ev_aux, st));
   // launch B -- everything else that needs only the strings -- is queued BEHIND the copy and runs while the
   // host waits for the pointers and cuts the work lists: occupation (J) tables, the diagonal, the row minima
   SQD_TRY(c->hdiag.reserve((size_t)na * nb * 8));
@@ -823,8 +847,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
                        tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + na));
   }
   SQD_HIP_CHECK(hipGetLastError());
-  SQD_HIP_CHECK(hipEventSynchronize(c->ev_aux));
-  c->h_sptr = static_cast<const int64_t*>(h_ptrs);
+  // the scan of launch A posted the pointers to their host-visible twin: spin on its sequence word
+  SQD_TRY(spin_wait_word(c->h_mail + 3 * 128 + 256, seq_ptrs, st));
+  c->h_sptr = c->h_ptrs_map;
   c->h_dptr = c->h_sptr + (na + 1);
   c->h_sptr_b = c->h_dptr + (na + 1);
   c->h_dptr_b = c->h_sptr_b + (nb + 1);
@@ -1024,9 +1049,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_HIP_CHECK(hipGetLastError());
   }
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
-  SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
+  if (c->want_timing) SQD_HIP_CHECK(hipEventRecord(c->ev[1], st));
   c->stage_pending = true;
-  c->ms_setup = -1.0;
+  c->ms_setup = c->want_timing ? -1.0 : 0.0;
   c->have_subspace = true;
   return SQD_OK;
 }

@@ -37,7 +37,7 @@ static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 typedef int hipError_t;
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeMaxSharedMemoryPerBlock = 2 };
@@ -218,6 +218,8 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
