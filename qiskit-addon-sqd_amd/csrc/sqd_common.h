@@ -171,6 +171,10 @@ struct sqd_ctx {
   const int64_t *h_sptr = nullptr, *h_dptr = nullptr, *h_sptr_b = nullptr, *h_dptr_b = nullptr;
   std::vector<sqd::WorkItem> h_items;
   std::vector<sqd::MultiRow> h_multi;
+  std::vector<int32_t> h_rowinfo;   // per alpha row {first partial slot, number of slots} (0 slots: sigma was written directly)
+  sqd::DevBuf rowinfo;
+  bool sigma_defer_reduce = false;  // Davidson: the fixed-order sum of a split row's partial rows is done by the
+                                    // consumer of the new sigma vector (k_dots_eig) instead of a k_sigma_reduce launch
   sqd::VRowsHost hv_s, hv_d;
   sqd::DevBuf items, multi, sig_partial;
   int64_t n_items = 0, n_multi = 0, n_slots = 0;

@@ -511,22 +511,51 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
 
 // sums[0] = |X_{m-1}|^2, sums[1+v] = X_v . y  (v < m <= MV), y = A X_{m-1}, m = st->m_next; the workgroup that
 // arrives LAST folds the per-block partials (fixed order) and one of its wavefronts solves the projected problem.
+// The new sigma vector may still be in pieces: rows of C that k_sigma cut into several work items were written as
+// partial rows (no atomics).  split.rowinfo != nullptr: this kernel is the first reader of that vector, so it adds
+// a split row's partial rows in slot order (fixed => bitwise reproducible) and stores the finished elements -- the
+// k_sigma_reduce launch that used to sit between k_sigma and here (5 us per iteration) is gone.
+struct SplitRows {
+  const int32_t* rowinfo;  // [2 A] first slot, [2 A + 1] slots (0: the row was written directly)
+  const double* partial;   // [slots][nb]
+  int64_t nb;
+};
 template <int MV>
-__global__ void k_dots_eig(int64_t n, const double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+__global__ void k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                            double* __restrict__ partial, int width, unsigned* counter, DavState* st,
-                           const DavParams prm) {
+                           const DavParams prm, const SplitRows split) {
   __shared__ double red[16 * (MV + 1)];
   __shared__ double tot[MV + 1];
   __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
   if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
                          // kernel before every workgroup has arrived)
   const int nvec = st->m_next;
-  const double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
+  double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
   double acc[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double yv = y[i];
+    double yv;
+    if (split.rowinfo) {
+      const int64_t A = i / split.nb, B = i - A * split.nb;
+      const int slot0 = split.rowinfo[2 * A], ns = split.rowinfo[2 * A + 1];
+      if (ns > 0) {
+        double sacc = 0.0;
+        for (int j0 = 0; j0 < ns; j0 += 8) {  // eight partial rows in flight per round, added in slot order
+          double pv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pv[u] = split.partial[(int64_t)(slot0 + (j0 + u < ns ? j0 + u : j0)) * split.nb + B];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sacc += (j0 + u < ns) ? pv[u] : 0.0;
+        }
+        yv = sacc;
+        y[i] = sacc;
+      } else {
+        yv = y[i];
+      }
+    } else {
+      yv = y[i];
+    }
     double xv[MV];
     load_vectors<MV>(X, stride, nvec, i, xv);
 #pragma unroll
@@ -923,10 +952,24 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     ~IndexGuard() {
       c->sigma_stop = nullptr;
       c->sigma_index = nullptr;
+      c->sigma_defer_reduce = false;
     }
   } guard{c};
   c->sigma_stop = &dst->stop;
   c->sigma_index = &dst->m_next;
+  // split rows are summed by k_dots_eig (the squared-penalty form chains three sigma launches through scratch
+  // vectors and keeps its reduce launches)
+  int form_sel = o->use_spin;
+  if (form_sel == 3) {
+    const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    form_sel = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+  }
+  SplitRows split{nullptr, nullptr, c->nb};
+  if (c->n_multi > 0 && form_sel != 2) {
+    c->sigma_defer_reduce = true;
+    split.rowinfo = c->rowinfo.as<int32_t>();
+    split.partial = c->sig_partial.as<double>();
+  }
 
   // Host loop: iteration j is enqueued as soon as the progress record of iteration j - 1 - AHEAD has been seen
   // without a stop.  AHEAD = 1 keeps one whole iteration queued behind the running one, so no launch waits for
@@ -962,15 +1005,15 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     const long long seq = ++c->mail_seq;
     seq_of[enq & 3] = seq;
     if (max_space <= 12) {
-      hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D,
-                         c->partial.as<double>(), width, counter, dst, prm);
+      hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                         c->partial.as<double>(), width, counter, dst, prm, split);
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
                          (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
       hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,
                          (int)gb, width, mail_prog, seq);
     } else {
-      hipLaunchKernelGGL((k_dots_eig<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, (const double*)AX, D,
-                         c->partial.as<double>(), width, counter, dst, prm);
+      hipLaunchKernelGGL((k_dots_eig<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                         c->partial.as<double>(), width, counter, dst, prm, split);
       hipLaunchKernelGGL((k_residual_precond<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
                          (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
       hipLaunchKernelGGL((k_orth_dev<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,

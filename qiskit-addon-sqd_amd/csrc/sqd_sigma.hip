@@ -608,7 +608,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   else if (R <= 8) rc = launch_sigma_r<8>(c, g);
   else rc = launch_sigma_r<16>(c, g);
   if (rc != SQD_OK) return rc;
-  if (c->n_multi > 0) {
+  if (c->n_multi > 0 && !(c->sigma_defer_reduce && indexed && mode == 0)) {
     hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
                        d_sigma, g.stop, g.vec_index, out_stride);

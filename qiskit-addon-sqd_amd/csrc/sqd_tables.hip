@@ -651,6 +651,7 @@ static int build_sigma_work(sqd_ctx* c) {
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();
   multi.clear();
+  c->h_rowinfo.assign((size_t)2 * na, 0);
   int32_t nslots = 0;
   std::vector<WorkItem> row;
   for (int64_t A = 0; A < na; ++A) {
@@ -665,6 +666,8 @@ static int build_sigma_work(sqd_ctx* c) {
       row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
     if (row.size() > 1) {  // several items: partial rows + fixed-order reduce
       multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
+      c->h_rowinfo[2 * A] = nslots;
+      c->h_rowinfo[2 * A + 1] = (int32_t)row.size();
       for (auto& it : row) it.slot = nslots++;
     }
     items.insert(items.end(), row.begin(), row.end());
@@ -994,6 +997,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
         {&t.vs_chunk, vs.chunk.data(), vs.chunk.size() * 4}, {&t.vd_chunk, vd.chunk.data(), vd.chunk.size() * 4},
         {&c->items, c->h_items.data(), c->h_items.size() * sizeof(WorkItem)},
         {&c->multi, c->h_multi.data(), c->h_multi.size() * sizeof(MultiRow)},
+        {&c->rowinfo, c->h_rowinfo.data(), c->h_rowinfo.size() * 4},
     };
     size_t blob = 0;
     for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);
