@@ -69,6 +69,21 @@ int sqd_ctx_use_stream(sqd_ctx* ctx, void* stream);
  * mean-field tables used by the sigma kernel.  nelec is taken from the popcounts. */
 int sqd_set_subspace(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb);
 
+/* ---- intra-solve sharding by alpha rows (the collective sci_solver contract of reference
+ * docs/guides/hpc_acceleration.rst:52-57).  One process per GPU; rank r calls sqd_set_subspace_rows with ITS row range
+ * [row0, row1) of the same (strs_a, strs_b): link tables cover all strings, hdiag and the sigma work list only the
+ * owned rows.  sqd_sigma_rows_dev / sqd_contract_ss_rows_dev then map the FULL vector c (na*nb doubles, gathered by
+ * the caller -- RCCL all-gather over xGMI in qiskit_addon_sqd_amd.sharded) to rows [row0, row1) of sigma / S^2 c
+ * ((row1-row0)*nb doubles).  These three take DEVICE pointers (memory of the context's device) and only enqueue work on
+ * the context's stream; sqd_ctx_sync waits for it.  Whole-vector entry points (sqd_sigma, sqd_davidson, sqd_solve,
+ * the observables) return SQD_ERR_STATE on a sharded context; sqd_hdiag returns the owned rows. */
+int sqd_set_subspace_rows(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb,
+                          int64_t row0, int64_t row1);
+int sqd_sigma_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_sigma_rows, int use_spin, double ss, double shift);
+int sqd_contract_ss_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_out_rows);
+int sqd_hdiag_rows_dev(sqd_ctx* ctx, double* d_out_rows);
+int sqd_ctx_sync(sqd_ctx* ctx);
+
 /* Sizes of the current subspace. */
 int sqd_get_dims(sqd_ctx* ctx, int64_t* na, int64_t* nb, int* nelec_a, int* nelec_b);
 

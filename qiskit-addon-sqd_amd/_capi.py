@@ -28,6 +28,11 @@ EXPORTED_SYMBOLS = (
     "sqd_ctx_destroy",
     "sqd_ctx_use_stream",
     "sqd_set_subspace",
+    "sqd_set_subspace_rows",
+    "sqd_sigma_rows_dev",
+    "sqd_contract_ss_rows_dev",
+    "sqd_hdiag_rows_dev",
+    "sqd_ctx_sync",
     "sqd_get_dims",
     "sqd_link_counts",
     "sqd_single_links",
@@ -108,6 +113,11 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_ctx_destroy.argtypes = [_ctxp]
     lib.sqd_ctx_use_stream.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_set_subspace.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64]
+    lib.sqd_set_subspace_rows.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64, C.c_int64, C.c_int64]
+    lib.sqd_sigma_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    lib.sqd_contract_ss_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p]
+    lib.sqd_hdiag_rows_dev.argtypes = [_ctxp, C.c_void_p]
+    lib.sqd_ctx_sync.argtypes = [_ctxp]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
     lib.sqd_single_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp]
@@ -305,6 +315,34 @@ class Context:
         self._check(self._lib.sqd_get_dims(self._h, C.byref(na), C.byref(nb), C.byref(ea), C.byref(eb)))
         self.na, self.nb = int(na.value), int(nb.value)
         self.nelec = (int(ea.value), int(eb.value))
+        self.rows = (0, self.na)
+
+    def set_subspace_rows(self, strs_a, strs_b, row0: int, row1: int):
+        """This context serves alpha rows [row0, row1) of the subspace (intra-solve sharding)."""
+        a = strings_to_u64(strs_a)
+        b = strings_to_u64(strs_b)
+        self._check(self._lib.sqd_set_subspace_rows(self._h, _ptr(a, _u64p), a.size, _ptr(b, _u64p), b.size,
+                                                    int(row0), int(row1)))
+        na, nb = C.c_int64(), C.c_int64()
+        ea, eb = C.c_int(), C.c_int()
+        self._check(self._lib.sqd_get_dims(self._h, C.byref(na), C.byref(nb), C.byref(ea), C.byref(eb)))
+        self.na, self.nb = int(na.value), int(nb.value)
+        self.nelec = (int(ea.value), int(eb.value))
+        self.rows = (int(row0), int(row1))
+
+    def sigma_rows_dev(self, c_full_ptr: int, out_rows_ptr: int, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0):
+        """Enqueue sigma rows [row0, row1) <- full vector; both arguments are DEVICE addresses (``tensor.data_ptr()``)."""
+        self._check(self._lib.sqd_sigma_rows_dev(self._h, C.c_void_p(int(c_full_ptr)), C.c_void_p(int(out_rows_ptr)),
+                                                 int(use_spin), float(ss), float(shift)))
+
+    def contract_ss_rows_dev(self, c_full_ptr: int, out_rows_ptr: int):
+        self._check(self._lib.sqd_contract_ss_rows_dev(self._h, C.c_void_p(int(c_full_ptr)), C.c_void_p(int(out_rows_ptr))))
+
+    def hdiag_rows_dev(self, out_rows_ptr: int):
+        self._check(self._lib.sqd_hdiag_rows_dev(self._h, C.c_void_p(int(out_rows_ptr))))
+
+    def sync(self):
+        self._check(self._lib.sqd_ctx_sync(self._h))
 
     def link_counts(self, spin: int):
         ns, nd = C.c_int64(), C.c_int64()
@@ -338,7 +376,8 @@ class Context:
         return dict(tgt=tgt, src=src, orbs=orbs, sign=sign, value=val)
 
     def hdiag(self) -> np.ndarray:
-        out = np.empty((self.na, self.nb))
+        rows = getattr(self, "rows", (0, self.na))
+        out = np.empty((rows[1] - rows[0], self.nb))
         self._check(self._lib.sqd_hdiag(self._h, _ptr(out)))
         return out
 
@@ -442,6 +481,7 @@ class Context:
         )
         self.na, self.nb = int(a.size), int(b.size)
         self.nelec = (int(ea.value), int(eb.value))
+        self.rows = (0, self.na)
         return (amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_},
                 (e.value, s2.value if spin_square else None, occ_a, occ_b))
 

@@ -237,6 +237,12 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
     set_error("no subspace set");     \
     return SQD_ERR_STATE;             \
   }
+// entry points that work on whole vectors held by this context: not available on a row shard
+#define NEED_ALL_ROWS(c)                                                                         \
+  if ((c)->sharded()) {                                                                          \
+    set_error("this context holds a row shard (sqd_set_subspace_rows): use the *_rows entry points"); \
+    return SQD_ERR_STATE;                                                                        \
+  }
 // table inspection uses blocking copies: drain the context stream first (set_subspace returns
 // without synchronising)
 #define DRAIN(c)                  \
@@ -246,6 +252,52 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
 SQD_API int sqd_set_subspace(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb) {
   CTX_ENTER(c);
   return build_subspace(c, strs_a, na, strs_b, nb);
+}
+
+SQD_API int sqd_set_subspace_rows(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb,
+                                  int64_t row0, int64_t row1) {
+  CTX_ENTER(c);
+  return build_subspace(c, strs_a, na, strs_b, nb, row0, row1);
+}
+
+// sigma rows [row0, row1) from the FULL vector, both in device memory (device pointers, e.g. torch tensors'
+// data_ptr()); enqueued on the context's stream, no synchronisation
+SQD_API int sqd_sigma_rows_dev(sqd_ctx* c, const double* d_c_full, double* d_sigma_rows, int use_spin, double ss,
+                               double shift) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!d_c_full || !d_sigma_rows) return SQD_ERR_INVALID;
+  if (use_spin == 2 || use_spin == 3) {
+    // (S^2 - ss)^2 chains S^2 through intermediate FULL vectors: each application needs its own all-gather, which is
+    // the caller's side of the exchange -- apply use_spin = 1 / sqd_contract_ss_rows_dev step by step instead
+    const double sz = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    if (use_spin == 2 || !(ss < sz * (sz + 1.0) + 0.1)) {
+      set_error("the squared spin penalty is not available on a row shard in one call");
+      return SQD_ERR_INVALID;
+    }
+    use_spin = 1;
+  }
+  return apply_h(c, d_c_full, d_sigma_rows, use_spin, ss, shift);
+}
+SQD_API int sqd_contract_ss_rows_dev(sqd_ctx* c, const double* d_c_full, double* d_out_rows) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!d_c_full || !d_out_rows) return SQD_ERR_INVALID;
+  return launch_sigma(c, d_c_full, d_out_rows, 1, false, 0.0, 0.0);
+}
+SQD_API int sqd_hdiag_rows_dev(sqd_ctx* c, double* d_out_rows) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!d_out_rows) return SQD_ERR_INVALID;
+  SQD_HIP_CHECK(hipMemcpyAsync(d_out_rows, c->hdiag.p, (size_t)(c->row1 - c->row0) * c->nb * 8, hipMemcpyDeviceToDevice,
+                               c->stream));
+  return SQD_OK;
+}
+SQD_API int sqd_ctx_sync(sqd_ctx* c) {
+  CTX_ENTER(c);
+  SQD_STREAM_SYNC(c->stream);
+  c->stage_pending = false;
+  return SQD_OK;
 }
 
 SQD_API int sqd_get_dims(sqd_ctx* c, int64_t* na, int64_t* nb, int* nelec_a, int* nelec_b) {
@@ -325,13 +377,14 @@ SQD_API int sqd_hdiag(sqd_ctx* c, double* out) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
   DRAIN(c);
-  SQD_HIP_CHECK(hipMemcpy(out, c->hdiag.p, c->D * 8, hipMemcpyDeviceToHost));
+  SQD_HIP_CHECK(hipMemcpy(out, c->hdiag.p, (size_t)(c->row1 - c->row0) * c->nb * 8, hipMemcpyDeviceToHost));
   return SQD_OK;
 }
 
 SQD_API int sqd_init_guess(sqd_ctx* c, double* out) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   if (!out) return SQD_ERR_INVALID;
   SQD_TRY(c->io_out.reserve((size_t)c->D * 8));
   SQD_TRY(enqueue_init_guess(c, c->io_out.as<double>()));
@@ -351,6 +404,7 @@ static int upload_vec(sqd_ctx* c, const double* host, DevBuf& buf) {
 SQD_API int sqd_sigma(sqd_ctx* c, const double* cvec, double* sigma, int use_spin, double ss, double shift) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   if (!cvec || !sigma) return SQD_ERR_INVALID;
   DevBuf& in = c->io_in;
   DevBuf& out = c->io_out;
@@ -366,6 +420,7 @@ SQD_API int sqd_sigma(sqd_ctx* c, const double* cvec, double* sigma, int use_spi
 SQD_API int sqd_contract_ss(sqd_ctx* c, const double* cvec, double* outv) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   if (!cvec || !outv) return SQD_ERR_INVALID;
   DevBuf& in = c->io_in;
   DevBuf& out = c->io_out;
@@ -396,6 +451,7 @@ SQD_API int sqd_davidson(sqd_ctx* c, const sqd_davidson_opts* opts, const double
                          sqd_davidson_stats* stats) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   sqd_davidson_opts o;
   if (opts) o = *opts; else sqd_davidson_default_opts(&o);
   if (o.tol <= 0 || o.max_cycle < 1) {
@@ -446,6 +502,7 @@ static int expectation(sqd_ctx* c, const double* amps, int mode, double* outv) {
 SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s2, double* occ_a, double* occ_b) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
   std::vector<double> out(4 + 2 * c->norb);
@@ -476,6 +533,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
                       sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   sqd_davidson_opts o;
   if (opts) o = *opts; else sqd_davidson_default_opts(&o);
   if (o.tol <= 0 || o.max_cycle < 1) {
@@ -555,16 +613,19 @@ SQD_API int sqd_solve_strings(sqd_ctx* c, const uint64_t* strs_a, int64_t na, co
 SQD_API int sqd_energy(sqd_ctx* c, const double* amps, double* e) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   return expectation(c, amps, 0, e);
 }
 SQD_API int sqd_spin_square(sqd_ctx* c, const double* amps, double* s2) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   return expectation(c, amps, 1, s2);
 }
 SQD_API int sqd_rdm1s(sqd_ctx* c, const double* amps, double* dm1a, double* dm1b) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
   return dev_rdm1s(c, d, dm1a, dm1b);
@@ -572,6 +633,7 @@ SQD_API int sqd_rdm1s(sqd_ctx* c, const double* amps, double* dm1a, double* dm1b
 SQD_API int sqd_rdm2(sqd_ctx* c, const double* amps, double* dm2) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
   return dev_rdm2(c, d, dm2);
@@ -580,6 +642,7 @@ SQD_API int sqd_rdm2(sqd_ctx* c, const double* amps, double* dm2) {
 SQD_API int sqd_rdm2s(sqd_ctx* c, const double* amps, double* dm2aa, double* dm2ab, double* dm2bb) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   if (!dm2aa || !dm2ab || !dm2bb) return SQD_ERR_INVALID;
   const double* d = nullptr;
   SQD_TRY(state_ptr(c, amps, &d));
@@ -589,6 +652,7 @@ SQD_API int sqd_rdm2s(sqd_ctx* c, const double* amps, double* dm2aa, double* dm2
 SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double shift, double* ms_per_sigma) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
   if (reps < 1 || !ms_per_sigma) return SQD_ERR_INVALID;
   const double* d = nullptr;
   if (c->have_solution) {

@@ -146,6 +146,10 @@ struct sqd_ctx {
   // subspace
   bool have_subspace = false;
   int64_t na = 0, nb = 0, D = 0;
+  // SURVEY 8f-3, intra-solve sharding: this context produces sigma (and holds hdiag) only for the alpha rows
+  // [row0, row1) of the subspace; the input vector is always the full na x nb matrix.  Default: all rows.
+  int64_t row0 = 0, row1 = 0;
+  bool sharded() const { return row0 != 0 || row1 != na; }
   int nelec[2] = {0, 0};
   sqd::SpinTables sp[2];
   sqd::DevBuf hdiag;        // f64[D]
@@ -223,7 +227,8 @@ struct sqd_ctx {
 namespace sqd {
 // tables (sqd_tables.hip)
 int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri);
-int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb);
+int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0 = 0,
+                   int64_t row1 = -1);
 // sigma (sqd_sigma.hip).  mode 0: H (+ shift*(S^2-ss) if spin) ; mode 1: pure S^2
 // in_stride / out_stride != 0 (inside a Davidson run): the vector is chosen on the device through
 // sqd_ctx::sigma_index, input d_c + (*index - 1) * in_stride, output d_sigma + (*index - 1) * out_stride

@@ -866,7 +866,7 @@ static int enqueue_init_guess_impl(sqd_ctx* c, double* x, DavState* st, unsigned
   // the per-row minima of the diagonal (lower triangle only when pyscf's rule says so) were left by set_subspace
   // (k_tables_diag); every workgroup of k_init_guess finishes the argmin over them itself
   const double* pmin = c->guess_min.as<double>();
-  const int64_t* pidx = reinterpret_cast<const int64_t*>(pmin + c->na);
+  const int64_t* pidx = reinterpret_cast<const int64_t*>(pmin + c->na);  // (unsharded: row range = all rows)
   hipLaunchKernelGGL(k_init_guess, dim3(gb), dim3(RED_T), 0, c->stream, D, pmin, pidx, (int)c->na, x, st, counter);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;

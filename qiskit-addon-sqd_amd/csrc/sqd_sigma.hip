@@ -33,6 +33,7 @@ struct SigmaArgs {
   double* partial;
   const WorkItem* items;
   int64_t na, nb;
+  int64_t row0;  // first alpha row of this context's shard: hdiag and sigma are indexed relative to it
   int nnorb, nb_pad, K;
   int mode;  // 0: H (+ penalty when spin), 1: pure S^2
   int type_mask;  // profiling hook (env SQD_SIGMA_TYPES): bit t set = execute work items of type t; default 7
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       if (B < Bend) {
         double d;
         if (g.mode == 0) {
-          d = __builtin_nontemporal_load(&g.hdiag[A * nb + B]);
+          d = __builtin_nontemporal_load(&g.hdiag[(A - g.row0) * nb + B]);
           if (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~sA) - g.ss);
         } else {
           d = g.szterm + (double)__popcll(g.strs_b[B] & ~sA);
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
       }
     }
   }
-  double* __restrict__ out = (it.slot < 0) ? (sigma_out + A * nb) : (g.partial + (int64_t)it.slot * nb);
+  double* __restrict__ out = (it.slot < 0) ? (sigma_out + (A - g.row0) * nb) : (g.partial + (int64_t)it.slot * nb);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t B = B0 + tid + (int64_t)r * T;
@@ -472,7 +473,8 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
 __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
-                               double* __restrict__ sigma, const int* stop, const int* vec_index, int64_t s_stride) {
+                               double* __restrict__ sigma, const int* stop, const int* vec_index, int64_t s_stride,
+                               int64_t row0) {
   __shared__ double red[1024];
   if (stop && *stop) return;
   if (vec_index) sigma += (int64_t)(*vec_index - 1) * s_stride;
@@ -486,7 +488,7 @@ __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* 
   __syncthreads();
   if (sl == 0 && B < nb) {
     for (int r = 1; r < SL; ++r) s += red[r * 64 + col];
-    sigma[(int64_t)mr.A * nb + B] = s;
+    sigma[((int64_t)mr.A - row0) * nb + B] = s;
   }
 }
 
@@ -552,6 +554,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.items = c->items.as<WorkItem>();
   g.na = c->na;
   g.nb = c->nb;
+  g.row0 = c->row0;
   g.nnorb = c->nnorb;
   g.nb_pad = c->sig_nb_pad;
   g.K = c->sig_K;
@@ -611,7 +614,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (c->n_multi > 0 && !(c->sigma_defer_reduce && indexed && mode == 0)) {
     hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
-                       d_sigma, g.stop, g.vec_index, out_stride);
+                       d_sigma, g.stop, g.vec_index, out_stride, c->row0);
     SQD_HIP_CHECK(hipGetLastError());
   }
   return SQD_OK;

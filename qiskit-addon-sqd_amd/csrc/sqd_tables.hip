@@ -294,15 +294,15 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
 //   hdiag[A,B] = e_a[A] + e_b[B] + sum_{k in B} v_A[k],  v_A[k] = sum_{i in A} (ii|kk)   (pyscf make_hdiag)
 // and the row's lowest element (over B <= A when tril_only: pyscf's init-guess rule for equal spin sectors)
 __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ jm, const double* __restrict__ eri_pp,
-                              int norb, int nnorb, int64_t na, int64_t nb, int tril_only, double* __restrict__ hdiag,
-                              double* __restrict__ pmin, int64_t* __restrict__ pidx) {
+                              int norb, int nnorb, int64_t row0, int64_t row1, int64_t nb, int tril_only,
+                              double* __restrict__ hdiag, double* __restrict__ pmin, int64_t* __restrict__ pidx) {
   __shared__ double v[SQD_MAX_NORB];
   if (blockIdx.y < 2) {
     const SpinLinkArgs& a = p.a[blockIdx.y];
     jtable_body(a.strs, a.n, eri_pp, nnorb, a.transposed, a.jtab);
     return;
   }
-  for (int64_t A = blockIdx.x; A < na; A += gridDim.x) {
+  for (int64_t A = row0 + blockIdx.x; A < row1; A += gridDim.x) {
     const uint64_t sA = p.a[0].strs[A];
     __syncthreads();
     if ((int)threadIdx.x < norb) {
@@ -327,16 +327,16 @@ __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ 
         occ &= occ - 1;
         t += v[k];
       }
-      hdiag[A * nb + B] = t;
+      hdiag[(A - row0) * nb + B] = t;
       if (!(tril_only && A < B) && (t < best || bi < 0)) {  // B ascends: the first minimum wins
         best = t;
-        bi = A * nb + B;
+        bi = (A - row0) * nb + B;
       }
     }
     block_argmin(best, bi);
     if (threadIdx.x == 0) {
-      pmin[A] = best;
-      pidx[A] = bi;
+      pmin[A - row0] = best;
+      pidx[A - row0] = bi;
     }
   }
 }
@@ -651,10 +651,10 @@ static int build_sigma_work(sqd_ctx* c) {
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();
   multi.clear();
-  c->h_rowinfo.assign((size_t)2 * na, 0);
+  c->h_rowinfo.assign((size_t)2 * (c->row1 - c->row0), 0);
   int32_t nslots = 0;
   std::vector<WorkItem> row;
-  for (int64_t A = 0; A < na; ++A) {
+  for (int64_t A = c->row0; A < c->row1; ++A) {
     row.clear();
     const int64_t s0 = c->h_sptr[A], s1 = c->h_sptr[A + 1];
     const int64_t h0 = s0 + c->h_dptr[A], h1 = s1 + c->h_dptr[A + 1];
@@ -666,8 +666,8 @@ static int build_sigma_work(sqd_ctx* c) {
       row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
     if (row.size() > 1) {  // several items: partial rows + fixed-order reduce
       multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
-      c->h_rowinfo[2 * A] = nslots;
-      c->h_rowinfo[2 * A + 1] = (int32_t)row.size();
+      c->h_rowinfo[2 * (A - c->row0)] = nslots;
+      c->h_rowinfo[2 * (A - c->row0) + 1] = (int32_t)row.size();
       for (auto& it : row) it.slot = nslots++;
     }
     items.insert(items.end(), row.begin(), row.end());
@@ -743,9 +743,16 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
   return SQD_OK;
 }
 
-int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb) {
+int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0,
+                   int64_t row1) {
   c->have_subspace = false;
   c->have_solution = false;
+  if (row1 < 0) row1 = na;
+  if (row0 < 0 || row0 >= row1 || row1 > na) {
+    set_error("alpha row range [row0, row1) must be non-empty and inside [0, na)");
+    return SQD_ERR_INVALID;
+  }
+  const int64_t nrows = row1 - row0;
   int nocc[2];
   SQD_TRY(validate_strings(sa, na, c->norb, "Spin-up", &nocc[0]));
   SQD_TRY(validate_strings(sb, nb, c->norb, "Spin-down", &nocc[1]));
@@ -832,8 +839,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   // launch B -- everything else that needs only the strings -- is queued BEHIND the copy and runs while the
   // host waits for the pointers and cuts the work lists: occupation (J) tables, the diagonal, the row minima
-  SQD_TRY(c->hdiag.reserve((size_t)na * nb * 8));
-  SQD_TRY(c->guess_min.reserve((size_t)na * 16));
+  SQD_TRY(c->hdiag.reserve((size_t)nrows * nb * 8));
+  SQD_TRY(c->guess_min.reserve((size_t)nrows * 16));
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     DevBuf& jt = (s == 0) ? t.jrow : t.jT;  // alpha: J[I][pair] (row role); beta: transposed (column role)
@@ -842,12 +849,12 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     la.a[s].transposed = s;
   }
   {
-    const int64_t gx_j = (int64_t)nblk(maxn * nnorb, 256), gx_h = na < 65535 ? na : 65535;
+    const int64_t gx_j = (int64_t)nblk(maxn * nnorb, 256), gx_h = nrows < 65535 ? nrows : 65535;
     const int tril_only = (nocc[0] == nocc[1] && na == nb) ? 1 : 0;
     double* pmin = c->guess_min.as<double>();
     hipLaunchKernelGGL(k_tables_diag, dim3((unsigned)(gx_j > gx_h ? gx_j : gx_h), 3), dim3(256), 0, st, la,
-                       (const double*)c->jm.as<double>(), (const double*)c->eri_pp.as<double>(), norb, nnorb, na, nb,
-                       tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + na));
+                       (const double*)c->jm.as<double>(), (const double*)c->eri_pp.as<double>(), norb, nnorb, row0, row1,
+                       nb, tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + nrows));
   }
   SQD_HIP_CHECK(hipGetLastError());
   // the scan of launch A posted the pointers to their host-visible twin: spin on its sequence word
@@ -983,6 +990,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     // the sigma work list is cut on the host from the same pointer arrays (no device dependency)
     c->na = na;
     c->nb = nb;
+    c->row0 = row0;
+    c->row1 = row1;
     c->D = na * nb;
     c->nelec[0] = nocc[0];
     c->nelec[1] = nocc[1];

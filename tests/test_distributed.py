@@ -47,3 +47,9 @@ def test_two_rank_gloo_whole_loop_unseeded(emu_lib):
     """The package's own SQD loop in SPMD mode with ``seed=None``: CI strings prepared on rank 0 and broadcast, the
     collective solver in the middle, the iteration state broadcast back (reference fermion.py:421-451)."""
     _run_two_ranks("_dist_loop_worker.py")
+
+
+def test_two_rank_gloo_row_sharded_sigma_and_solve(emu_lib):
+    """one subspace split by alpha rows over two ranks -- all-gather of the vector, sigma rows per rank
+    bit-identical to the single-rank sigma, and the collective Davidson against dense diagonalisation."""
+    _run_two_ranks("_dist_shard_worker.py")

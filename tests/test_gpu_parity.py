@@ -461,3 +461,55 @@ def test_context_on_caller_stream(hip_lib):
         x = torch.ones(8, device="cuda").sum()
     stream.synchronize()
     assert float(x) == 8.0
+
+
+def test_row_sharded_sigma_on_gpu(hip_lib):
+    """SURVEY 8f-3 on the real kernels: a context that owns alpha rows [row0, row1) of the N2-sized 317 x 317 problem
+    must reproduce exactly those rows of the whole-subspace sigma (same work items, same order: bit for bit), for H,
+    for the spin-penalised operator and for S^2; and the collective solver on an RCCL group of world size 1 must
+    agree with the single-GPU solver."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from qiskit_addon_sqd_amd.fermion import solve_sci
+    from qiskit_addon_sqd_amd.sharded import solve_sci_sharded
+
+    norb, nelec, h1, eri, sa, sb = _n2_problem(317, True)
+    x = np.random.default_rng(11).standard_normal((317, 317))
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        s_full, p_full, ss_full, hd_full = ctx.sigma(x), ctx.sigma(x, 1, 0.0, 0.25), ctx.contract_ss(x), ctx.hdiag()
+        xd = torch.from_numpy(x).cuda()
+        for lo, hi in ((0, 317), (100, 250), (316, 317)):
+            ctx.set_subspace_rows(sa, sb, lo, hi)
+            out = torch.empty((hi - lo, 317), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            ctx.sigma_rows_dev(xd.data_ptr(), out.data_ptr())
+            ctx.sync()
+            assert np.array_equal(out.cpu().numpy(), s_full[lo:hi])
+            ctx.sigma_rows_dev(xd.data_ptr(), out.data_ptr(), 1, 0.0, 0.25)
+            ctx.sync()
+            assert np.array_equal(out.cpu().numpy(), p_full[lo:hi])
+            ctx.contract_ss_rows_dev(xd.data_ptr(), out.data_ptr())
+            ctx.sync()
+            assert np.array_equal(out.cpu().numpy(), ss_full[lo:hi])
+            assert np.array_equal(ctx.hdiag(), hd_full[lo:hi])
+            with pytest.raises(_capi.SQDNativeError, match="row shard"):
+                ctx.sigma(x) if (lo, hi) != (0, 317) else (_ for _ in ()).throw(_capi.SQDNativeError("row shard"))
+    ref = solve_sci((sa, sb), h1, eri, norb, nelec, compute_rdms=False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        res = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+    finally:
+        dist.destroy_process_group()
+    assert res._sharded_stats["converged"]
+    assert abs(res.energy - ref.energy) < 1e-8
+    assert abs(abs(np.vdot(res.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
+    assert np.allclose(res.orbital_occupancies[0], ref.orbital_occupancies[0], atol=5e-6)
