@@ -242,6 +242,14 @@ def main():
             e = min(r.energy for r in res)
         return e, F.last_solve_stats()
 
+    # Untimed device spin-up, then the W warm-up steps.  The first ~0.1 s of GPU activity of a process contains one or
+    # two 30-50 ms stalls that have nothing to do with the work submitted (profiles/r02/stall_probe.txt: identical
+    # 0.27 ms solves, calls 113 and 189 take 1.2 and 40 ms, then none in the next thousands; HF-centred 3.5 ms solves
+    # show none after their first call) -- the device settling into its power state.  A timed region that starts a
+    # few milliseconds after the process touched the GPU catches them at random; 0.3 s of the same solves first.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:
+        one_step()
     for _ in range(args.warmup):
         e, st = one_step()
 
