@@ -32,6 +32,25 @@ def _dist():
     return dist
 
 
+_XBUF: dict = {}
+
+
+def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
+    import torch
+
+    key = (id(group), str(tdev), nb, width)
+    hit = _XBUF.get(key)
+    if hit is None:
+        host = torch.zeros((nb, width), dtype=torch.float64)
+        if on_gpu:
+            host = host.pin_memory()
+        dev = torch.zeros((nb, width), dtype=torch.float64, device=tdev) if on_gpu else host
+        hit = _XBUF[key] = (dev, host)
+        while len(_XBUF) > 16:
+            _XBUF.pop(next(iter(_XBUF)))
+    return hit
+
+
 def shard_indices(num_batches: int, rank: int, world: int) -> list[int]:
     """Batches owned by ``rank``: round-robin, ``i % world == rank``."""
     return list(range(rank, num_batches, world))
@@ -85,23 +104,37 @@ def solve_sci_batch_distributed(
         table[i, 1 : 1 + norb] = res.orbital_occupancies[0]
         table[i, 1 + norb :] = res.orbital_occupancies[1]
 
-    # ---- the path's single exchange: all-reduce(sum) of the per-batch records
-    t = torch.from_numpy(table).to(tdev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    table = t.cpu().numpy()
+    # ---- the path's single exchange: all-reduce(sum) of the per-batch records.  Device and pinned host buffers
+    # are cached per (group, shape): the record table is 61 doubles per batch at norb = 30, so everything but the
+    # collective itself is overhead worth removing (allocation, pageable copies)
+    dev_table, host_table = _exchange_buffers(group, tdev, nb, width, on_gpu)
+    host_np = host_table.numpy()
+    host_np[:] = table
+    if on_gpu:
+        dev_table.copy_(host_table, non_blocking=True)
+        dist.all_reduce(dev_table, op=dist.ReduceOp.SUM, group=group)
+        host_table.copy_(dev_table, non_blocking=True)
+        torch.cuda.current_stream(tdev).synchronize()
+    else:
+        dist.all_reduce(host_table, op=dist.ReduceOp.SUM, group=group)
+    table = host_np.copy()
     best = int(np.argmin(table[:, 0]))
     owner = best % world
 
-    # ---- winner's state to every rank
+    # ---- winner's state to every rank (the loop's control process needs it for the carry-over, reference
+    # fermion.py:608-631; the reference ships it inside the pickled iteration state)
     sa, sb = ci_strings[best]
-    if rank == owner:
-        amps = np.ascontiguousarray(local[best].sci_state.amplitudes, dtype=np.float64)
+    if world > 1 or on_gpu:  # (also on a one-rank RCCL group: the collective path is the tested path)
+        if rank == owner:
+            amps = np.ascontiguousarray(local[best].sci_state.amplitudes, dtype=np.float64)
+            ta = torch.from_numpy(amps).to(tdev, non_blocking=True) if on_gpu else torch.from_numpy(amps)
+        else:
+            ta = torch.empty((len(sa), len(sb)), dtype=torch.float64, device=tdev)
+        src = dist.get_global_rank(group, owner) if group is not None else owner
+        dist.broadcast(ta, src=src, group=group)
+        amps = local[best].sci_state.amplitudes if rank == owner else ta.cpu().numpy()
     else:
-        amps = np.empty((len(sa), len(sb)))
-    ta = torch.from_numpy(amps).to(tdev)
-    src = dist.get_global_rank(group, owner) if group is not None else owner
-    dist.broadcast(ta, src=src, group=group)
-    amps = ta.cpu().numpy()
+        amps = local[best].sci_state.amplitudes
 
     mean_occ = (table[:, 1 : 1 + norb].mean(axis=0), table[:, 1 + norb :].mean(axis=0))
     out: list[SCIResult] = []
