@@ -340,16 +340,17 @@ def solve_sci_batch(
     ``devices=[0, 1, ...]`` batch ``i`` runs on ``devices[i % len(devices)]`` (one host thread and one
     context per device; ctypes releases the GIL during native calls).  ``concurrency=k`` runs ``k``
     solves at a time on each device (own context + HIP stream each): a 1e5-determinant solve is
-    latency-bound and leaves most of the GPU idle, so independent batches overlap well (measured: 16
-    HF-centred 317 x 317 batches 3.4 -> 1.6 ms per batch at k = 6).  Default (``None``): device 0, up to 6
-    batches in flight while every subspace stays below 4e6 determinants (26 resident vectors each), else one
-    at a time.  The results do not depend on the concurrency.
+    latency-bound and leaves most of the GPU idle, so independent batches overlap well.  Steady-state
+    measurement, 16 batches of 317 x 317 on one MI355X (``profiles/r02/concurrency_probe.txt``, median of 7
+    runs after spin-up): HF-centred 3.33 / 2.11 / 1.67 / 1.54 / 1.66 / 1.81 ms per batch at
+    k = 1 / 2 / 3 / 4 / 6 / 8, uniform 0.284 / 0.227 / 0.192 / 0.216 / 0.207 / 0.215.  Default (``None``): device 0,
+    up to 4 batches in flight -- the best setting for well-connected subspaces and within 12 % of the best for
+    sparse ones -- while every subspace stays below 4e6 determinants (26 resident vectors each), else one at a
+    time.  The results do not depend on the concurrency.
     """
     if concurrency is None:
         biggest = max((len(a) * len(b) for a, b in ci_strings), default=0)
-        # 6, not 4: with no more streams than hardware queues (k <= 4) one run in ~15 stalls for 40-60 ms
-        # (profiles/probes/_concurrency_order_probe.py); k = 6 and 8 never did, and 6 is the fastest of them
-        concurrency = min(6, len(ci_strings)) if 0 < biggest <= 4_000_000 else 1
+        concurrency = min(4, len(ci_strings)) if 0 < biggest <= 4_000_000 else 1
     if concurrency > 1:
         devices = [d for d in (devices or [0]) for _ in range(concurrency)]
     if not devices or len(devices) == 1 or len(ci_strings) <= 1:
