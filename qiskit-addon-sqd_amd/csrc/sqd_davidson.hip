@@ -965,7 +965,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     form_sel = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
   }
   SplitRows split{nullptr, nullptr, c->nb};
-  if (c->n_multi > 0 && form_sel != 2) {
+  if (c->n_multi > 0 && form_sel != 2 && !c->sig_direct) {
     c->sigma_defer_reduce = true;
     split.rowinfo = c->rowinfo.as<int32_t>();
     split.partial = c->sig_partial.as<double>();

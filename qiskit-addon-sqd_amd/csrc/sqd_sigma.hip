@@ -469,6 +469,85 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   }
 }
 
+// ---- "direct" sigma for ultra-sparse coupling (about one in-set link per string or fewer: uniform-random string
+// sets of up to ~1000 strings per spin, BASELINE's headline configuration).  There is nothing to stage or balance
+// then: one thread per output element gathers its handful of contributions straight from the CSR link lists,
+//   sigma[A,B] = hdiag C[A,B] + sum_{beta links of B} (...) C[A,B'] + sum_{alpha links of A} (...) C[A',B]
+//              + sum_{alpha singles of A} sum_{beta singles of B} s t (pq|rs) C[A',B'],
+// most loops being empty.  The work-item kernel above pays ~6 dependent memory round trips per row for its LDS
+// staging and virtual-row bookkeeping whether or not a row has links (9.7 us for 319 workgroups at 317 x 317);
+// this one is a single pass.  Same fixed summation order on every run (bitwise reproducible).
+struct DirectArgs {
+  const double* c;
+  double* sigma;
+  const double* hdiag;
+  int64_t row0, row1, nb;
+  int nnorb, mode, spin;
+  double ss, shift, szterm;
+  const uint64_t *strs_a, *strs_b;
+  const int64_t *sa_ptr, *da_ptr, *sb_ptr, *db_ptr, *ha_ptr;
+  const SRec *sa_rec, *sb_rec;
+  const double* sb_val;
+  const uint32_t *ha_src, *db_src;
+  const double *ha_val, *db_val;
+  const double *ja_row, *jbT, *eri_pp;
+  const int* stop;
+  const int* vec_index;
+  int64_t c_stride, s_stride;
+};
+template <bool SPIN>
+__global__ void k_sigma_direct(const DirectArgs g) {
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  double* __restrict__ out = g.sigma + vsel * g.s_stride;
+  const int64_t nb = g.nb, n = (g.row1 - g.row0) * nb;
+  const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t Ar = i / nb, B = i - Ar * nb, A = g.row0 + Ar;
+    const double* crow = C + A * nb;
+    double a;
+    if (g.mode == 0) {
+      double d = g.hdiag[i];
+      if (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
+      a = d * crow[B];
+    } else {
+      a = (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A])) * crow[B];
+    }
+    const int64_t sb0 = g.sb_ptr[B], sb1 = g.sb_ptr[B + 1], sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
+    if (g.mode == 0) {
+      // beta singles: same-spin value + alpha occupation term; beta doubles
+      for (int64_t l = sb0; l < sb1; ++l) {
+        const SRec r = g.sb_rec[l];
+        a += (g.sb_val[l] + srec_sign(r.meta) * g.ja_row[A * g.nnorb + (srec_widx(r.meta) >> 1)]) * crow[r.src];
+      }
+      for (int64_t l = g.db_ptr[B]; l < g.db_ptr[B + 1]; ++l) a += g.db_val[l] * crow[g.db_src[l]];
+      // alpha same-spin links (singles' one-body part and doubles), then alpha singles x beta occupation
+      for (int64_t l = g.ha_ptr[A]; l < g.ha_ptr[A + 1]; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
+      for (int64_t l = sa0; l < sa1; ++l) {
+        const SRec r = g.sa_rec[l];
+        a += srec_sign(r.meta) * g.jbT[(int64_t)(srec_widx(r.meta) >> 1) * nb + B] * C[(int64_t)r.src * nb + B];
+      }
+    }
+    // single x single (and the S^2 exchange term: the beta link that undoes the alpha link's orbital move)
+    for (int64_t la = sa0; la < sa1; ++la) {
+      const SRec ra = g.sa_rec[la];
+      const double* srow = C + (int64_t)ra.src * nb;
+      const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
+      const int partner = (int)srec_widx(ra.meta) ^ 1;
+      double t = 0.0;
+      for (int64_t lb = sb0; lb < sb1; ++lb) {
+        const SRec rb = g.sb_rec[lb];
+        double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
+        if (SPIN) wv += ((int)srec_widx(rb.meta) == partner) ? pen : 0.0;
+        t += srec_sign(rb.meta) * wv * srow[rb.src];
+      }
+      a += srec_sign(ra.meta) * t;
+    }
+    out[i] = a;
+  }
+}
+
 // sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items.
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
@@ -539,12 +618,68 @@ static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
                                  : launch_sigma_rs<R, false, false, false>(c, g);
 }
 
+static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss,
+                               double shift, int64_t in_stride, int64_t out_stride) {
+  const SpinTables& a = c->sp[0];
+  const SpinTables& b = c->sp[1];
+  DirectArgs g;
+  g.c = d_c;
+  g.sigma = d_sigma;
+  g.hdiag = c->hdiag.as<double>();
+  g.row0 = c->row0;
+  g.row1 = c->row1;
+  g.nb = c->nb;
+  g.nnorb = c->nnorb;
+  g.mode = mode;
+  g.spin = spin ? 1 : 0;
+  g.ss = ss;
+  g.shift = shift;
+  const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+  g.szterm = sz * (sz + 1.0);
+  g.strs_a = a.strs.as<uint64_t>();
+  g.strs_b = b.strs.as<uint64_t>();
+  g.sa_ptr = a.s_ptr.as<int64_t>();
+  g.da_ptr = a.d_ptr.as<int64_t>();
+  g.sb_ptr = b.s_ptr.as<int64_t>();
+  g.db_ptr = b.d_ptr.as<int64_t>();
+  g.ha_ptr = a.hs_ptr.as<int64_t>();
+  g.sa_rec = a.s_rec.as<SRec>();
+  g.sb_rec = b.s_rec.as<SRec>();
+  g.sb_val = b.s_val.as<double>();
+  g.ha_src = a.hs_src.as<uint32_t>();
+  g.ha_val = a.hs_val.as<double>();
+  g.db_src = b.d_src.as<uint32_t>();
+  g.db_val = b.d_val.as<double>();
+  g.ja_row = a.jrow.as<double>();
+  g.jbT = b.jT.as<double>();
+  g.eri_pp = c->eri_pp.as<double>();
+  g.stop = c->sigma_stop;
+  const bool indexed = c->sigma_index && (in_stride || out_stride);
+  g.vec_index = indexed ? c->sigma_index : nullptr;
+  g.c_stride = in_stride;
+  g.s_stride = out_stride;
+  const int64_t n = (c->row1 - c->row0) * c->nb;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (mode == 1 || spin)
+    hipLaunchKernelGGL((k_sigma_direct<true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, g);
+  else
+    hipLaunchKernelGGL((k_sigma_direct<false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, g);
+  SQD_HIP_CHECK(hipGetLastError());
+  if (c->ev_after_sigma_kernel) {
+    SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+    c->ev_after_sigma_kernel = nullptr;
+  }
+  return SQD_OK;
+}
+
 int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
                  int64_t in_stride, int64_t out_stride) {
   if (!c->have_subspace) {
     set_error("no subspace set");
     return SQD_ERR_STATE;
   }
+  if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   SigmaArgs g;
   const SpinTables& a = c->sp[0];
   const SpinTables& b = c->sp[1];

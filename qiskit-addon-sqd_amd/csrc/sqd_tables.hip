@@ -864,6 +864,13 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   c->h_sptr_b = c->h_dptr + (na + 1);
   c->h_dptr_b = c->h_sptr_b + (nb + 1);
   const int64_t tot[4] = {c->h_sptr[na], c->h_dptr[na], c->h_sptr_b[nb], c->h_dptr_b[nb]};
+  // Ultra-sparse coupling (at most two links per string on average, either spin): sigma is the element-gather
+  // kernel.  SQD_SIGMA_DIRECT=1 / 0 forces / forbids it (tests run both kernels on the same inputs).
+  {
+    bool direct = (tot[0] + tot[1] <= 2 * na) && (tot[2] + tot[3] <= 2 * nb);
+    if (const char* env = std::getenv("SQD_SIGMA_DIRECT")) direct = std::atoi(env) != 0;
+    c->sig_direct = direct;
+  }
   // launch C: fill + decorate
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];

@@ -41,6 +41,15 @@ def test_emu_many_axpy_items(emu_lib, monkeypatch):
     run_operator_parity(emu_lib, 8, (4, 4), 9, 30, 5, False)
 
 
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_emu_direct_and_work_item_sigma(emu_lib, monkeypatch, direct):
+    # SQD_SIGMA_DIRECT forces (1) / forbids (0) the element-gather sigma kernel that ultra-sparse string sets take
+    # by default: both kernels must reproduce the oracle on the same inputs (H, S^2, both penalty forms, Davidson)
+    monkeypatch.setenv("SQD_SIGMA_DIRECT", direct)
+    run_full_parity(emu_lib, 6, (3, 2), 12, 9, 5, False, variants=False)
+    run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
+
+
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,

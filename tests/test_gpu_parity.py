@@ -34,6 +34,27 @@ def test_full_parity(hip_lib, norb, nelec, na, nb, seed, hf):
     run_full_parity(hip_lib, norb, nelec, na, nb, seed, hf, with_rdm2=(norb <= 10))
 
 
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_direct_and_work_item_sigma_forced(hip_lib, monkeypatch, direct):
+    """Both sigma kernels on the same inputs: SQD_SIGMA_DIRECT=1 forces the element-gather kernel (the default only
+    for ultra-sparse string sets such as the uniform headline batch), 0 forbids it."""
+    monkeypatch.setenv("SQD_SIGMA_DIRECT", direct)
+    run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
+    run_full_parity(hip_lib, 12, (4, 6), 30, 70, 13, False, with_rdm2=False)
+    # the headline size, uniform strings, against the string-space oracle
+    norb, nelec, h1, eri, sa, sb = _n2_problem(317, False)
+    x = np.random.default_rng(5).standard_normal((317, 317))
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        s = ctx.sigma(x)
+        p = ctx.sigma(x, 1, 0.0, 0.3)
+        ss = ctx.contract_ss(x)
+    assert np.abs(s - O.sigma_string_space(h1, eri, sa, sb, x, norb)).max() < 1e-10
+    S2x = O.build_spin_square(sa, sb, norb, nelec, sparse=True) @ x.ravel()
+    assert np.abs(ss.ravel() - S2x).max() < 1e-11
+    assert np.abs(p.ravel() - (s.ravel() + 0.3 * S2x)).max() < 1e-10
+
+
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
