@@ -204,7 +204,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   if (c->stream) e = hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
-                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min};
+                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();

@@ -143,6 +143,7 @@ struct sqd_ctx {
   std::vector<hipEvent_t> sig_ev;  // (start, stop) pairs bracketing the sigma launches of a Davidson run
   // integrals
   sqd::DevBuf h1, eri4, eri_pp, jm, km;  // eri_pp[nnorb][nnorb]; jm/km[norb][norb]
+  sqd::DevBuf jdiag;                     // [nnorb][norb]: (pq|kk)
   // subspace
   bool have_subspace = false;
   int64_t na = 0, nb = 0, D = 0;

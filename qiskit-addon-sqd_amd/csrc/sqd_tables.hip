@@ -117,7 +117,7 @@ __device__ inline uint64_t below_mask(int p) { return (p >= 64) ? ~0ull : ((1ull
 // ------------------------------------------------------------------ integral tables
 // eri_pp[tril(p,q)][tril(r,s)] = (pq|rs);  jm[i][j] = (ii|jj);  km[i][j] = (ij|ji)
 __global__ void k_pack_eri(const double* __restrict__ eri4, int norb, int nnorb, double* __restrict__ eri_pp,
-                           double* __restrict__ jm, double* __restrict__ km) {
+                           double* __restrict__ jm, double* __restrict__ km, double* __restrict__ jdiag) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n4 = (int64_t)norb * norb * norb * norb;
   if (idx >= n4) return;
@@ -127,6 +127,7 @@ __global__ void k_pack_eri(const double* __restrict__ eri4, int norb, int nnorb,
   const int p = idx / ((int64_t)norb * norb * norb);
   const double v = eri4[idx];
   if (p >= q && r >= s) eri_pp[(int64_t)tril(p, q) * nnorb + tril(r, s)] = v;
+  if (p >= q && r == s) jdiag[(int64_t)tril(p, q) * norb + r] = v;  // (pq|kk), contiguous in k: the J tables' operand
   if (p == q && r == s) jm[p * norb + r] = v;
   if (p == s && q == r) km[p * norb + q] = v;
 }
@@ -160,8 +161,8 @@ __device__ inline void string_energy_body(const uint64_t* __restrict__ strs, int
 }
 
 // J[I][pair] = sum_{k in I} (pair|kk).  transposed == 0: out[I*nnorb + pair]; else out[pair*n + I]
-__device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ eri_pp,
-                                   int nnorb, int transposed, double* __restrict__ out) {
+__device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ jdiag,
+                                   int nnorb, int norb, int transposed, double* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * nnorb) return;
   int64_t I, pair;
@@ -177,7 +178,7 @@ __device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n,
   while (occ) {
     const int k = ctz64(occ);
     occ &= occ - 1;
-    v += eri_pp[pair * nnorb + (int64_t)k * (k + 1) / 2 + k];
+    v += jdiag[pair * norb + k];  // (the occupied orbitals of one string read 2-4 cache lines of one 8 * norb byte row)
   }
   out[idx] = v;
 }
@@ -226,8 +227,15 @@ __device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restric
   const int64_t chunk = (n + 63) / 64;
   const int64_t lo = (int64_t)lane * chunk;
   const int64_t hi = (lo + chunk < n) ? lo + chunk : n;
+  // (eight loads in flight per round: as a plain loop this was one L2 round trip per element, twice -- 10 us)
   int64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += coherent_load_i64(&in[i]);
+  for (int64_t i0 = lo; i0 < hi; i0 += 8) {
+    int64_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = coherent_load_i64(&in[i0 + u < hi ? i0 + u : i0]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (i0 + u < hi) ? v[u] : 0;
+  }
   // inclusive prefix over the lanes (Hillis-Steele on shuffles), then exclusive
   int64_t incl = s;
   for (int off = 1; off < 64; off <<= 1) {
@@ -236,11 +244,17 @@ __device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restric
   }
   int64_t run = incl - s;
   const int64_t total = (int64_t)__shfl((long long)incl, 63);
-  for (int64_t i = lo; i < hi; ++i) {
-    const int64_t v = coherent_load_i64(&in[i]);
-    out[i] = run;
-    __hip_atomic_store(&host[i], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    run += v;
+  for (int64_t i0 = lo; i0 < hi; i0 += 8) {
+    int64_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = coherent_load_i64(&in[i0 + u < hi ? i0 + u : i0]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < hi) {
+        out[i0 + u] = run;
+        __hip_atomic_store(&host[i0 + u], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        run += v[u];
+      }
   }
   if (lane == 0) {
     out[n] = total;
@@ -293,13 +307,13 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
 // B: blockIdx.y = 0 alpha J table | 1 beta J table (transposed) | 2 the diagonal, one alpha string per workgroup:
 //   hdiag[A,B] = e_a[A] + e_b[B] + sum_{k in B} v_A[k],  v_A[k] = sum_{i in A} (ii|kk)   (pyscf make_hdiag)
 // and the row's lowest element (over B <= A when tril_only: pyscf's init-guess rule for equal spin sectors)
-__global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ jm, const double* __restrict__ eri_pp,
+__global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ jm, const double* __restrict__ jdiag,
                               int norb, int nnorb, int64_t row0, int64_t row1, int64_t nb, int tril_only,
                               double* __restrict__ hdiag, double* __restrict__ pmin, int64_t* __restrict__ pidx) {
   __shared__ double v[SQD_MAX_NORB];
   if (blockIdx.y < 2) {
     const SpinLinkArgs& a = p.a[blockIdx.y];
-    jtable_body(a.strs, a.n, eri_pp, nnorb, a.transposed, a.jtab);
+    jtable_body(a.strs, a.n, jdiag, nnorb, norb, a.transposed, a.jtab);
     return;
   }
   for (int64_t A = row0 + blockIdx.x; A < row1; A += gridDim.x) {
@@ -704,10 +718,11 @@ int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri) {
   SQD_TRY(c->eri_pp.reserve((int64_t)nnorb * nnorb * 8));
   SQD_TRY(c->jm.reserve(n2 * 8));
   SQD_TRY(c->km.reserve(n2 * 8));
+  SQD_TRY(c->jdiag.reserve((int64_t)nnorb * norb * 8));
   SQD_HIP_CHECK(hipMemcpyAsync(c->h1.p, h1, n2 * 8, hipMemcpyHostToDevice, c->stream));
   SQD_HIP_CHECK(hipMemcpyAsync(c->eri4.p, eri, n4 * 8, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_pack_eri, dim3(nblk(n4, 256)), dim3(256), 0, c->stream, c->eri4.as<double>(), norb, nnorb,
-                     c->eri_pp.as<double>(), c->jm.as<double>(), c->km.as<double>());
+                     c->eri_pp.as<double>(), c->jm.as<double>(), c->km.as<double>(), c->jdiag.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
   SQD_STREAM_SYNC(c->stream);
   return SQD_OK;
@@ -853,7 +868,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     const int tril_only = (nocc[0] == nocc[1] && na == nb) ? 1 : 0;
     double* pmin = c->guess_min.as<double>();
     hipLaunchKernelGGL(k_tables_diag, dim3((unsigned)(gx_j > gx_h ? gx_j : gx_h), 3), dim3(256), 0, st, la,
-                       (const double*)c->jm.as<double>(), (const double*)c->eri_pp.as<double>(), norb, nnorb, row0, row1,
+                       (const double*)c->jm.as<double>(), (const double*)c->jdiag.as<double>(), norb, nnorb, row0, row1,
                        nb, tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + nrows));
   }
   SQD_HIP_CHECK(hipGetLastError());
@@ -908,6 +923,33 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
     SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
   }
+  if (c->sig_direct) {
+    // the element-gather sigma kernel reads the CSR lists as they are: no work items, no ELL copies, no descriptor
+    // upload -- only the merged same-spin alpha list (launch D, first job)
+    c->na = na;
+    c->nb = nb;
+    c->row0 = row0;
+    c->row1 = row1;
+    c->D = na * nb;
+    c->nelec[0] = nocc[0];
+    c->nelec[1] = nocc[1];
+    c->n_items = c->n_multi = c->n_slots = 0;
+    const SpinTables& ta = c->sp[0];
+    EllArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.n_a = ta.n;
+    g.sa_ptr = ta.s_ptr.as<int64_t>();
+    g.da_ptr = ta.d_ptr.as<int64_t>();
+    g.sa_rec = ta.s_rec.as<SRec>();
+    g.sa_val = ta.s_val.as<double>();
+    g.da_src = ta.d_src.as<uint32_t>();
+    g.da_val = ta.d_val.as<double>();
+    g.hs_ptr = ta.hs_ptr.as<int64_t>();
+    g.hs_src = ta.hs_src.as<uint32_t>();
+    g.hs_val = ta.hs_val.as<double>();
+    hipLaunchKernelGGL(k_tables_ell, dim3(nblk(ta.n + 1, 4), 1), dim3(256), 0, st, g);
+    SQD_HIP_CHECK(hipGetLastError());
+  } else
   // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
   {
     SpinTables& t = c->sp[1];
