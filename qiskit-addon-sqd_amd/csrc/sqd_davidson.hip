@@ -296,7 +296,7 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
           pk = (pk < 0.0) ? -tiny : tiny;
           if (lane == k) m[k] = pk;
         }
-        const double f = (act && lane > k) ? m[k] / pk : 0.0;
+        const double f = (act && lane > k) ? m[k] * fast_rcp(pk) : 0.0;
 #pragma unroll
         for (int j = k + 1; j < MV; ++j)
           if (j < n) m[j] -= f * wave_bcast(m[j], k);
@@ -314,7 +314,7 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
           if (j < n) r -= m[j] * sol[j];
         double pk = m[k];
         if (k == n - 1 && fabs(pk) < tiny) pk = (pk < 0.0) ? -tiny : tiny;  // the pivot that vanishes at convergence
-        sol[k] = wave_bcast(r / pk, k);
+        sol[k] = wave_bcast(r * fast_rcp(pk), k);
       }
     }
     double yl = 0.0;

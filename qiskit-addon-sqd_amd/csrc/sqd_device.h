@@ -130,6 +130,13 @@ __device__ inline double wave_bcast(double v, int src) {
   __builtin_memcpy(&r, w, 8);
   return r;
 }
+// 1/x to ~1 ulp from the hardware reciprocal + one Newton step: 4 instructions instead of the ~35 of an IEEE
+// division.  For the shifted solves of the Rayleigh-quotient iteration only (self-correcting: the acceptance test
+// looks at the residual of the final pair, which is computed with ordinary arithmetic).
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  return r * (2.0 - x * r);
+}
 // index of the largest value (ties to the lower index); lanes without a candidate pass a negative value
 __device__ inline int wave_argmax(double v, int idx) {
   for (int off = 32; off > 0; off >>= 1) {

@@ -384,8 +384,11 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
   __syncthreads();
   if (r < nres && j == 0) {
     for (int k = 1; k < J; ++k) t += red[threadIdx.x + k];
-    mail_store(&out[r], t);
+    red[512 + r] = t;
   }
+  __syncthreads();
+  // results leave the chip from consecutive lanes: a few full-line writes over PCIe instead of one per result
+  if ((int)threadIdx.x < nres) mail_store(&out[threadIdx.x], red[512 + threadIdx.x]);
 }
 
 constexpr int OBS_MAIL = 3 * 128;  // doubles into the host-visible mailbox (slots 0..2 belong to the Davidson)

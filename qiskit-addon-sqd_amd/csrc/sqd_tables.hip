@@ -217,12 +217,14 @@ struct SpinLinkArgs2 {
 struct ScanJobs {
   const int64_t* in[4];
   int64_t* out[4];
-  int64_t* host[4];
   int64_t n[4];
-  long long* seq_word;  // host-visible: written last
+  const int64_t* dev_block;  // the four pointer arrays, contiguous
+  int64_t* host_block;       // ... and their host-visible twin
+  int64_t nptr;
+  long long* seq_word;       // host-visible: written last
   long long seq;
 };
-__device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t* host, int64_t n) {
+__device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t n) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (n + 63) / 64;
   const int64_t lo = (int64_t)lane * chunk;
@@ -251,15 +253,11 @@ __device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restric
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u < hi) {
-        out[i0 + u] = run;
-        __hip_atomic_store(&host[i0 + u], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        coherent_store_i64(&out[i0 + u], run);
         run += v[u];
       }
   }
-  if (lane == 0) {
-    out[n] = total;
-    __hip_atomic_store(&host[n], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (lane == 0) coherent_store_i64(&out[n], total);
 }
 
 // A: blockIdx.y = spin (link counts) | 2 + spin (string energies)
@@ -294,8 +292,16 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
   if (!arrive_last(counter, blockIdx.y * gridDim.x + blockIdx.x, 2 * gridDim.x)) return;
   {
     const int j = threadIdx.x >> 6;  // blockDim.x == 256: one wavefront per scan
-    wave_exclusive_scan(jobs.in[j], jobs.out[j], jobs.host[j], jobs.n[j]);
+    wave_exclusive_scan(jobs.in[j], jobs.out[j], jobs.n[j]);
   }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  // the whole pointer block to its host-visible twin with unit-stride stores (the first version let every lane of the
+  // scans write its own elements: ~800 scattered 8-byte PCIe writes, 25 us; consecutive lanes -> consecutive words
+  // leave the chip as a few dozen full-line writes)
+  for (int64_t i = threadIdx.x; i < jobs.nptr; i += blockDim.x)
+    __hip_atomic_store(&jobs.host_block[i], coherent_load_i64(&jobs.dev_block[i]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -838,13 +844,14 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       la.a[s].e_str = t.e_str.as<double>();
       jobs.in[2 * s] = cnt_s;
       jobs.out[2 * s] = t.s_ptr.as<int64_t>();
-      jobs.host[2 * s] = c->d_ptrs_map + (jobs.out[2 * s] - c->ptrs.as<int64_t>());
       jobs.n[2 * s] = t.n;
       jobs.in[2 * s + 1] = cnt_d;
       jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
-      jobs.host[2 * s + 1] = c->d_ptrs_map + (jobs.out[2 * s + 1] - c->ptrs.as<int64_t>());
       jobs.n[2 * s + 1] = t.n;
     }
+    jobs.dev_block = c->ptrs.as<int64_t>();
+    jobs.host_block = c->d_ptrs_map;
+    jobs.nptr = nptr;
     jobs.seq = ++c->mail_seq;
     jobs.seq_word = reinterpret_cast<long long*>(c->d_mail + 3 * 128 + 256);  // its own word of the mailbox page
     seq_ptrs = jobs.seq;

@@ -168,6 +168,7 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
   return emu_exchange(v, (lane / width) * width + (src % width));
 }
 inline int __builtin_amdgcn_readlane(int v, int src) { return emu_exchange(v, src); }
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
