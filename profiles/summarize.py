@@ -5,7 +5,7 @@ profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traf
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
@@ -22,7 +22,7 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
-for wl in ("uniform317", "hf317"):
+for wl in ("uniform317", "hf317", "big"):
     out = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
         acc = defaultdict(list)
@@ -37,7 +37,8 @@ for wl in ("uniform317", "hf317"):
             w = out["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
             hbm[k] = {"dispatches": v["dispatches"], "hbm_bytes_per_launch": (2.0 * v["avg_KB"] + w["avg_KB"]) * 1024.0}
         out["HBM_BYTES"] = hbm
-        json.dump(out, open(os.path.join(dst, "pmc", f"final_{wl}_pmc_summary.json"), "w"), indent=1)
+        name = wl if wl != "big" else "uniform10000"
+        json.dump(out, open(os.path.join(dst, "pmc", f"final_{name}_pmc_summary.json"), "w"), indent=1)
         top = sorted(hbm.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]
         print(wl, [(k, round(v["hbm_bytes_per_launch"] / 1e6, 3), v["dispatches"]) for k, v in top])
 print("written to", dst)
