@@ -187,7 +187,6 @@ struct sqd_ctx {
   int sig_kmax = 4;              // batch size limit chosen by the layout search in build_subspace
   size_t sig_shmem = 0;
   bool sig_lds_rows = true;      // C rows staged in LDS (false: rows too long, read from global/L2)
-  bool sig_panel = false;        // large states: the same-spin alpha links run as the column-panel pass k_sigma_alpha_panel
   bool sig_direct = false;       // ultra-sparse coupling: the element-gather kernel k_sigma_direct, no work items
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;

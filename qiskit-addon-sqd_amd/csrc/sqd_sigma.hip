@@ -548,68 +548,6 @@ __global__ void k_sigma_direct(const DirectArgs g) {
   }
 }
 
-// ---- same-spin alpha links of LARGE states as a second, column-panel pass (D beyond what the L2s hold).
-// Inside the row items every alpha link is a unit-stride read of a whole source row C[A',:] (80 KB at nb = 1e4);
-// the ~11 source rows of a target row are anywhere in the 0.8 GB vector, so they come over the fabric every time:
-// 9 GB of the 15.8 GB that one sigma moves at 1e4 x 1e4 (profiles/r02/pmc/final_uniform10000_pmc_summary.json)
-// against 1.6 GB algorithmic.  Here the columns are cut into panels of PANEL_W columns (all rows x 16 columns =
-// 1.3 MB at na = 1e4: resident in ONE XCD's 4 MB L2) and the grid is persistent: workgroup b runs on XCD b % 8
-// (MI355X_MICROARCH.md, workgroup dispatch) and, together with the other workgroups of that XCD, sweeps the panels
-// c = xcd, xcd + 8, ... one after the other, all rows each -- so a panel is fetched from HBM once and every further
-// source-row segment is an L2 hit.  sigma (or the first partial row of a split row) is updated in place by exactly
-// one thread per element: same bits every run.
-constexpr int PANEL_W = 16;
-struct PanelArgs {
-  const double* c;
-  double* sigma;
-  double* partial;
-  const int32_t* rowinfo;  // [2 (A - row0)] first slot, [2 (A - row0) + 1] slots
-  const int64_t* hs_ptr;
-  const uint32_t* hs_src;
-  const double* hs_val;
-  int64_t row0, row1, nb;
-  const int* stop;
-  const int* vec_index;
-  int64_t c_stride, s_stride;
-};
-__global__ void k_sigma_alpha_panel(const PanelArgs g) {
-  if (g.stop && *g.stop) return;
-  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
-  const double* __restrict__ C = g.c + vsel * g.c_stride;
-  double* __restrict__ sig = g.sigma + vsel * g.s_stride;
-  const int64_t nb = g.nb, nrows = g.row1 - g.row0;
-  const int64_t npanels = (nb + PANEL_W - 1) / PANEL_W;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int col = threadIdx.x % PANEL_W, rl = threadIdx.x / PANEL_W, RL = blockDim.x / PANEL_W;
-  for (int64_t p = xcd; p < npanels; p += 8) {
-    const int64_t B = p * PANEL_W + col;
-    if (B >= nb) continue;
-    for (int64_t Ar = (int64_t)slot * RL + rl; Ar < nrows; Ar += (int64_t)nslots * RL) {
-      const int64_t A = g.row0 + Ar;
-      const int64_t l0 = g.hs_ptr[A], l1 = g.hs_ptr[A + 1];
-      if (l1 == l0) continue;
-      double a = 0.0;
-      for (int64_t l = l0; l < l1; l += 8) {  // eight links' records, then their eight segments, in flight together
-        uint32_t s8[8];
-        double v8[8], x8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int64_t ll = (l + u < l1) ? l + u : l;
-          s8[u] = g.hs_src[ll];
-          v8[u] = g.hs_val[ll];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x8[u] = C[(int64_t)s8[u] * nb + B];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a += (l + u < l1) ? v8[u] * x8[u] : 0.0;
-      }
-      const int ns = g.rowinfo[2 * Ar + 1];
-      double* dst = (ns > 0) ? (g.partial + (int64_t)g.rowinfo[2 * Ar] * nb + B) : (sig + Ar * nb + B);
-      *dst += a;
-    }
-  }
-}
-
 // sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items.
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
@@ -808,27 +746,6 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   else if (R <= 8) rc = launch_sigma_r<8>(c, g);
   else rc = launch_sigma_r<16>(c, g);
   if (rc != SQD_OK) return rc;
-  if (c->sig_panel && mode == 0) {
-    const SpinTables& ta = c->sp[0];
-    PanelArgs pg;
-    pg.c = d_c;
-    pg.sigma = d_sigma;
-    pg.partial = c->sig_partial.as<double>();
-    pg.rowinfo = c->rowinfo.as<int32_t>();
-    pg.hs_ptr = ta.hs_ptr.as<int64_t>();
-    pg.hs_src = ta.hs_src.as<uint32_t>();
-    pg.hs_val = ta.hs_val.as<double>();
-    pg.row0 = c->row0;
-    pg.row1 = c->row1;
-    pg.nb = c->nb;
-    pg.stop = g.stop;
-    pg.vec_index = g.vec_index;
-    pg.c_stride = in_stride;
-    pg.s_stride = out_stride;
-    // persistent grid: 8 XCDs x (32 CUs x 4 workgroups of 256 threads)
-    hipLaunchKernelGGL(k_sigma_alpha_panel, dim3(8 * 128), dim3(256), 0, c->stream, pg);
-    SQD_HIP_CHECK(hipGetLastError());
-  }
   if (c->n_multi > 0 && !(c->sigma_defer_reduce && indexed && mode == 0)) {
     hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
                        (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,

@@ -667,11 +667,6 @@ static int build_sigma_work(sqd_ctx* c) {
     const int v = std::atoi(env);
     if (v >= 0 && v <= 4096) L0 = v;
   }
-  // Large states (one vector beyond what the eight L2s hold together): the same-spin alpha links leave the row items
-  // and run as the column-panel pass (sqd_sigma.hip).  SQD_SIGMA_PANEL=1 / 0 forces / forbids it (tests, tuning).
-  c->sig_panel = (double)na * (double)nb * 8.0 > 48.0 * 1024 * 1024;
-  if (const char* env = std::getenv("SQD_SIGMA_PANEL")) c->sig_panel = std::atoi(env) != 0;
-  if (c->sig_panel) L0 = 0;
   std::vector<WorkItem>& items = c->h_items;
   std::vector<MultiRow>& multi = c->h_multi;
   items.clear();
@@ -687,9 +682,8 @@ static int build_sigma_work(sqd_ctx* c) {
     row.push_back(own);
     for (int64_t l = s0; l < s1; l += K)
       row.push_back(WorkItem{l, (uint32_t)A, 1, (uint16_t)((s1 - l < K) ? (s1 - l) : K), -1, 0});
-    if (!c->sig_panel)
-      for (int64_t l = h0 + L0; l < h1; l += L)
-        row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
+    for (int64_t l = h0 + L0; l < h1; l += L)
+      row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
     if (row.size() > 1) {  // several items: partial rows + fixed-order reduce
       multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
       c->h_rowinfo[2 * (A - c->row0)] = nslots;
@@ -947,7 +941,6 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->nelec[0] = nocc[0];
     c->nelec[1] = nocc[1];
     c->n_items = c->n_multi = c->n_slots = 0;
-    c->sig_panel = false;
     const SpinTables& ta = c->sp[0];
     EllArgs g;
     std::memset(&g, 0, sizeof(g));

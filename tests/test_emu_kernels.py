@@ -50,15 +50,6 @@ def test_emu_direct_and_work_item_sigma(emu_lib, monkeypatch, direct):
     run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
 
 
-def test_emu_alpha_panel_pass(emu_lib, monkeypatch):
-    # SQD_SIGMA_PANEL=1 forces the layout of large states at oracle size: the same-spin alpha links leave the row items
-    # and run as the column-panel pass, updating sigma -- or the first partial row of a split row -- in place
-    monkeypatch.setenv("SQD_SIGMA_PANEL", "1")
-    monkeypatch.setenv("SQD_SIGMA_DIRECT", "0")
-    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
-    run_operator_parity(emu_lib, 6, (3, 2), 12, 9, 5, False)
-
-
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,

@@ -55,31 +55,6 @@ def test_direct_and_work_item_sigma_forced(hip_lib, monkeypatch, direct):
     assert np.abs(p.ravel() - (s.ravel() + 0.3 * S2x)).max() < 1e-10
 
 
-def test_alpha_panel_pass_forced(hip_lib, monkeypatch):
-    """The layout of large states (same-spin alpha links as the XCD-aware column-panel pass) forced at oracle sizes,
-    and at the headline HF-centred size against the whole-row layout (different summation order: 1e-12 relative)."""
-    monkeypatch.setenv("SQD_SIGMA_PANEL", "1")
-    monkeypatch.setenv("SQD_SIGMA_DIRECT", "0")
-    run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
-    run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
-    run_full_parity(hip_lib, 12, (4, 6), 30, 70, 13, False, with_rdm2=False)
-    norb, nelec, h1, eri, sa, sb = _n2_problem(317, True)
-    x = np.random.default_rng(5).standard_normal((317, 317))
-    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
-        ctx.set_subspace(sa, sb)
-        s_panel = ctx.sigma(x)
-        amps, st = ctx.davidson()
-        e_panel = st["e_davidson"]
-    monkeypatch.setenv("SQD_SIGMA_PANEL", "0")
-    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
-        ctx.set_subspace(sa, sb)
-        s_rows = ctx.sigma(x)
-        _, st2 = ctx.davidson()
-    assert np.abs(s_panel - s_rows).max() < 1e-11 * np.abs(s_rows).max()
-    assert np.abs(s_panel - O.sigma_string_space(h1, eri, sa, sb, x, norb)).max() < 1e-10
-    assert abs(e_panel - st2["e_davidson"]) < 1e-9 and st["converged"] == 1
-
-
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
