@@ -96,7 +96,7 @@ def pmc_traffic(args):
         try:
             d = json.loads(f.read_text())["HBM_BYTES"]
             # the H-sigma instantiation is the one the Davidson launches (most dispatches); S^2 runs once per solve
-            key = max((k for k in d if "k_sigma<" in k), key=lambda k: d[k]["dispatches"])
+            key = max((k for k in d if "k_sigma" in k and "reduce" not in k), key=lambda k: d[k]["dispatches"])
             return d[key]["hbm_bytes_per_launch"], f"committed profile {f.relative_to(ROOT)} (not measured in this run)"
         except Exception:
             continue
