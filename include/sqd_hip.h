@@ -83,6 +83,11 @@ int sqd_sigma_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_sigma_row
 int sqd_contract_ss_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_out_rows);
 int sqd_hdiag_rows_dev(sqd_ctx* ctx, double* d_out_rows);
 int sqd_ctx_sync(sqd_ctx* ctx);
+/* on != 0: bracket every following sqd_set_subspace and Davidson run of this context with HIP events, so that
+ * sqd_davidson_stats::ms_setup / ms_total are filled.  Off by default: each event record is a bubble in a stream of
+ * ~5 us kernels (four records cost ~40 us of a 0.2 ms solve).  The sigma-launch sampling of time_sigma_every is
+ * independent of this switch. */
+int sqd_ctx_set_phase_timing(sqd_ctx* ctx, int on);
 
 /* Sizes of the current subspace. */
 int sqd_get_dims(sqd_ctx* ctx, int64_t* na, int64_t* nb, int* nelec_a, int* nelec_b);

@@ -15,7 +15,7 @@ python bench.py --strings hf --spin-sq 0 --skip-cpu --skip-secondary > $OUT/benc
 python bench.py --skip-cpu --skip-secondary --extra > $OUT/bench_extra_ladder.json 2>/dev/null
 python bench.py --norb 40 --nelec 15 --na 707 --nb 707 --skip-cpu --skip-secondary > $OUT/bench_fes_uniform707.json 2>/dev/null
 python bench.py --norb 40 --nelec 15 --na 707 --nb 707 --strings hf --skip-cpu --skip-secondary --steps 5 --warmup 1 > $OUT/bench_fes_hf707.json 2>/dev/null
-SQD_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --skip-cpu --skip-secondary > $OUT/bench_forced_dist_1gpu.json 2>/dev/null
+SQD_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --skip-cpu --skip-secondary > $OUT/bench_forced_dist_1gpu.json 2> $OUT/bench_forced_dist_1gpu.err
 python bench_pauli.py > $OUT/bench_pauli.json 2>/dev/null
 python profiles/probes/_phase_probe2.py 2>&1 | grep -v amdgpu.ids > $OUT/phase_probe.txt
 python profiles/probes/_jitter_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/jitter_probe.txt

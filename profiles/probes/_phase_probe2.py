@@ -9,12 +9,16 @@ ctx = F._get_context(h1, eri, 0)
 
 
 def t(f, n=30):
+    """median wall time of one call, ms (the median: a process' first ~0.1 s of GPU activity contains one or two
+    30-50 ms stalls, stall_probe.txt, which a mean over 30 calls would charge to whichever phase they land in)"""
     for _ in range(3):
         f()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(n):
+        t0 = time.perf_counter()
         f()
-    return (time.perf_counter() - t0) / n * 1e3
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
 
 
 for name, gen in (('uniform', S.uniform_strings), ('hf', S.hf_centred_strings)):

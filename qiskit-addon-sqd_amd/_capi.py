@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "sqd_contract_ss_rows_dev",
     "sqd_hdiag_rows_dev",
     "sqd_ctx_sync",
+    "sqd_ctx_set_phase_timing",
     "sqd_get_dims",
     "sqd_link_counts",
     "sqd_single_links",
@@ -118,6 +119,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_contract_ss_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p]
     lib.sqd_hdiag_rows_dev.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_sync.argtypes = [_ctxp]
+    lib.sqd_ctx_set_phase_timing.argtypes = [_ctxp, C.c_int]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
     lib.sqd_single_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp]
@@ -340,6 +342,11 @@ class Context:
 
     def hdiag_rows_dev(self, out_rows_ptr: int):
         self._check(self._lib.sqd_hdiag_rows_dev(self._h, C.c_void_p(int(out_rows_ptr))))
+
+    def set_phase_timing(self, on: bool):
+        """Fill ``ms_setup`` / ``ms_total`` of the Davidson statistics (HIP events around the table build and the
+        Davidson run of every following solve; costs stream bubbles, off by default)."""
+        self._check(self._lib.sqd_ctx_set_phase_timing(self._h, 1 if on else 0))
 
     def sync(self):
         self._check(self._lib.sqd_ctx_sync(self._h))

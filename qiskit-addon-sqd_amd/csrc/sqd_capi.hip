@@ -251,6 +251,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
 
 SQD_API int sqd_set_subspace(sqd_ctx* c, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb) {
   CTX_ENTER(c);
+  c->want_timing = c->phase_timing;
   return build_subspace(c, strs_a, na, strs_b, nb);
 }
 
@@ -291,6 +292,11 @@ SQD_API int sqd_hdiag_rows_dev(sqd_ctx* c, double* d_out_rows) {
   if (!d_out_rows) return SQD_ERR_INVALID;
   SQD_HIP_CHECK(hipMemcpyAsync(d_out_rows, c->hdiag.p, (size_t)(c->row1 - c->row0) * c->nb * 8, hipMemcpyDeviceToDevice,
                                c->stream));
+  return SQD_OK;
+}
+SQD_API int sqd_ctx_set_phase_timing(sqd_ctx* c, int on) {
+  if (!c) return SQD_ERR_INVALID;
+  c->phase_timing = on != 0;
   return SQD_OK;
 }
 SQD_API int sqd_ctx_sync(sqd_ctx* c) {
@@ -458,7 +464,7 @@ SQD_API int sqd_davidson(sqd_ctx* c, const sqd_davidson_opts* opts, const double
     set_error("bad Davidson options");
     return SQD_ERR_INVALID;
   }
-  c->want_timing = (o.time_sigma_every > 0 || o.verbose);
+  c->want_timing = c->phase_timing || o.verbose;
   SQD_TRY(run_davidson(c, &o, ci0, stats));
   if (amps) {
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, c->D * 8, hipMemcpyDeviceToHost, c->stream));
@@ -540,7 +546,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     set_error("bad Davidson options");
     return SQD_ERR_INVALID;
   }
-  c->want_timing = (o.time_sigma_every > 0 || o.verbose);
+  c->want_timing = c->phase_timing || o.verbose;
   SQD_TRY(run_davidson(c, &o, ci0, nullptr, /*defer_sync=*/true));
   const size_t bytes = (size_t)c->D * 8;
   // small states go through a pinned staging buffer (a truly asynchronous copy); large ones straight to
@@ -603,7 +609,7 @@ SQD_API int sqd_solve_strings(sqd_ctx* c, const uint64_t* strs_a, int64_t na, co
                               const sqd_davidson_opts* opts, const double* ci0, double* amps, sqd_davidson_stats* stats,
                               double* e, double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b) {
   CTX_ENTER(c);
-  c->want_timing = opts && (opts->time_sigma_every > 0 || opts->verbose);
+  c->want_timing = c->phase_timing || (opts && opts->verbose);
   SQD_TRY(build_subspace(c, strs_a, na, strs_b, nb));
   if (nelec_a) *nelec_a = c->nelec[0];
   if (nelec_b) *nelec_b = c->nelec[1];

@@ -165,7 +165,8 @@ struct sqd_ctx {
   char* stage_cur = nullptr;
   size_t stage_cap = 0, stage_off = 0, stage_total = 0;
   bool stage_pending = false;   // uploads of the last set_subspace may still read the arena (cleared by any full sync)
-  bool want_timing = false;     // record the set_subspace / Davidson timing events (costs stream bubbles: off unless asked)
+  bool want_timing = false;     // record the set_subspace / Davidson phase events this call (stream bubbles: off unless asked)
+  bool phase_timing = false;    // sticky request for the above (sqd_ctx_set_phase_timing)
   sqd::DevBuf ptrs;                 // [s_ptr_a | d_ptr_a | s_ptr_b | d_ptr_b]; SpinTables::s_ptr/d_ptr are views
   // host-visible (mapped, coherent) twin of `ptrs`: the scan writes every pointer to both, so the host reads them
   // without a copy command or an event; grow-only
