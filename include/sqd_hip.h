@@ -153,6 +153,8 @@ typedef struct sqd_davidson_stats {
   double ms_setup;     /* device time of the last sqd_set_subspace */
   int n_sigma_timed;   /* number of sigma launches bracketed by events in this run */
   double ms_sigma_kernel; /* of which: the k_sigma launches alone (start event .. event after k_sigma) */
+  double ms_event_overhead; /* summed duration of the EMPTY event bracket recorded right behind every timed sigma: what
+                               two event records cost by themselves; ms_sigma_kernel minus this is the kernel time */
 } sqd_davidson_stats;
 
 void sqd_davidson_default_opts(sqd_davidson_opts* o);

@@ -93,6 +93,7 @@ class DavidsonStats(C.Structure):
         ("ms_setup", C.c_double),
         ("n_sigma_timed", C.c_int),
         ("ms_sigma_kernel", C.c_double),
+        ("ms_event_overhead", C.c_double),
     ]
 
 

@@ -152,7 +152,7 @@ SQD_API int sqd_ctx_create(int device, int norb, const double* h1, const double*
       return SQD_ERR_HIP;
     }
   }
-  c->sig_ev.resize(3 * 128, nullptr);  // (start, after k_sigma, end) per timed sigma application
+  c->sig_ev.resize(4 * 128, nullptr);  // (start, after k_sigma, end, end of an empty bracket) per timed sigma application
   for (auto& evt : c->sig_ev) {
     e = hipEventCreate(&evt);
     if (e != hipSuccess) {

@@ -942,7 +942,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   // every time_sigma_every-th sigma launch of this context is bracketed by events (stats->ms_sigma); an
   // event pair costs ~10 us of stream time, so this is sampling, and off unless asked for
   const int ev_every = o->time_sigma_every > 0 ? o->time_sigma_every : 0;
-  const int max_ev = ev_every ? (int)c->sig_ev.size() / 3 : 0;
+  const int max_ev = ev_every ? (int)c->sig_ev.size() / 4 : 0;
   int nev = 0;
   c->dav_ev_iter.clear();
 
@@ -991,14 +991,16 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
     ++c->sigma_launches;
     if (timed) {
-      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev], s));
-      c->ev_after_sigma_kernel = c->sig_ev[3 * nev + 1];  // recorded by launch_sigma right after k_sigma
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[4 * nev], s));
+      c->ev_after_sigma_kernel = c->sig_ev[4 * nev + 1];  // recorded by launch_sigma right after k_sigma
     }
     const int rc_h = apply_h(c, X, AX, o->use_spin, o->ss, o->shift, D, D);
     c->ev_after_sigma_kernel = nullptr;
     SQD_TRY(rc_h);
     if (timed) {
-      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[3 * nev + 2], s));
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[4 * nev + 2], s));
+      // an EMPTY bracket right behind: what two event records cost by themselves at this point of the stream
+      SQD_HIP_CHECK(hipEventRecord(c->sig_ev[4 * nev + 3], s));
       c->dav_ev_iter.push_back(enq);
       ++nev;
     }
@@ -1060,19 +1062,22 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st) {
     st->e_davidson = res[3];
     st->residual = std::sqrt(res[4] > 0.0 ? res[4] : 0.0);
     st->ms_total = ms;
-    double msig = 0.0, mker = 0.0;
+    double msig = 0.0, mker = 0.0, mempty = 0.0;
     int counted = 0;
     for (int i = 0; i < c->dav_nev; ++i) {
       if (c->dav_ev_iter[i] >= iterations) continue;  // enqueued ahead of the stop: that launch returned at once
       float t = 0.f;
-      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 2]));
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[4 * i], c->sig_ev[4 * i + 2]));
       msig += t;
-      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[3 * i], c->sig_ev[3 * i + 1]));
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[4 * i], c->sig_ev[4 * i + 1]));
       mker += t;
+      SQD_HIP_CHECK(hipEventElapsedTime(&t, c->sig_ev[4 * i + 2], c->sig_ev[4 * i + 3]));
+      mempty += t;
       ++counted;
     }
     st->ms_sigma = msig;
     st->ms_sigma_kernel = mker;
+    st->ms_event_overhead = mempty;
     st->n_sigma_timed = counted;
     st->ms_setup = c->ms_setup;
   }
