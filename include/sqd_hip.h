@@ -83,6 +83,10 @@ int sqd_sigma_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_sigma_row
 int sqd_contract_ss_rows_dev(sqd_ctx* ctx, const double* d_c_full, double* d_out_rows);
 int sqd_hdiag_rows_dev(sqd_ctx* ctx, double* d_out_rows);
 int sqd_ctx_sync(sqd_ctx* ctx);
+/* Device address of the resident Davidson solution (na*nb doubles, normalised), valid until the next solve or
+ * sqd_set_subspace on this context.  For collectives that ship the winning state between GPUs without a detour through
+ * the host (the broadcast after the reference's batch loop, fermion.py:432 / :608-631). */
+int sqd_solution_device_ptr(sqd_ctx* ctx, const double** d_ptr);
 /* on != 0: bracket every following sqd_set_subspace and Davidson run of this context with HIP events, so that
  * sqd_davidson_stats::ms_setup / ms_total are filled.  Off by default: each event record is a bubble in a stream of
  * ~5 us kernels (four records cost ~40 us of a 0.2 ms solve).  The sigma-launch sampling of time_sigma_every is

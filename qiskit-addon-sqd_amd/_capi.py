@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "sqd_contract_ss_rows_dev",
     "sqd_hdiag_rows_dev",
     "sqd_ctx_sync",
+    "sqd_solution_device_ptr",
     "sqd_ctx_set_phase_timing",
     "sqd_get_dims",
     "sqd_link_counts",
@@ -120,6 +121,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_contract_ss_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p]
     lib.sqd_hdiag_rows_dev.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_sync.argtypes = [_ctxp]
+    lib.sqd_solution_device_ptr.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
     lib.sqd_ctx_set_phase_timing.argtypes = [_ctxp, C.c_int]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
@@ -343,6 +345,12 @@ class Context:
 
     def hdiag_rows_dev(self, out_rows_ptr: int):
         self._check(self._lib.sqd_hdiag_rows_dev(self._h, C.c_void_p(int(out_rows_ptr))))
+
+    def solution_device_ptr(self) -> int:
+        """Device address of the resident Davidson solution (valid until the next solve on this context)."""
+        out = C.c_void_p()
+        self._check(self._lib.sqd_solution_device_ptr(self._h, C.byref(out)))
+        return int(out.value)
 
     def set_phase_timing(self, on: bool):
         """Fill ``ms_setup`` / ``ms_total`` of the Davidson statistics (HIP events around the table build and the

@@ -294,6 +294,17 @@ SQD_API int sqd_hdiag_rows_dev(sqd_ctx* c, double* d_out_rows) {
                                c->stream));
   return SQD_OK;
 }
+SQD_API int sqd_solution_device_ptr(sqd_ctx* c, const double** d_ptr) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!d_ptr) return SQD_ERR_INVALID;
+  if (!c->have_solution) {
+    set_error("no resident solution: run sqd_davidson / sqd_solve first");
+    return SQD_ERR_STATE;
+  }
+  *d_ptr = c->sol.as<double>();
+  return SQD_OK;
+}
 SQD_API int sqd_ctx_set_phase_timing(sqd_ctx* c, int on) {
   if (!c) return SQD_ERR_INVALID;
   c->phase_timing = on != 0;

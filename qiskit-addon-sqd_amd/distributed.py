@@ -51,6 +51,29 @@ def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
     return hit
 
 
+class _DeviceView:
+    """Zero-copy handle on device memory for ``torch.as_tensor`` (``__cuda_array_interface__``, version 2)."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _resident_solution(one_body_tensor, two_body_tensor, device, shape, tdev):
+    """The Davidson solution still resident in this rank's solver context as a torch tensor, or None."""
+    import torch
+
+    from .fermion import _get_context
+
+    try:
+        ctx = _get_context(np.asarray(one_body_tensor, dtype=np.float64), two_body_tensor, device)
+        if (ctx.na, ctx.nb) != tuple(shape):
+            return None
+        return torch.as_tensor(_DeviceView(ctx.solution_device_ptr(), shape), device=tdev)
+    except Exception:  # any doubt: take the host path
+        return None
+
+
 def shard_indices(num_batches: int, rank: int, world: int) -> list[int]:
     """Batches owned by ``rank``: round-robin, ``i % world == rank``."""
     return list(range(rank, num_batches, world))
@@ -125,14 +148,33 @@ def solve_sci_batch_distributed(
     # fermion.py:608-631; the reference ships it inside the pickled iteration state)
     sa, sb = ci_strings[best]
     if world > 1 or on_gpu:  # (also on a one-rank RCCL group: the collective path is the tested path)
+        src = dist.get_global_rank(group, owner) if group is not None else owner
+        dev_view = None
         if rank == owner:
-            amps = np.ascontiguousarray(local[best].sci_state.amplitudes, dtype=np.float64)
-            ta = torch.from_numpy(amps).to(tdev, non_blocking=True) if on_gpu else torch.from_numpy(amps)
+            amps = local[best].sci_state.amplitudes
+            if on_gpu and local_solver is None and shard_indices(nb, rank, world)[-1] == best:
+                # the winner is this rank's LAST solve: its state is still resident in the solver context -- ship it
+                # from there, no host-to-device copy
+                dev_view = _resident_solution(one_body_tensor, two_body_tensor, device, amps.shape, tdev)
+            if dev_view is not None:
+                ta = dev_view
+            else:
+                a = np.ascontiguousarray(amps, dtype=np.float64)
+                ta = torch.from_numpy(a).to(tdev, non_blocking=True) if on_gpu else torch.from_numpy(a)
         else:
             ta = torch.empty((len(sa), len(sb)), dtype=torch.float64, device=tdev)
-        src = dist.get_global_rank(group, owner) if group is not None else owner
         dist.broadcast(ta, src=src, group=group)
-        amps = local[best].sci_state.amplitudes if rank == owner else ta.cpu().numpy()
+        if rank == owner:
+            if on_gpu:
+                torch.cuda.current_stream(tdev).synchronize()  # the resident buffer is free again for the next solve
+        elif on_gpu:
+            from ._capi import pinned_empty
+
+            amps = pinned_empty(tuple(ta.shape))
+            torch.from_numpy(amps).copy_(ta, non_blocking=True)
+            torch.cuda.current_stream(tdev).synchronize()
+        else:
+            amps = ta.numpy()
     else:
         amps = local[best].sci_state.amplitudes
 
