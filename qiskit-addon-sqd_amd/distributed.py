@@ -33,6 +33,19 @@ def _dist():
 
 
 _XBUF: dict = {}
+_GROUPS: dict = {}
+
+
+def _group_info(dist, group):
+    """(rank, world, backend is RCCL) of a process group, cached: three c10d queries cost ~10 us per call."""
+    key = id(group)
+    hit = _GROUPS.get(key)
+    if hit is None or hit[3] is not (group if group is not None else dist.group.WORLD):
+        pg = group if group is not None else dist.group.WORLD
+        hit = _GROUPS[key] = (dist.get_rank(group), dist.get_world_size(group), dist.get_backend(group) == "nccl", pg)
+        while len(_GROUPS) > 16:
+            _GROUPS.pop(next(iter(_GROUPS)))
+    return hit[0], hit[1], hit[2]
 
 
 def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
@@ -105,9 +118,7 @@ def solve_sci_batch_distributed(
     import torch
 
     dist = _dist()
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    on_gpu = backend == "nccl"
+    rank, world, on_gpu = _group_info(dist, group)
     if device is None:
         device = torch.cuda.current_device() if on_gpu else 0
     tdev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
@@ -116,9 +127,11 @@ def solve_sci_batch_distributed(
     nb = len(ci_strings)
     width = 1 + 2 * norb
 
-    # ---- independent solves, no communication
+    # ---- independent solves, no communication.  The records go straight into the (cached, pinned) exchange buffer.
     local: dict[int, SCIResult] = {}
-    table = np.zeros((nb, width))
+    dev_table, host_table = _exchange_buffers(group, tdev, nb, width, on_gpu)
+    table = host_table.numpy()
+    table[:] = 0.0
     for i in shard_indices(nb, rank, world):
         res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
                      device=device, **kwargs)  # fmt: skip
@@ -130,9 +143,6 @@ def solve_sci_batch_distributed(
     # ---- the path's single exchange: all-reduce(sum) of the per-batch records.  Device and pinned host buffers
     # are cached per (group, shape): the record table is 61 doubles per batch at norb = 30, so everything but the
     # collective itself is overhead worth removing (allocation, pageable copies)
-    dev_table, host_table = _exchange_buffers(group, tdev, nb, width, on_gpu)
-    host_np = host_table.numpy()
-    host_np[:] = table
     if on_gpu:
         dev_table.copy_(host_table, non_blocking=True)
         dist.all_reduce(dev_table, op=dist.ReduceOp.SUM, group=group)
@@ -140,7 +150,7 @@ def solve_sci_batch_distributed(
         torch.cuda.current_stream(tdev).synchronize()
     else:
         dist.all_reduce(host_table, op=dist.ReduceOp.SUM, group=group)
-    table = host_np.copy()
+    table = table.copy()
     best = int(np.argmin(table[:, 0]))
     owner = best % world
 
