@@ -252,6 +252,22 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
   const int lane = threadIdx.x & 63;
   const bool act = lane < n;
   double xi = (act && lane < n - 1) ? xi_io : 0.0;
+  {
+    // first-order estimate of the new vector's weight in the Ritz vector instead of a zero: -(h . v_old) / (a_nn - e_old),
+    // h = coupling of the new basis vector to the old ones (row n-1, owned by lane n-1).  One dot product that usually
+    // saves the second shifted solve.
+    double hv = 0.0;
+#pragma unroll
+    for (int j = 0; j < MV; ++j)
+      if (j < n - 1) hv += a[j] * wave_bcast(xi, j);
+    double ann = 0.0;
+#pragma unroll
+    for (int j = 0; j < MV; ++j) ann = (j == n - 1) ? a[j] : ann;
+    const double den = ann - e_old;
+    const double delta = (fabs(den) > 1e-12) ? -hv / den : 0.0;
+    const double dlast = wave_bcast(delta, n - 1);
+    if (lane == n - 1 && fabs(dlast) < 0.5) xi = dlast;
+  }
   double rowabs = 0.0;
 #pragma unroll
   for (int j = 0; j < MV; ++j) rowabs += (j < n) ? fabs(a[j]) : 0.0;
