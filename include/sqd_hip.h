@@ -159,6 +159,8 @@ typedef struct sqd_davidson_stats {
   double ms_sigma_kernel; /* of which: the k_sigma launches alone (start event .. event after k_sigma) */
   double ms_event_overhead; /* summed duration of the EMPTY event bracket recorded right behind every timed sigma: what
                                two event records cost by themselves; ms_sigma_kernel minus this is the kernel time */
+  int n_eig_solves;    /* device-side projected eigenproblem: shifted solves of the warm-started Rayleigh-quotient iteration */
+  int n_eig_fallbacks; /* ... and how many projected problems fell back to the Jacobi solver */
 } sqd_davidson_stats;
 
 void sqd_davidson_default_opts(sqd_davidson_opts* o);

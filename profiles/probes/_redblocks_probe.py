@@ -15,5 +15,5 @@ for name, gen, n in (('uniform', S.uniform_strings, 60), ('hf', S.hf_centred_str
     ts = []
     for _ in range(n):
         t0 = time.perf_counter(); _, st = ctx.davidson(fetch=False); ts.append((time.perf_counter() - t0) * 1e3)
-    out.append(f'{name} davidson {np.median(ts):.3f} ms ({st["n_sigma"]} sigma, {1e3*np.median(ts)/st["n_sigma"]:.1f} us/iter)')
+    out.append(f'{name} davidson {np.median(ts):.3f} ms ({st["n_sigma"]} sigma, {1e3*np.median(ts)/st["n_sigma"]:.1f} us/iter, eig solves {st["n_eig_solves"]}, jacobi {st["n_eig_fallbacks"]})')
 print('SQD_RED_BLOCKS=' + os.environ.get('SQD_RED_BLOCKS', 'default(197)'), ' | '.join(out), flush=True)

@@ -95,6 +95,8 @@ class DavidsonStats(C.Structure):
         ("n_sigma_timed", C.c_int),
         ("ms_sigma_kernel", C.c_double),
         ("ms_event_overhead", C.c_double),
+        ("n_eig_solves", C.c_int),
+        ("n_eig_fallbacks", C.c_int),
     ]
 
 

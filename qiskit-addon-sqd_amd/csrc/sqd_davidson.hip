@@ -106,6 +106,8 @@ struct DavState {
   int restart;   // the current iteration collapses the basis to {Ritz vector, correction}
   int err;       // 1: the start vector has zero norm
   int sol_m;     // the solution is sum_{v < sol_m} sol_coef[v] X_v
+  int n_rqi;     // diagnostics: shifted solves of the warm-started eigen-solver, and how often it gave way to Jacobi
+  int n_jacobi;
   int pad;
   double e, de, rnorm2;
   double sv[MAXB + 1];        // 1 / |X_v| (basis vector v is sv_v X_v: vectors are never normalised by a pass)
@@ -141,6 +143,8 @@ __device__ inline void dav_state_init(DavState* st, unsigned* counter) {
     st->restart = 0;
     st->err = 0;
     st->sol_m = 1;
+    st->n_rqi = 0;
+    st->n_jacobi = 0;
     st->e = 0.0;
     st->de = 0.0;
     st->rnorm2 = 0.0;
@@ -248,7 +252,8 @@ __global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks
 // correctness, is what the missing pivoting can cost.
 // a[j] = A[lane][j]; xi: previous Ritz vector component of this lane in, new one out.
 template <int MV>
-__device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double& xi_io, double e_old, double* e_out) {
+__device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double& xi_io, double e_old, double* e_out,
+                                           int* n_solves) {
   const int lane = threadIdx.x & 63;
   const bool act = lane < n;
   double xi = (act && lane < n - 1) ? xi_io : 0.0;
@@ -286,7 +291,10 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
   double theta = wave_sum(xi * yi);
   for (int it = 0; it < 6; ++it) {
     const double res = wave_sum(act ? (yi - theta * xi) * (yi - theta * xi) : 0.0);
-    if (sqrt(res) <= 8.0 * tiny) {
+    // accepted at 1e-11 |A| (the residual of the small eigenpair, not of the big one): the Ritz value is second order
+    // in it and the Ritz coefficients feed a Davidson residual whose own threshold is 1e-6; rounding level (8 tiny)
+    // cost a second shifted solve on nearly every call (72 solves for 35 calls on the HF-centred headline problem)
+    if (sqrt(res) <= 1e-11 * anorm) {
       if (!(theta <= e_old + 64.0 * tiny)) return false;  // not provably the lowest eigenvalue
       // (a new vector that does not couple to the old Ritz vector leaves that pair an eigenpair of the grown
       // matrix although its own diagonal may lie lower: the lowest eigenvalue is below every diagonal element)
@@ -300,6 +308,7 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
       return true;
     }
     // z = (A - theta I)^-1 x: elimination in the natural order, row k owned by lane k
+    if (lane == 0) *n_solves += 1;
     double m[MV];
 #pragma unroll
     for (int j = 0; j < MV; ++j) m[j] = a[j] - ((j == lane) ? theta : 0.0);
@@ -486,10 +495,11 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
     done = true;
   } else if (m == st->m_eig + 1 && !st->first) {
     ci = (lane < m - 1) ? st->coef[lane] : 0.0;  // previous Ritz vector as the warm start
-    done = wave_lowest_eig_rqi<MV>(m, a, ci, st->e, &e_new);
+    done = wave_lowest_eig_rqi<MV>(m, a, ci, st->e, &e_new, &st->n_rqi);
     if (!done) ci = 0.0;
   }
   if (!done) {  // fallback: cyclic Jacobi on an LDS copy
+    if (lane == 0) st->n_jacobi += 1;
     wave_sync();
     if (lane < m) {
 #pragma unroll
@@ -801,6 +811,8 @@ __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stri
     mail_store(&res[4], st->rnorm2);
     mail_store(&res[5], (double)st->err);
     mail_store(&res[6], (double)st->stop);
+    mail_store(&res[7], (double)st->n_rqi);
+    mail_store(&res[8], (double)st->n_jacobi);
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double s = 0.0;
@@ -1077,6 +1089,8 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st) {
     st->n_sigma = (int)res[2];
     st->e_davidson = res[3];
     st->residual = std::sqrt(res[4] > 0.0 ? res[4] : 0.0);
+    st->n_eig_solves = (int)res[7];
+    st->n_eig_fallbacks = (int)res[8];
     st->ms_total = ms;
     double msig = 0.0, mker = 0.0, mempty = 0.0;
     int counted = 0;
