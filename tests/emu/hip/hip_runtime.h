@@ -17,6 +17,8 @@
 #include <atomic>
 #include <barrier>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +75,53 @@ inline Wave& my_wave() { return cur_block()->waves[tl().tid.x / 64]; }
 inline std::mutex& atomic_mu() { static std::mutex m; return m; }
 inline std::mutex& launch_mu() { static std::mutex m; return m; }
 
+// Worker threads are kept between launches (creating and joining up to 1024 OS threads per launch was most of the
+// emulator's run time: a Davidson iteration is four launches).  Never joined: the pool lives as long as the process.
+struct Pool {
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  std::vector<std::thread> threads;
+  std::function<void(int)> job;
+  long gen = 0;
+  int active = 0, done = 0;
+  void worker(int id) {
+    long seen = 0;
+    for (;;) {
+      std::function<void(int)> j;
+      bool mine;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_start.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        mine = id < active;
+        if (mine) j = job;
+      }
+      if (!mine) continue;
+      j(id);
+      std::lock_guard<std::mutex> lk(mu);
+      if (++done == active) cv_done.notify_one();
+    }
+  }
+  void run(int T, std::function<void(int)> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while ((int)threads.size() < T) {
+        const int id = (int)threads.size();
+        threads.emplace_back([this, id] { worker(id); });
+        threads.back().detach();
+      }
+      job = std::move(f);
+      active = T;
+      done = 0;
+      ++gen;
+    }
+    cv_start.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return done == active; });
+  }
+};
+inline Pool& pool() { static Pool* p = new Pool(); return *p; }
+
 template <class K, class... A>
 void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
   // one kernel at a time: the current block and the `__shared__ static` variables are process-wide, and host
@@ -87,23 +136,18 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
   for (int w = 0; w < nw; ++w) blk.waves[w].bar.reset(new std::barrier<>(std::min(64, T - 64 * w)));
   cur_block() = &blk;
   std::barrier<> block_seq(T);  // all threads move from block b to block b+1 together
-  std::vector<std::thread> th;
-  th.reserve(T);
-  for (int t = 0; t < T; ++t) {
-    th.emplace_back([&, t]() {
-      TL& x = tl();
-      x.bdim = block;
-      x.gdim = grid;
-      x.tid = dim3(t, 0, 0);
-      for (unsigned by = 0; by < grid.y; ++by)
-        for (unsigned bx = 0; bx < grid.x; ++bx) {
-          x.bid = dim3(bx, by, 0);
-          kernel(args...);
-          block_seq.arrive_and_wait();
-        }
-    });
-  }
-  for (auto& t : th) t.join();
+  pool().run(T, [&](int t) {
+    TL& x = tl();
+    x.bdim = block;
+    x.gdim = grid;
+    x.tid = dim3(t, 0, 0);
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        x.bid = dim3(bx, by, 0);
+        kernel(args...);
+        block_seq.arrive_and_wait();
+      }
+  });
   cur_block() = nullptr;
 }
 }  // namespace emu
