@@ -1,23 +1,22 @@
 // Host-side kernel-LOGIC emulator for the `-m "not gpu"` unit tests.  TEST TOOL ONLY.
 //
 // It lets the unmodified HIP kernel sources under qiskit-addon-sqd_amd/csrc be
-// compiled with g++ (-fsanitize=address) and executed by OS threads, so index /
+// compiled with g++ and executed on the host (one fiber per GPU thread), so index /
 // sign / bounds bugs are caught in the GPU-less authoring container before a
 // gpurun call is spent.  It is NOT a backend: the product loader
 // (qiskit_addon_sqd_amd/_capi.py) only ever loads the hipcc-built
 // libsqd_hip.so, and tests/emu builds into tests/emu/_build/libsqd_emu.so which
 // nothing outside tests/ knows about.
 //
-// Model: one OS thread per GPU thread of a block; the blocks of a grid run one
-// after another; wave = 64 consecutive threads; wave-level builtins rendezvous
-// on a per-wave barrier, __syncthreads on a per-block barrier.  "Device memory"
-// is host memory.  Streams and events are no-ops.
+// Model: one fiber per GPU thread of a block, all on the launching OS thread;
+// the blocks of a grid run one after another; wave = 64 consecutive threads;
+// wave-level builtins rendezvous on a per-wave barrier, __syncthreads on a
+// per-block barrier.  "Device memory" is host memory.  Streams and events are
+// no-ops.
 #pragma once
 #include <algorithm>
 #include <atomic>
-#include <barrier>
 #include <cmath>
-#include <condition_variable>
 #include <functional>
 #include <cstdint>
 #include <cstdio>
@@ -25,7 +24,6 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 struct dim3 {
@@ -54,18 +52,36 @@ enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent 
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu::dyn_smem());
 
 namespace emu {
+// Execution model: the threads of a block are FIBERS (user-level contexts with their own stacks) multiplexed on the
+// launching OS thread; a barrier is "mark myself waiting and switch to the scheduler".  (The first version ran one OS
+// thread per GPU thread on std::barrier: with 512-thread blocks on an 8-core box the futex traffic was > 90 % of the
+// CPU suite's run time.)  Threads that have returned from the kernel count as arrived at every later barrier, as on
+// the hardware.
 struct Wave {
-  std::unique_ptr<std::barrier<>> bar;
   unsigned long long slot[64];
 };
 struct Block {
-  std::unique_ptr<std::barrier<>> bar;
   std::vector<Wave> waves;
   std::vector<char> dyn;
 };
 inline Block*& cur_block() { static Block* b = nullptr; return b; }
 struct TL { dim3 tid, bid, bdim, gdim; };
-inline TL& tl() { static thread_local TL t; return t; }
+enum { FIBER_RUNNABLE = 0, FIBER_AT_BLOCK_BARRIER = 1, FIBER_AT_WAVE_BARRIER = 2, FIBER_DONE = 3 };
+struct Fiber {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  int state = FIBER_DONE;
+  TL tl;
+};
+constexpr size_t FIBER_STACK = 256 * 1024;
+struct Sched {  // one for the process; guarded by launch_mu
+  std::vector<Fiber> fib;
+  void* main_sp = nullptr;
+  int cur = 0;
+  std::function<void()> body;
+};
+inline Sched& sched() { static Sched* s = new Sched(); return *s; }
+inline TL& tl() { Sched& s = sched(); return s.fib[s.cur].tl; }
 inline void* dyn_smem() {
   // 16-byte aligned start
   auto p = reinterpret_cast<uintptr_t>(cur_block()->dyn.data());
@@ -75,79 +91,106 @@ inline Wave& my_wave() { return cur_block()->waves[tl().tid.x / 64]; }
 inline std::mutex& atomic_mu() { static std::mutex m; return m; }
 inline std::mutex& launch_mu() { static std::mutex m; return m; }
 
-// Worker threads are kept between launches (creating and joining up to 1024 OS threads per launch was most of the
-// emulator's run time: a Davidson iteration is four launches).  Never joined: the pool lives as long as the process.
-struct Pool {
-  std::mutex mu;
-  std::condition_variable cv_start, cv_done;
-  std::vector<std::thread> threads;
-  std::function<void(int)> job;
-  long gen = 0;
-  int active = 0, done = 0;
-  void worker(int id) {
-    long seen = 0;
-    for (;;) {
-      std::function<void(int)> j;
-      bool mine;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv_start.wait(lk, [&] { return gen != seen; });
-        seen = gen;
-        mine = id < active;
-        if (mine) j = job;
+#if !defined(__x86_64__)
+#error "tests/emu: the fiber switch is written for x86-64"
+#endif
+// save the callee-saved registers and the stack pointer of the running context in *save_sp, continue on load_sp
+__attribute__((naked, noinline, unused)) static void emu_switch(void** /*save_sp*/, void* /*load_sp*/) {
+  __asm__ volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret\n\t");
+}
+// the running fiber gives way to the scheduler (state = why)
+inline void fiber_yield(int state) {
+  Sched& s = sched();
+  Fiber& f = s.fib[s.cur];
+  f.state = state;
+  emu_switch(&f.sp, s.main_sp);
+}
+__attribute__((unused)) static void fiber_main() {
+  Sched& s = sched();
+  s.body();
+  fiber_yield(FIBER_DONE);
+  std::abort();  // a finished fiber is never resumed
+}
+inline void fiber_prepare(Fiber& f) {
+  if (!f.stack) f.stack = static_cast<char*>(std::malloc(FIBER_STACK));
+  auto top = reinterpret_cast<uintptr_t>(f.stack + FIBER_STACK) & ~uintptr_t(15);
+  void** sp = reinterpret_cast<void**>(top);
+  *--sp = nullptr;                                   // keeps rsp = 8 (mod 16) at the entry of fiber_main, as after a call
+  *--sp = reinterpret_cast<void*>(&fiber_main);      // "return address" of the first switch
+  for (int r = 0; r < 6; ++r) *--sp = nullptr;       // rbp rbx r12 r13 r14 r15
+  f.sp = sp;
+  f.state = FIBER_RUNNABLE;
+}
+// run the T fibers of one block to completion
+inline void run_block(int T) {
+  Sched& s = sched();
+  int remaining = T;
+  const int nw = (T + 63) / 64;
+  while (remaining > 0) {
+    bool progress = false;
+    for (int t = 0; t < T; ++t) {
+      if (s.fib[t].state != FIBER_RUNNABLE) continue;
+      s.cur = t;
+      emu_switch(&s.main_sp, s.fib[t].sp);
+      progress = true;
+      if (s.fib[t].state == FIBER_DONE) --remaining;
+    }
+    // barriers whose every live participant has arrived open
+    for (int w = 0; w < nw; ++w) {
+      const int lo = 64 * w, hi = std::min(T, lo + 64);
+      int waiting = 0, other = 0;
+      for (int t = lo; t < hi; ++t) {
+        waiting += s.fib[t].state == FIBER_AT_WAVE_BARRIER;
+        other += s.fib[t].state == FIBER_RUNNABLE || s.fib[t].state == FIBER_AT_BLOCK_BARRIER;
       }
-      if (!mine) continue;
-      j(id);
-      std::lock_guard<std::mutex> lk(mu);
-      if (++done == active) cv_done.notify_one();
+      if (waiting && !other) {
+        for (int t = lo; t < hi; ++t)
+          if (s.fib[t].state == FIBER_AT_WAVE_BARRIER) s.fib[t].state = FIBER_RUNNABLE;
+        progress = true;
+      }
+    }
+    int at_block = 0, elsewhere = 0;
+    for (int t = 0; t < T; ++t) {
+      at_block += s.fib[t].state == FIBER_AT_BLOCK_BARRIER;
+      elsewhere += s.fib[t].state == FIBER_RUNNABLE || s.fib[t].state == FIBER_AT_WAVE_BARRIER;
+    }
+    if (at_block && !elsewhere) {
+      for (int t = 0; t < T; ++t)
+        if (s.fib[t].state == FIBER_AT_BLOCK_BARRIER) s.fib[t].state = FIBER_RUNNABLE;
+      progress = true;
+    }
+    if (!progress) {
+      std::fprintf(stderr, "tests/emu: barrier deadlock (divergent __syncthreads / wave builtin)\n");
+      std::abort();
     }
   }
-  void run(int T, std::function<void(int)> f) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      while ((int)threads.size() < T) {
-        const int id = (int)threads.size();
-        threads.emplace_back([this, id] { worker(id); });
-        threads.back().detach();
-      }
-      job = std::move(f);
-      active = T;
-      done = 0;
-      ++gen;
-    }
-    cv_start.notify_all();
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return done == active; });
-  }
-};
-inline Pool& pool() { static Pool* p = new Pool(); return *p; }
+}
 
 template <class K, class... A>
 void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
-  // one kernel at a time: the current block and the `__shared__ static` variables are process-wide, and host
-  // threads (solve_sci_batch runs several contexts concurrently) may launch at the same moment
+  // one kernel at a time: the scheduler, the current block and the `__shared__ static` variables are process-wide,
+  // and host threads (solve_sci_batch runs several contexts concurrently) may launch at the same moment
   std::lock_guard<std::mutex> launch_guard(launch_mu());
   const int T = block.x;
+  Sched& s = sched();
+  if ((int)s.fib.size() < T) s.fib.resize(T);
   Block blk;
   blk.dyn.assign(shmem + 64, 0);
-  const int nw = (T + 63) / 64;
-  blk.waves.resize(nw);
-  blk.bar.reset(new std::barrier<>(T));
-  for (int w = 0; w < nw; ++w) blk.waves[w].bar.reset(new std::barrier<>(std::min(64, T - 64 * w)));
+  blk.waves.resize((T + 63) / 64);
   cur_block() = &blk;
-  std::barrier<> block_seq(T);  // all threads move from block b to block b+1 together
-  pool().run(T, [&](int t) {
-    TL& x = tl();
-    x.bdim = block;
-    x.gdim = grid;
-    x.tid = dim3(t, 0, 0);
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        x.bid = dim3(bx, by, 0);
-        kernel(args...);
-        block_seq.arrive_and_wait();
+  s.body = [&] { kernel(args...); };
+  for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+      for (int t = 0; t < T; ++t) {
+        fiber_prepare(s.fib[t]);
+        s.fib[t].tl = TL{dim3(t, 0, 0), dim3(bx, by, 0), block, grid};
       }
-  });
+      run_block(T);
+    }
+  s.body = nullptr;
   cur_block() = nullptr;
 }
 }  // namespace emu
@@ -167,18 +210,18 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 inline void __threadfence_system() {}
 inline void __threadfence() {}
-inline void __syncthreads() { emu::cur_block()->bar->arrive_and_wait(); }
+inline void __syncthreads() { emu::fiber_yield(emu::FIBER_AT_BLOCK_BARRIER); }
 
 inline unsigned long long __ballot(int pred) {
   emu::Wave& w = emu::my_wave();
   const int lane = threadIdx.x & 63;
   w.slot[lane] = pred ? 1ull : 0ull;
-  w.bar->arrive_and_wait();
+  emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER);
   const int base = (threadIdx.x / 64) * 64;
   const int n = std::min(64, (int)blockDim.x - base);
   unsigned long long m = 0;
   for (int i = 0; i < n; ++i) m |= (w.slot[i] & 1ull) << i;
-  w.bar->arrive_and_wait();
+  emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER);
   return m;
 }
 template <class T>
@@ -189,12 +232,12 @@ inline T emu_exchange(T v, int src_lane) {
   unsigned long long bits = 0;
   std::memcpy(&bits, &v, sizeof(T));
   w.slot[lane] = bits;
-  w.bar->arrive_and_wait();
+  emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER);
   const int base = (threadIdx.x / 64) * 64;
   const int n = std::min(64, (int)blockDim.x - base);
   T out = v;
   if (src_lane >= 0 && src_lane < n) std::memcpy(&out, &w.slot[src_lane], sizeof(T));
-  w.bar->arrive_and_wait();
+  emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER);
   return out;
 }
 template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
@@ -233,7 +276,7 @@ template <class T> inline T atomicExch(T* p, T v) {
 #define __hip_atomic_load(p, order, scope) (*(p))
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-inline void __builtin_amdgcn_wave_barrier() { emu::my_wave().bar->arrive_and_wait(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER); }
 template <class T> inline T atomicMax(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());
   T old = *p; if (v > old) *p = v; return old;
