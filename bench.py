@@ -255,6 +255,8 @@ def main():
     # 0.27 ms solves, calls 113 and 189 take 1.2 and 40 ms, then none in the next thousands; HF-centred 3.5 ms solves
     # show none after their first call) -- the device settling into its power state.  A timed region that starts a
     # few milliseconds after the process touched the GPU catches them at random; 0.3 s of the same solves first.
+    # (event sampling of the sigma kernel is switched on BEFORE the warm-up: the first sampled solve creates the events)
+    F.set_profiling(time_sigma_every=args.time_sigma_every)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
         one_step()
@@ -267,14 +269,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    F.set_profiling(time_sigma_every=args.time_sigma_every)
     sync()
     t0 = time.perf_counter()
     nsig = 0
     ms_sigma = ms_apply = ms_empty = 0.0
     n_timed = 0
+    step_marks = [] if os.environ.get("SQD_BENCH_DEBUG") else None
     for _ in range(args.steps):
         e, st = one_step()
+        if step_marks is not None:
+            step_marks.append(time.perf_counter())
         nsig += st["n_sigma"]
         n_timed += st["n_sigma_timed"]
         ms_sigma += st["ms_sigma_kernel"]
@@ -283,6 +287,10 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     F.set_profiling(0)
+    if step_marks is not None and rank == 0:
+        d = np.diff([t0] + step_marks) * 1e3
+        print("step ms:", " ".join(f"{x:.3f}" for x in d), "| closing sync %.3f" % ((t0 + elapsed - step_marks[-1]) * 1e3),
+              file=sys.stderr)
     # device time of the two phases of a solve (HIP events around the table build and around the Davidson run): five
     # extra, untimed steps -- the events are bubbles in the stream and are kept out of the timed region
     ctx_t = F._get_context(h1, eri, local_rank)

@@ -21,15 +21,15 @@ print('solve_sci alone            %.1f us' % med(lambda: F.solve_sci((sa, sb), h
 print('solve_sci_batch_distributed %.1f us' % med(lambda: D.solve_sci_batch_distributed(batches, h1, eri, 30, (8, 8), compute_rdms=False)))
 dt, ht = D._exchange_buffers(None, dev, 1, 61, True)
 def table():
-    dt.copy_(ht, non_blocking=True); dist.all_reduce(dt); ht.copy_(dt, non_blocking=True); torch.cuda.current_stream().synchronize()
+    dt.copy_(ht, non_blocking=True); dist.all_reduce(dt); ht.copy_(dt, non_blocking=True); D._wait_stream(torch.cuda.current_stream())
 print('table exchange             %.1f us' % med(table))
 def ar_only():
-    dist.all_reduce(dt); torch.cuda.current_stream().synchronize()
-print('  all_reduce + sync         %.1f us' % med(ar_only))
+    dist.all_reduce(dt); D._wait_stream(torch.cuda.current_stream())
+print('  all_reduce + wait         %.1f us' % med(ar_only))
 ta = torch.empty((317, 317), dtype=torch.float64, device=dev)
 def bc():
-    dist.broadcast(ta, src=0); torch.cuda.current_stream().synchronize()
-print('broadcast 0.8 MB + sync    %.1f us' % med(bc))
+    dist.broadcast(ta, src=0); D._wait_stream(torch.cuda.current_stream())
+print('broadcast 0.8 MB + wait    %.1f us' % med(bc))
 amps = _capi.pinned_empty((317, 317))
 def d2h():
     torch.from_numpy(amps).copy_(ta, non_blocking=True); torch.cuda.current_stream().synchronize()
@@ -37,4 +37,10 @@ print('D2H 0.8 MB pinned + sync   %.1f us' % med(d2h))
 res = F.solve_sci((sa, sb), h1, eri, 30, (8, 8), compute_rdms=False)
 print('resident view              %.1f us' % med(lambda: D._resident_solution(h1, eri, 0, (317, 317), dev)))
 print('SCIResult rebuild          %.1f us' % med(lambda: F.SCIResult(res.energy, res.sci_state, res.orbital_occupancies)))
+def sync_blocking():
+    dist.all_reduce(dt); torch.cuda.current_stream().synchronize()
+print('  all_reduce + blocking sync %.1f us' % med(sync_blocking))
+def copies_only():
+    dt.copy_(ht, non_blocking=True); ht.copy_(dt, non_blocking=True); D._wait_stream(torch.cuda.current_stream())
+print('  two 488-byte copies + wait %.1f us' % med(copies_only))
 dist.destroy_process_group()

@@ -83,7 +83,8 @@ bool is_pinned(const void* p, size_t bytes) {
 SQD_API int sqd_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return SQD_ERR_INVALID;
   void* p = nullptr;
-  SQD_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  // (portable + mapped: every device of the process may write into it from a kernel, see sqd_solve)
+  SQD_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped));
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     g_pinned[static_cast<const char*>(p)] = bytes;
@@ -560,10 +561,21 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   c->want_timing = c->phase_timing || o.verbose;
   SQD_TRY(run_davidson(c, &o, ci0, nullptr, /*defer_sync=*/true));
   const size_t bytes = (size_t)c->D * 8;
-  // small states go through a pinned staging buffer (a truly asynchronous copy); large ones straight to
-  // the caller's memory
-  const bool staged = amps && bytes <= (size_t(64) << 20) && !is_pinned(amps, bytes);
-  if (amps) {
+  // Three ways for the state to reach the caller:
+  //  * the caller's buffer is page-locked (sqd_host_alloc) and the state is small: the observables' kernel, which
+  //    reads every element anyway, also WRITES it there (posted PCIe writes) -- no second stream, no event, no DMA
+  //    set-up, one wait.  (Beyond 64 MB the DMA engine on the copy stream wins: it overlaps the S^2 sigma build.)
+  //  * small and pageable: through the context's pinned staging buffer on the copy stream (a truly asynchronous copy)
+  //  * large: DMA straight to the caller's memory on the copy stream
+  double* twin = nullptr;
+  if (amps && bytes <= (size_t(64) << 20) && is_pinned(amps, bytes)) {
+    void* dptr = nullptr;
+    SQD_HIP_CHECK(hipHostGetDevicePointer(&dptr, amps, 0));
+    twin = static_cast<double*>(dptr);
+  }
+  const bool by_copy = amps && !twin;
+  const bool staged = by_copy && bytes <= (size_t(64) << 20);
+  if (by_copy) {
     SQD_HIP_CHECK(hipEventRecord(c->ev_sol, c->stream));
     SQD_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_sol, 0));
     if (staged) {
@@ -583,10 +595,10 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     form = (o.ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
   }
   const bool need_s2 = (s2 != nullptr) || form != 0;
-  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2));
-  if (amps && !staged)
+  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin));
+  if (by_copy && !staged)
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
-  if (amps) SQD_STREAM_SYNC(c->copy_stream);
+  if (by_copy) SQD_STREAM_SYNC(c->copy_stream);
   if (staged) std::memcpy(amps, c->h_amps, bytes);
   SQD_STREAM_SYNC(c->stream);
   c->stage_pending = false;

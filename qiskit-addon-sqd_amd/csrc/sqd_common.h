@@ -188,6 +188,9 @@ struct sqd_ctx {
   int sig_kmax = 4;              // batch size limit chosen by the layout search in build_subspace
   size_t sig_shmem = 0;
   bool sig_lds_rows = true;      // C rows staged in LDS (false: rows too long, read from global/L2)
+  // set_subspace's last launch leaves the state block + pyscf's start vector in X[0] (guess_x == X.p, one-shot)
+  double* guess_x = nullptr;
+  int dav_nvecs_hint = 13;       // vectors of the last Davidson workspace (12 + 1 by default)
   bool sig_direct = false;       // ultra-sparse coupling: the element-gather kernel k_sigma_direct, no work items
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
@@ -251,6 +254,7 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st);
 // themselves after every use; a Davidson run also zeroes them, so a kernel aborted mid-way cannot poison later ones.
 int reserve_counters(sqd_ctx* c);
 unsigned* counter_ptr(sqd_ctx* c);
+void* dav_state_ptr(sqd_ctx* c);  // DavState* (sqd_davstate.h)
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
 int dev_rdm2(sqd_ctx* c, const double* d_c, double* dm2);
@@ -259,6 +263,7 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 // kernels only, no synchronisation.  with_h: <c|H|c> by a sigma build (else out[0] = 0); with_s2: S^2 c is built and
 // <c|S^2|c>, |S^2 c|^2 reduced (else 0).  Results land in host-visible memory, read by dev_observables_collect:
 // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
-int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true);
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true,
+                            double* host_twin = nullptr);
 void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised
 }  // namespace sqd

@@ -269,7 +269,7 @@ constexpr int OBS_ROWS = 8;              // alpha strings per row-role workgroup
 __global__ void k_observables(const double* __restrict__ C, const double* __restrict__ T1, const double* __restrict__ T2,
                               int64_t na, int64_t nb, const uint64_t* __restrict__ strs_a,
                               const uint64_t* __restrict__ strs_b, int norb, unsigned nrb, double* partial,
-                              unsigned* counter, double* out) {
+                              unsigned* counter, double* out, double* __restrict__ host_c) {
   __shared__ double red[1024];
   __shared__ double wrow[64];
   __shared__ double dots[OBS_ROWS][4];
@@ -279,13 +279,28 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
     const int64_t A = (int64_t)blockIdx.x * OBS_ROWS + wv;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (A < na) {
-      for (int64_t b = lane; b < nb; b += 64) {
-        const double v = C[A * nb + b];
-        const double h = T1 ? T1[A * nb + b] : 0.0, t = T2 ? T2[A * nb + b] : 0.0;
-        s[0] += h * v;
-        s[1] += t * v;
-        s[2] += v * v;
-        s[3] += t * t;
+      // eight elements per lane requested per round (a row of the headline problem is five: one round trip instead
+      // of five in sequence), accumulated in the order of the plain loop.  host_c != nullptr: this pass is also the
+      // transfer of the state to the caller's page-locked buffer -- full-line posted writes over PCIe from the
+      // kernel that reads every element anyway, instead of a DMA copy on a second stream behind an event.
+      for (int64_t b0 = lane; b0 < nb; b0 += 64 * 8) {
+        double v[8], h[8], t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t b = b0 + 64 * u, idx = A * nb + (b < nb ? b : b0);
+          v[u] = C[idx];
+          h[u] = T1 ? T1[idx] : 0.0;
+          t[u] = T2 ? T2[idx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = b0 + 64 * u < nb;
+          if (ok && host_c) __builtin_nontemporal_store(v[u], &host_c[A * nb + b0 + 64 * u]);
+          s[0] += ok ? h[u] * v[u] : 0.0;
+          s[1] += ok ? t[u] * v[u] : 0.0;
+          s[2] += ok ? v[u] * v[u] : 0.0;
+          s[3] += ok ? t[u] * t[u] : 0.0;
+        }
       }
     }
 #pragma unroll
@@ -403,7 +418,7 @@ void dev_observables_collect(sqd_ctx* c, double* out_host) {
   const int nres = 3 + 2 * c->norb + 1;
   for (int i = 0; i < nres; ++i) out_host[i] = c->h_mail[OBS_MAIL + i];
 }
-int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2) {
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2, double* host_twin) {
   const int norb = c->norb;
   hipStream_t st = c->stream;
   const int64_t D = c->D;
@@ -423,7 +438,7 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool wit
   SQD_TRY(reserve_counters(c));
   hipLaunchKernelGGL(k_observables, dim3(nrb + ncb), dim3(512), 0, st, d_c, t1, t2, c->na, c->nb,
                      (const uint64_t*)c->sp[0].strs.as<uint64_t>(), (const uint64_t*)c->sp[1].strs.as<uint64_t>(), norb,
-                     nrb, c->scratch.as<double>(), counter_ptr(c), c->d_mail + OBS_MAIL);
+                     nrb, c->scratch.as<double>(), counter_ptr(c), c->d_mail + OBS_MAIL, host_twin);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }

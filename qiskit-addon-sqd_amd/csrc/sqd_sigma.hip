@@ -485,11 +485,11 @@ struct DirectArgs {
   int nnorb, mode, spin;
   double ss, shift, szterm;
   const uint64_t *strs_a, *strs_b;
-  const int64_t *sa_ptr, *da_ptr, *sb_ptr, *db_ptr, *ha_ptr;
+  const int64_t *sa_ptr, *da_ptr, *sb_ptr, *db_ptr;
   const SRec *sa_rec, *sb_rec;
-  const double* sb_val;
-  const uint32_t *ha_src, *db_src;
-  const double *ha_val, *db_val;
+  const double *sa_val, *sb_val;
+  const uint32_t *da_src, *db_src;
+  const double *da_val, *db_val;
   const double *ja_row, *jbT, *eri_pp;
   const int* stop;
   const int* vec_index;
@@ -522,8 +522,10 @@ __global__ void k_sigma_direct(const DirectArgs g) {
         a += (g.sb_val[l] + srec_sign(r.meta) * g.ja_row[A * g.nnorb + (srec_widx(r.meta) >> 1)]) * crow[r.src];
       }
       for (int64_t l = g.db_ptr[B]; l < g.db_ptr[B + 1]; ++l) a += g.db_val[l] * crow[g.db_src[l]];
-      // alpha same-spin links (singles' one-body part and doubles), then alpha singles x beta occupation
-      for (int64_t l = g.ha_ptr[A]; l < g.ha_ptr[A + 1]; ++l) a += g.ha_val[l] * C[(int64_t)g.ha_src[l] * nb + B];
+      // alpha same-spin links (singles' one-body part, then doubles: the CSR lists as the table build left them,
+      // in the order of the merged list the work-item kernel reads), then alpha singles x beta occupation
+      for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + B];
+      for (int64_t l = g.da_ptr[A]; l < g.da_ptr[A + 1]; ++l) a += g.da_val[l] * C[(int64_t)g.da_src[l] * nb + B];
       for (int64_t l = sa0; l < sa1; ++l) {
         const SRec r = g.sa_rec[l];
         a += srec_sign(r.meta) * g.jbT[(int64_t)(srec_widx(r.meta) >> 1) * nb + B] * C[(int64_t)r.src * nb + B];
@@ -642,12 +644,12 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
   g.da_ptr = a.d_ptr.as<int64_t>();
   g.sb_ptr = b.s_ptr.as<int64_t>();
   g.db_ptr = b.d_ptr.as<int64_t>();
-  g.ha_ptr = a.hs_ptr.as<int64_t>();
   g.sa_rec = a.s_rec.as<SRec>();
   g.sb_rec = b.s_rec.as<SRec>();
+  g.sa_val = a.s_val.as<double>();
   g.sb_val = b.s_val.as<double>();
-  g.ha_src = a.hs_src.as<uint32_t>();
-  g.ha_val = a.hs_val.as<double>();
+  g.da_src = a.d_src.as<uint32_t>();
+  g.da_val = a.d_val.as<double>();
   g.db_src = b.d_src.as<uint32_t>();
   g.db_val = b.d_val.as<double>();
   g.ja_row = a.jrow.as<double>();

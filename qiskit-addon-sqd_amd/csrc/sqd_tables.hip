@@ -18,6 +18,7 @@
 
 #include "sqd_common.h"
 #include "sqd_device.h"
+#include "sqd_davstate.h"
 
 namespace sqd {
 
@@ -363,9 +364,31 @@ __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ 
 
 // C: one wavefront per target string (blockIdx.y = spin): enumerate, compact with ballot + prefix popcount, and let
 // the lane that found a link decorate it
+// The launch also prepares the Davidson run that normally follows (job.x != nullptr): state block, arrival counters and
+// pyscf's start vector from the row minima k_tables_diag left -- the k_init_guess launch of the solver, folded in
+// here because this is the last launch of the table build that every string set with any link goes through.
+struct GuessJob {
+  double* x;  // X[0] of the Davidson workspace (nullptr: no job)
+  const double* pmin;
+  const int64_t* pidx;
+  int nrows;
+  int64_t n;  // D
+  DavState* st;
+  unsigned* counter;
+};
+__device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __restrict__ h1,
+                                        const double* __restrict__ eri4, int norb);
 __global__ void k_tables_fill(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ eri4,
-                              int norb) {
-  const SpinLinkArgs& a = p.a[blockIdx.y];
+                              int norb, const GuessJob job) {
+  tables_fill_wave(p.a[blockIdx.y], h1, eri4, norb);
+  if (!job.x) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0) dav_state_init(job.st, job.counter);
+  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  init_guess_write(job.n, job.pmin, job.pidx, job.nrows, job.x, blk * blockDim.x + threadIdx.x,
+                   (int64_t)gridDim.x * gridDim.y * blockDim.x);
+}
+__device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __restrict__ h1,
+                                        const double* __restrict__ eri4, int norb) {
   const uint64_t* __restrict__ strs = a.strs;
   const int64_t n = a.n;
   const int lane = threadIdx.x & 63;
@@ -767,6 +790,7 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
 int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0,
                    int64_t row1) {
   c->have_subspace = false;
+  c->guess_x = nullptr;
   c->have_solution = false;
   if (row1 < 0) row1 = na;
   if (row0 < 0 || row0 >= row1 || row1 > na) {
@@ -919,20 +943,38 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     int64_t maxl = 0;
     for (int64_t v : tot) maxl = v > maxl ? v : maxl;
     if (maxl > 0) {
+      GuessJob job;
+      std::memset(&job, 0, sizeof(job));
+      c->guess_x = nullptr;
+      if (row0 == 0 && row1 == na && (size_t)c->dav_nvecs_hint * na * nb * 8 <= (size_t(1) << 30)) {
+        // (small problems only: there a launch matters, and the workspace costs nothing to have early)
+        // the Davidson workspace at the size the last run used (default max_space + 1 vectors): if the run that
+        // follows needs more, its reserve moves the buffer and it falls back to its own k_init_guess launch
+        SQD_TRY(c->X.reserve((size_t)c->dav_nvecs_hint * na * nb * 8));
+        SQD_TRY(reserve_counters(c));
+        job.x = c->X.as<double>();
+        job.pmin = c->guess_min.as<double>();
+        job.pidx = reinterpret_cast<const int64_t*>(job.pmin + nrows);
+        job.nrows = (int)nrows;
+        job.n = na * nb;
+        job.st = static_cast<DavState*>(dav_state_ptr(c));
+        job.counter = counter_ptr(c);
+        c->guess_x = job.x;
+      }
       hipLaunchKernelGGL(k_tables_fill, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
-                         (const double*)c->eri4.as<double>(), norb);
+                         (const double*)c->eri4.as<double>(), norb, job);
       SQD_HIP_CHECK(hipGetLastError());
     }
   }
-  {
+  if (!c->sig_direct) {
     SpinTables& t = c->sp[0];  // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY items
     SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
     SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
     SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
   }
   if (c->sig_direct) {
-    // the element-gather sigma kernel reads the CSR lists as they are: no work items, no ELL copies, no descriptor
-    // upload -- only the merged same-spin alpha list (launch D, first job)
+    // the element-gather sigma kernel reads the CSR lists as they are: no work items, no ELL copies, no merged
+    // same-spin list, no descriptor upload -- launch D does not exist
     c->na = na;
     c->nb = nb;
     c->row0 = row0;
@@ -941,21 +983,6 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->nelec[0] = nocc[0];
     c->nelec[1] = nocc[1];
     c->n_items = c->n_multi = c->n_slots = 0;
-    const SpinTables& ta = c->sp[0];
-    EllArgs g;
-    std::memset(&g, 0, sizeof(g));
-    g.n_a = ta.n;
-    g.sa_ptr = ta.s_ptr.as<int64_t>();
-    g.da_ptr = ta.d_ptr.as<int64_t>();
-    g.sa_rec = ta.s_rec.as<SRec>();
-    g.sa_val = ta.s_val.as<double>();
-    g.da_src = ta.d_src.as<uint32_t>();
-    g.da_val = ta.d_val.as<double>();
-    g.hs_ptr = ta.hs_ptr.as<int64_t>();
-    g.hs_src = ta.hs_src.as<uint32_t>();
-    g.hs_val = ta.hs_val.as<double>();
-    hipLaunchKernelGGL(k_tables_ell, dim3(nblk(ta.n + 1, 4), 1), dim3(256), 0, st, g);
-    SQD_HIP_CHECK(hipGetLastError());
   } else
   // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
   {

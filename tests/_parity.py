@@ -58,7 +58,11 @@ def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=
     # the start vector is pyscf's get_init_guess (lower-triangle rule included), normalised
     x0 = O.init_guess(np.diag(H), len(sa), len(sb), nelec=ctx.nelec)
     assert np.allclose(ctx.init_guess().ravel(), x0 / np.linalg.norm(x0), rtol=0, atol=1e-15)
-    amps, st = ctx.davidson()
+    amps, st = ctx.davidson()  # first run after set_subspace: state block + start vector prepared by the table build
+    amps_b, st_b = ctx.davidson()  # second run: the solver's own k_init_guess launch -- the same bits either way
+    assert np.array_equal(amps, amps_b) and st["n_sigma"] == st_b["n_sigma"] and st["e_davidson"] == st_b["e_davidson"]
+    amps_c, st_c, _obs = ctx.solve(sa, sb)  # the one-call path (state written to the page-locked buffer by a kernel)
+    assert np.array_equal(amps, amps_c) and st_c["e_davidson"] == st["e_davidson"]
     w, v = np.linalg.eigh(H)
     assert st["converged"] == 1
     assert abs(st["e_davidson"] - w[0]) < e_tol
