@@ -213,6 +213,10 @@ int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
  * width + the integral / J rows the populated links touch): the honest denominator beside SURVEY 8d's B_sigma, which
  * charges the whole packed integral tables whether or not a string set has the links that read them. */
 int sqd_sigma_bytes_needed(sqd_ctx* ctx, double* bytes);
+/* Which sigma kernel the current subspace selected (benchmark / test hook, no reference counterpart):
+ * kind 0 = work items (k_sigma), 1 = element gather (k_sigma_direct), 2 = whole rows in LDS (k_sigma_rows);
+ * rows_per_workgroup is set for kind 2, else 0. */
+int sqd_sigma_kernel(sqd_ctx* ctx, int* kind, int* rows_per_workgroup);
 
 /* ---- qubit / Pauli path (reference qiskit_addon_sqd/qubit.py) -----------------
  * Projection of sum_t c_t P_t onto the subspace spanned by the computational basis states `rows`

@@ -9,5 +9,5 @@ sa, sb = S.uniform_strings(30, 8, n, 11), S.uniform_strings(30, 8, n, 13)
 t0 = time.perf_counter(); ctx.set_subspace(sa, sb); ctx.sync(); t1 = time.perf_counter()
 ms = ctx.time_sigma(5)
 b = ctx.sigma_bytes()
-print({k: os.environ[k] for k in os.environ if k.startswith('SQD_')}, f'n={n} set_subspace {1e3*(t1-t0):.1f} ms  sigma {ms:.3f} ms  '
+print({k: os.environ[k] for k in os.environ if k.startswith('SQD_')}, ctx.sigma_kernel(), f'n={n} set_subspace {1e3*(t1-t0):.1f} ms  sigma {ms:.3f} ms  '
       f'{b/ms/1e6:.0f} GB/s  frac {b/ms/1e6/8000:.4f}', flush=True)

@@ -56,6 +56,7 @@ EXPORTED_SYMBOLS = (
     "sqd_time_sigma",
     "sqd_sigma_bytes",
     "sqd_sigma_bytes_needed",
+    "sqd_sigma_kernel",
     "sqd_pauli_count",
     "sqd_pauli_fill",
     "sqd_pauli_free",
@@ -148,6 +149,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
     lib.sqd_sigma_bytes_needed.argtypes = [_ctxp, _dp]
+    lib.sqd_sigma_kernel.argtypes = [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_pauli_count.argtypes = [C.c_int, _u64p, C.c_int64, C.c_int, _u64p, _i64p, _u64p, _dp, _i64p, _i64p,
                                     C.POINTER(_ctxp)]
     lib.sqd_pauli_fill.argtypes = [_ctxp, _i64p, _dp, _dp]
@@ -565,4 +567,11 @@ class Context:
         out = C.c_double()
         self._check(self._lib.sqd_sigma_bytes_needed(self._h, C.byref(out)))
         return float(out.value)
+
+    def sigma_kernel(self) -> str:
+        """Name of the sigma kernel the current subspace selected: ``k_sigma`` (work items), ``k_sigma_direct``
+        (element gather) or ``k_sigma_rows<R>`` (R whole rows of C per workgroup in LDS)."""
+        kind, rows = C.c_int(), C.c_int()
+        self._check(self._lib.sqd_sigma_kernel(self._h, C.byref(kind), C.byref(rows)))
+        return ("k_sigma", "k_sigma_direct", f"k_sigma_rows<{rows.value}>")[kind.value]
 

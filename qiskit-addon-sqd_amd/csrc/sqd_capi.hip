@@ -718,6 +718,14 @@ SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
   return SQD_OK;
 }
 
+SQD_API int sqd_sigma_kernel(sqd_ctx* c, int* kind, int* rows_per_workgroup) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (kind) *kind = c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : 0);
+  if (rows_per_workgroup) *rows_per_workgroup = c->sig_rows;
+  return SQD_OK;
+}
+
 SQD_API int sqd_sigma_bytes_needed(sqd_ctx* c, double* bytes) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);

@@ -88,6 +88,7 @@ struct SpinTables {
   DevBuf d_src;                  // u32[n_d]
   DevBuf d_orb;                  // u32[n_d]
   DevBuf d_val;                  // f64[n_d] sign*((pq|rs)-(ps|rq))
+  DevBuf jd_src, jd_val;         // the doubles in per-slice jagged-diagonal order (k_sigma_rows; beta only)
   DevBuf hs_ptr, hs_src, hs_val; // merged same-spin CSR {src, value}: singles then doubles per row (row role)
   DevBuf jrow;                   // f64[n][nnorb]   J[I][pair] = sum_{k in I} (pair|kk)   (row role)
   DevBuf jT;                     // f64[nnorb][n]   transposed copy                        (col role)
@@ -191,6 +192,8 @@ struct sqd_ctx {
   // set_subspace's last launch leaves the state block + pyscf's start vector in X[0] (guess_x == X.p, one-shot)
   double* guess_x = nullptr;
   int dav_nvecs_hint = 13;       // vectors of the last Davidson workspace (12 + 1 by default)
+  int sig_rows = 0;              // > 0: k_sigma_rows with this many rows of C per workgroup (implies sig_direct's
+                                 // table layout: CSR lists only)
   bool sig_direct = false;       // ultra-sparse coupling: the element-gather kernel k_sigma_direct, no work items
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;

@@ -494,6 +494,10 @@ struct DirectArgs {
   const int* stop;
   const int* vec_index;
   int64_t c_stride, s_stride;
+  // k_sigma_rows only: the beta doubles in per-slice jagged-diagonal order (k_tables_jds) and the LDS row pitch
+  const uint32_t* jd_src;
+  const double* jd_val;
+  int64_t nb_pad;
 };
 template <bool SPIN>
 __global__ void k_sigma_direct(const DirectArgs g) {
@@ -547,6 +551,146 @@ __global__ void k_sigma_direct(const DirectArgs g) {
       a += srec_sign(ra.meta) * t;
     }
     out[i] = a;
+  }
+}
+
+// ---- Long rows, short lists (uniform-random string sets from ~10^3 strings per spin up to rows of 19 968 strings).
+// The work-item kernel spends such a sigma on BYTES THROUGH THE VECTOR L1 (profiles/r01/sigma_tuning_notes.txt 10:
+// 2.8 MB per 80 KB row of output at 10^4 x 10^4 -- 1.3 MB of it the beta link records, which are the same for every
+// row -- at ~50 GB/s per CU, plus a pass that adds partial rows).  Here a workgroup owns R whole rows of C:
+//  * the R rows are staged in LDS (R = 2 at nb = 10^4: 156 KB), so every beta record read serves R rows and its
+//    operands are LDS gathers;
+//  * a lane owns a target column B and walks ALL of B's links itself: the sums stay in registers -- no virtual rows,
+//    no partial sums in LDS, no partial rows in memory, no reduce launch.  That is only sound because the lists are
+//    short and even (the selection rule in build_subspace); Hartree-Fock-centred sets keep the work-item kernel;
+//  * the beta doubles are read in per-slice jagged-diagonal order (k_tables_jds): at step k the lanes of a wavefront
+//    whose list is longer than k read consecutive records -- coalesced and without padding; positions come from a
+//    ballot, no index array;
+//  * the alpha lists are wave-uniform (scalar loads) and their source rows are read coalesced, eight in flight.
+// The order of accumulation per element is k_sigma_direct's, so the two kernels agree to the bit.
+template <int R, bool SPIN>
+__global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
+  HIP_DYNAMIC_SHARED(double, srow)
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  double* __restrict__ out = g.sigma + vsel * g.s_stride;
+  const int64_t nb = g.nb, pitch = g.nb_pad;
+  const int64_t A0 = g.row0 + (int64_t)blockIdx.x * R;
+  const int nr = (int)((g.row1 - A0) < R ? (g.row1 - A0) : R);  // rows of this workgroup (the last one may be short)
+  const double pen = (g.mode == 1) ? -1.0 : -g.shift;
+  for (int r = 0; r < nr; ++r)
+    for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) srow[r * pitch + b] = C[(A0 + r) * nb + b];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // a wavefront takes whole slices of 64 consecutive columns (the unit of the jagged-diagonal order)
+  for (int64_t B0 = (int64_t)(threadIdx.x >> 6) * 64; B0 < nb; B0 += blockDim.x) {
+    const int64_t B = B0 + lane;
+    const bool live = B < nb;
+    const int64_t Bc = live ? B : nb - 1;  // dead lanes shadow the last column and store nothing
+    double acc[R];
+    const uint64_t sB = g.strs_b[Bc];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t A = A0 + (r < nr ? r : 0);
+      const double cv = srow[(r < nr ? r : 0) * pitch + Bc];
+      if (g.mode == 0) {
+        double d = g.hdiag[(A - g.row0) * nb + Bc];
+        if (SPIN) d += g.shift * (g.szterm + (double)__popcll(sB & ~g.strs_a[A]) - g.ss);
+        acc[r] = d * cv;
+      } else {
+        acc[r] = (g.szterm + (double)__popcll(sB & ~g.strs_a[A])) * cv;
+      }
+    }
+    const int64_t sb0 = g.sb_ptr[Bc], sb1 = live ? g.sb_ptr[Bc + 1] : sb0;
+    if (g.mode == 0) {
+      // beta singles (CSR: rare in this regime): same-spin value + alpha occupation term
+      for (int64_t l = sb0; l < sb1; ++l) {
+        const SRec rec = g.sb_rec[l];
+        const double v = g.sb_val[l], sg = srec_sign(rec.meta);
+        const int64_t jw = srec_widx(rec.meta) >> 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (r < nr) acc[r] += (v + sg * g.ja_row[(A0 + r) * g.nnorb + jw]) * srow[r * pitch + rec.src];
+      }
+      // beta doubles, jagged-diagonal order of the slice
+      const int64_t d0 = g.db_ptr[Bc];
+      const int len = live ? (int)(g.db_ptr[Bc + 1] - d0) : 0;
+      // (eight steps per round: the eight positions come from eight ballots, then all sixteen loads are in flight
+      // together -- a step at a time the walk was a chain of ~11 dependent L2 round trips per column.  Lanes past
+      // the end of their list re-read the slice's first record with weight zero.)
+      const int64_t slice0 = g.db_ptr[B0];
+      int64_t base = slice0;
+      for (int k0 = 0;; k0 += 8) {
+        if (!__ballot(k0 < len)) break;
+        uint32_t src[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool on = k0 + u < len;
+          const unsigned long long m = __ballot(on);
+          const int64_t pos = on ? base + __popcll(m & lt) : slice0;
+          base += __popcll(m);
+          src[u] = g.jd_src[pos];
+          const double val = g.jd_val[pos];
+          v[u] = on ? val : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (r < nr) acc[r] += v[u] * srow[r * pitch + src[u]];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r >= nr) continue;  // (uniform over the workgroup)
+      const int64_t A = A0 + r;
+      const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
+      double a = acc[r];
+      if (g.mode == 0) {
+        // alpha same-spin links: singles' one-body part, then doubles (wave-uniform lists, coalesced source rows)
+        for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + Bc];
+        const int64_t da0 = g.da_ptr[A], da1 = g.da_ptr[A + 1];
+        // eight source rows in flight per round; the padding of the last round re-reads the list's last link (the
+        // same cache line again) with weight zero
+        for (int64_t l = da0; l < da1; l += 8) {
+          double x[8], w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool on = l + u < da1;
+            const int64_t lu = on ? l + u : da1 - 1;
+            w[u] = on ? g.da_val[lu] : 0.0;
+            x[u] = C[(int64_t)g.da_src[lu] * nb + Bc];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a += w[u] * x[u];
+        }
+        // alpha singles x beta occupation
+        for (int64_t ls = sa0; ls < sa1; ++ls) {
+          const SRec rec = g.sa_rec[ls];
+          a += srec_sign(rec.meta) * g.jbT[(int64_t)(srec_widx(rec.meta) >> 1) * nb + Bc] * C[(int64_t)rec.src * nb + Bc];
+        }
+      }
+      // single x single (and the S^2 exchange term: the beta link that undoes the alpha link's orbital move)
+      for (int64_t la = sa0; la < sa1; ++la) {
+        const SRec ra = g.sa_rec[la];
+        const double* srcrow = C + (int64_t)ra.src * nb;
+        const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
+        const int partner = (int)srec_widx(ra.meta) ^ 1;
+        double t = 0.0;
+        for (int64_t lb = sb0; lb < sb1; ++lb) {
+          const SRec rb = g.sb_rec[lb];
+          double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
+          if (SPIN) wv += ((int)srec_widx(rb.meta) == partner) ? pen : 0.0;
+          t += srec_sign(rb.meta) * wv * srcrow[rb.src];
+        }
+        a += srec_sign(ra.meta) * t;
+      }
+      if (live) out[(A - g.row0) * nb + B] = a;
+    }
   }
 }
 
@@ -660,6 +804,46 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
   g.vec_index = indexed ? c->sigma_index : nullptr;
   g.c_stride = in_stride;
   g.s_stride = out_stride;
+  if (c->sig_rows > 0) {
+    g.jd_src = b.jd_src.as<uint32_t>();
+    g.jd_val = b.jd_val.as<double>();
+    g.nb_pad = (c->nb + 1) & ~int64_t(1);
+    const int R = c->sig_rows;
+    const size_t shmem = (size_t)R * g.nb_pad * 8;
+    const unsigned blocks_r = (unsigned)((c->row1 - c->row0 + R - 1) / R);
+    static const int T = [] {  // tuning hook
+      const char* env = std::getenv("SQD_ROWS_T");
+      const int v = env ? std::atoi(env) : 1024;
+      return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 1024;
+    }();
+    const bool sp = (mode == 1 || spin);
+#define SQD_ROWS_LAUNCH(RR, SS)                                                                                  \
+  do {                                                                                                           \
+    if (shmem > 64 * 1024) {                                                                                     \
+      static std::atomic<size_t> granted[64];                                                                    \
+      const int dev = c->device & 63;                                                                            \
+      if (shmem > granted[dev].load(std::memory_order_relaxed)) {                                                \
+        SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma_rows<RR, SS>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));              \
+        granted[dev].store(shmem, std::memory_order_relaxed);                                                    \
+      }                                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL((k_sigma_rows<RR, SS>), dim3(blocks_r), dim3(T), shmem, c->stream, g);                    \
+  } while (0)
+    switch (R) {
+      case 1: if (sp) SQD_ROWS_LAUNCH(1, true); else SQD_ROWS_LAUNCH(1, false); break;
+      case 2: if (sp) SQD_ROWS_LAUNCH(2, true); else SQD_ROWS_LAUNCH(2, false); break;
+      case 4: if (sp) SQD_ROWS_LAUNCH(4, true); else SQD_ROWS_LAUNCH(4, false); break;
+      default: if (sp) SQD_ROWS_LAUNCH(8, true); else SQD_ROWS_LAUNCH(8, false); break;
+    }
+#undef SQD_ROWS_LAUNCH
+    SQD_HIP_CHECK(hipGetLastError());
+    if (c->ev_after_sigma_kernel) {
+      SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+      c->ev_after_sigma_kernel = nullptr;
+    }
+    return SQD_OK;
+  }
   const int64_t n = (c->row1 - c->row0) * c->nb;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;

@@ -60,7 +60,7 @@ void DevBuf::release() {
 }
 void SpinTables::release() {
   DevBuf* all[] = {&strs, &e_str, &s_ptr, &d_ptr, &s_row, &d_row, &s_rec, &s_val, &d_src, &d_orb,
-                   &d_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val,
+                   &d_val, &jd_src, &jd_val, &hs_ptr, &hs_src, &hs_val, &jrow, &jT, &es_sl, &ed_sl, &es_rec, &es_val, &ed_src, &ed_val,
                    &vs_cnt, &vs_own, &vs_start, &vd_cnt, &vd_own, &vd_start, &vs_chunk, &vd_chunk};
   for (DevBuf* b : all) b->release();
 }
@@ -457,6 +457,32 @@ __device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __r
     }
     ps += __popcll(ms);
     pd += __popcll(md);
+  }
+}
+
+// The double links of 64 consecutive strings (a slice) re-ordered for k_sigma_rows: step k of every list first, lists
+// shorter than k skipped -- the slice keeps its CSR range [d_ptr[64 s], d_ptr[64 s + 64]) and needs no index of its
+// own: a reader rebuilds positions from ballots exactly as this writer does.  One wavefront per slice.
+__global__ void k_tables_jds(int64_t n, const int64_t* __restrict__ d_ptr, const uint32_t* __restrict__ d_src,
+                             const double* __restrict__ d_val, uint32_t* __restrict__ jd_src,
+                             double* __restrict__ jd_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t B0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+  if (B0 >= n) return;
+  const int64_t B = B0 + lane;
+  const int64_t d0 = (B < n) ? d_ptr[B] : 0;
+  const int len = (B < n) ? (int)(d_ptr[B + 1] - d0) : 0;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int64_t base = d_ptr[B0];
+  for (int k = 0;; ++k) {
+    const unsigned long long m = __ballot(k < len);
+    if (!m) break;
+    if (k < len) {
+      const int64_t pos = base + __popcll(m & lt);
+      jd_src[pos] = d_src[d0 + k];
+      jd_val[pos] = d_val[d0 + k];
+    }
+    base += __popcll(m);
   }
 }
 
@@ -912,10 +938,27 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   const int64_t tot[4] = {c->h_sptr[na], c->h_dptr[na], c->h_sptr_b[nb], c->h_dptr_b[nb]};
   // Ultra-sparse coupling (at most two links per string on average, either spin): sigma is the element-gather
   // kernel.  SQD_SIGMA_DIRECT=1 / 0 forces / forbids it (tests run both kernels on the same inputs).
+  // Long rows with short, even lists (uniform-random sets beyond ~10^3 strings per spin): k_sigma_rows, R whole rows
+  // of C per workgroup in LDS.  It shares the element-gather kernel's table layout (CSR lists only) plus the beta
+  // doubles in jagged-diagonal order.  SQD_SIGMA_ROWS=0 forbids it, =R forces R rows per workgroup.
   {
     bool direct = (tot[0] + tot[1] <= 2 * na) && (tot[2] + tot[3] <= 2 * nb);
-    if (const char* env = std::getenv("SQD_SIGMA_DIRECT")) direct = std::atoi(env) != 0;
-    c->sig_direct = direct;
+    const char* env_d = std::getenv("SQD_SIGMA_DIRECT");
+    if (env_d) direct = std::atoi(env_d) != 0;
+    const size_t lds_rows = ((size_t)c->lds_bytes - 3 * 1024) / ((size_t)((nb + 1) & ~int64_t(1)) * 8);  // rows that fit
+    int rows = 0;
+    if (!direct && !env_d && lds_rows >= 1 && nb >= 1024 && tot[2] + tot[3] <= 32 * nb && tot[0] + tot[1] <= 64 * na)
+      rows = (int)(lds_rows < 8 ? lds_rows : 8);
+    if (const char* env = std::getenv("SQD_SIGMA_ROWS")) {
+      rows = std::atoi(env);
+      if (rows > 0 && lds_rows < 1) rows = 0;
+      if (rows > (int)lds_rows) rows = (int)lds_rows;
+      if (rows > 8) rows = 8;
+    }
+    // template instantiations: 1, 2, 4, 8
+    while (rows > 1 && (rows & (rows - 1))) --rows;
+    c->sig_rows = rows > 0 ? rows : 0;
+    c->sig_direct = direct || c->sig_rows > 0;
   }
   // launch C: fill + decorate
   for (int s = 0; s < 2; ++s) {
@@ -983,6 +1026,17 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->nelec[0] = nocc[0];
     c->nelec[1] = nocc[1];
     c->n_items = c->n_multi = c->n_slots = 0;
+    if (c->sig_rows) {
+      SpinTables& t = c->sp[1];
+      SQD_TRY(t.jd_src.reserve((size_t)t.n_d * 4));
+      SQD_TRY(t.jd_val.reserve((size_t)t.n_d * 8));
+      if (t.n_d > 0) {
+        hipLaunchKernelGGL(k_tables_jds, dim3(nblk((nb + 63) / 64, 4)), dim3(256), 0, st, nb,
+                           (const int64_t*)t.d_ptr.as<int64_t>(), (const uint32_t*)t.d_src.as<uint32_t>(),
+                           (const double*)t.d_val.as<double>(), t.jd_src.as<uint32_t>(), t.jd_val.as<double>());
+        SQD_HIP_CHECK(hipGetLastError());
+      }
+    }
   } else
   // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
   {

@@ -50,6 +50,21 @@ def test_emu_direct_and_work_item_sigma(emu_lib, monkeypatch, direct):
     run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
 
 
+@pytest.mark.parametrize("rows", ["1", "2", "8"])
+def test_emu_rows_kernel(emu_lib, monkeypatch, rows):
+    # SQD_SIGMA_ROWS=R forces k_sigma_rows (R whole rows of C per workgroup in LDS, beta doubles in per-slice
+    # jagged-diagonal order), which large uniform-random sets take by default: ragged last workgroup (12 rows in
+    # groups of 8), ragged last slice (70 columns), all operator forms, Davidson
+    monkeypatch.setenv("SQD_SIGMA_ROWS", rows)
+    h1, eri, sa, sb = make_problem(8, (3, 4), 12, 70, 23)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == f"k_sigma_rows<{rows}>"
+    run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
+    run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
+    run_operator_parity(emu_lib, 9, (2, 4), 7, 100, 29, True)
+
+
 def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,

@@ -55,6 +55,57 @@ def test_direct_and_work_item_sigma_forced(hip_lib, monkeypatch, direct):
     assert np.abs(p.ravel() - (s.ravel() + 0.3 * S2x)).max() < 1e-10
 
 
+@pytest.mark.parametrize("rows", ["1", "2", "8"])
+def test_rows_sigma_kernel_forced(hip_lib, monkeypatch, rows):
+    """k_sigma_rows (R whole rows of C per workgroup in LDS; the default for large uniform-random sets) forced at
+    sizes the oracles check: all operator forms, Davidson, HF-centred and uniform sets, the headline size."""
+    monkeypatch.setenv("SQD_SIGMA_ROWS", rows)
+    run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
+    run_full_parity(hip_lib, 12, (4, 6), 30, 70, 13, False, with_rdm2=False)
+    for hf in (False, True):
+        norb, nelec, h1, eri, sa, sb = _n2_problem(317, hf)
+        x = np.random.default_rng(5).standard_normal((317, 317))
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == f"k_sigma_rows<{rows}>"
+            s = ctx.sigma(x)
+            p = ctx.sigma(x, 1, 0.0, 0.3)
+            ss = ctx.contract_ss(x)
+        ref = O.sigma_string_space(h1, eri, sa, sb, x, norb)
+        assert np.abs(s - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+        S2x = O.build_spin_square(sa, sb, norb, nelec, sparse=True) @ x.ravel()
+        assert np.abs(ss.ravel() - S2x).max() < 1e-11 * max(1.0, np.abs(S2x).max())
+        assert np.abs(p.ravel() - (s.ravel() + 0.3 * S2x)).max() < 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_rows_sigma_kernel_default_selection(hip_lib, monkeypatch):
+    """Uniform 2048 x 2048 (D = 4.2e6, ~4 links per string): the rows kernel is the default; its sigma, S^2 and
+    penalty forms agree with the work-item kernel forced on the same inputs, and a whole solve agrees in energy."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, 2048, 21), S.uniform_strings(30, 8, 2048, 22)
+    x = np.random.default_rng(6).standard_normal((2048, 2048))
+    out = {}
+    for forced in (None, "0"):
+        if forced is None:
+            monkeypatch.delenv("SQD_SIGMA_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("SQD_SIGMA_ROWS", forced)
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            kern = ctx.sigma_kernel()
+            assert kern.startswith("k_sigma_rows") if forced is None else kern == "k_sigma"
+            amps, st = ctx.davidson()
+            out[forced] = (ctx.sigma(x), ctx.contract_ss(x), ctx.sigma(x, 1, 0.0, 0.3), st["e_davidson"], st["converged"])
+    a, b = out[None], out["0"]
+    scale = np.abs(b[0]).max()
+    assert np.abs(a[0] - b[0]).max() < 1e-12 * scale
+    assert np.abs(a[1] - b[1]).max() < 1e-12 * np.abs(b[1]).max()
+    assert np.abs(a[2] - b[2]).max() < 1e-12 * scale
+    assert a[4] == 1 and b[4] == 1 and abs(a[3] - b[3]) < 1e-9
+
+
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
