@@ -203,7 +203,7 @@ def roofline_entry(ctx, t_bracket_ms, t_apply_ms, n_timed, traffic=None, source=
     b_need = ctx.sigma_bytes_needed()
     ach = b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else 0.0
     return {
-        "bound": "hbm", "kernel": "sqd::k_sigma", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "sqd::" + ctx.sigma_kernel(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
         "bytes_per_launch": b_alg, "bytes_needed": b_need,
         "frac_on_bytes_needed": (b_need / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_kernel_ms > 0 else 0.0,

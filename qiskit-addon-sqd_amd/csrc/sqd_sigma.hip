@@ -571,6 +571,11 @@ __global__ void k_sigma_direct(const DirectArgs g) {
 template <int R, bool SPIN>
 __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
   HIP_DYNAMIC_SHARED(double, srow)
+  // J slices (of 64 columns) in flight per wavefront, K links per round: a workgroup that fills the CU's LDS runs
+  // alone on it, so nothing but its own instruction stream hides the latency of a chain pointers -> records ->
+  // operands.  One slice at a time that chain was ~7 round trips per slice and the skeleton alone (no links at all)
+  // took 1.8 ms at 10^4 x 10^4; four independent chains interleaved cut it by the same factor.
+  constexpr int J = (R >= 8) ? 1 : (R >= 3) ? 2 : 4, K = 4;  // (registers: J R sums + J K operands under 128 VGPRs)
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
@@ -584,64 +589,83 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // a wavefront takes whole slices of 64 consecutive columns (the unit of the jagged-diagonal order)
-  for (int64_t B0 = (int64_t)(threadIdx.x >> 6) * 64; B0 < nb; B0 += blockDim.x) {
-    const int64_t B = B0 + lane;
-    const bool live = B < nb;
-    const int64_t Bc = live ? B : nb - 1;  // dead lanes shadow the last column and store nothing
-    double acc[R];
-    const uint64_t sB = g.strs_b[Bc];
+  const int64_t T = blockDim.x;
+  for (int64_t Bw = (int64_t)(threadIdx.x >> 6) * 64; Bw < nb; Bw += T * J) {
+    // slice j of this pass: columns Bw + j T .. + 63.  Dead lanes (and dead slices) shadow the last column, have
+    // empty lists and store nothing.
+    int64_t Bc[J];
+    bool live[J];
+    int len[J];
+    int64_t base[J], slice0[J], sb0[J], sb1[J];
+    double acc[J][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t A = A0 + (r < nr ? r : 0);
-      const double cv = srow[(r < nr ? r : 0) * pitch + Bc];
-      if (g.mode == 0) {
-        double d = g.hdiag[(A - g.row0) * nb + Bc];
-        if (SPIN) d += g.shift * (g.szterm + (double)__popcll(sB & ~g.strs_a[A]) - g.ss);
-        acc[r] = d * cv;
-      } else {
-        acc[r] = (g.szterm + (double)__popcll(sB & ~g.strs_a[A])) * cv;
+    for (int j = 0; j < J; ++j) {
+      const int64_t B = Bw + j * T + lane;
+      live[j] = B < nb;
+      Bc[j] = live[j] ? B : nb - 1;
+      const int64_t first = (Bw + j * T < nb) ? Bw + j * T : nb - 1;
+      const int64_t d0 = g.db_ptr[Bc[j]], d1 = g.db_ptr[Bc[j] + 1];
+      len[j] = live[j] ? (int)(d1 - d0) : 0;
+      slice0[j] = g.db_ptr[first];
+      base[j] = slice0[j];
+      sb0[j] = g.sb_ptr[Bc[j]];
+      sb1[j] = live[j] ? g.sb_ptr[Bc[j] + 1] : sb0[j];
+      const uint64_t sB = g.strs_b[Bc[j]];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rr = r < nr ? r : 0;
+        const int64_t A = A0 + rr;
+        const double cv = srow[rr * pitch + Bc[j]];
+        if (g.mode == 0) {
+          double d = g.hdiag[(A - g.row0) * nb + Bc[j]];
+          if (SPIN) d += g.shift * (g.szterm + (double)__popcll(sB & ~g.strs_a[A]) - g.ss);
+          acc[j][r] = d * cv;
+        } else {
+          acc[j][r] = (g.szterm + (double)__popcll(sB & ~g.strs_a[A])) * cv;
+        }
       }
     }
-    const int64_t sb0 = g.sb_ptr[Bc], sb1 = live ? g.sb_ptr[Bc + 1] : sb0;
     if (g.mode == 0) {
       // beta singles (CSR: rare in this regime): same-spin value + alpha occupation term
-      for (int64_t l = sb0; l < sb1; ++l) {
-        const SRec rec = g.sb_rec[l];
-        const double v = g.sb_val[l], sg = srec_sign(rec.meta);
-        const int64_t jw = srec_widx(rec.meta) >> 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (r < nr) acc[r] += (v + sg * g.ja_row[(A0 + r) * g.nnorb + jw]) * srow[r * pitch + rec.src];
-      }
-      // beta doubles, jagged-diagonal order of the slice
-      const int64_t d0 = g.db_ptr[Bc];
-      const int len = live ? (int)(g.db_ptr[Bc + 1] - d0) : 0;
-      // (eight steps per round: the eight positions come from eight ballots, then all sixteen loads are in flight
-      // together -- a step at a time the walk was a chain of ~11 dependent L2 round trips per column.  Lanes past
-      // the end of their list re-read the slice's first record with weight zero.)
-      const int64_t slice0 = g.db_ptr[B0];
-      int64_t base = slice0;
-      for (int k0 = 0;; k0 += 8) {
-        if (!__ballot(k0 < len)) break;
-        uint32_t src[8];
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bool on = k0 + u < len;
-          const unsigned long long m = __ballot(on);
-          const int64_t pos = on ? base + __popcll(m & lt) : slice0;
-          base += __popcll(m);
-          src[u] = g.jd_src[pos];
-          const double val = g.jd_val[pos];
-          v[u] = on ? val : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+      for (int j = 0; j < J; ++j)
+        for (int64_t l = sb0[j]; l < sb1[j]; ++l) {
+          const SRec rec = g.sb_rec[l];
+          const double v = g.sb_val[l], sg = srec_sign(rec.meta);
+          const int64_t jw = srec_widx(rec.meta) >> 1;
 #pragma unroll
           for (int r = 0; r < R; ++r)
-            if (r < nr) acc[r] += v[u] * srow[r * pitch + src[u]];
+            if (r < nr) acc[j][r] += (v + sg * g.ja_row[(A0 + r) * g.nnorb + jw]) * srow[r * pitch + rec.src];
         }
+      // beta doubles, jagged-diagonal order of each slice: the K positions of a round come from K ballots, then the
+      // 2 J K loads are in flight together.  Lanes past the end of their list re-read the slice's first record with
+      // weight zero.
+      for (int k0 = 0;; k0 += K) {
+        bool more = false;
+#pragma unroll
+        for (int j = 0; j < J; ++j) more = more || (k0 < len[j]);
+        if (!__ballot(more)) break;
+        uint32_t src[J][K];
+        double v[J][K];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+          for (int u = 0; u < K; ++u) {
+            const bool on = k0 + u < len[j];
+            const unsigned long long m = __ballot(on);
+            const int64_t pos = on ? base[j] + __popcll(m & lt) : slice0[j];
+            base[j] += __popcll(m);
+            src[j][u] = g.jd_src[pos];
+            const double val = g.jd_val[pos];
+            v[j][u] = on ? val : 0.0;
+          }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+          for (int u = 0; u < K; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (r < nr) acc[j][r] += v[j][u] * srow[r * pitch + src[j][u]];
       }
     }
 #pragma unroll
@@ -649,29 +673,41 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
       if (r >= nr) continue;  // (uniform over the workgroup)
       const int64_t A = A0 + r;
       const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
-      double a = acc[r];
       if (g.mode == 0) {
-        // alpha same-spin links: singles' one-body part, then doubles (wave-uniform lists, coalesced source rows)
-        for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + Bc];
-        const int64_t da0 = g.da_ptr[A], da1 = g.da_ptr[A + 1];
-        // eight source rows in flight per round; the padding of the last round re-reads the list's last link (the
-        // same cache line again) with weight zero
-        for (int64_t l = da0; l < da1; l += 8) {
-          double x[8], w[8];
+        // alpha same-spin links (wave-uniform lists, coalesced source rows): singles' one-body part, then doubles,
+        // K source rows x J slices in flight per round; the padding of the last round re-reads the list's last link
+        // (the same cache lines again) with weight zero
+        for (int64_t l = sa0; l < sa1; ++l) {
+          const double w = g.sa_val[l];
+          const double* __restrict__ srcrow = C + (int64_t)g.sa_rec[l].src * nb;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int j = 0; j < J; ++j) acc[j][r] += w * srcrow[Bc[j]];
+        }
+        const int64_t da0 = g.da_ptr[A], da1 = g.da_ptr[A + 1];
+        for (int64_t l = da0; l < da1; l += K) {
+          double x[J][K], w[K];
+#pragma unroll
+          for (int u = 0; u < K; ++u) {
             const bool on = l + u < da1;
             const int64_t lu = on ? l + u : da1 - 1;
             w[u] = on ? g.da_val[lu] : 0.0;
-            x[u] = C[(int64_t)g.da_src[lu] * nb + Bc];
+            const double* __restrict__ srcrow = C + (int64_t)g.da_src[lu] * nb;
+#pragma unroll
+            for (int j = 0; j < J; ++j) x[j][u] = srcrow[Bc[j]];
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) a += w[u] * x[u];
+          for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int u = 0; u < K; ++u) acc[j][r] += w[u] * x[j][u];
         }
         // alpha singles x beta occupation
         for (int64_t ls = sa0; ls < sa1; ++ls) {
           const SRec rec = g.sa_rec[ls];
-          a += srec_sign(rec.meta) * g.jbT[(int64_t)(srec_widx(rec.meta) >> 1) * nb + Bc] * C[(int64_t)rec.src * nb + Bc];
+          const double sg = srec_sign(rec.meta);
+          const double* __restrict__ jrow = g.jbT + (int64_t)(srec_widx(rec.meta) >> 1) * nb;
+          const double* __restrict__ srcrow = C + (int64_t)rec.src * nb;
+#pragma unroll
+          for (int j = 0; j < J; ++j) acc[j][r] += sg * jrow[Bc[j]] * srcrow[Bc[j]];
         }
       }
       // single x single (and the S^2 exchange term: the beta link that undoes the alpha link's orbital move)
@@ -680,16 +716,21 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
         const double* srcrow = C + (int64_t)ra.src * nb;
         const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
         const int partner = (int)srec_widx(ra.meta) ^ 1;
-        double t = 0.0;
-        for (int64_t lb = sb0; lb < sb1; ++lb) {
-          const SRec rb = g.sb_rec[lb];
-          double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
-          if (SPIN) wv += ((int)srec_widx(rb.meta) == partner) ? pen : 0.0;
-          t += srec_sign(rb.meta) * wv * srcrow[rb.src];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          double t = 0.0;
+          for (int64_t lb = sb0[j]; lb < sb1[j]; ++lb) {
+            const SRec rb = g.sb_rec[lb];
+            double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
+            if (SPIN) wv += ((int)srec_widx(rb.meta) == partner) ? pen : 0.0;
+            t += srec_sign(rb.meta) * wv * srcrow[rb.src];
+          }
+          acc[j][r] += srec_sign(ra.meta) * t;
         }
-        a += srec_sign(ra.meta) * t;
       }
-      if (live) out[(A - g.row0) * nb + B] = a;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (live[j]) out[(A - g.row0) * nb + Bw + j * T + lane] = acc[j][r];
     }
   }
 }
@@ -833,7 +874,9 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
     switch (R) {
       case 1: if (sp) SQD_ROWS_LAUNCH(1, true); else SQD_ROWS_LAUNCH(1, false); break;
       case 2: if (sp) SQD_ROWS_LAUNCH(2, true); else SQD_ROWS_LAUNCH(2, false); break;
+      case 3: if (sp) SQD_ROWS_LAUNCH(3, true); else SQD_ROWS_LAUNCH(3, false); break;
       case 4: if (sp) SQD_ROWS_LAUNCH(4, true); else SQD_ROWS_LAUNCH(4, false); break;
+      case 6: if (sp) SQD_ROWS_LAUNCH(6, true); else SQD_ROWS_LAUNCH(6, false); break;
       default: if (sp) SQD_ROWS_LAUNCH(8, true); else SQD_ROWS_LAUNCH(8, false); break;
     }
 #undef SQD_ROWS_LAUNCH

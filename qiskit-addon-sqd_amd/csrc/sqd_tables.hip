@@ -955,8 +955,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
       if (rows > (int)lds_rows) rows = (int)lds_rows;
       if (rows > 8) rows = 8;
     }
-    // template instantiations: 1, 2, 4, 8
-    while (rows > 1 && (rows & (rows - 1))) --rows;
+    // template instantiations: 1, 2, 3, 4, 6, 8
+    if (rows == 5) rows = 4;
+    if (rows == 7) rows = 6;
     c->sig_rows = rows > 0 ? rows : 0;
     c->sig_direct = direct || c->sig_rows > 0;
   }

@@ -50,7 +50,7 @@ def test_emu_direct_and_work_item_sigma(emu_lib, monkeypatch, direct):
     run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
 
 
-@pytest.mark.parametrize("rows", ["1", "2", "8"])
+@pytest.mark.parametrize("rows", ["1", "2", "3", "8"])
 def test_emu_rows_kernel(emu_lib, monkeypatch, rows):
     # SQD_SIGMA_ROWS=R forces k_sigma_rows (R whole rows of C per workgroup in LDS, beta doubles in per-slice
     # jagged-diagonal order), which large uniform-random sets take by default: ragged last workgroup (12 rows in

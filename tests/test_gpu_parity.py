@@ -55,7 +55,7 @@ def test_direct_and_work_item_sigma_forced(hip_lib, monkeypatch, direct):
     assert np.abs(p.ravel() - (s.ravel() + 0.3 * S2x)).max() < 1e-10
 
 
-@pytest.mark.parametrize("rows", ["1", "2", "8"])
+@pytest.mark.parametrize("rows", ["1", "2", "3", "6", "8"])
 def test_rows_sigma_kernel_forced(hip_lib, monkeypatch, rows):
     """k_sigma_rows (R whole rows of C per workgroup in LDS; the default for large uniform-random sets) forced at
     sizes the oracles check: all operator forms, Davidson, HF-centred and uniform sets, the headline size."""
