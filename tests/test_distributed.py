@@ -23,14 +23,14 @@ def test_shard_indices():
     assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
 
 
-def _run_two_ranks(worker: str):
+def _run_two_ranks(worker: str, **extra_env):
     from conftest import EMU_LIB
 
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SQD_EMU_LIB=str(EMU_LIB), OMP_NUM_THREADS="1")
+                   SQD_EMU_LIB=str(EMU_LIB), OMP_NUM_THREADS="1", **extra_env)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -49,7 +49,13 @@ def test_two_rank_gloo_whole_loop_unseeded(emu_lib):
     _run_two_ranks("_dist_loop_worker.py")
 
 
-def test_two_rank_gloo_row_sharded_sigma_and_solve(emu_lib):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("kernel_env", [{}, {"SQD_SIGMA_ROWS": "2"}, {"SQD_SIGMA_DIRECT": "1"}],
+                         ids=["work-items", "rows", "direct"])
+def test_two_rank_gloo_row_sharded_sigma_and_solve(emu_lib, kernel_env):
     """one subspace split by alpha rows over two ranks -- all-gather of the vector, sigma rows per rank
-    bit-identical to the single-rank sigma, and the collective Davidson against dense diagonalisation."""
-    _run_two_ranks("_dist_shard_worker.py")
+    bit-identical to the single-rank sigma, and the collective Davidson against dense diagonalisation; with each of
+    the three sigma kernels on the row range."""
+    _run_two_ranks("_dist_shard_worker.py", **kernel_env)
