@@ -129,7 +129,7 @@ constexpr int SCAL_RED = 2;
 constexpr int MAIL_PAYLOAD = 8;  // doubles; mail[0] is the sequence word
 constexpr int MAIL_SLOT = 128;   // doubles per mailbox slot: 0 stand-alone reductions, 1 Davidson progress, 2 Davidson result
 template <int MAXV>
-__global__ void k_reduce_to_mail(const double* __restrict__ partial, int nblocks, int width, int nv,
+__global__ void __launch_bounds__(128) k_reduce_to_mail(const double* __restrict__ partial, int nblocks, int width, int nv,
                                  const double* __restrict__ scal, double* __restrict__ mail, long long seq) {
   __shared__ double red[16 * MAXV];
   double vals[MAXV];
@@ -467,7 +467,7 @@ struct SplitRows {
   int64_t nb;
 };
 template <int MV>
-__global__ void k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+__global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                            double* __restrict__ partial, int width, unsigned* counter, DavState* st,
                            const DavParams prm, const SplitRows split) {
   __shared__ double red[16 * (MV + 1)];
@@ -533,7 +533,7 @@ __global__ void k_dots_eig(int64_t n, const double* __restrict__ X, double* __re
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
 // partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]; k_orth_dev (next in the stream) folds them.
 template <int MV>
-__global__ void k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+__global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
                                    const DavState* __restrict__ st, const double* __restrict__ hdiag,
                                    const PenaltyDiag pd, double* __restrict__ partial, int width) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
@@ -607,7 +607,7 @@ __device__ inline void post_progress(double* mail, long long seq, const DavState
 // When the iteration is a restart (basis full), the same pass collapses the basis: X0 <- Ritz vector,
 // AX0 <- A * Ritz (linear combinations, element by element in place), X1 <- the correction.
 template <int MV>
-__global__ void k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
+__global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                            const DavParams prm, const double* __restrict__ partial, int nblocks, int width,
                            double* mail, long long seq) {
   __shared__ double red[16 * (MV + 2)];
