@@ -584,8 +584,27 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
   const int64_t A0 = g.row0 + (int64_t)blockIdx.x * R;
   const int nr = (int)((g.row1 - A0) < R ? (g.row1 - A0) : R);  // rows of this workgroup (the last one may be short)
   const double pen = (g.mode == 1) ? -1.0 : -g.shift;
-  for (int r = 0; r < nr; ++r)
-    for (int64_t b = threadIdx.x; b < nb; b += blockDim.x) srow[r * pitch + b] = C[(A0 + r) * nb + b];
+  {
+    // staging: eight loads per thread in flight, then the eight LDS stores (element by element the loop was a chain of
+    // ~10 dependent round trips per row for a workgroup that has the CU to itself)
+    const int64_t T8 = (int64_t)blockDim.x * 8;
+    for (int r = 0; r < nr; ++r) {
+      const double* __restrict__ crow = C + (A0 + r) * nb;
+      for (int64_t b0 = threadIdx.x; b0 < nb; b0 += T8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t b = b0 + (int64_t)u * blockDim.x;
+          v[u] = crow[b < nb ? b : b0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t b = b0 + (int64_t)u * blockDim.x;
+          if (b < nb) srow[r * pitch + b] = v[u];
+        }
+      }
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
