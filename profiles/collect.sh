@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $ROOT
 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1
-python bench.py > $OUT/bench_uniform317.json 2> $OUT/bench_uniform317.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_uniform317.json 2> $OUT/bench_uniform317.err  # the driver's command line
 python bench.py --strings hf --skip-cpu --skip-secondary > $OUT/bench_hf317.json 2>/dev/null
 python bench.py --strings hf --spin-sq 0 --skip-cpu --skip-secondary > $OUT/bench_hf317_spin0.json 2>/dev/null
 python bench.py --skip-cpu --skip-secondary --extra > $OUT/bench_extra_ladder.json 2>/dev/null
@@ -22,6 +22,15 @@ python profiles/probes/_jitter_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/jitter_
 python profiles/probes/_concurrency_probe2.py 2>&1 | grep -v amdgpu.ids > $OUT/concurrency_probe.txt
 python profiles/probes/_loop_probe.py > $OUT/loop_probe.txt 2>&1
 python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/big_sigma_probe.txt
+# sigma of uniform n x n sets with the work-item kernel (SQD_SIGMA_ROWS=0) and with the default selection
+: > $OUT/sigma_ladder.txt
+for n in 1000 2000 3000 4000 6000 8000 10000 14000; do
+  SQD_SIGMA_ROWS=0 N=$n python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/sigma_ladder.txt
+  N=$n python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/sigma_ladder.txt
+done
+python profiles/probes/_eig_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/eig_probe.txt
+python profiles/probes/_bench_gap_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/bench_gap_probe.txt
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29551 profiles/probes/_exchange_probe2.py 2>&1 | grep -v -e amdgpu.ids -e socket.cpp > $OUT/exchange_probe.txt
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel traces of the SAME commands as the bench lines

@@ -10,7 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
 
-for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*_probe.txt")) + [os.path.join(src, "gpu_tests.txt"), os.path.join(src, "smoke.txt")]:
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*_probe.txt")) + [os.path.join(src, "gpu_tests.txt"), os.path.join(src, "smoke.txt"), os.path.join(src, "sigma_ladder.txt")]:
     if os.path.exists(f) and os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, "final_" + os.path.basename(f)))
 for d in glob.glob(os.path.join(src, "prof_*")):
