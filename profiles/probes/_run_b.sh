@@ -1,2 +1,3 @@
 P=profiles/probes/_big_sigma_probe.py
-for d in 0 3 7 11 15 31 63 51 35; do SQD_DBG=$d N=10000 python $P 2>&1 | grep -v amdgpu; done
+for n in 2000 3000 4000 6000 8000 10000 14000; do N=$n python $P 2>&1 | grep -v amdgpu; done
+python -m pytest tests -x -q -m gpu -k "rows or sharded" 2>&1 | grep -E "passed|failed|error" | tail -3
