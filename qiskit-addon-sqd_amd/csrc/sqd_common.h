@@ -28,10 +28,10 @@ void set_error(const std::string& msg);
     if (_rc != SQD_OK) return _rc; \
   } while (0)
 
-// ---- host waits.  hipStreamSynchronize / hipEventSynchronize go to sleep on an interrupt inside the runtime; on this
-// stack about one wait in a thousand then wakes up ~50 ms late (profiles/r02/jitter_probe.txt: two of 200 identical
-// 0.3 ms solves took 54 ms; round 1 saw the same "40-60 ms stall, cause not found" in its concurrency probe).  The
-// solves here are sub-millisecond, so the host polls instead (hipStreamQuery / hipEventQuery never block) and only
+// ---- host waits.  hipStreamSynchronize / hipEventSynchronize go to sleep on an interrupt inside the runtime and wake
+// up 10-20 us after the work is done.  (The 40-60 ms stalls round 1 saw are something else: the device settling its
+// power state in a process' first ~0.1 s of activity, profiles/r02/stall_probe.txt.)  The solves here are
+// sub-millisecond, so the host polls instead (hipStreamQuery / hipEventQuery never block) and only
 // falls back to the blocking call after two seconds.
 int spin_stream_sync(hipStream_t s);
 // wait until a device-written sequence word in host-visible memory reaches `seq` (falls back to a stream sync)

@@ -341,10 +341,10 @@ def solve_sci_batch(
     context per device; ctypes releases the GIL during native calls).  ``concurrency=k`` runs ``k``
     solves at a time on each device (own context + HIP stream each): a 1e5-determinant solve is
     latency-bound and leaves most of the GPU idle, so independent batches overlap well.  Steady-state
-    measurement, 16 batches of 317 x 317 on one MI355X (``profiles/r02/concurrency_probe.txt``, median of 7
-    runs after spin-up): HF-centred 3.33 / 2.11 / 1.67 / 1.54 / 1.66 / 1.81 ms per batch at
-    k = 1 / 2 / 3 / 4 / 6 / 8, uniform 0.284 / 0.227 / 0.192 / 0.216 / 0.207 / 0.215.  Default (``None``): device 0,
-    up to 4 batches in flight -- the best setting for well-connected subspaces and within 12 % of the best for
+    measurement, 16 batches of 317 x 317 on one MI355X (``profiles/r02/final_concurrency_probe.txt``, median of 7
+    runs after spin-up): HF-centred 3.17 / 2.05 / 1.69 / 1.56 / 1.66 / 1.78 ms per batch at
+    k = 1 / 2 / 3 / 4 / 6 / 8, uniform 0.198 / 0.180 / 0.169 / 0.184 / 0.194 / 0.201.  Default (``None``): device 0,
+    up to 4 batches in flight -- the best setting for well-connected subspaces and within 10 % of the best for
     sparse ones -- while every subspace stays below 4e6 determinants (26 resident vectors each), else one at a
     time.  The results do not depend on the concurrency.
     """
