@@ -472,7 +472,8 @@ class Context:
 
     def solve(self, strs_a, strs_b, ci0=None, *, tol: float = 1e-9, tol_residual: float | None = None,
               lindep: float = 1e-14, max_cycle: int = 100, max_space: int = 12, spin_sq: float | None = None,
-              shift: float = 0.2, verbose: int = 0, time_sigma_every: int = 0, spin_square: bool = True):
+              shift: float = 0.2, verbose: int = 0, time_sigma_every: int = 0, spin_square: bool = True,
+              pageable_result: bool = False):
         """``set_subspace`` + ``davidson(observables=True)`` in one native call (``sqd_solve_strings``).
         Returns (amps, stats, (energy, spin_square | None, occ_a, occ_b))."""
         a = strings_to_u64(strs_a)
@@ -486,7 +487,9 @@ class Context:
         if spin_sq is not None:
             opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
         stats = DavidsonStats()
-        amps = pinned_empty((a.size, b.size))
+        # (pageable_result: an ordinary numpy buffer for the state, the way a C caller without sqd_host_alloc would
+        # pass it -- the copy-stream path of sqd_solve instead of the kernel-written one; tests compare the two)
+        amps = np.empty((a.size, b.size)) if pageable_result else pinned_empty((a.size, b.size))
         ci0p = None
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(a.size, b.size)

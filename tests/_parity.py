@@ -61,8 +61,11 @@ def check_ground_state(ctx, H, S2, h1, eri, sa, sb, norb, e_tol=1e-8, with_rdm2=
     amps, st = ctx.davidson()  # first run after set_subspace: state block + start vector prepared by the table build
     amps_b, st_b = ctx.davidson()  # second run: the solver's own k_init_guess launch -- the same bits either way
     assert np.array_equal(amps, amps_b) and st["n_sigma"] == st_b["n_sigma"] and st["e_davidson"] == st_b["e_davidson"]
-    amps_c, st_c, _obs = ctx.solve(sa, sb)  # the one-call path (state written to the page-locked buffer by a kernel)
+    amps_c, st_c, obs_c = ctx.solve(sa, sb)  # the one-call path (state written to the page-locked buffer by a kernel)
     assert np.array_equal(amps, amps_c) and st_c["e_davidson"] == st["e_davidson"]
+    amps_d, st_d, obs_d = ctx.solve(sa, sb, pageable_result=True)  # ... and through the copy stream into pageable memory
+    assert np.array_equal(amps, amps_d) and obs_c[0] == obs_d[0] and obs_c[1] == obs_d[1]
+    assert np.array_equal(obs_c[2], obs_d[2]) and np.array_equal(obs_c[3], obs_d[3])
     w, v = np.linalg.eigh(H)
     assert st["converged"] == 1
     assert abs(st["e_davidson"] - w[0]) < e_tol
