@@ -1,11 +1,12 @@
-"""GPU probe (not a test): one sigma at uniform 1e4 x 1e4 (D = 1e8) under the tuning hooks given in the environment."""
+"""GPU probe (not a test): one sigma at uniform (GEN=hf: HF-centred) N x N under the tuning hooks given in the environment."""
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from qiskit_addon_sqd_amd import synthetic as S, fermion as F
 n = int(os.environ.get('N', '10000'))
 h1, eri = S.synthetic_integrals(30)
 ctx = F._get_context(h1, eri, 0)
-sa, sb = S.uniform_strings(30, 8, n, 11), S.uniform_strings(30, 8, n, 13)
+gen = S.hf_centred_strings if os.environ.get('GEN') == 'hf' else S.uniform_strings
+sa, sb = gen(30, 8, n, 11), gen(30, 8, n, 13)
 t0 = time.perf_counter(); ctx.set_subspace(sa, sb); ctx.sync(); t1 = time.perf_counter()
 ms = ctx.time_sigma(5)
 b = ctx.sigma_bytes()

@@ -1,3 +1,5 @@
 P=profiles/probes/_big_sigma_probe.py
-for n in 2000 3000 4000 6000 8000 10000 14000; do N=$n python $P 2>&1 | grep -v amdgpu; done
-python -m pytest tests -x -q -m gpu -k "rows or sharded" 2>&1 | grep -E "passed|failed|error" | tail -3
+for n in 317 707 1000 2000; do
+  GEN=hf N=$n python $P 2>&1 | grep -v amdgpu
+  for r in 2 8; do GEN=hf SQD_SIGMA_ROWS=$r N=$n python $P 2>&1 | grep -v amdgpu; done
+done

@@ -947,7 +947,9 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     if (env_d) direct = std::atoi(env_d) != 0;
     const size_t lds_rows = ((size_t)c->lds_bytes - 3 * 1024) / ((size_t)((nb + 1) & ~int64_t(1)) * 8);  // rows that fit
     int rows = 0;
-    if (!direct && !env_d && lds_rows >= 1 && nb >= 1024 && tot[2] + tot[3] <= 32 * nb && tot[0] + tot[1] <= 64 * na)
+    // (single links at most two per string on average: the single x single term is a nested per-element loop there)
+    if (!direct && !env_d && lds_rows >= 1 && nb >= 1024 && tot[2] + tot[3] <= 32 * nb && tot[0] + tot[1] <= 64 * na &&
+        tot[0] <= 2 * na && tot[2] <= 2 * nb)
       rows = (int)(lds_rows < 8 ? lds_rows : 8);
     if (const char* env = std::getenv("SQD_SIGMA_ROWS")) {
       rows = std::atoi(env);
