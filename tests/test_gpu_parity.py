@@ -106,6 +106,27 @@ def test_rows_sigma_kernel_default_selection(hip_lib, monkeypatch):
     assert a[4] == 1 and b[4] == 1 and abs(a[3] - b[3]) < 1e-9
 
 
+@pytest.mark.parametrize("na,nb,rows", [(1500, 1111, "3"), (1111, 2050, "6"), (700, 4097, "1")])
+def test_rows_sigma_kernel_ragged_against_work_items(hip_lib, monkeypatch, na, nb, rows):
+    """Ragged shapes (last workgroup short, last 64-column slice partial, rectangular), every operator form incl. the
+    squared spin penalty: k_sigma_rows forced against the work-item kernel forced, same inputs."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, na, 31), S.uniform_strings(30, 7, nb, 32)
+    x = np.random.default_rng(8).standard_normal((na, nb))
+    out = {}
+    for forced in (rows, "0"):
+        monkeypatch.setenv("SQD_SIGMA_ROWS", forced)
+        monkeypatch.setenv("SQD_SIGMA_DIRECT", "0") if forced == "0" else monkeypatch.delenv("SQD_SIGMA_DIRECT", raising=False)
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == (f"k_sigma_rows<{rows}>" if forced != "0" else "k_sigma")
+            out[forced] = (ctx.sigma(x), ctx.contract_ss(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.sigma(x, 2, 0.75, 0.3))
+    for a, b in zip(out[rows], out["0"]):
+        assert np.abs(a - b).max() < 1e-12 * max(1.0, np.abs(b).max())
+
+
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
