@@ -42,8 +42,8 @@ const char* sqd_last_error(void);
 int sqd_device_count(int* count);
 
 /* Page-locked host memory for result buffers (hipHostMalloc / hipHostFree).  An `amps` buffer obtained here is
- * filled by the DMA engine directly (sqd_solve, sqd_solve_strings); any other pointer goes through an internal pinned
- * staging buffer and a host copy.  No counterpart in the reference (pyscf returns numpy arrays it allocates itself). */
+ * written by the GPU directly (sqd_solve, sqd_solve_strings: by the observables kernel up to 64 MB, by the DMA engine
+ * beyond); any other pointer goes through an internal pinned staging buffer and a host copy.  No counterpart in the reference (pyscf returns numpy arrays it allocates itself). */
 int sqd_host_alloc(size_t bytes, void** out);
 int sqd_host_free(void* p);
 
@@ -184,8 +184,9 @@ int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0,
 int sqd_observables(sqd_ctx* ctx, const double* amps, double* e, double* s2, double* occ_a, double* occ_b);
 
 /* sqd_solve = sqd_davidson + sqd_observables of the solution, as one call: everything reference
- * solve_fermion does between building the solver and returning (fermion.py:803-830).  The observables'
- * kernels run while the amplitudes travel to the host on a second stream; one host synchronisation.
+ * solve_fermion does between building the solver and returning (fermion.py:803-830).  One fused observables kernel;
+ * it also writes the amplitudes into `amps` when that buffer came from sqd_host_alloc (else a copy on a second stream
+ * overlaps it); one host wait.
  * Any of amps / stats / e / s2 / occ_a / occ_b may be NULL. */
 int sqd_solve(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, double* amps,
               sqd_davidson_stats* stats, double* e, double* s2, double* occ_a, double* occ_b);

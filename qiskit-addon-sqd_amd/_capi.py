@@ -439,7 +439,7 @@ class Context:
     ):
         """Ground state of the projected Hamiltonian.  Returns (amps, stats); with ``observables=True`` the
         fused native call ``sqd_solve`` is used and (amps, stats, (energy, spin_square, occ_a, occ_b)) is
-        returned -- the observables' kernels overlap the transfer of the amplitudes."""
+        returned -- the observables kernel also writes the amplitudes into the (page-locked) result buffer."""
         opts = DavidsonOpts()
         self._lib.sqd_davidson_default_opts(C.byref(opts))
         opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
