@@ -1,5 +1,3 @@
-P=profiles/probes/_big_sigma_probe.py
-for n in 317 707 1000 2000; do
-  GEN=hf N=$n python $P 2>&1 | grep -v amdgpu
-  for r in 2 8; do GEN=hf SQD_SIGMA_ROWS=$r N=$n python $P 2>&1 | grep -v amdgpu; done
-done
+python profiles/probes/_concurrency_probe2.py 2>&1 | grep -v amdgpu
+python profiles/probes/_jitter_probe.py 2>&1 | grep -v amdgpu | tail -6
+python -m pytest tests -x -q -m gpu -k "config3 or concurrent or headline or full_parity" 2>&1 | grep -E "passed|failed|error" | tail -2

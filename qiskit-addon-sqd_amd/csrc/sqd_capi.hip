@@ -21,8 +21,9 @@ int spin_stream_sync(hipStream_t s) {
       set_error(std::string("hipStreamQuery: ") + hipGetErrorString(e));
       return SQD_ERR_HIP;
     }
-    if (spin > 4000000L) break;  // ~2 s of polling: something is badly wrong, let the runtime wait (and report)
-    __builtin_ia32_pause();
+    if (spin > 1000000L) break;  // ~2 s of polling: something is badly wrong, let the runtime wait (and report)
+    // (hipStreamQuery takes a runtime lock that other host threads need for their launches: ~1 us between polls)
+    for (int p = 0; p < 64; ++p) __builtin_ia32_pause();
   }
   SQD_HIP_CHECK(hipStreamSynchronize(s));
   return SQD_OK;
@@ -600,7 +601,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
   if (by_copy) SQD_STREAM_SYNC(c->copy_stream);
   if (staged) std::memcpy(amps, c->h_amps, bytes);
-  SQD_STREAM_SYNC(c->stream);
+  SQD_TRY(dev_observables_wait(c));
   c->stage_pending = false;
   sqd_davidson_stats local;
   sqd_davidson_stats* stp = stats ? stats : &local;

@@ -215,6 +215,7 @@ struct sqd_ctx {
   double* h_mail = nullptr;    // host pointer; [0] = sequence word (as int64), [8..] = payload
   double* d_mail = nullptr;    // the same memory as seen from the device
   int64_t mail_seq = 0;
+  int64_t obs_seq = 0;  // sequence number the latest k_observables posts behind its results
   int64_t sigma_launches = 0;  // sigma launches of Davidson runs on this context (event sampling)
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
@@ -268,5 +269,6 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true,
                             double* host_twin = nullptr);
+int dev_observables_wait(sqd_ctx* c);
 void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised
 }  // namespace sqd
