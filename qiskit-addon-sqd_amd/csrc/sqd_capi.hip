@@ -68,17 +68,24 @@ using namespace sqd;
 SQD_API int sqd_abi_version(void) { return 2; }
 
 // ---- page-locked host buffers for results.  A caller that hands sqd_solve an amplitude buffer obtained here gets the
-// device-to-host copy written straight into it by the DMA engine: no staging copy, and no first-touch page faults of
-// a fresh 0.8 MB numpy allocation per solve (together ~60 us of a 0.3 ms solve).
+// state written straight into it by the GPU (by the observables kernel up to 64 MB, by the DMA engine beyond): no
+// staging copy, and no first-touch page faults of a fresh 0.8 MB numpy allocation per solve (together ~60 us of a
+// 0.3 ms solve).
 namespace {
 std::mutex g_pin_mu;
-std::map<const char*, size_t> g_pinned;  // start -> bytes
-bool is_pinned(const void* p, size_t bytes) {
+struct PinnedBlock {
+  size_t bytes;
+  char* dev;  // the block's address as the devices see it (looked up once, at allocation)
+};
+std::map<const char*, PinnedBlock> g_pinned;  // start -> block
+// device-side address of a host range if it lies inside one block of sqd_host_alloc, else nullptr
+void* pinned_device_ptr(const void* p, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_pin_mu);
   auto it = g_pinned.upper_bound(static_cast<const char*>(p));
-  if (it == g_pinned.begin()) return false;
+  if (it == g_pinned.begin()) return nullptr;
   --it;
-  return static_cast<const char*>(p) + bytes <= it->first + it->second;
+  if (static_cast<const char*>(p) + bytes > it->first + it->second.bytes) return nullptr;
+  return it->second.dev + (static_cast<const char*>(p) - it->first);
 }
 }  // namespace
 SQD_API int sqd_host_alloc(size_t bytes, void** out) {
@@ -86,9 +93,11 @@ SQD_API int sqd_host_alloc(size_t bytes, void** out) {
   void* p = nullptr;
   // (portable + mapped: every device of the process may write into it from a kernel, see sqd_solve)
   SQD_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped));
+  void* dptr = nullptr;
+  SQD_HIP_CHECK(hipHostGetDevicePointer(&dptr, p, 0));
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pinned[static_cast<const char*>(p)] = bytes;
+    g_pinned[static_cast<const char*>(p)] = PinnedBlock{bytes, static_cast<char*>(dptr)};
   }
   *out = p;
   return SQD_OK;
@@ -569,11 +578,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   //  * small and pageable: through the context's pinned staging buffer on the copy stream (a truly asynchronous copy)
   //  * large: DMA straight to the caller's memory on the copy stream
   double* twin = nullptr;
-  if (amps && bytes <= (size_t(64) << 20) && is_pinned(amps, bytes)) {
-    void* dptr = nullptr;
-    SQD_HIP_CHECK(hipHostGetDevicePointer(&dptr, amps, 0));
-    twin = static_cast<double*>(dptr);
-  }
+  if (amps && bytes <= (size_t(64) << 20)) twin = static_cast<double*>(pinned_device_ptr(amps, bytes));
   const bool by_copy = amps && !twin;
   const bool staged = by_copy && bytes <= (size_t(64) << 20);
   if (by_copy) {
