@@ -139,8 +139,11 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_davidson.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats)]
     lib.sqd_observables.argtypes = [_ctxp, _dp, _dp, _dp, _dp, _dp]
     lib.sqd_solve.argtypes = [_ctxp, C.POINTER(DavidsonOpts), _dp, _dp, C.POINTER(DavidsonStats), _dp, _dp, _dp, _dp]
-    lib.sqd_solve_strings.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64, C.POINTER(DavidsonOpts), _dp, _dp,
-                                      C.POINTER(DavidsonStats), _dp, _dp, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    # (the hot entry point: array arguments are passed as plain addresses -- building a typed ctypes pointer per array
+    # costs ~2 us each, five of them per solve)
+    _vp = C.c_void_p
+    lib.sqd_solve_strings.argtypes = [_ctxp, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(DavidsonOpts), _vp, _vp,
+                                      C.POINTER(DavidsonStats), _dp, _dp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
@@ -204,7 +207,9 @@ class _PinnedPool:
         self._free: dict[int, list[int]] = {}
 
     def empty(self, shape) -> np.ndarray:
-        n = int(np.prod(shape))
+        n = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            n *= int(d)
         nbytes = max(8 * n, 8)
         size = 1 << max(12, (nbytes - 1).bit_length())  # power-of-two size classes
         with self._lock:
@@ -249,6 +254,11 @@ def _as_f64(a, shape=None) -> np.ndarray:
 
 def _ptr(a: np.ndarray, typ=_dp):
     return a.ctypes.data_as(typ)
+
+
+def _addr(a: np.ndarray) -> int:
+    """Address of a (contiguous) array's first element, for arguments declared ``c_void_p``."""
+    return a.__array_interface__["data"][0]
 
 
 def strings_to_u64(strs) -> np.ndarray:
@@ -493,14 +503,16 @@ class Context:
         ci0p = None
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(a.size, b.size)
-            ci0p = _ptr(ci0)
+            ci0p = _addr(ci0)
         e, s2 = C.c_double(), C.c_double()
         ea, eb = C.c_int(), C.c_int()
-        occ_a, occ_b = np.empty(self.norb), np.empty(self.norb)
+        occ = np.empty((2, self.norb))
+        occ_a, occ_b = occ[0], occ[1]
+        base = _addr(occ)
         self._check(
-            self._lib.sqd_solve_strings(self._h, _ptr(a, _u64p), a.size, _ptr(b, _u64p), b.size, C.byref(opts), ci0p,
-                                        _ptr(amps), C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,
-                                        _ptr(occ_a), _ptr(occ_b), C.byref(ea), C.byref(eb))
+            self._lib.sqd_solve_strings(self._h, _addr(a), a.size, _addr(b), b.size, C.byref(opts), ci0p,
+                                        _addr(amps), C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,
+                                        base, base + 8 * self.norb, C.byref(ea), C.byref(eb))
         )
         self.na, self.nb = int(a.size), int(b.size)
         self.nelec = (int(ea.value), int(eb.value))
