@@ -13,12 +13,17 @@ rng = np.random.default_rng(int(os.environ.get('SOAK_SEED', '1')))
 ncase = int(os.environ.get('SOAK_CASES', '200'))
 fails = 0
 modes = [{}, {'SQD_SIGMA_DIRECT': '1'}, {'SQD_SIGMA_DIRECT': '0'}, {'SQD_SIGMA_ROWS': '1'}, {'SQD_SIGMA_ROWS': '2'},
-         {'SQD_SIGMA_ROWS': '3'}, {'SQD_SIGMA_ROWS': '8'}, {'SQD_ELL_CAP': '2', 'SQD_SIGMA_DIRECT': '0'}]
+         {'SQD_SIGMA_ROWS': '3'}, {'SQD_SIGMA_ROWS': '8'}, {'SQD_ELL_CAP': '2', 'SQD_SIGMA_DIRECT': '0'},
+         {'SQD_SIGMA_GLOBAL_ROWS': '64', 'SQD_SIGMA_DIRECT': '0'}, {'SQD_SIGMA_PASS': '5', 'SQD_SIGMA_DIRECT': '0'},
+         {'SQD_SIGMA_L': '2', 'SQD_SIGMA_DIRECT': '0'}, {'SQD_SIGMA_L0': '0', 'SQD_SIGMA_DIRECT': '0'}]
+BIG = int(os.environ.get('SOAK_BIG', '0'))
 for case in range(ncase):
-    norb = int(rng.integers(3, 11))
+    norb = int(rng.integers(3, 14 if BIG else 11))
     ne = (int(rng.integers(1, norb)), int(rng.integers(1, norb)))
-    na = int(rng.integers(1, min(comb(norb, ne[0]), 70) + 1))
-    nb = int(rng.integers(1, min(comb(norb, ne[1]), 140) + 1))
+    na = int(rng.integers(1, min(comb(norb, ne[0]), 130 if BIG else 70) + 1))
+    nb = int(rng.integers(1, min(comb(norb, ne[1]), 260 if BIG else 140) + 1))
+    while na * nb > 9000:
+        na = max(1, na // 2)
     hf = bool(rng.integers(0, 2))
     seed = int(rng.integers(0, 10**6))
     h1, eri = O.synthetic_integrals(norb, seed=seed)
@@ -30,7 +35,7 @@ for case in range(ncase):
     w = np.linalg.eigvalsh(H)
     ss = float(rng.choice([0.0, 0.75, 2.0]))
     mode = modes[case % len(modes)]
-    for k in ('SQD_SIGMA_DIRECT', 'SQD_SIGMA_ROWS', 'SQD_ELL_CAP'):
+    for k in ('SQD_SIGMA_DIRECT', 'SQD_SIGMA_ROWS', 'SQD_ELL_CAP', 'SQD_SIGMA_GLOBAL_ROWS', 'SQD_SIGMA_PASS', 'SQD_SIGMA_L', 'SQD_SIGMA_L0'):
         os.environ.pop(k, None)
     os.environ.update(mode)
     try:
