@@ -7,8 +7,11 @@
 // Conventions: dm1s[p,q] = <a+_p a_q>;  dm2[p,q,r,s] = sum_{st} <p+_s r+_t s_t q_s>.
 // Orbital occupancies (the diagonal of dm1s, the only part that feeds back into the SQD loop) are
 // reduced in a fixed order and are bitwise reproducible; off-diagonal bins use f64 atomics.
+#include <cstring>
+
 #include "sqd_common.h"
 #include "sqd_device.h"
+#include "sqd_direct.h"
 
 namespace sqd {
 
@@ -270,7 +273,7 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
                               int64_t na, int64_t nb, const uint64_t* __restrict__ strs_a,
                               const uint64_t* __restrict__ strs_b, int norb, unsigned nrb, double* partial,
                               unsigned* counter, double* out, double* __restrict__ host_c, long long* seq_word,
-                              long long seq) {
+                              long long seq, const int s2_inline, const DirectArgs dg) {
   __shared__ double red[1024];
   __shared__ double wrow[64];
   __shared__ double dots[OBS_ROWS][4];
@@ -291,7 +294,9 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
           const int64_t b = b0 + 64 * u, idx = A * nb + (b < nb ? b : b0);
           v[u] = C[idx];
           h[u] = T1 ? T1[idx] : 0.0;
-          t[u] = T2 ? T2[idx] : 0.0;
+          // (s2_inline: S^2 c of this element evaluated here from the CSR lists -- ultra-sparse sets, where a
+          // sigma launch of its own would cost more than the handful of links it walks)
+          t[u] = s2_inline ? direct_element<true>(dg, C, idx, -1.0) : (T2 ? T2[idx] : 0.0);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -446,7 +451,14 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool wit
     SQD_TRY(launch_sigma(c, d_c, c->tmp1.as<double>(), 0, false, 0.0, 0.0));
     t1 = c->tmp1.as<double>();
   }
-  if (with_s2) {
+  DirectArgs dg;
+  std::memset(&dg, 0, sizeof(dg));
+  const bool s2_inline = with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sharded();
+  if (s2_inline) {
+    fill_direct_args(c, d_c, nullptr, /*mode=*/1, /*spin=*/false, 0.0, 0.0, 0, 0, &dg);
+    dg.stop = nullptr;
+    dg.vec_index = nullptr;
+  } else if (with_s2) {
     SQD_TRY(c->tmp2.reserve((size_t)D * 8));
     SQD_TRY(launch_sigma(c, d_c, c->tmp2.as<double>(), 1, false, 0.0, 0.0));
     t2 = c->tmp2.as<double>();
@@ -458,7 +470,7 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool wit
   hipLaunchKernelGGL(k_observables, dim3(nrb + ncb), dim3(512), 0, st, d_c, t1, t2, c->na, c->nb,
                      (const uint64_t*)c->sp[0].strs.as<uint64_t>(), (const uint64_t*)c->sp[1].strs.as<uint64_t>(), norb,
                      nrb, c->scratch.as<double>(), counter_ptr(c), c->d_mail + OBS_MAIL, host_twin,
-                     reinterpret_cast<long long*>(c->d_mail + OBS_SEQ), (long long)c->obs_seq);
+                     reinterpret_cast<long long*>(c->d_mail + OBS_SEQ), (long long)c->obs_seq, s2_inline ? 1 : 0, dg);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }

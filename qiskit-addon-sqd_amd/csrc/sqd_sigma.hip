@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "sqd_common.h"
+#include "sqd_direct.h"
 
 namespace sqd {
 
@@ -477,81 +478,16 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 // most loops being empty.  The work-item kernel above pays ~6 dependent memory round trips per row for its LDS
 // staging and virtual-row bookkeeping whether or not a row has links (9.7 us for 319 workgroups at 317 x 317);
 // this one is a single pass.  Same fixed summation order on every run (bitwise reproducible).
-struct DirectArgs {
-  const double* c;
-  double* sigma;
-  const double* hdiag;
-  int64_t row0, row1, nb;
-  int nnorb, mode, spin;
-  double ss, shift, szterm;
-  const uint64_t *strs_a, *strs_b;
-  const int64_t *sa_ptr, *da_ptr, *sb_ptr, *db_ptr;
-  const SRec *sa_rec, *sb_rec;
-  const double *sa_val, *sb_val;
-  const uint32_t *da_src, *db_src;
-  const double *da_val, *db_val;
-  const double *ja_row, *jbT, *eri_pp;
-  const int* stop;
-  const int* vec_index;
-  int64_t c_stride, s_stride;
-  // k_sigma_rows only: the beta doubles in per-slice jagged-diagonal order (k_tables_jds) and the LDS row pitch
-  const uint32_t* jd_src;
-  const double* jd_val;
-  int64_t nb_pad;
-};
 template <bool SPIN>
 __global__ void k_sigma_direct(const DirectArgs g) {
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ out = g.sigma + vsel * g.s_stride;
-  const int64_t nb = g.nb, n = (g.row1 - g.row0) * nb;
+  const int64_t n = (g.row1 - g.row0) * g.nb;
   const double pen = (g.mode == 1) ? -1.0 : -g.shift;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t Ar = i / nb, B = i - Ar * nb, A = g.row0 + Ar;
-    const double* crow = C + A * nb;
-    double a;
-    if (g.mode == 0) {
-      double d = g.hdiag[i];
-      if (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
-      a = d * crow[B];
-    } else {
-      a = (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A])) * crow[B];
-    }
-    const int64_t sb0 = g.sb_ptr[B], sb1 = g.sb_ptr[B + 1], sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1];
-    if (g.mode == 0) {
-      // beta singles: same-spin value + alpha occupation term; beta doubles
-      for (int64_t l = sb0; l < sb1; ++l) {
-        const SRec r = g.sb_rec[l];
-        a += (g.sb_val[l] + srec_sign(r.meta) * g.ja_row[A * g.nnorb + (srec_widx(r.meta) >> 1)]) * crow[r.src];
-      }
-      for (int64_t l = g.db_ptr[B]; l < g.db_ptr[B + 1]; ++l) a += g.db_val[l] * crow[g.db_src[l]];
-      // alpha same-spin links (singles' one-body part, then doubles: the CSR lists as the table build left them,
-      // in the order of the merged list the work-item kernel reads), then alpha singles x beta occupation
-      for (int64_t l = sa0; l < sa1; ++l) a += g.sa_val[l] * C[(int64_t)g.sa_rec[l].src * nb + B];
-      for (int64_t l = g.da_ptr[A]; l < g.da_ptr[A + 1]; ++l) a += g.da_val[l] * C[(int64_t)g.da_src[l] * nb + B];
-      for (int64_t l = sa0; l < sa1; ++l) {
-        const SRec r = g.sa_rec[l];
-        a += srec_sign(r.meta) * g.jbT[(int64_t)(srec_widx(r.meta) >> 1) * nb + B] * C[(int64_t)r.src * nb + B];
-      }
-    }
-    // single x single (and the S^2 exchange term: the beta link that undoes the alpha link's orbital move)
-    for (int64_t la = sa0; la < sa1; ++la) {
-      const SRec ra = g.sa_rec[la];
-      const double* srow = C + (int64_t)ra.src * nb;
-      const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
-      const int partner = (int)srec_widx(ra.meta) ^ 1;
-      double t = 0.0;
-      for (int64_t lb = sb0; lb < sb1; ++lb) {
-        const SRec rb = g.sb_rec[lb];
-        double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
-        if (SPIN) wv += ((int)srec_widx(rb.meta) == partner) ? pen : 0.0;
-        t += srec_sign(rb.meta) * wv * srow[rb.src];
-      }
-      a += srec_sign(ra.meta) * t;
-    }
-    out[i] = a;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = direct_element<SPIN>(g, C, i, pen);
 }
 
 // ---- Long rows, short lists (uniform-random string sets from ~10^3 strings per spin up to rows of 19 968 strings).
@@ -824,11 +760,11 @@ static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
                                  : launch_sigma_rs<R, false, false, false>(c, g);
 }
 
-static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss,
-                               double shift, int64_t in_stride, int64_t out_stride) {
+void fill_direct_args(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                      int64_t in_stride, int64_t out_stride, DirectArgs* gp) {
   const SpinTables& a = c->sp[0];
   const SpinTables& b = c->sp[1];
-  DirectArgs g;
+  DirectArgs& g = *gp;
   g.c = d_c;
   g.sigma = d_sigma;
   g.hdiag = c->hdiag.as<double>();
@@ -864,10 +800,16 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
   g.vec_index = indexed ? c->sigma_index : nullptr;
   g.c_stride = in_stride;
   g.s_stride = out_stride;
+  g.jd_src = b.jd_src.as<uint32_t>();
+  g.jd_val = b.jd_val.as<double>();
+  g.nb_pad = (c->nb + 1) & ~int64_t(1);
+}
+
+static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss,
+                               double shift, int64_t in_stride, int64_t out_stride) {
+  DirectArgs g;
+  fill_direct_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);
   if (c->sig_rows > 0) {
-    g.jd_src = b.jd_src.as<uint32_t>();
-    g.jd_val = b.jd_val.as<double>();
-    g.nb_pad = (c->nb + 1) & ~int64_t(1);
     const int R = c->sig_rows;
     const size_t shmem = (size_t)R * g.nb_pad * 8;
     const unsigned blocks_r = (unsigned)((c->row1 - c->row0 + R - 1) / R);
