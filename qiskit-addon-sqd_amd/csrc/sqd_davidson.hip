@@ -923,14 +923,19 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     split.partial = c->sig_partial.as<double>();
   }
 
-  // Host loop: iteration j is enqueued as soon as the progress record of iteration j - 1 - AHEAD has been seen
-  // without a stop.  AHEAD = 1 keeps one whole iteration queued behind the running one, so no launch waits for
-  // the host; when the solve stops, at most AHEAD + 1 iterations of early-exit kernels are wasted.
-  const int ahead = o->verbose ? 0 : 1;
-  long long seq_of[4] = {0, 0, 0, 0};  // sequence numbers of the latest iterations enqueued (ring)
+  // Host loop.  A round = the sigma build (part A) + the three BLAS-1 launches behind it (part B); the device decides
+  // everything, the host only keeps the queue fed and watches the progress records.  How far ahead it enqueues:
+  //  * from round FULL_FROM on, one WHOLE round is queued behind the running one: no launch ever waits for the host,
+  //    and a stop wastes one round of early-exit launches (4 dependent dispatches, ~10 us) -- nothing on a long solve;
+  //  * in the first rounds only the NEXT SIGMA BUILD is queued ahead: part B of round r + 1 is enqueued when the
+  //    record of round r has been seen, while that sigma build runs (5 us at the headline, 27 us HF-centred: time for
+  //    the three launches).  A stop then wastes one dispatch instead of four -- the solves of uniform-random sets
+  //    converge in 2-3 rounds, and 8 us are 5 % of them.
+  const bool lockstep = o->verbose != 0;  // verbose: round by round, each record printed before the next round starts
+  const int full_from = 3;
+  long long seq_of[4] = {0, 0, 0, 0};  // sequence numbers of the latest rounds enqueued (ring)
   bool stopped = false;
-  int enq = 0;
-  auto settle = [&](int j) -> int {  // wait for iteration j's progress record
+  auto settle = [&](int j) -> int {  // wait for round j's progress record
     SQD_TRY(wait_mail(c, 1, seq_of[j & 3]));
     if (h_prog[MAIL_PAYLOAD + 1] != 0.0) stopped = true;
     if (o->verbose)
@@ -939,7 +944,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
                    std::sqrt(h_prog[MAIL_PAYLOAD + 4]));
     return SQD_OK;
   };
-  while (!stopped && enq < o->max_cycle) {
+  auto part_a = [&](int round) -> int {  // the sigma build of a round (reads "which vector" from the state block)
     const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
     ++c->sigma_launches;
     if (timed) {
@@ -953,11 +958,14 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
       SQD_HIP_CHECK(hipEventRecord(c->sig_ev[4 * nev + 2], s));
       // an EMPTY bracket right behind: what two event records cost by themselves at this point of the stream
       SQD_HIP_CHECK(hipEventRecord(c->sig_ev[4 * nev + 3], s));
-      c->dav_ev_iter.push_back(enq);
+      c->dav_ev_iter.push_back(round);
       ++nev;
     }
+    return SQD_OK;
+  };
+  auto part_b = [&](int round) -> int {
     const long long seq = ++c->mail_seq;
-    seq_of[enq & 3] = seq;
+    seq_of[round & 3] = seq;
     if (max_space <= 12) {
       hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
                          c->partial.as<double>(), width, counter, dst, prm, split);
@@ -974,8 +982,26 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
                          (int)gb, width, mail_prog, seq);
     }
     SQD_HIP_CHECK(hipGetLastError());
-    ++enq;
-    if (enq - 1 - ahead >= 0) SQD_TRY(settle(enq - 1 - ahead));
+    return SQD_OK;
+  };
+  {
+    const int max_rounds = o->max_cycle;
+    int n_a = 0, n_b = 0;  // rounds whose part A / part B have been enqueued
+    SQD_TRY(part_a(n_a++));
+    SQD_TRY(part_b(n_b++));
+    for (int r = 0;;) {  // r = the round whose record is waited for next
+      if (!lockstep) {
+        if (n_a == r + 1 && n_a < max_rounds) SQD_TRY(part_a(n_a++));
+        if (n_a == r + 2 && n_b == r + 1 && r + 1 >= full_from) SQD_TRY(part_b(n_b++));
+      }
+      SQD_TRY(settle(r));
+      if (stopped) break;
+      ++r;
+      // round r has to be complete in the queue before its record can be waited for
+      if (n_a == r && n_a < max_rounds) SQD_TRY(part_a(n_a++));
+      if (n_b == r && n_b < n_a) SQD_TRY(part_b(n_b++));
+      if (n_b == r) break;  // the cycle limit: nothing more to run
+    }
   }
   // solution = Ritz vector of the last projected problem, normalised; the run's outcome to mailbox slot 2
   hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
