@@ -342,8 +342,8 @@ def solve_sci_batch(
     solves at a time on each device (own context + HIP stream each): a 1e5-determinant solve is
     latency-bound and leaves most of the GPU idle, so independent batches overlap well.  Steady-state
     measurement, 16 batches of 317 x 317 on one MI355X (``profiles/r02/final_concurrency_probe.txt``, median of 7
-    runs after spin-up): HF-centred 3.16 / 2.05 / 1.68 / 1.55 / 1.66 / 1.78 ms per batch at
-    k = 1 / 2 / 3 / 4 / 6 / 8, uniform 0.202 / 0.152 / 0.144 / 0.160 / 0.171 / 0.185.  Default (``None``): device 0,
+    runs after spin-up): HF-centred 3.18 / 2.05 / 1.69 / 1.60 / 1.65 / 1.79 ms per batch at
+    k = 1 / 2 / 3 / 4 / 6 / 8, uniform 0.190 / 0.161 / 0.140 / 0.138 / 0.156 / 0.173.  Default (``None``): device 0,
     up to 4 batches in flight -- the best setting for well-connected subspaces and within 20 % of the best for
     sparse ones -- while every subspace stays below 4e6 determinants (26 resident vectors each), else one at a
     time.  The results do not depend on the concurrency.
