@@ -196,6 +196,34 @@ int sqd_solve(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, do
 int sqd_solve_strings(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const uint64_t* strs_b, int64_t nb,
                       const sqd_davidson_opts* opts, const double* ci0, double* amps, sqd_davidson_stats* stats,
                       double* e, double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b);
+
+/* ---- the whole list of subspaces the reference hands its sci_solver at once (fermion.py:432; solved one after
+ * another by reference solve_sci_batch, fermion.py:670-681, "embarrassingly parallel" README.md:76) as ONE batched
+ * solve: the table build, every Davidson round and the observables of ALL nbatch subspaces advance in the same set of
+ * kernel launches (blockIdx.z = subspace) on the context's stream; each subspace keeps its own device-resident Davidson
+ * state and stops itself, the call returns when all have.  Per subspace the arithmetic is sqd_solve_strings' -- same
+ * kernels bodies on the same per-subspace grids -- so every output equals the one-by-one result bit for bit.
+ *   strs_a[i] / na[i] / strs_b[i] / nb[i]: the strings of batch i (as sqd_set_subspace).
+ *   e / s2 / nelec_a / nelec_b: nbatch values; occ_a / occ_b: nbatch * norb doubles, row i = batch i; stats: nbatch
+ *   records.  s2 may be NULL (then <S^2> is not evaluated unless the spin penalty needs it); so may stats, nelec_*.
+ *   amps: NULL, or nbatch pointers; amps[i] (NULL = leave the state on the device) receives batch i's na[i]*nb[i]
+ *   amplitudes -- written by the observables kernel itself when it came from sqd_host_alloc.
+ *   best_amps (may be NULL): room for the largest subspace; receives the amplitudes of the lowest-energy batch --
+ *   the only state the reference's loop consumes (fermion.py:577, :608-631) -- and *best its index.  Every other
+ *   state stays resident until the next sqd_solve_batch / sqd_ctx_destroy on this context: sqd_batch_state copies one
+ *   out on demand.
+ * opts->verbose and opts->time_sigma_every are ignored; ci0 is not available (pyscf's start vector is used).
+ * Subspaces outside the batched launch classes (rows too long for LDS staging, the (S^2-ss)^2 penalty form) are
+ * solved one by one inside the same call. */
+int sqd_solve_batch(sqd_ctx* ctx, int nbatch, const uint64_t* const* strs_a, const int64_t* na,
+                    const uint64_t* const* strs_b, const int64_t* nb, const sqd_davidson_opts* opts,
+                    double* const* amps, double* best_amps, int* best, sqd_davidson_stats* stats, double* e, double* s2,
+                    double* occ_a, double* occ_b, int* nelec_a, int* nelec_b);
+/* amplitudes of batch `index` of the latest sqd_solve_batch (na*nb doubles) from their device-resident copy */
+int sqd_batch_state(sqd_ctx* ctx, int index, double* amps);
+/* the sub-context that holds batch `index` of the latest sqd_solve_batch (tables + resident solution): usable with the
+ * observables / RDM entry points (amps = NULL: the resident solution) until the next sqd_solve_batch.  Owned by ctx. */
+int sqd_batch_ctx(sqd_ctx* ctx, int index, sqd_ctx** sub);
 int sqd_energy(sqd_ctx* ctx, const double* amps, double* e);
 int sqd_spin_square(sqd_ctx* ctx, const double* amps, double* s2);
 int sqd_rdm1s(sqd_ctx* ctx, const double* amps, double* dm1a, double* dm1b);

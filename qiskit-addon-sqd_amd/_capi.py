@@ -48,6 +48,9 @@ EXPORTED_SYMBOLS = (
     "sqd_observables",
     "sqd_solve",
     "sqd_solve_strings",
+    "sqd_solve_batch",
+    "sqd_batch_state",
+    "sqd_batch_ctx",
     "sqd_energy",
     "sqd_spin_square",
     "sqd_rdm1s",
@@ -144,6 +147,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     _vp = C.c_void_p
     lib.sqd_solve_strings.argtypes = [_ctxp, _vp, C.c_int64, _vp, C.c_int64, C.POINTER(DavidsonOpts), _vp, _vp,
                                       C.POINTER(DavidsonStats), _dp, _dp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.sqd_solve_batch.argtypes = [_ctxp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(DavidsonOpts), _vp, _vp,
+                                    C.POINTER(C.c_int), _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.sqd_batch_state.argtypes = [_ctxp, C.c_int, _vp]
+    lib.sqd_batch_ctx.argtypes = [_ctxp, C.c_int, C.POINTER(_ctxp)]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm1s.argtypes = [_ctxp, _dp, _dp, _dp]
@@ -200,21 +207,31 @@ class _PinnedPool:
     block is garbage collected.  The DMA engine writes the amplitudes of a solve straight into such an array; an
     ordinary ``np.empty`` of 0.8 MB costs a staging copy plus a fresh mmap with ~200 first-touch page faults per solve."""
 
+    KEEP_BYTES = 256 << 20  # page-locked bytes kept for reuse (not swappable, shared by the node: bounded)
+    CLASS_MAX = 64 << 20    # larger blocks are allocated at their exact size and returned to the OS when released
+
     def __init__(self):
         import threading
 
-        self._lock = threading.Lock()
+        # re-entrant: _release runs from a weakref finaliser, which the garbage collector may start on a thread that
+        # is inside empty() / _release() already
+        self._lock = threading.RLock()
         self._free: dict[int, list[int]] = {}
+        self._kept = 0
 
     def empty(self, shape) -> np.ndarray:
         n = 1
         for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
             n *= int(d)
         nbytes = max(8 * n, 8)
-        size = 1 << max(12, (nbytes - 1).bit_length())  # power-of-two size classes
+        # power-of-two size classes up to CLASS_MAX, the exact size (to the page) beyond
+        size = 1 << max(12, (nbytes - 1).bit_length()) if nbytes <= self.CLASS_MAX else (nbytes + 4095) & ~4095
+        ptr = None
         with self._lock:
             blocks = self._free.get(size)
-            ptr = blocks.pop() if blocks else None
+            if blocks:
+                ptr = blocks.pop()
+                self._kept -= size
         if ptr is None:
             out = C.c_void_p()
             rc = load_library().sqd_host_alloc(size, C.byref(out))
@@ -228,9 +245,12 @@ class _PinnedPool:
 
     def _release(self, ptr, size):
         with self._lock:
-            blocks = self._free.setdefault(size, [])
-            if len(blocks) < 64:  # keep up to 64 blocks of a size class for reuse
+            if size <= self.CLASS_MAX and self._kept + size <= self.KEEP_BYTES:
+                blocks = self._free.get(size)
+                if blocks is None:
+                    blocks = self._free[size] = []
                 blocks.append(ptr)
+                self._kept += size
                 return
         lib = _LIB
         if lib is not None:
@@ -519,6 +539,73 @@ class Context:
         self.rows = (0, self.na)
         return (amps, {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_},
                 (e.value, s2.value if spin_square else None, occ_a, occ_b))
+
+    def solve_batch(self, ci_strings, *, tol: float = 1e-9, tol_residual: float | None = None, lindep: float = 1e-14,
+                    max_cycle: int = 100, max_space: int = 12, spin_sq: float | None = None, shift: float = 0.2,
+                    spin_square: bool = False, fetch: str = "best"):
+        """The whole list of subspaces as ONE batched solve (``sqd_solve_batch``): tables, every Davidson round and the
+        observables of all of them advance in the same kernel launches.  ``fetch``: ``"best"`` -- only the state of the
+        lowest-energy batch comes to the host (the others stay on the device until the next batched solve;
+        ``batch_state(i)`` copies one out), ``"all"``, or ``"none"``.  Returns a dict with ``energy[n]``,
+        ``spin_square[n] | None``, ``occ_a[n, norb]``, ``occ_b[n, norb]``, ``stats[n]``, ``nelec[n]``, ``best`` and
+        ``amps`` (list: arrays, or None where the state was left on the device)."""
+        n = len(ci_strings)
+        if n < 1:
+            raise ValueError("empty batch list")
+        a_arr = [strings_to_u64(a) for a, _ in ci_strings]
+        b_arr = [strings_to_u64(b) for _, b in ci_strings]
+        pa = (C.c_void_p * n)(*[_addr(x) for x in a_arr])
+        pb = (C.c_void_p * n)(*[_addr(x) for x in b_arr])
+        na = (C.c_int64 * n)(*[x.size for x in a_arr])
+        nb = (C.c_int64 * n)(*[x.size for x in b_arr])
+        opts = DavidsonOpts()
+        self._lib.sqd_davidson_default_opts(C.byref(opts))
+        opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
+        opts.tol_residual = float(tol_residual) if tol_residual else 0.0
+        if spin_sq is not None:
+            opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
+        stats = (DavidsonStats * n)()
+        e = np.empty(n)
+        s2 = np.empty(n) if spin_square else None
+        occ = np.empty((2, n, self.norb))
+        ea, eb = (C.c_int * n)(), (C.c_int * n)()
+        amps: list = [None] * n
+        pamps = None
+        best_buf, best = None, C.c_int(-1)
+        if fetch == "all":
+            amps = [pinned_empty((a_arr[i].size, b_arr[i].size)) for i in range(n)]
+            pamps = (C.c_void_p * n)(*[_addr(x) for x in amps])
+        elif fetch == "best":
+            best_buf = pinned_empty(max(a_arr[i].size * b_arr[i].size for i in range(n)))
+        elif fetch != "none":
+            raise ValueError("fetch must be 'best', 'all' or 'none'")
+        self._batch_gen = getattr(self, "_batch_gen", 0) + 1
+        self._check(
+            self._lib.sqd_solve_batch(self._h, n, C.addressof(pa), C.addressof(na), C.addressof(pb), C.addressof(nb),
+                                      C.byref(opts), C.addressof(pamps) if pamps is not None else None,
+                                      _addr(best_buf) if best_buf is not None else None, C.byref(best),
+                                      C.addressof(stats), _addr(e), _addr(s2) if s2 is not None else None, _addr(occ[0]),
+                                      _addr(occ[1]), C.addressof(ea), C.addressof(eb))
+        )
+        self._batch_shapes = [(a_arr[i].size, b_arr[i].size) for i in range(n)]
+        if best_buf is not None:
+            w = int(best.value)
+            sh = self._batch_shapes[w]
+            amps[w] = best_buf[: sh[0] * sh[1]].reshape(sh)
+        names = [f[0] for f in DavidsonStats._fields_]
+        return {
+            "energy": e, "spin_square": s2, "occ_a": occ[0], "occ_b": occ[1],
+            "stats": [{k: getattr(stats[i], k) for k in names} for i in range(n)],
+            "nelec": [(int(ea[i]), int(eb[i])) for i in range(n)], "best": int(best.value), "amps": amps,
+            "generation": self._batch_gen,
+        }
+
+    def batch_state(self, index: int) -> np.ndarray:
+        """Amplitudes of batch ``index`` of the latest ``solve_batch`` from their device-resident copy."""
+        sh = self._batch_shapes[index]
+        out = pinned_empty(sh)
+        self._check(self._lib.sqd_batch_state(self._h, int(index), _addr(out)))
+        return out
 
     # -- observables (amps=None -> resident Davidson solution)
     def _state(self, amps):

@@ -65,7 +65,7 @@ using namespace sqd;
 
 #define SQD_API extern "C" __attribute__((visibility("default")))
 
-SQD_API int sqd_abi_version(void) { return 2; }
+SQD_API int sqd_abi_version(void) { return 3; }
 
 // ---- page-locked host buffers for results.  A caller that hands sqd_solve an amplitude buffer obtained here gets the
 // state written straight into it by the GPU (by the observables kernel up to 64 MB, by the DMA engine beyond): no
@@ -205,6 +205,7 @@ SQD_API int sqd_ctx_use_stream(sqd_ctx* c, void* stream) {
   if (c->stream && c->owns_stream) SQD_HIP_CHECK(hipStreamDestroy(c->stream));
   c->stream = reinterpret_cast<hipStream_t>(stream);
   c->owns_stream = false;
+  for (sqd_ctx* sub : c->subs) sub->stream = c->stream;  // sub-contexts of batched solves share the stream
   return SQD_OK;
 }
 
@@ -213,6 +214,9 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   hipError_t e = hipSetDevice(c->device);
   (void)e;
   if (c->stream) e = hipStreamSynchronize(c->stream);
+  for (sqd_ctx* sub : c->subs) sqd_ctx_destroy(sub);  // (their integral tables are views of this context's)
+  c->subs.clear();
+  for (auto& bs : c->bstage) bs.release();
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
                     &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo};
@@ -548,6 +552,41 @@ SQD_API int sqd_observables(sqd_ctx* c, const double* amps, double* e, double* s
   return SQD_OK;
 }
 
+// after the Davidson and the observables kernel of a solve have completed: the run's statistics and the results
+// derived from the reduced records (energy: see sqd_solve)
+static int solve_collect(sqd_ctx* c, const sqd_davidson_opts& o, int form, sqd_davidson_stats* stats, double* e, double* s2,
+                         double* occ_a, double* occ_b) {
+  sqd_davidson_stats local;
+  sqd_davidson_stats* stp = stats ? stats : &local;
+  SQD_TRY(davidson_collect(c, stp));
+  std::vector<double> out(4 + 2 * c->norb);
+  dev_observables_collect(c, out.data());
+  const double cc = out[2];
+  if (!(cc > 0.0)) {
+    set_error("state has zero norm");
+    return SQD_ERR_INVALID;
+  }
+  const double ct = out[1] / cc, tt = out[3 + 2 * c->norb] / cc;
+  double penalty = 0.0;
+  if (form == 1) penalty = ct - o.ss;
+  else if (form == 2) penalty = tt - 2.0 * o.ss * ct + o.ss * o.ss;
+  if (e) *e = stp->e_davidson - (form ? o.shift * penalty : 0.0);
+  if (s2) *s2 = ct;
+  for (int p = 0; p < c->norb; ++p) {
+    if (occ_a) occ_a[p] = out[3 + p] / cc;
+    if (occ_b) occ_b[p] = out[3 + c->norb + p] / cc;
+  }
+  return SQD_OK;
+}
+static int penalty_form(const sqd_ctx* c, const sqd_davidson_opts& o) {
+  int form = o.use_spin;
+  if (form == 3) {
+    const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+    form = (o.ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+  }
+  return form;
+}
+
 // One call for the whole of solve_fermion's device work: Davidson, then the observables' kernels on the
 // compute stream WHILE the amplitudes travel to the host on the copy stream; one synchronisation.
 //
@@ -608,27 +647,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   if (staged) std::memcpy(amps, c->h_amps, bytes);
   SQD_TRY(dev_observables_wait(c));
   c->stage_pending = false;
-  sqd_davidson_stats local;
-  sqd_davidson_stats* stp = stats ? stats : &local;
-  SQD_TRY(davidson_collect(c, stp));
-  std::vector<double> out(4 + 2 * c->norb);
-  dev_observables_collect(c, out.data());
-  const double cc = out[2];
-  if (!(cc > 0.0)) {
-    set_error("state has zero norm");
-    return SQD_ERR_INVALID;
-  }
-  const double ct = out[1] / cc, tt = out[3 + 2 * c->norb] / cc;
-  double penalty = 0.0;
-  if (form == 1) penalty = ct - o.ss;
-  else if (form == 2) penalty = tt - 2.0 * o.ss * ct + o.ss * o.ss;
-  if (e) *e = stp->e_davidson - (form ? o.shift * penalty : 0.0);
-  if (s2) *s2 = ct;
-  for (int p = 0; p < c->norb; ++p) {
-    if (occ_a) occ_a[p] = out[3 + p] / cc;
-    if (occ_b) occ_b[p] = out[3 + c->norb + p] / cc;
-  }
-  return SQD_OK;
+  return solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
 }
 
 // sqd_set_subspace + sqd_solve in ONE crossing of the boundary: the body of reference solve_fermion / solve_sci from
@@ -643,6 +662,180 @@ SQD_API int sqd_solve_strings(sqd_ctx* c, const uint64_t* strs_a, int64_t na, co
   if (nelec_a) *nelec_a = c->nelec[0];
   if (nelec_b) *nelec_b = c->nelec[1];
   return sqd_solve(c, opts, ci0, amps, stats, e, s2, occ_a, occ_b);
+}
+
+// ---- batched solve of a whole ci_strings list (declared and documented in include/sqd_hip.h)
+static int sub_ctx_create(sqd_ctx* parent, sqd_ctx** out) {
+  sqd_ctx* c = new sqd_ctx();
+  c->device = parent->device;
+  c->norb = parent->norb;
+  c->nnorb = parent->nnorb;
+  c->num_cu = parent->num_cu;
+  c->lds_bytes = parent->lds_bytes;
+  c->stream = parent->stream;
+  c->owns_stream = false;
+  c->parent = parent;
+  c->h1.set_view(parent->h1.p);
+  c->eri4.set_view(parent->eri4.p);
+  c->eri_pp.set_view(parent->eri_pp.p);
+  c->jm.set_view(parent->jm.p);
+  c->km.set_view(parent->km.p);
+  c->jdiag.set_view(parent->jdiag.p);
+  hipError_t e = hipStreamCreate(&c->copy_stream);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_sol);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev_aux);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, 4096 * sizeof(double), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_mail, 1024 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c->d_mail, c->h_mail, 0);
+  if (e != hipSuccess) {
+    set_error(std::string("sub-context resources: ") + hipGetErrorString(e));
+    sqd_ctx_destroy(c);
+    return SQD_ERR_HIP;
+  }
+  std::memset(c->h_mail, 0, 1024 * sizeof(double));
+  *out = c;
+  return SQD_OK;
+}
+
+SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_a, const int64_t* na,
+                            const uint64_t* const* strs_b, const int64_t* nb, const sqd_davidson_opts* opts,
+                            double* const* amps, double* best_amps, int* best, sqd_davidson_stats* stats, double* e,
+                            double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b) {
+  CTX_ENTER(c);
+  if (c->parent) {
+    set_error("sqd_solve_batch on a sub-context");
+    return SQD_ERR_STATE;
+  }
+  if (nbatch < 1 || !strs_a || !na || !strs_b || !nb) {
+    set_error("sqd_solve_batch: null argument or empty batch list");
+    return SQD_ERR_INVALID;
+  }
+  if ((best || best_amps) && !e) {
+    set_error("sqd_solve_batch: `e` is required with best / best_amps");
+    return SQD_ERR_INVALID;
+  }
+  sqd_davidson_opts o;
+  if (opts) o = *opts; else sqd_davidson_default_opts(&o);
+  if (o.tol <= 0 || o.max_cycle < 1) {
+    set_error("bad Davidson options");
+    return SQD_ERR_INVALID;
+  }
+  o.verbose = 0;
+  o.time_sigma_every = 0;
+  c->batch_n = 0;
+  while ((int)c->subs.size() < nbatch) {
+    sqd_ctx* sub = nullptr;
+    SQD_TRY(sub_ctx_create(c, &sub));
+    c->subs.push_back(sub);
+  }
+  std::vector<sqd_ctx*> subs(c->subs.begin(), c->subs.begin() + nbatch);
+  for (sqd_ctx* sub : subs) {
+    sub->stream = c->stream;
+    sub->want_timing = false;
+  }
+  hipStream_t st = c->stream;
+  // ---- tables of every subspace: 2 copies + 4-5 launches for the whole batch
+  SQD_TRY(build_subspace_batch(c, subs, strs_a, na, strs_b, nb));
+  for (int p = 0; p < nbatch; ++p) {
+    if (nelec_a) nelec_a[p] = subs[p]->nelec[0];
+    if (nelec_b) nelec_b[p] = subs[p]->nelec[1];
+  }
+  // ---- which subspaces the batched launches cover; the others are solved one by one at the end
+  std::vector<int> bidx, sidx;
+  for (int p = 0; p < nbatch; ++p) {
+    if (sigma_batch_supported(subs[p]) && penalty_form(subs[p], o) != 2) bidx.push_back(p);
+    else sidx.push_back(p);
+  }
+  bool need_s2 = (s2 != nullptr);
+  for (int p : bidx) need_s2 = need_s2 || penalty_form(subs[p], o) != 0;
+  if (!bidx.empty()) {
+    std::vector<sqd_ctx*> bs;
+    std::vector<double*> twins;
+    for (int p : bidx) {
+      bs.push_back(subs[p]);
+      const size_t bytes = (size_t)subs[p]->D * 8;
+      double* twin = nullptr;
+      if (amps && amps[p] && bytes <= (size_t(64) << 20)) twin = static_cast<double*>(pinned_device_ptr(amps[p], bytes));
+      twins.push_back(twin);
+    }
+    // ---- the solver's argument records (Davidson, sigma, observables) of every subspace: one copy
+    BatchStage& s3 = c->bstage[2];
+    SQD_TRY(s3.reserve(davidson_batch_bytes(bs.size()) + observables_batch_bytes(bs.size())));
+    size_t off = 0;
+    DavBatchPlan dplan;
+    ObsBatchPlan oplan;
+    char* d3 = static_cast<char*>(s3.dev.p);
+    SQD_TRY(davidson_batch_prepare(c, bs, &o, s3.host, d3, &off, &dplan));
+    SQD_TRY(observables_batch_prepare(c, bs, need_s2, twins, s3.host, d3, &off, &oplan));
+    SQD_HIP_CHECK(hipMemcpyAsync(d3, s3.host, off, hipMemcpyHostToDevice, st));
+    SQD_TRY(davidson_batch_run(c, bs, dplan));
+    SQD_TRY(observables_batch_launch(c, oplan));
+    // states whose buffer the observables kernel could not write itself (pageable memory, or beyond 64 MB)
+    for (size_t k = 0; k < bidx.size(); ++k) {
+      const int p = bidx[k];
+      if (amps && amps[p] && !twins[k])
+        SQD_HIP_CHECK(hipMemcpyAsync(amps[p], subs[p]->sol.p, (size_t)subs[p]->D * 8, hipMemcpyDeviceToHost, st));
+    }
+    for (sqd_ctx* sub : bs) SQD_TRY(spin_wait_word(sub->h_mail + 3 * 128 + 200, sub->obs_seq, st));
+    SQD_TRY(spin_stream_sync(st));
+    for (int p : bidx) {
+      sqd_ctx* sub = subs[p];
+      sub->stage_pending = false;
+      SQD_TRY(solve_collect(sub, o, penalty_form(sub, o), stats ? &stats[p] : nullptr, e ? &e[p] : nullptr,
+                            s2 ? &s2[p] : nullptr, occ_a ? occ_a + (size_t)p * c->norb : nullptr,
+                            occ_b ? occ_b + (size_t)p * c->norb : nullptr));
+    }
+  }
+  for (int p : sidx) {
+    double e_p = 0.0;
+    SQD_TRY(sqd_solve(subs[p], &o, nullptr, amps ? amps[p] : nullptr, stats ? &stats[p] : nullptr, &e_p,
+                      s2 ? &s2[p] : nullptr, occ_a ? occ_a + (size_t)p * c->norb : nullptr,
+                      occ_b ? occ_b + (size_t)p * c->norb : nullptr));
+    if (e) e[p] = e_p;
+  }
+  c->batch_n = nbatch;
+  if (best || best_amps) {
+    int w = 0;
+    for (int p = 1; p < nbatch; ++p)
+      if (e[p] < e[w]) w = p;  // first minimum, as numpy.argmin (reference fermion.py:577)
+    if (best) *best = w;
+    if (best_amps) {
+      const size_t bytes = (size_t)subs[w]->D * 8;
+      if (amps && amps[w]) std::memcpy(best_amps, amps[w], bytes);
+      else {
+        SQD_HIP_CHECK(hipMemcpyAsync(best_amps, subs[w]->sol.p, bytes, hipMemcpyDeviceToHost, st));
+        SQD_TRY(spin_stream_sync(st));
+      }
+    }
+  }
+  return SQD_OK;
+}
+
+SQD_API int sqd_batch_ctx(sqd_ctx* c, int index, sqd_ctx** sub) {
+  CTX_ENTER(c);
+  if (!sub || index < 0 || index >= c->batch_n) {
+    set_error("sqd_batch_ctx: no such batch in the latest sqd_solve_batch");
+    return SQD_ERR_INVALID;
+  }
+  *sub = c->subs[index];
+  return SQD_OK;
+}
+
+SQD_API int sqd_batch_state(sqd_ctx* c, int index, double* amps) {
+  CTX_ENTER(c);
+  if (!amps || index < 0 || index >= c->batch_n) {
+    set_error("sqd_batch_state: no such batch in the latest sqd_solve_batch");
+    return SQD_ERR_INVALID;
+  }
+  sqd_ctx* sub = c->subs[index];
+  if (!sub->have_solution) {
+    set_error("sqd_batch_state: no resident solution");
+    return SQD_ERR_STATE;
+  }
+  SQD_HIP_CHECK(hipMemcpyAsync(amps, sub->sol.p, (size_t)sub->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_TRY(spin_stream_sync(c->stream));
+  return SQD_OK;
 }
 
 SQD_API int sqd_energy(sqd_ctx* c, const double* amps, double* e) {

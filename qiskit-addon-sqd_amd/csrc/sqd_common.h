@@ -55,6 +55,41 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// ---- batched solves (sqd_solve_batch): one host-to-device copy per phase carries the kernel arguments of every
+// subspace, the strings and the descriptor blobs: pinned host arena + its device twin, grow-only
+struct BatchStage {
+  char* host = nullptr;
+  size_t cap = 0;
+  DevBuf dev;
+  int reserve(size_t bytes);  // contents are NOT preserved on growth
+  void release();
+};
+
+// ---- pointers in kernel-argument records.  The batched kernels (sqd_solve_batch) read their arguments from device
+// memory, and a plain pointer LOADED from memory is a generic ("flat") pointer to the compiler: every access through it
+// becomes flat_load / flat_store, which also ties up the LDS counter (measured: the batched sigma kernel 1.5x slower per
+// workgroup than the same body with by-value arguments).  A field declared GPtr<T> is typed as a global-address-space
+// pointer in device code, so loads through it are global_load (s_load when uniform) wherever the record lives; in host
+// code -- and to every reader -- it is a T*.  Same size and layout as T*.
+template <class T>
+struct GPtr {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+  T __attribute__((address_space(1)))* p;
+  __host__ __device__ GPtr& operator=(T* q) {
+    p = (T __attribute__((address_space(1)))*)q;
+    return *this;
+  }
+  __host__ __device__ operator T*() const { return (T*)p; }
+#else
+  T* p;
+  __host__ __device__ GPtr& operator=(T* q) {
+    p = q;
+    return *this;
+  }
+  __host__ __device__ operator T*() const { return p; }
+#endif
+};
+
 // ---- link record encodings ----------------------------------------------------
 // single-excitation record: {src address, meta}
 //   meta bits  0..12 : widx = 2*pair + dir   (pair = tril index of (cre,des); dir = cre > des)
@@ -232,6 +267,13 @@ struct sqd_ctx {
   size_t h_amps_cap = 0;
   bool dav_timed = false;  // the latest Davidson run recorded its start / end events
   int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)
+  // ---- batched solves (sqd_solve_batch).  A parent context owns one sub-context per subspace of the batch: the
+  // per-subspace state (tables, Davidson workspace, state block, mailbox) in the same struct a single solve uses, on
+  // the PARENT's stream and with views of the parent's integral tables.
+  sqd_ctx* parent = nullptr;        // set on a sub-context
+  std::vector<sqd_ctx*> subs;       // grow-only; subs[i] serves batch i of the latest sqd_solve_batch
+  int batch_n = 0;                  // subspaces of the latest sqd_solve_batch (0: none)
+  sqd::BatchStage bstage[3];        // [0] table build phase 1, [1] phase 2, [2] solver (sigma / Davidson / observables)
 };
 
 namespace sqd {
@@ -239,6 +281,8 @@ namespace sqd {
 int build_integral_tables(sqd_ctx* c, const double* h1, const double* eri);
 int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0 = 0,
                    int64_t row1 = -1);
+int build_subspace_batch(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const uint64_t* const* sa,
+                         const int64_t* na, const uint64_t* const* sb, const int64_t* nb);
 // sigma (sqd_sigma.hip).  mode 0: H (+ shift*(S^2-ss) if spin) ; mode 1: pure S^2
 // in_stride / out_stride != 0 (inside a Davidson run): the vector is chosen on the device through
 // sqd_ctx::sigma_index, input d_c + (*index - 1) * in_stride, output d_sigma + (*index - 1) * out_stride
@@ -246,6 +290,26 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
                  int64_t in_stride = 0, int64_t out_stride = 0);
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride = 0,
             int64_t out_stride = 0);
+// batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class
+struct SigmaBatchPlan {
+  struct Launch {
+    int kind;  // 0 work items, 1 element gather, 3 the fixed-order sum of split rows
+    int R;
+    bool spin;
+    unsigned gx, gy;
+    int T, n;
+    size_t shmem;
+    const char* args;  // device array of the class' argument structs
+  };
+  std::vector<Launch> launches;
+};
+bool sigma_batch_supported(const sqd_ctx* c);
+size_t sigma_batch_bytes(size_t nsub);
+// stride_scale != 0: inside a Davidson run (vector chosen on the device, strides = each subspace's D)
+int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const double*>& d_c,
+                     const std::vector<double*>& d_sigma, int mode, bool spin, double ss, double shift,
+                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan);
+int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan);
 // blas-1 (sqd_davidson.hip)
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
 int enqueue_init_guess(sqd_ctx* c, double* d_x);  // pyscf get_init_guess into d_x (no synchronisation)
@@ -254,6 +318,18 @@ int enqueue_init_guess(sqd_ctx* c, double* d_x);  // pyscf get_init_guess into d
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync = false);
 int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st);
+// batched Davidson (sqd_solve_batch): prepare writes the per-subspace argument records (and the sigma plan) into the
+// staging blob at *off_io; run enqueues rounds until every subspace has stopped, then the solutions
+struct DavBatchPlan {
+  const char* args = nullptr;  // device array of DavBatchArgs
+  int n = 0, max_space = 12, max_cycle = 100;
+  unsigned gb = 1;
+  SigmaBatchPlan sigma;
+};
+size_t davidson_batch_bytes(size_t nsub);
+int davidson_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const sqd_davidson_opts* o, char* h,
+                           char* d, size_t* off_io, DavBatchPlan* plan);
+int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const DavBatchPlan& plan);
 // arrival counters shared by the fused ("last workgroup finishes") reductions of a context's stream.  They reset
 // themselves after every use; a Davidson run also zeroes them, so a kernel aborted mid-way cannot poison later ones.
 int reserve_counters(sqd_ctx* c);
@@ -270,5 +346,18 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true,
                             double* host_twin = nullptr);
 int dev_observables_wait(sqd_ctx* c);
+// batched (sqd_solve_batch)
+struct ObsBatchPlan {
+  const char* args = nullptr;  // device array of ObsArgs
+  int n = 0;
+  unsigned gx = 1;
+  bool have_s2_sigma = false;
+  SigmaBatchPlan s2_sigma;
+};
+size_t observables_batch_bytes(size_t nsub);
+int observables_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, bool with_s2,
+                              const std::vector<double*>& host_twin, char* h, char* d, size_t* off_io,
+                              ObsBatchPlan* plan);
+int observables_batch_launch(sqd_ctx* parent, const ObsBatchPlan& plan);
 void dev_observables_collect(sqd_ctx* c, double* out_host);   // after the stream has been synchronised
 }  // namespace sqd

@@ -79,8 +79,8 @@ __global__ void k_dots(int64_t n, const double* __restrict__ X, int64_t stride, 
 struct PenaltyDiag {
   int form;
   double shift, ss, szterm;
-  const uint64_t* sa;
-  const uint64_t* sb;
+  GPtr<const uint64_t> sa;
+  GPtr<const uint64_t> sb;
   int64_t nb;
 };
 __device__ inline double penalty_diag(const PenaltyDiag& p, int64_t i) {
@@ -462,14 +462,16 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
 // a split row's partial rows in slot order (fixed => bitwise reproducible) and stores the finished elements -- the
 // k_sigma_reduce launch that used to sit between k_sigma and here (5 us per iteration) is gone.
 struct SplitRows {
-  const int32_t* rowinfo;  // [2 A] first slot, [2 A + 1] slots (0: the row was written directly)
-  const double* partial;   // [slots][nb]
+  GPtr<const int32_t> rowinfo;  // [2 A] first slot, [2 A + 1] slots (0: the row was written directly)
+  GPtr<const double> partial;  // [slots][nb]
   int64_t nb;
 };
+// (bx, nbx): this workgroup's index in ITS subspace's grid and that grid's size -- the whole launch for the single
+// kernels, one z-slice for the batched ones (sqd_solve_batch)
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
-                           double* __restrict__ partial, int width, unsigned* counter, DavState* st,
-                           const DavParams prm, const SplitRows split) {
+__device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+                                     double* __restrict__ partial, int width, unsigned* counter, DavState* st,
+                                     const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx) {
   __shared__ double red[16 * (MV + 1)];
   __shared__ double tot[MV + 1];
   __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
   double acc[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
     double yv;
     if (split.rowinfo) {
       const int64_t A = i / split.nb, B = i - A * split.nb;
@@ -512,12 +514,12 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
   }
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
   if ((int)threadIdx.x < nvec + 1)
-    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
-  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+    coherent_store(&partial[(int64_t)bx * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
+  if (!arrive_last(counter, bx, nbx)) return;
   double vals[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) vals[v] = 0.0;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+  for (int b = threadIdx.x; b < (int)nbx; b += blockDim.x) {
     double p[MV + 1];
     load_partials<MV + 1, true>(partial, (int64_t)b * width, nvec + 1, p);  // all requests in flight together
 #pragma unroll
@@ -529,13 +531,20 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
   if (threadIdx.x >= 64) return;
   wave_eig_step<MV>(st, tot, prm, sA, sM, sv_eig);
 }
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+                           double* __restrict__ partial, int width, unsigned* counter, DavState* st,
+                           const DavParams prm, const SplitRows split) {
+  dots_eig_body<MV>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
+}
 
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
 // partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]; k_orth_dev (next in the stream) folds them.
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
-                                   const DavState* __restrict__ st, const double* __restrict__ hdiag,
-                                   const PenaltyDiag pd, double* __restrict__ partial, int width) {
+__device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+                                             const DavState* __restrict__ st, const double* __restrict__ hdiag,
+                                             const PenaltyDiag& pd, double* __restrict__ partial, int width, unsigned bx,
+                                             unsigned nbx) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   __shared__ double s_raw[MV];
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* _
   double vals[MV + 2];
 #pragma unroll
   for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
     double r = 0.0;
     double xv[MV];
     const double hd = hdiag[i];
@@ -576,7 +585,13 @@ __global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* _
   }
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   if ((int)threadIdx.x < nvec + 2)
-    partial[(int64_t)blockIdx.x * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+    partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+}
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+                                   const DavState* __restrict__ st, const double* __restrict__ hdiag,
+                                   const PenaltyDiag pd, double* __restrict__ partial, int width) {
+  residual_precond_body<MV>(n, X, AX, stride, st, hdiag, pd, partial, width, blockIdx.x, gridDim.x);
 }
 
 // progress record of one iteration in host-visible memory: {sequence word | it, stop, e, de, |r|^2, m}
@@ -607,9 +622,9 @@ __device__ inline void post_progress(double* mail, long long seq, const DavState
 // When the iteration is a restart (basis full), the same pass collapses the basis: X0 <- Ritz vector,
 // AX0 <- A * Ritz (linear combinations, element by element in place), X1 <- the correction.
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
-                           const DavParams prm, const double* __restrict__ partial, int nblocks, int width,
-                           double* mail, long long seq) {
+__device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
+                                     const DavParams& prm, const double* __restrict__ partial, int nblocks, int width,
+                                     double* mail, long long seq, unsigned bx, unsigned nbx) {
   __shared__ double red[16 * (MV + 2)];
   __shared__ double tot[MV + 2];
   __shared__ double g[MV + 2];
@@ -621,7 +636,7 @@ __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restric
   if (threadIdx.x == 0) s_was_stopped = st->stop;
   __syncthreads();
   if (s_was_stopped) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) post_progress(mail, seq, st, 1, st->rnorm2);
+    if (bx == 0 && threadIdx.x == 0) post_progress(mail, seq, st, 1, st->rnorm2);
     return;
   }
   const int nvec = st->m_cur;
@@ -656,7 +671,7 @@ __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restric
     for (int v = 0; v < nvec; ++v) g[v] *= inv * st->sv[v];
     const int de_small = fabs(st->de) < prm.tol;
     s_stop = ((de_small && rr < prm.tol2) || !(rr > prm.lindep) || !(tt > 0.0)) ? 1 : 0;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       st->rnorm2 = rr;
       if (s_stop) {
         st->conv = (rr < prm.tol2) ? 1 : 0;
@@ -675,7 +690,7 @@ __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restric
   const double scale = s_scale;
   double* __restrict__ t = X + (int64_t)nvec * stride;
   if (!restart) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
       double s = scale * t[i];
       for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
         double x[8];
@@ -689,7 +704,7 @@ __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restric
     return;
   }
   // restart: the same pass also forms the Ritz vector and A * Ritz, in place, element by element
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
     double s = scale * t[i];
     double x0 = 0.0, ax0 = 0.0;
     for (int v0 = 0; v0 < nvec; v0 += 8) {
@@ -714,16 +729,22 @@ __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restric
     X[stride + i] = s;
   }
 }
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
+                           const DavParams prm, const double* __restrict__ partial, int nblocks, int width,
+                           double* mail, long long seq) {
+  orth_dev_body<MV>(n, X, AX, stride, st, prm, partial, nblocks, width, mail, seq, blockIdx.x, gridDim.x);
+}
 
 // the solution: sum_{v < sol_m} sol_coef[v] X_v (unit norm: orthonormal basis, unit Ritz coefficients), and the
 // run's outcome for the host (read after the stream has been synchronised)
-__global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
-                           double* __restrict__ out, double* res) {
+__device__ inline void solution_body(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
+                                     double* __restrict__ out, double* res, unsigned bx, unsigned nbx) {
   __shared__ double s_c[MAXB + 1];
   const int nvec = st->sol_m;
   if ((int)threadIdx.x <= MAXB) s_c[threadIdx.x] = ((int)threadIdx.x < nvec) ? st->sol_coef[threadIdx.x] : 0.0;
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bx == 0 && threadIdx.x == 0) {
     mail_store(&res[0], (double)st->conv);
     mail_store(&res[1], (double)st->it);
     mail_store(&res[2], (double)st->nsig);
@@ -734,7 +755,7 @@ __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stri
     mail_store(&res[7], (double)st->n_rqi);
     mail_store(&res[8], (double)st->n_jacobi);
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
     double s = 0.0;
     for (int v0 = 0; v0 < nvec; v0 += 8) {
       double x[8];
@@ -745,6 +766,53 @@ __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stri
     }
     out[i] = s;
   }
+}
+__global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
+                           double* __restrict__ out, double* res) {
+  solution_body(n, X, stride, st, out, res, blockIdx.x, gridDim.x);
+}
+
+// ---- batched forms (sqd_solve_batch): blockIdx.z = subspace, one argument record per subspace in device memory.
+// Every subspace runs on exactly the grid a single solve would give it (gb workgroups; the launch is sized for the
+// largest), so its reductions fold the same partials in the same order: the same bits.
+struct DavBatchArgs {
+  int64_t n;           // D
+  GPtr<double> X, AX;  // stride = n
+  GPtr<double> partial, part_res;
+  int width;
+  unsigned gb;
+  GPtr<unsigned> counter;
+  GPtr<DavState> st;
+  DavParams prm;
+  SplitRows split;
+  GPtr<const double> hdiag;
+  PenaltyDiag pd;
+  GPtr<double> mail;  // progress records (host-visible)
+  GPtr<double> sol;
+  GPtr<double> res;  // the run's outcome (host-visible)
+};
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_dots_eig_b(const DavBatchArgs* __restrict__ as) {
+  const DavBatchArgs& a = as[blockIdx.z];
+  if (blockIdx.x >= a.gb) return;
+  dots_eig_body<MV>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
+}
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
+  const DavBatchArgs& a = as[blockIdx.z];
+  if (blockIdx.x >= a.gb) return;
+  residual_precond_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.hdiag, a.pd, a.part_res, a.width, blockIdx.x, a.gb);
+}
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_orth_dev_b(const DavBatchArgs* __restrict__ as, long long seq) {
+  const DavBatchArgs& a = as[blockIdx.z];
+  if (blockIdx.x >= a.gb) return;
+  orth_dev_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.prm, a.part_res, (int)a.gb, a.width, a.mail, seq, blockIdx.x, a.gb);
+}
+__global__ void k_solution_b(const DavBatchArgs* __restrict__ as) {
+  const DavBatchArgs& a = as[blockIdx.z];
+  if (blockIdx.x >= a.gb) return;
+  solution_body(a.n, a.X, a.n, a.st, a.sol, a.res, blockIdx.x, a.gb);
 }
 
 // host side of a mailbox post: wait for sequence word `seq` in mailbox slot `slot`
@@ -1015,6 +1083,181 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   if (defer_sync) return SQD_OK;
   SQD_STREAM_SYNC(s);
   return davidson_collect(c, st);
+}
+
+// ---- batched Davidson (sqd_solve_batch): the same four launches per round advance EVERY subspace of the batch.  Each
+// subspace has its own state block, arrival counters, partial arrays and mailbox (its sub-context's), stops itself, and
+// from then on its workgroups return at once; the host keeps rounds coming until every subspace has stopped.
+size_t davidson_batch_bytes(size_t nsub) { return nsub * (sizeof(DavBatchArgs) + 64) + sigma_batch_bytes(nsub) + 256; }
+
+static long long common_seq(const std::vector<sqd_ctx*>& subs) {
+  // one sequence number for the same mailbox word of every subspace: above everything any of them has used
+  int64_t s = 0;
+  for (sqd_ctx* c : subs) s = c->mail_seq > s ? c->mail_seq : s;
+  ++s;
+  for (sqd_ctx* c : subs) c->mail_seq = s;
+  return (long long)s;
+}
+
+int davidson_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const sqd_davidson_opts* o, char* h,
+                           char* d, size_t* off_io, DavBatchPlan* plan) {
+  const int n = (int)subs.size();
+  int max_space = o->max_space;
+  if (max_space < 2) max_space = 2;
+  if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
+  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
+  const int nvecs = max_space + 1;
+  const int width = SQD_MAX_SPACE + 4;
+  plan->max_space = max_space;
+  plan->max_cycle = o->max_cycle;
+  plan->n = n;
+  plan->gb = 1;
+  size_t off = (*off_io + 63) & ~size_t(63);
+  DavBatchArgs* ha = reinterpret_cast<DavBatchArgs*>(h + off);
+  plan->args = d + off;
+  off += (size_t)n * sizeof(DavBatchArgs);
+  std::vector<const double*> xin(n);
+  std::vector<double*> axout(n);
+  int form = o->use_spin;
+  for (int p = 0; p < n; ++p) {
+    sqd_ctx* c = subs[p];
+    const int64_t D = c->D;
+    SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
+    SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
+    SQD_TRY(c->sol.reserve((size_t)D * 8));
+    SQD_TRY(reserve_reduction_buffers(c));
+    double* X = c->X.as<double>();
+    DavState* dst = state_ptr_dev(c);
+    unsigned* counter = counter_ptr(c);
+    const bool guess_ready = (c->guess_x != nullptr && c->guess_x == X);
+    c->guess_x = nullptr;
+    c->dav_nvecs_hint = nvecs;
+    if (!guess_ready) SQD_TRY(enqueue_init_guess_impl(c, X, dst, counter));  // (workspace moved: rare)
+    DavBatchArgs& a = ha[p];
+    a.n = D;
+    a.X = X;
+    a.AX = c->AX.as<double>();
+    a.partial = c->partial.as<double>();
+    a.part_res = c->partial.as<double>() + (size_t)RED_BLOCKS * width;
+    a.width = width;
+    a.gb = red_blocks(D);
+    plan->gb = a.gb > plan->gb ? a.gb : plan->gb;
+    a.counter = counter;
+    a.st = dst;
+    a.prm.tol = o->tol;
+    a.prm.tol2 = toloose * toloose;
+    a.prm.lindep = o->lindep;
+    a.prm.max_space = max_space;
+    {
+      int f = o->use_spin;
+      const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+      if (f == 3) f = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+      if (f == 2) {
+        set_error("the squared spin penalty is not available in a batched solve");
+        return SQD_ERR_STATE;
+      }
+      form = f;
+      const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+      a.pd.form = f;
+      a.pd.shift = o->shift;
+      a.pd.ss = o->ss;
+      a.pd.szterm = sz * (sz + 1.0);
+      a.pd.sa = c->sp[0].strs.as<uint64_t>();
+      a.pd.sb = c->sp[1].strs.as<uint64_t>();
+      a.pd.nb = c->nb;
+    }
+    a.hdiag = c->hdiag.as<double>();
+    a.mail = c->d_mail + MAIL_SLOT;
+    a.sol = c->sol.as<double>();
+    a.res = c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD;
+    a.split = SplitRows{nullptr, nullptr, c->nb};
+    // sigma reads "which vector" and "whether to stop" from the state block; split rows are added by k_dots_eig
+    c->sigma_stop = &dst->stop;
+    c->sigma_index = &dst->m_next;
+    c->sigma_defer_reduce = false;
+    if (c->n_multi > 0 && !c->sig_direct) {
+      c->sigma_defer_reduce = true;
+      a.split.rowinfo = c->rowinfo.as<int32_t>();
+      a.split.partial = c->sig_partial.as<double>();
+    }
+    xin[p] = X;
+    axout[p] = c->AX.as<double>();
+    c->dav_timed = false;
+    c->dav_nev = 0;
+    c->dav_ev_iter.clear();
+    c->have_solution = true;
+  }
+  const int rc = sigma_batch_plan(subs, xin, axout, 0, form == 1, o->ss, o->shift, 1, h, d, &off, &plan->sigma);
+  for (sqd_ctx* c : subs) {
+    c->sigma_stop = nullptr;
+    c->sigma_index = nullptr;
+    c->sigma_defer_reduce = false;
+  }
+  SQD_TRY(rc);
+  *off_io = off;
+  return SQD_OK;
+}
+
+int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const DavBatchPlan& plan) {
+  hipStream_t s = parent->stream;
+  const int n = plan.n;
+  const DavBatchArgs* args = reinterpret_cast<const DavBatchArgs*>(plan.args);
+  const dim3 grid(plan.gb, 1, (unsigned)n);
+  long long seq_of[4] = {0, 0, 0, 0};
+  bool stopped = false;
+  auto settle = [&](int j) -> int {  // round j's progress record of every subspace
+    bool all = true;
+    for (sqd_ctx* c : subs) {
+      SQD_TRY(spin_wait_word(c->h_mail + MAIL_SLOT, seq_of[j & 3], s));
+      if (c->h_mail[MAIL_SLOT + MAIL_PAYLOAD + 1] == 0.0) all = false;
+    }
+    stopped = all;
+    return SQD_OK;
+  };
+  auto part_a = [&]() -> int { return sigma_batch_launch(parent, plan.sigma); };
+  auto part_b = [&](int round) -> int {
+    const long long seq = common_seq(subs);
+    seq_of[round & 3] = seq;
+    if (plan.max_space <= 12) {
+      hipLaunchKernelGGL((k_dots_eig_b<13>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_residual_precond_b<13>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_orth_dev_b<13>), grid, dim3(RED_T), 0, s, args, seq);
+    } else {
+      hipLaunchKernelGGL((k_dots_eig_b<MAXB>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_residual_precond_b<MAXB>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_orth_dev_b<MAXB>), grid, dim3(RED_T), 0, s, args, seq);
+    }
+    SQD_HIP_CHECK(hipGetLastError());
+    return SQD_OK;
+  };
+  {
+    // the single solve's enqueue-ahead policy (run_davidson): the next sigma build always, a whole round from the
+    // fourth round on
+    const int max_rounds = plan.max_cycle, full_from = 3;
+    int n_a = 0, n_b = 0;
+    SQD_TRY(part_a());
+    ++n_a;
+    SQD_TRY(part_b(n_b++));
+    for (int r = 0;;) {
+      if (n_a == r + 1 && n_a < max_rounds) {
+        SQD_TRY(part_a());
+        ++n_a;
+      }
+      if (n_a == r + 2 && n_b == r + 1 && r + 1 >= full_from) SQD_TRY(part_b(n_b++));
+      SQD_TRY(settle(r));
+      if (stopped) break;
+      ++r;
+      if (n_a == r && n_a < max_rounds) {
+        SQD_TRY(part_a());
+        ++n_a;
+      }
+      if (n_b == r && n_b < n_a) SQD_TRY(part_b(n_b++));
+      if (n_b == r) break;  // the cycle limit
+    }
+  }
+  hipLaunchKernelGGL(k_solution_b, grid, dim3(RED_T), 0, s, args);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
 }
 
 // outcome and event timings of the latest run (the stream must have been synchronised since)

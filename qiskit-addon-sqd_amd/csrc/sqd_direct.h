@@ -6,26 +6,27 @@
 namespace sqd {
 
 struct DirectArgs {
-  const double* c;
-  double* sigma;
-  const double* hdiag;
+  GPtr<const double> c;
+  GPtr<double> sigma;
+  GPtr<const double> hdiag;
   int64_t row0, row1, nb;
   int nnorb, mode, spin;
   double ss, shift, szterm;
-  const uint64_t *strs_a, *strs_b;
-  const int64_t *sa_ptr, *da_ptr, *sb_ptr, *db_ptr;
-  const SRec *sa_rec, *sb_rec;
-  const double *sa_val, *sb_val;
-  const uint32_t *da_src, *db_src;
-  const double *da_val, *db_val;
-  const double *ja_row, *jbT, *eri_pp;
-  const int* stop;
-  const int* vec_index;
+  GPtr<const uint64_t> strs_a, strs_b;
+  GPtr<const int64_t> sa_ptr, da_ptr, sb_ptr, db_ptr;
+  GPtr<const SRec> sa_rec, sb_rec;
+  GPtr<const double> sa_val, sb_val;
+  GPtr<const uint32_t> da_src, db_src;
+  GPtr<const double> da_val, db_val;
+  GPtr<const double> ja_row, jbT, eri_pp;
+  GPtr<const int> stop;
+  GPtr<const int> vec_index;
   int64_t c_stride, s_stride;
   // k_sigma_rows only: the beta doubles in per-slice jagged-diagonal order (k_tables_jds) and the LDS row pitch
-  const uint32_t* jd_src;
-  const double* jd_val;
+  GPtr<const uint32_t> jd_src;
+  GPtr<const double> jd_val;
   int64_t nb_pad;
+  unsigned gx;  // workgroups of THIS subspace (batched launches: gridDim.x is the largest of the class)
 };
 
 // element i (relative to row0 * nb) of the operator the arguments describe, applied to C

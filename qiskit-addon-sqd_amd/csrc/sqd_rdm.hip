@@ -269,18 +269,42 @@ int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b) {
 // result straight into host-visible memory: no reduce launches, no copy.
 constexpr int OBS_W = 4 + SQD_MAX_NORB;  // partial record: 4 dot products + one occupancy per orbital
 constexpr int OBS_ROWS = 8;              // alpha strings per row-role workgroup (512 threads)
-__global__ void k_observables(const double* __restrict__ C, const double* __restrict__ T1, const double* __restrict__ T2,
-                              int64_t na, int64_t nb, const uint64_t* __restrict__ strs_a,
-                              const uint64_t* __restrict__ strs_b, int norb, unsigned nrb, double* partial,
-                              unsigned* counter, double* out, double* __restrict__ host_c, long long* seq_word,
-                              long long seq, const int s2_inline, const DirectArgs dg) {
+struct ObsArgs {
+  GPtr<const double> C, T1, T2;
+  int64_t na, nb;
+  GPtr<const uint64_t> strs_a, strs_b;
+  int norb;
+  unsigned nrb, gx;  // row-role workgroups, all workgroups of this subspace
+  GPtr<double> partial;
+  GPtr<unsigned> counter;
+  GPtr<double> out;
+  GPtr<double> host_c;
+  GPtr<long long> seq_word;
+  long long seq;
+  int s2_inline;
+  DirectArgs dg;
+};
+__device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned nbx) {
   __shared__ double red[1024];
   __shared__ double wrow[64];
   __shared__ double dots[OBS_ROWS][4];
+  const double* __restrict__ C = g.C;
+  const double* __restrict__ T1 = g.T1;
+  const double* __restrict__ T2 = g.T2;
+  const int64_t na = g.na, nb = g.nb;
+  const uint64_t* __restrict__ strs_a = g.strs_a;
+  const uint64_t* __restrict__ strs_b = g.strs_b;
+  const int norb = g.norb;
+  const unsigned nrb = g.nrb;
+  double* partial = g.partial;
+  double* out = g.out;
+  double* __restrict__ host_c = g.host_c;
+  const int s2_inline = g.s2_inline;
+  const DirectArgs& dg = g.dg;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double* rec = partial + (int64_t)blockIdx.x * OBS_W;
-  if (blockIdx.x < nrb) {
-    const int64_t A = (int64_t)blockIdx.x * OBS_ROWS + wv;
+  double* rec = partial + (int64_t)bx * OBS_W;
+  if (bx < nrb) {
+    const int64_t A = (int64_t)bx * OBS_ROWS + wv;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (A < na) {
       // eight elements per lane requested per round (a row of the headline problem is five: one round trip instead
@@ -326,14 +350,14 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
       const int p = threadIdx.x - 4;
       double t = 0.0;
       for (int w = 0; w < OBS_ROWS; ++w) {
-        const int64_t Aw = (int64_t)blockIdx.x * OBS_ROWS + w;
+        const int64_t Aw = (int64_t)bx * OBS_ROWS + w;
         if (Aw < na && ((strs_a[Aw] >> p) & 1ull)) t += wrow[w];
       }
       coherent_store(&rec[4 + p], t);
     }
   } else {
     const int col = lane, rl = wv, RL = blockDim.x >> 6;
-    const int64_t B = (int64_t)(blockIdx.x - nrb) * 64 + col;
+    const int64_t B = (int64_t)(bx - nrb) * 64 + col;
     double s = 0.0;
     if (B < nb)
       for (int64_t a0 = rl; a0 < na; a0 += (int64_t)RL * 8) {
@@ -359,13 +383,13 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
       const int p = threadIdx.x - 4;
       double t = 0.0;
       for (int j = 0; j < 64; ++j) {
-        const int64_t Bj = (int64_t)(blockIdx.x - nrb) * 64 + j;
+        const int64_t Bj = (int64_t)(bx - nrb) * 64 + j;
         if (Bj < nb && ((strs_b[Bj] >> p) & 1ull)) t += wrow[j];
       }
       coherent_store(&rec[4 + p], t);
     }
   }
-  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+  if (!arrive_last(g.counter, bx, nbx)) return;
   // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}.  J threads share one result: thread (r, j) adds the
   // partial records b0 + j, b0 + j + J, ... (eight write-through loads in flight per round -- one thread per result
   // walked the records in ~2 us rounds, 10 us for 45 workgroups), the J sub-sums are added in order j = 0..J-1.
@@ -387,7 +411,7 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
     } else if (r < 3 + 2 * norb) {
       field = 4 + (r - 3 - norb);
       b0 = nrb;
-      b1 = gridDim.x;
+      b1 = nbx;
     } else {
       field = 3;
       b0 = 0;
@@ -417,8 +441,15 @@ __global__ void k_observables(const double* __restrict__ C, const double* __rest
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();
-    *reinterpret_cast<volatile long long*>(seq_word) = seq;
+    *static_cast<volatile long long*>(static_cast<long long*>(g.seq_word)) = g.seq;
   }
+}
+__global__ void k_observables(const ObsArgs g) { observables_body(g, blockIdx.x, gridDim.x); }
+// batched (sqd_solve_batch): blockIdx.z = subspace, every subspace on the grid a single solve would give it
+__global__ void k_observables_b(const ObsArgs* __restrict__ gs) {
+  const ObsArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  observables_body(g, blockIdx.x, g.gx);
 }
 
 constexpr int OBS_MAIL = 3 * 128;  // doubles into the host-visible mailbox (slots 0..2 belong to the Davidson)
@@ -441,8 +472,43 @@ void dev_observables_collect(sqd_ctx* c, double* out_host) {
   const int nres = 3 + 2 * c->norb + 1;
   for (int i = 0; i < nres; ++i) out_host[i] = c->h_mail[OBS_MAIL + i];
 }
+// arguments of k_observables for the state d_c of this subspace; t1 / t2: H c and S^2 c already built, or nullptr
+static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const double* t2, bool s2_inline,
+                         double* host_twin, ObsArgs* gp) {
+  ObsArgs& g = *gp;
+  std::memset(&g.dg, 0, sizeof(g.dg));
+  if (s2_inline) {
+    fill_direct_args(c, d_c, nullptr, /*mode=*/1, /*spin=*/false, 0.0, 0.0, 0, 0, &g.dg);
+    g.dg.stop = nullptr;
+    g.dg.vec_index = nullptr;
+  }
+  const unsigned nrb = (unsigned)((c->na + OBS_ROWS - 1) / OBS_ROWS), ncb = (unsigned)((c->nb + 63) / 64);
+  SQD_TRY(c->scratch.reserve((size_t)(nrb + ncb) * OBS_W * 8 + 64));
+  SQD_TRY(reserve_counters(c));
+  c->obs_seq = ++c->mail_seq;
+  g.C = d_c;
+  g.T1 = t1;
+  g.T2 = t2;
+  g.na = c->na;
+  g.nb = c->nb;
+  g.strs_a = c->sp[0].strs.as<uint64_t>();
+  g.strs_b = c->sp[1].strs.as<uint64_t>();
+  g.norb = c->norb;
+  g.nrb = nrb;
+  g.gx = nrb + ncb;
+  g.partial = c->scratch.as<double>();
+  g.counter = counter_ptr(c);
+  g.out = c->d_mail + OBS_MAIL;
+  g.host_c = host_twin;
+  g.seq_word = reinterpret_cast<long long*>(c->d_mail + OBS_SEQ);
+  g.seq = (long long)c->obs_seq;
+  g.s2_inline = s2_inline ? 1 : 0;
+  return SQD_OK;
+}
+static bool obs_s2_inline(const sqd_ctx* c, bool with_s2) {
+  return with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sharded();
+}
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2, double* host_twin) {
-  const int norb = c->norb;
   hipStream_t st = c->stream;
   const int64_t D = c->D;
   const double *t1 = nullptr, *t2 = nullptr;
@@ -451,26 +517,62 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool wit
     SQD_TRY(launch_sigma(c, d_c, c->tmp1.as<double>(), 0, false, 0.0, 0.0));
     t1 = c->tmp1.as<double>();
   }
-  DirectArgs dg;
-  std::memset(&dg, 0, sizeof(dg));
-  const bool s2_inline = with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sharded();
-  if (s2_inline) {
-    fill_direct_args(c, d_c, nullptr, /*mode=*/1, /*spin=*/false, 0.0, 0.0, 0, 0, &dg);
-    dg.stop = nullptr;
-    dg.vec_index = nullptr;
-  } else if (with_s2) {
+  const bool s2_inline = obs_s2_inline(c, with_s2);
+  if (with_s2 && !s2_inline) {
     SQD_TRY(c->tmp2.reserve((size_t)D * 8));
     SQD_TRY(launch_sigma(c, d_c, c->tmp2.as<double>(), 1, false, 0.0, 0.0));
     t2 = c->tmp2.as<double>();
   }
-  const unsigned nrb = (unsigned)((c->na + OBS_ROWS - 1) / OBS_ROWS), ncb = (unsigned)((c->nb + 63) / 64);
-  SQD_TRY(c->scratch.reserve((size_t)(nrb + ncb) * OBS_W * 8 + 64));
-  SQD_TRY(reserve_counters(c));
-  c->obs_seq = ++c->mail_seq;
-  hipLaunchKernelGGL(k_observables, dim3(nrb + ncb), dim3(512), 0, st, d_c, t1, t2, c->na, c->nb,
-                     (const uint64_t*)c->sp[0].strs.as<uint64_t>(), (const uint64_t*)c->sp[1].strs.as<uint64_t>(), norb,
-                     nrb, c->scratch.as<double>(), counter_ptr(c), c->d_mail + OBS_MAIL, host_twin,
-                     reinterpret_cast<long long*>(c->d_mail + OBS_SEQ), (long long)c->obs_seq, s2_inline ? 1 : 0, dg);
+  ObsArgs g;
+  SQD_TRY(fill_obs_args(c, d_c, t1, t2, s2_inline, host_twin, &g));
+  hipLaunchKernelGGL(k_observables, dim3(g.gx), dim3(512), 0, st, g);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
+// ---- batched (sqd_solve_batch): the observables of every subspace's resident solution in one launch; with_s2 and a
+// subspace outside the element-gather class: its S^2 c comes from a batched sigma launch in front (mode 1)
+size_t observables_batch_bytes(size_t nsub) { return nsub * (sizeof(ObsArgs) + 64) + sigma_batch_bytes(nsub) + 256; }
+int observables_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, bool with_s2,
+                              const std::vector<double*>& host_twin, char* h, char* d, size_t* off_io,
+                              ObsBatchPlan* plan) {
+  const int n = (int)subs.size();
+  size_t off = (*off_io + 63) & ~size_t(63);
+  ObsArgs* ha = reinterpret_cast<ObsArgs*>(h + off);
+  plan->args = d + off;
+  plan->n = n;
+  plan->gx = 1;
+  plan->have_s2_sigma = false;
+  off += (size_t)n * sizeof(ObsArgs);
+  std::vector<sqd_ctx*> ssubs;
+  std::vector<const double*> sin;
+  std::vector<double*> sout;
+  for (int p = 0; p < n; ++p) {
+    sqd_ctx* c = subs[p];
+    const double* d_c = c->sol.as<double>();
+    const bool inl = obs_s2_inline(c, with_s2);
+    const double* t2 = nullptr;
+    if (with_s2 && !inl) {
+      SQD_TRY(c->tmp2.reserve((size_t)c->D * 8));
+      t2 = c->tmp2.as<double>();
+      ssubs.push_back(c);
+      sin.push_back(d_c);
+      sout.push_back(c->tmp2.as<double>());
+    }
+    SQD_TRY(fill_obs_args(c, d_c, nullptr, t2, inl, host_twin[p], &ha[p]));
+    plan->gx = ha[p].gx > plan->gx ? ha[p].gx : plan->gx;
+  }
+  if (!ssubs.empty()) {
+    SQD_TRY(sigma_batch_plan(ssubs, sin, sout, 1, false, 0.0, 0.0, 0, h, d, &off, &plan->s2_sigma));
+    plan->have_s2_sigma = true;
+  }
+  *off_io = off;
+  return SQD_OK;
+}
+int observables_batch_launch(sqd_ctx* parent, const ObsBatchPlan& plan) {
+  if (plan.have_s2_sigma) SQD_TRY(sigma_batch_launch(parent, plan.s2_sigma));
+  hipLaunchKernelGGL(k_observables_b, dim3(plan.gx, 1, (unsigned)plan.n), dim3(512), 0, parent->stream,
+                     reinterpret_cast<const ObsArgs*>(plan.args));
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }

@@ -29,10 +29,10 @@
 namespace sqd {
 
 struct SigmaArgs {
-  const double* c;
-  double* sigma;
-  double* partial;
-  const WorkItem* items;
+  GPtr<const double> c;
+  GPtr<double> sigma;
+  GPtr<double> partial;
+  GPtr<const WorkItem> items;
   int64_t na, nb;
   int64_t row0;  // first alpha row of this context's shard: hdiag and sigma are indexed relative to it
   int nnorb, nb_pad, K;
@@ -40,42 +40,46 @@ struct SigmaArgs {
   int type_mask;  // profiling hook (env SQD_SIGMA_TYPES): bit t set = execute work items of type t; default 7
   int spin;
   double ss, shift, szterm;
-  const uint64_t* strs_a;
-  const uint64_t* strs_b;
-  const double* hdiag;
-  const SRec* sa_rec;     // alpha singles (CSR order)
-  const uint32_t* ha_src; // alpha merged same-spin links
-  const double* ha_val;
-  const double* ja_row;
+  GPtr<const uint64_t> strs_a;
+  GPtr<const uint64_t> strs_b;
+  GPtr<const double> hdiag;
+  GPtr<const SRec> sa_rec;  // alpha singles (CSR order)
+  GPtr<const uint32_t> ha_src;  // alpha merged same-spin links
+  GPtr<const double> ha_val;
+  GPtr<const double> ja_row;
   // beta lists as capped sliced ELL over virtual rows (sqd_tables.hip); own[3B..] = {first full row,
   // number of full rows, tail row or -1} of string B
-  const int32_t* vs_cnt;
-  const int32_t* vs_own;
-  const int32_t* vd_cnt;
-  const int32_t* vd_own;
+  GPtr<const int32_t> vs_cnt;
+  GPtr<const int32_t> vs_own;
+  GPtr<const int32_t> vd_cnt;
+  GPtr<const int32_t> vd_own;
   int nv_s, nv_d;
   // column chunks (gridDim.y): chunk k covers columns [k*chunk_cols, ...) and the virtual rows
   // [v*_chunk[k], v*_chunk[k+1]); nvs_max / nvd_max = capacity of the LDS partial-sum arrays: the longest
   // such range, or less -- then the range is walked in passes of that many virtual rows
-  const int32_t* vs_chunk;
-  const int32_t* vd_chunk;
+  GPtr<const int32_t> vs_chunk;
+  GPtr<const int32_t> vd_chunk;
   int64_t chunk_cols;
   int nvs_max, nvd_max;
-  const int64_t* esb_sl;
-  const SRec* esb_rec;
-  const double* esb_val;
-  const int64_t* edb_sl;
-  const uint32_t* edb_src;
-  const double* edb_val;
-  const double* jbT;
-  const double* eri_pp;
+  GPtr<const int64_t> esb_sl;
+  GPtr<const SRec> esb_rec;
+  GPtr<const double> esb_val;
+  GPtr<const int64_t> edb_sl;
+  GPtr<const uint32_t> edb_src;
+  GPtr<const double> edb_val;
+  GPtr<const double> jbT;
+  GPtr<const double> eri_pp;
   // Davidson enqueues whole iterations ahead of the host; when the device finds the solve finished it raises this
   // flag and the launch returns at once (nullptr: unconditional)
-  const int* stop;
+  GPtr<const int> stop;
   // device-controlled Davidson: the vector to work on is chosen on the device.  With vec_index != nullptr the
   // input is c + (*vec_index - 1) * c_stride and the output sigma + (*vec_index - 1) * s_stride.
-  const int* vec_index;
+  GPtr<const int> vec_index;
   int64_t c_stride, s_stride;
+  // launch geometry of THIS subspace: threads that work (a batched launch uses the largest workgroup of its class; the
+  // surplus threads of a smaller subspace idle), work items, column chunks
+  int T;
+  unsigned gx, gy;
 };
 
 // N consecutive same-spin links starting at l0: a += val[l] * C[src[l], B] in link order.  N is a compile-time
@@ -264,17 +268,19 @@ __device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t
 // read in place (global memory / L2), one alpha link per batch; everything else is unchanged.
 // PASS: the beta lists outgrow the LDS partial-sum arrays and continue in extra passes (staged rows of ~10^4
 // strings); a separate instantiation so that the tuned single-pass kernels keep their register budget.
+// (bx, by) = work item and column chunk of this workgroup within ITS subspace; T threads work, the others (a batched
+// launch is sized for the largest workgroup of its class) park on an index no loop reaches -- they still meet every
+// barrier
 template <int R, bool SPIN, bool LDSROW, bool PASS>
-__global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
-  HIP_DYNAMIC_SHARED(double, smem)
-  if (g.stop && *g.stop) return;  // uniform over the launch
-  const int T = blockDim.x, tid = threadIdx.x;
-  const WorkItem it = g.items[blockIdx.x];
+__device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx, unsigned by) {
+  if (g.stop && *g.stop) return;  // uniform over the subspace
+  const int T = g.T, tid = ((int)threadIdx.x < T) ? (int)threadIdx.x : (1 << 30);
+  const WorkItem it = g.items[bx];
   const int64_t A = it.A;
   const int64_t nb = g.nb;
   const int nnorb = g.nnorb;
   // this workgroup's column chunk and the virtual rows owned by its strings
-  const int chunk = blockIdx.y;
+  const int chunk = by;
   const int64_t B0 = (int64_t)chunk * g.chunk_cols;
   const int64_t Bend = (B0 + g.chunk_cols < nb) ? B0 + g.chunk_cols : nb;
   const int vs0 = g.vs_chunk[chunk], vs1 = g.vs_chunk[chunk + 1];
@@ -470,6 +476,20 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
   }
 }
 
+template <int R, bool SPIN, bool LDSROW, bool PASS>
+__global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  sigma_body<R, SPIN, LDSROW, PASS>(g, smem, blockIdx.x, blockIdx.y);
+}
+// batched (sqd_solve_batch): blockIdx.z = subspace of this launch class, arguments in device memory
+template <int R, bool SPIN, bool LDSROW, bool PASS>
+__global__ __launch_bounds__(1024) void k_sigma_b(const SigmaArgs* __restrict__ gs) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  const SigmaArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx || blockIdx.y >= g.gy) return;
+  sigma_body<R, SPIN, LDSROW, PASS>(g, smem, blockIdx.x, blockIdx.y);
+}
+
 // ---- "direct" sigma for ultra-sparse coupling (about one in-set link per string or fewer: uniform-random string
 // sets of up to ~1000 strings per spin, BASELINE's headline configuration).  There is nothing to stage or balance
 // then: one thread per output element gathers its handful of contributions straight from the CSR link lists,
@@ -479,15 +499,25 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 // staging and virtual-row bookkeeping whether or not a row has links (9.7 us for 319 workgroups at 317 x 317);
 // this one is a single pass.  Same fixed summation order on every run (bitwise reproducible).
 template <bool SPIN>
-__global__ void k_sigma_direct(const DirectArgs g) {
+__device__ inline void sigma_direct_body(const DirectArgs& g, unsigned bx, unsigned nbx) {
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ out = g.sigma + vsel * g.s_stride;
   const int64_t n = (g.row1 - g.row0) * g.nb;
   const double pen = (g.mode == 1) ? -1.0 : -g.shift;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x)
     out[i] = direct_element<SPIN>(g, C, i, pen);
+}
+template <bool SPIN>
+__global__ void k_sigma_direct(const DirectArgs g) {
+  sigma_direct_body<SPIN>(g, blockIdx.x, gridDim.x);
+}
+template <bool SPIN>
+__global__ void k_sigma_direct_b(const DirectArgs* __restrict__ gs) {
+  const DirectArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  sigma_direct_body<SPIN>(g, blockIdx.x, g.gx);
 }
 
 // ---- Long rows, short lists (uniform-random string sets from ~10^3 strings per spin up to rows of 19 968 strings).
@@ -505,8 +535,7 @@ __global__ void k_sigma_direct(const DirectArgs g) {
 //  * the alpha lists are wave-uniform (scalar loads) and their source rows are read coalesced, eight in flight.
 // The order of accumulation per element is k_sigma_direct's, so the two kernels agree to the bit.
 template <int R, bool SPIN>
-__global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
-  HIP_DYNAMIC_SHARED(double, srow)
+__device__ inline void sigma_rows_body(const DirectArgs& g, double* srow, unsigned bx) {
   // J slices (of 64 columns) in flight per wavefront, K links per round: a workgroup that fills the CU's LDS runs
   // alone on it, so nothing but its own instruction stream hides the latency of a chain pointers -> records ->
   // operands.  One slice at a time that chain was ~7 round trips per slice and the skeleton alone (no links at all)
@@ -517,7 +546,7 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ out = g.sigma + vsel * g.s_stride;
   const int64_t nb = g.nb, pitch = g.nb_pad;
-  const int64_t A0 = g.row0 + (int64_t)blockIdx.x * R;
+  const int64_t A0 = g.row0 + (int64_t)bx * R;
   const int nr = (int)((g.row1 - A0) < R ? (g.row1 - A0) : R);  // rows of this workgroup (the last one may be short)
   const double pen = (g.mode == 1) ? -1.0 : -g.shift;
   {
@@ -690,18 +719,43 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
   }
 }
 
+template <int R, bool SPIN>
+__global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
+  HIP_DYNAMIC_SHARED(double, srow)
+  sigma_rows_body<R, SPIN>(g, srow, blockIdx.x);
+}
+template <int R, bool SPIN>
+__global__ void __launch_bounds__(1024) k_sigma_rows_b(const DirectArgs* __restrict__ gs) {
+  HIP_DYNAMIC_SHARED(double, srow)
+  const DirectArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  sigma_rows_body<R, SPIN>(g, srow, blockIdx.x);
+}
+
 // sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items.
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
-__global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* __restrict__ partial, int64_t nb,
-                               double* __restrict__ sigma, const int* stop, const int* vec_index, int64_t s_stride,
-                               int64_t row0) {
+struct ReduceArgs {
+  GPtr<const MultiRow> rows;
+  GPtr<const double> partial;
+  int64_t nb;
+  GPtr<double> sigma;
+  GPtr<const int> stop;
+  GPtr<const int> vec_index;
+  int64_t s_stride, row0;
+  unsigned gx, gy;
+};
+__device__ inline void sigma_reduce_body(const ReduceArgs& g, unsigned bx, unsigned by) {
   __shared__ double red[1024];
-  if (stop && *stop) return;
-  if (vec_index) sigma += (int64_t)(*vec_index - 1) * s_stride;
-  const MultiRow mr = rows[blockIdx.x];
+  const MultiRow* __restrict__ rows = g.rows;
+  const double* __restrict__ partial = g.partial;
+  const int64_t nb = g.nb, row0 = g.row0;
+  double* __restrict__ sigma = g.sigma;
+  if (g.stop && *g.stop) return;
+  if (g.vec_index) sigma += (int64_t)(*g.vec_index - 1) * g.s_stride;
+  const MultiRow mr = rows[bx];
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6, SL = blockDim.x >> 6;
-  const int64_t B = (int64_t)blockIdx.y * 64 + col;
+  const int64_t B = (int64_t)by * 64 + col;
   double s = 0.0;
   if (B < nb)
     for (int j = sl; j < mr.nslots; j += SL) s += partial[(int64_t)(mr.slot0 + j) * nb + B];
@@ -711,6 +765,12 @@ __global__ void k_sigma_reduce(const MultiRow* __restrict__ rows, const double* 
     for (int r = 1; r < SL; ++r) s += red[r * 64 + col];
     sigma[((int64_t)mr.A - row0) * nb + B] = s;
   }
+}
+__global__ void k_sigma_reduce(const ReduceArgs g) { sigma_reduce_body(g, blockIdx.x, blockIdx.y); }
+__global__ void k_sigma_reduce_b(const ReduceArgs* __restrict__ gs) {
+  const ReduceArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx || blockIdx.y >= g.gy) return;
+  sigma_reduce_body(g, blockIdx.x, blockIdx.y);
 }
 
 // y = a*x + b*y   (x / y optionally selected on the device like the sigma vectors: stride 0 = not indexed)
@@ -760,6 +820,14 @@ static int launch_sigma_g(sqd_ctx* c, const SigmaArgs& g) {
                                  : launch_sigma_rs<R, false, false, false>(c, g);
 }
 
+// workgroups of the element-gather / whole-rows kernel on this subspace
+static unsigned direct_blocks(const sqd_ctx* c) {
+  if (c->sig_rows > 0) return (unsigned)((c->row1 - c->row0 + c->sig_rows - 1) / c->sig_rows);
+  const int64_t n = (c->row1 - c->row0) * c->nb;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  return (unsigned)blocks;
+}
 void fill_direct_args(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
                       int64_t in_stride, int64_t out_stride, DirectArgs* gp) {
   const SpinTables& a = c->sp[0];
@@ -803,6 +871,7 @@ void fill_direct_args(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, 
   g.jd_src = b.jd_src.as<uint32_t>();
   g.jd_val = b.jd_val.as<double>();
   g.nb_pad = (c->nb + 1) & ~int64_t(1);
+  g.gx = direct_blocks(c);
 }
 
 static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss,
@@ -812,7 +881,7 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
   if (c->sig_rows > 0) {
     const int R = c->sig_rows;
     const size_t shmem = (size_t)R * g.nb_pad * 8;
-    const unsigned blocks_r = (unsigned)((c->row1 - c->row0 + R - 1) / R);
+    const unsigned blocks_r = g.gx;
     static const int T = [] {  // tuning hook
       const char* env = std::getenv("SQD_ROWS_T");
       const int v = env ? std::atoi(env) : 1024;
@@ -848,13 +917,10 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
     }
     return SQD_OK;
   }
-  const int64_t n = (c->row1 - c->row0) * c->nb;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
   if (mode == 1 || spin)
-    hipLaunchKernelGGL((k_sigma_direct<true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, g);
+    hipLaunchKernelGGL((k_sigma_direct<true>), dim3(g.gx), dim3(256), 0, c->stream, g);
   else
-    hipLaunchKernelGGL((k_sigma_direct<false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, g);
+    hipLaunchKernelGGL((k_sigma_direct<false>), dim3(g.gx), dim3(256), 0, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   if (c->ev_after_sigma_kernel) {
     SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
@@ -863,14 +929,10 @@ static int launch_sigma_direct(sqd_ctx* c, const double* d_c, double* d_sigma, i
   return SQD_OK;
 }
 
-int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
-                 int64_t in_stride, int64_t out_stride) {
-  if (!c->have_subspace) {
-    set_error("no subspace set");
-    return SQD_ERR_STATE;
-  }
-  if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
-  SigmaArgs g;
+// arguments of the work-item kernel on this subspace
+static void fill_sigma_args(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                            int64_t in_stride, int64_t out_stride, SigmaArgs* gp) {
+  SigmaArgs& g = *gp;
   const SpinTables& a = c->sp[0];
   const SpinTables& b = c->sp[1];
   g.c = d_c;
@@ -926,7 +988,37 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   g.vec_index = indexed ? c->sigma_index : nullptr;
   g.c_stride = in_stride;
   g.s_stride = out_stride;
+  g.T = c->sig_T;
+  g.gx = (unsigned)c->n_items;
+  g.gy = (unsigned)c->sig_nchunks;
+}
+// does a work-item sigma build of this subspace need the k_sigma_reduce launch behind it?  (Inside a Davidson run the
+// first reader of the new vector adds the partial rows instead.)
+static bool sigma_needs_reduce(const sqd_ctx* c, int mode, bool indexed) {
+  return c->n_multi > 0 && !(c->sigma_defer_reduce && indexed && mode == 0);
+}
+static void fill_reduce_args(sqd_ctx* c, double* d_sigma, const SigmaArgs& g, ReduceArgs* r) {
+  r->rows = c->multi.as<MultiRow>();
+  r->partial = c->sig_partial.as<double>();
+  r->nb = c->nb;
+  r->sigma = d_sigma;
+  r->stop = g.stop;
+  r->vec_index = g.vec_index;
+  r->s_stride = g.s_stride;
+  r->row0 = c->row0;
+  r->gx = (unsigned)c->n_multi;
+  r->gy = (unsigned)((c->nb + 63) / 64);
+}
 
+int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                 int64_t in_stride, int64_t out_stride) {
+  if (!c->have_subspace) {
+    set_error("no subspace set");
+    return SQD_ERR_STATE;
+  }
+  if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
+  SigmaArgs g;
+  fill_sigma_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);
   const int R = c->sig_R;
   int rc;
   if (!c->sig_lds_rows) rc = (R <= 1) ? launch_sigma_g<1>(c, g) : launch_sigma_g<4>(c, g);
@@ -936,10 +1028,174 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   else if (R <= 8) rc = launch_sigma_r<8>(c, g);
   else rc = launch_sigma_r<16>(c, g);
   if (rc != SQD_OK) return rc;
-  if (c->n_multi > 0 && !(c->sigma_defer_reduce && indexed && mode == 0)) {
-    hipLaunchKernelGGL(k_sigma_reduce, dim3((unsigned)c->n_multi, (unsigned)((c->nb + 63) / 64)), dim3(512), 0, c->stream,
-                       (const MultiRow*)c->multi.as<MultiRow>(), (const double*)c->sig_partial.as<double>(), c->nb,
-                       d_sigma, g.stop, g.vec_index, out_stride, c->row0);
+  if (sigma_needs_reduce(c, mode, g.vec_index != nullptr)) {
+    ReduceArgs r;
+    fill_reduce_args(c, d_sigma, g, &r);
+    hipLaunchKernelGGL(k_sigma_reduce, dim3(r.gx, r.gy), dim3(512), 0, c->stream, r);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  return SQD_OK;
+}
+
+// ---- batched sigma (sqd_solve_batch).  One operator (mode, spin, ss, shift) applied to one vector of EVERY subspace
+// of a batch: the subspaces are grouped by launch class -- kernel instantiation -- and each class goes out as ONE
+// launch, blockIdx.z = subspace, sized for the class' largest grid / workgroup / LDS plan.  The arguments never
+// change during a Davidson run (the vector is chosen on the device through the state block), so they are written
+// once into the batch's staging blob.  Supported classes: the element-gather kernel and the work-item kernel with
+// LDS-staged rows in one pass -- every subspace up to a few thousand strings per spin; sigma_batch_supported()
+// says so, and callers solve anything else one by one.
+bool sigma_batch_supported(const sqd_ctx* c) {
+  if (c->sharded()) return false;
+  if (c->sig_rows > 0) return false;
+  if (c->sig_direct) return true;
+  return c->sig_lds_rows && !(c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max) && c->sig_R <= 16;
+}
+static int work_item_R(const sqd_ctx* c) {
+  const int R = c->sig_R;
+  return R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : R <= 8 ? 8 : 16;
+}
+size_t sigma_batch_bytes(size_t nsub) {
+  return nsub * (sizeof(SigmaArgs) + sizeof(DirectArgs) + sizeof(ReduceArgs) + 3 * 64) + 256;
+}
+int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const double*>& d_c,
+                     const std::vector<double*>& d_sigma, int mode, bool spin, double ss, double shift,
+                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan) {
+  plan->launches.clear();
+  const bool sp = (mode == 1 || spin);
+  size_t off = *off_io;
+  auto take = [&](size_t bytes) {
+    off = (off + 63) & ~size_t(63);
+    const size_t at = off;
+    off += bytes;
+    return at;
+  };
+  const int n = (int)subs.size();
+  // class 1: element gather
+  {
+    std::vector<int> idx;
+    for (int p = 0; p < n; ++p)
+      if (subs[p]->sig_direct && subs[p]->sig_rows == 0) idx.push_back(p);
+    if (!idx.empty()) {
+      const size_t at = take(idx.size() * sizeof(DirectArgs));
+      SigmaBatchPlan::Launch L;
+      L.kind = 1;
+      L.R = 0;
+      L.spin = sp;
+      L.T = 256;
+      L.shmem = 0;
+      L.gx = L.gy = 1;
+      L.n = (int)idx.size();
+      L.args = d + at;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        sqd_ctx* c = subs[idx[k]];
+        DirectArgs g;
+        const int64_t st = stride_scale ? c->D : 0;
+        fill_direct_args(c, d_c[idx[k]], d_sigma[idx[k]], mode, spin, ss, shift, st, st, &g);
+        reinterpret_cast<DirectArgs*>(h + at)[k] = g;
+        L.gx = g.gx > L.gx ? g.gx : L.gx;
+      }
+      plan->launches.push_back(L);
+    }
+  }
+  // classes 0: work items, one per template R
+  for (int R : {1, 2, 4, 8, 16}) {
+    std::vector<int> idx;
+    for (int p = 0; p < n; ++p)
+      if (!subs[p]->sig_direct && work_item_R(subs[p]) == R) idx.push_back(p);
+    if (idx.empty()) continue;
+    const size_t at = take(idx.size() * sizeof(SigmaArgs));
+    SigmaBatchPlan::Launch L;
+    L.kind = 0;
+    L.R = R;
+    L.spin = sp;
+    L.T = 64;
+    L.shmem = 0;
+    L.gx = L.gy = 1;
+    L.n = (int)idx.size();
+    L.args = d + at;
+    std::vector<ReduceArgs> red;
+    for (size_t k = 0; k < idx.size(); ++k) {
+      sqd_ctx* c = subs[idx[k]];
+      if (!sigma_batch_supported(c)) {
+        set_error("sigma_batch_plan: subspace outside the batched launch classes");
+        return SQD_ERR_STATE;
+      }
+      SigmaArgs g;
+      const int64_t st = stride_scale ? c->D : 0;
+      fill_sigma_args(c, d_c[idx[k]], d_sigma[idx[k]], mode, spin, ss, shift, st, st, &g);
+      reinterpret_cast<SigmaArgs*>(h + at)[k] = g;
+      L.gx = g.gx > L.gx ? g.gx : L.gx;
+      L.gy = g.gy > L.gy ? g.gy : L.gy;
+      L.T = g.T > L.T ? g.T : L.T;
+      L.shmem = c->sig_shmem > L.shmem ? c->sig_shmem : L.shmem;
+      if (sigma_needs_reduce(c, mode, g.vec_index != nullptr)) {
+        ReduceArgs r;
+        fill_reduce_args(c, d_sigma[idx[k]], g, &r);
+        red.push_back(r);
+      }
+    }
+    plan->launches.push_back(L);
+    if (!red.empty()) {
+      const size_t ar = take(red.size() * sizeof(ReduceArgs));
+      SigmaBatchPlan::Launch Lr;
+      Lr.kind = 3;
+      Lr.R = 0;
+      Lr.spin = false;
+      Lr.T = 512;
+      Lr.shmem = 0;
+      Lr.gx = Lr.gy = 1;
+      Lr.n = (int)red.size();
+      Lr.args = d + ar;
+      for (size_t k = 0; k < red.size(); ++k) {
+        reinterpret_cast<ReduceArgs*>(h + ar)[k] = red[k];
+        Lr.gx = red[k].gx > Lr.gx ? red[k].gx : Lr.gx;
+        Lr.gy = red[k].gy > Lr.gy ? red[k].gy : Lr.gy;
+      }
+      plan->launches.push_back(Lr);
+    }
+  }
+  *off_io = off;
+  return SQD_OK;
+}
+
+template <int R, bool SPIN>
+static int launch_sigma_b(sqd_ctx* c, const SigmaBatchPlan::Launch& L) {
+  if (L.shmem > 64 * 1024) {
+    static std::atomic<size_t> granted[64];
+    const int dev = c->device & 63;
+    if (L.shmem > granted[dev].load(std::memory_order_relaxed)) {
+      SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sigma_b<R, SPIN, true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.shmem));
+      granted[dev].store(L.shmem, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL((k_sigma_b<R, SPIN, true, false>), dim3(L.gx, L.gy, (unsigned)L.n), dim3(L.T), L.shmem, c->stream,
+                     reinterpret_cast<const SigmaArgs*>(L.args));
+  return SQD_OK;
+}
+int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan) {
+  for (const SigmaBatchPlan::Launch& L : plan.launches) {
+    if (L.kind == 1) {
+      if (L.spin)
+        hipLaunchKernelGGL((k_sigma_direct_b<true>), dim3(L.gx, 1, (unsigned)L.n), dim3(256), 0, parent->stream,
+                           reinterpret_cast<const DirectArgs*>(L.args));
+      else
+        hipLaunchKernelGGL((k_sigma_direct_b<false>), dim3(L.gx, 1, (unsigned)L.n), dim3(256), 0, parent->stream,
+                           reinterpret_cast<const DirectArgs*>(L.args));
+    } else if (L.kind == 3) {
+      hipLaunchKernelGGL(k_sigma_reduce_b, dim3(L.gx, L.gy, (unsigned)L.n), dim3(512), 0, parent->stream,
+                         reinterpret_cast<const ReduceArgs*>(L.args));
+    } else {
+      int rc = SQD_OK;
+      switch (L.R) {
+        case 1: rc = L.spin ? launch_sigma_b<1, true>(parent, L) : launch_sigma_b<1, false>(parent, L); break;
+        case 2: rc = L.spin ? launch_sigma_b<2, true>(parent, L) : launch_sigma_b<2, false>(parent, L); break;
+        case 4: rc = L.spin ? launch_sigma_b<4, true>(parent, L) : launch_sigma_b<4, false>(parent, L); break;
+        case 8: rc = L.spin ? launch_sigma_b<8, true>(parent, L) : launch_sigma_b<8, false>(parent, L); break;
+        default: rc = L.spin ? launch_sigma_b<16, true>(parent, L) : launch_sigma_b<16, false>(parent, L); break;
+      }
+      if (rc != SQD_OK) return rc;
+    }
     SQD_HIP_CHECK(hipGetLastError());
   }
   return SQD_OK;

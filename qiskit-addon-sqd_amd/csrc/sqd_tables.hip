@@ -137,11 +137,11 @@ __global__ void k_pack_eri(const double* __restrict__ eri4, int norb, int nnorb,
 // e_str[I] = sum_{i in I} h_ii + 1/2 sum_{i,j in I} (J_ij - K_ij)
 __device__ inline void string_energy_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ h1,
                                           const double* __restrict__ jm, const double* __restrict__ km, int norb,
-                                          double* __restrict__ e_str) {
+                                          double* __restrict__ e_str, unsigned bx) {
   // one wavefront per string: lane l takes the orbital pairs (i, j) = (l / nocc, l % nocc), l += 64;
   // the shuffle tree adds them in fixed order
   const int lane = threadIdx.x & 63;
-  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t I = (int64_t)bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= n) return;
   const uint64_t s = strs[I];
   const int nocc = __popcll(s);
@@ -163,8 +163,8 @@ __device__ inline void string_energy_body(const uint64_t* __restrict__ strs, int
 
 // J[I][pair] = sum_{k in I} (pair|kk).  transposed == 0: out[I*nnorb + pair]; else out[pair*n + I]
 __device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n, const double* __restrict__ jdiag,
-                                   int nnorb, int norb, int transposed, double* __restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                   int nnorb, int norb, int transposed, double* __restrict__ out, unsigned bx) {
+  const int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x;
   if (idx >= n * nnorb) return;
   int64_t I, pair;
   if (transposed) {
@@ -196,15 +196,15 @@ __device__ inline void jtable_body(const uint64_t* __restrict__ strs, int64_t n,
 //                       integral value) by the lane that found it
 //   D  k_tables_ell   : merged same-spin CSR (alpha) + the capped sliced-ELL copies (beta)
 struct SpinLinkArgs {
-  const uint64_t* strs;
+  GPtr<const uint64_t> strs;
   int64_t n, n_s, n_d;
-  int64_t *cnt_s, *cnt_d;        // pass 1
-  int64_t *s_ptr, *d_ptr;        // pass 2
-  SRec* s_rec;
-  uint32_t *s_row, *d_src, *d_row, *d_orb;
-  double *s_val, *d_val;
-  double* e_str;
-  double* jtab;                  // jrow (alpha: [I][pair]) or jT (beta: [pair][I])
+  GPtr<int64_t> cnt_s, cnt_d;  // pass 1
+  GPtr<int64_t> s_ptr, d_ptr;  // pass 2
+  GPtr<SRec> s_rec;
+  GPtr<uint32_t> s_row, d_src, d_row, d_orb;
+  GPtr<double> s_val, d_val;
+  GPtr<double> e_str;
+  GPtr<double> jtab;  // jrow (alpha: [I][pair]) or jT (beta: [pair][I])
   int transposed;
 };
 struct SpinLinkArgs2 {
@@ -216,13 +216,13 @@ struct SpinLinkArgs2 {
 // written twice: to the device array the later kernels read and to its host-visible twin, so that the host -- which
 // cuts the sigma work list and the ELL descriptors from them -- needs no copy command and no event.
 struct ScanJobs {
-  const int64_t* in[4];
-  int64_t* out[4];
+  GPtr<const int64_t> in[4];
+  GPtr<int64_t> out[4];
   int64_t n[4];
-  const int64_t* dev_block;  // the four pointer arrays, contiguous
-  int64_t* host_block;       // ... and their host-visible twin
+  GPtr<const int64_t> dev_block;  // the four pointer arrays, contiguous
+  GPtr<int64_t> host_block;  // ... and their host-visible twin
   int64_t nptr;
-  long long* seq_word;       // host-visible: written last
+  GPtr<long long> seq_word;  // host-visible: written last
   long long seq;
 };
 __device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restrict__ out, int64_t n) {
@@ -261,19 +261,29 @@ __device__ inline void wave_exclusive_scan(const int64_t* in, int64_t* __restric
   if (lane == 0) coherent_store_i64(&out[n], total);
 }
 
-// A: blockIdx.y = spin (link counts) | 2 + spin (string energies)
-__global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ jm,
-                               const double* __restrict__ km, int norb, const ScanJobs jobs, unsigned* counter) {
-  if (blockIdx.y >= 2) {
-    const SpinLinkArgs& a = p.a[blockIdx.y & 1];
-    string_energy_body(a.strs, a.n, h1, jm, km, norb, a.e_str);
+// A: by = spin (link counts) | 2 + spin (string energies).  (bx, by) = this workgroup's place in ITS problem's grid of
+// (nbx, 4) workgroups: the whole launch for k_tables_count, one z-slice of it for the batched k_tables_count_b.
+struct CountArgs {
+  SpinLinkArgs2 p;
+  GPtr<const double> h1, jm, km;
+  int norb;
+  ScanJobs jobs;
+  GPtr<unsigned> counter;
+  unsigned gx;  // workgroups along x of this problem (batched launches: gridDim.x is the largest of them)
+};
+__device__ inline void tables_count_body(const CountArgs& g, unsigned bx, unsigned by, unsigned nbx) {
+  const SpinLinkArgs2& p = g.p;
+  const ScanJobs& jobs = g.jobs;
+  if (by >= 2) {
+    const SpinLinkArgs& a = p.a[by & 1];
+    string_energy_body(a.strs, a.n, g.h1, g.jm, g.km, g.norb, a.e_str, bx);
     return;
   }
   {
-    const SpinLinkArgs& a = p.a[blockIdx.y];
+    const SpinLinkArgs& a = p.a[by];
     // one wavefront per target string I.  pc = popcount(I ^ J): 2 -> single, 4 -> double.
     const int lane = threadIdx.x & 63;
-    const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t I = (int64_t)bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (I < a.n) {
       const uint64_t sI = a.strs[I];
       int64_t cs = 0, cd = 0;
@@ -290,7 +300,7 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
       }
     }
   }
-  if (!arrive_last(counter, blockIdx.y * gridDim.x + blockIdx.x, 2 * gridDim.x)) return;
+  if (!arrive_last(g.counter, by * nbx + bx, 2 * nbx)) return;
   {
     const int j = threadIdx.x >> 6;  // blockDim.x == 256: one wavefront per scan
     wave_exclusive_scan(jobs.in[j], jobs.out[j], jobs.n[j]);
@@ -307,23 +317,41 @@ __global__ void k_tables_count(const SpinLinkArgs2 p, const double* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence_system();
-    *reinterpret_cast<volatile long long*>(jobs.seq_word) = jobs.seq;
+    *static_cast<volatile long long*>(static_cast<long long*>(jobs.seq_word)) = jobs.seq;
   }
 }
+__global__ void k_tables_count(const CountArgs g) { tables_count_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
+// batched: blockIdx.z = problem; the arguments of every problem live in device memory (uniform address: scalar loads)
+__global__ void k_tables_count_b(const CountArgs* __restrict__ gs) {
+  const CountArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  tables_count_body(g, blockIdx.x, blockIdx.y, g.gx);
+}
 
-// B: blockIdx.y = 0 alpha J table | 1 beta J table (transposed) | 2 the diagonal, one alpha string per workgroup:
+// B: by = 0 alpha J table | 1 beta J table (transposed) | 2 the diagonal, one alpha string per workgroup:
 //   hdiag[A,B] = e_a[A] + e_b[B] + sum_{k in B} v_A[k],  v_A[k] = sum_{i in A} (ii|kk)   (pyscf make_hdiag)
 // and the row's lowest element (over B <= A when tril_only: pyscf's init-guess rule for equal spin sectors)
-__global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ jm, const double* __restrict__ jdiag,
-                              int norb, int nnorb, int64_t row0, int64_t row1, int64_t nb, int tril_only,
-                              double* __restrict__ hdiag, double* __restrict__ pmin, int64_t* __restrict__ pidx) {
+struct DiagArgs {
+  SpinLinkArgs2 p;
+  GPtr<const double> jm, jdiag;
+  int norb, nnorb;
+  int64_t row0, row1, nb;
+  int tril_only;
+  GPtr<double> hdiag, pmin;
+  GPtr<int64_t> pidx;
+  unsigned gx;
+};
+__device__ inline void tables_diag_body(const DiagArgs& g, unsigned bx, unsigned by, unsigned nbx) {
   __shared__ double v[SQD_MAX_NORB];
-  if (blockIdx.y < 2) {
-    const SpinLinkArgs& a = p.a[blockIdx.y];
-    jtable_body(a.strs, a.n, jdiag, nnorb, norb, a.transposed, a.jtab);
+  const SpinLinkArgs2& p = g.p;
+  const int norb = g.norb;
+  const int64_t row0 = g.row0, nb = g.nb;
+  if (by < 2) {
+    const SpinLinkArgs& a = p.a[by];
+    jtable_body(a.strs, a.n, g.jdiag, g.nnorb, norb, a.transposed, a.jtab, bx);
     return;
   }
-  for (int64_t A = row0 + blockIdx.x; A < row1; A += gridDim.x) {
+  for (int64_t A = row0 + bx; A < g.row1; A += nbx) {
     const uint64_t sA = p.a[0].strs[A];
     __syncthreads();
     if ((int)threadIdx.x < norb) {
@@ -332,7 +360,7 @@ __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ 
       while (occ) {
         const int i = ctz64(occ);
         occ &= occ - 1;
-        t += jm[i * norb + threadIdx.x];
+        t += g.jm[i * norb + threadIdx.x];
       }
       v[threadIdx.x] = t;
     }
@@ -348,18 +376,24 @@ __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ 
         occ &= occ - 1;
         t += v[k];
       }
-      hdiag[(A - row0) * nb + B] = t;
-      if (!(tril_only && A < B) && (t < best || bi < 0)) {  // B ascends: the first minimum wins
+      g.hdiag[(A - row0) * nb + B] = t;
+      if (!(g.tril_only && A < B) && (t < best || bi < 0)) {  // B ascends: the first minimum wins
         best = t;
         bi = (A - row0) * nb + B;
       }
     }
     block_argmin(best, bi);
     if (threadIdx.x == 0) {
-      pmin[A - row0] = best;
-      pidx[A - row0] = bi;
+      g.pmin[A - row0] = best;
+      g.pidx[A - row0] = bi;
     }
   }
+}
+__global__ void k_tables_diag(const DiagArgs g) { tables_diag_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ void k_tables_diag_b(const DiagArgs* __restrict__ gs) {
+  const DiagArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  tables_diag_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
 
 // C: one wavefront per target string (blockIdx.y = spin): enumerate, compact with ballot + prefix popcount, and let
@@ -368,31 +402,44 @@ __global__ void k_tables_diag(const SpinLinkArgs2 p, const double* __restrict__ 
 // pyscf's start vector from the row minima k_tables_diag left -- the k_init_guess launch of the solver, folded in
 // here because this is the last launch of the table build that every string set with any link goes through.
 struct GuessJob {
-  double* x;  // X[0] of the Davidson workspace (nullptr: no job)
-  const double* pmin;
-  const int64_t* pidx;
+  GPtr<double> x;  // X[0] of the Davidson workspace (nullptr: no job)
+  GPtr<const double> pmin;
+  GPtr<const int64_t> pidx;
   int nrows;
   int64_t n;  // D
-  DavState* st;
-  unsigned* counter;
+  GPtr<DavState> st;
+  GPtr<unsigned> counter;
 };
 __device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __restrict__ h1,
-                                        const double* __restrict__ eri4, int norb);
-__global__ void k_tables_fill(const SpinLinkArgs2 p, const double* __restrict__ h1, const double* __restrict__ eri4,
-                              int norb, const GuessJob job) {
-  tables_fill_wave(p.a[blockIdx.y], h1, eri4, norb);
+                                        const double* __restrict__ eri4, int norb, unsigned bx);
+struct FillArgs {
+  SpinLinkArgs2 p;
+  GPtr<const double> h1, eri4;
+  int norb;
+  GuessJob job;
+  unsigned gx;
+};
+__device__ inline void tables_fill_body(const FillArgs& g, unsigned bx, unsigned by, unsigned nbx) {
+  tables_fill_wave(g.p.a[by], g.h1, g.eri4, g.norb, bx);
+  const GuessJob& job = g.job;
   if (!job.x) return;
-  if (blockIdx.x == 0 && blockIdx.y == 0) dav_state_init(job.st, job.counter);
-  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (bx == 0 && by == 0) dav_state_init(job.st, job.counter);
+  const int64_t blk = (int64_t)by * nbx + bx;
   init_guess_write(job.n, job.pmin, job.pidx, job.nrows, job.x, blk * blockDim.x + threadIdx.x,
-                   (int64_t)gridDim.x * gridDim.y * blockDim.x);
+                   (int64_t)nbx * 2 * blockDim.x);
+}
+__global__ void k_tables_fill(const FillArgs g) { tables_fill_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ void k_tables_fill_b(const FillArgs* __restrict__ gs) {
+  const FillArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  tables_fill_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
 __device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __restrict__ h1,
-                                        const double* __restrict__ eri4, int norb) {
+                                        const double* __restrict__ eri4, int norb, unsigned bx) {
   const uint64_t* __restrict__ strs = a.strs;
   const int64_t n = a.n;
   const int lane = threadIdx.x & 63;
-  const int64_t I = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t I = (int64_t)bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= n) return;
   const uint64_t sI = strs[I];
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -463,11 +510,20 @@ __device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __r
 // The double links of 64 consecutive strings (a slice) re-ordered for k_sigma_rows: step k of every list first, lists
 // shorter than k skipped -- the slice keeps its CSR range [d_ptr[64 s], d_ptr[64 s + 64]) and needs no index of its
 // own: a reader rebuilds positions from ballots exactly as this writer does.  One wavefront per slice.
-__global__ void k_tables_jds(int64_t n, const int64_t* __restrict__ d_ptr, const uint32_t* __restrict__ d_src,
-                             const double* __restrict__ d_val, uint32_t* __restrict__ jd_src,
-                             double* __restrict__ jd_val) {
+struct JdsArgs {
+  int64_t n;
+  GPtr<const int64_t> d_ptr;
+  GPtr<const uint32_t> d_src;
+  GPtr<const double> d_val;
+  GPtr<uint32_t> jd_src;
+  GPtr<double> jd_val;
+  unsigned gx;
+};
+__device__ inline void tables_jds_body(int64_t n, const int64_t* __restrict__ d_ptr, const uint32_t* __restrict__ d_src,
+                                       const double* __restrict__ d_val, uint32_t* __restrict__ jd_src,
+                                       double* __restrict__ jd_val, unsigned bx) {
   const int lane = threadIdx.x & 63;
-  const int64_t B0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+  const int64_t B0 = ((int64_t)bx * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
   if (B0 >= n) return;
   const int64_t B = B0 + lane;
   const int64_t d0 = (B < n) ? d_ptr[B] : 0;
@@ -485,6 +541,14 @@ __global__ void k_tables_jds(int64_t n, const int64_t* __restrict__ d_ptr, const
     base += __popcll(m);
   }
 }
+__global__ void k_tables_jds(const JdsArgs g) {
+  tables_jds_body(g.n, g.d_ptr, g.d_src, g.d_val, g.jd_src, g.jd_val, blockIdx.x);
+}
+__global__ void k_tables_jds_b(const JdsArgs* __restrict__ gs) {
+  const JdsArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  tables_jds_body(g.n, g.d_ptr, g.d_src, g.d_val, g.jd_src, g.jd_val, blockIdx.x);
+}
 
 // ------------------------------------------------------------------ capped sliced ELL (column role)
 // Lanes of the sigma kernel would map to beta strings, so one string with hundreds of links (the
@@ -499,32 +563,33 @@ __global__ void k_tables_jds(int64_t n, const int64_t* __restrict__ d_ptr, const
 struct EllArgs {
   // merged same-spin CSR of the row role (alpha): row i = its single links (value incl. sign) then its double links
   int64_t n_a;
-  const int64_t *sa_ptr, *da_ptr;
-  const SRec* sa_rec;
-  const double* sa_val;
-  const uint32_t* da_src;
-  const double* da_val;
-  int64_t* hs_ptr;
-  uint32_t* hs_src;
-  double* hs_val;
+  GPtr<const int64_t> sa_ptr, da_ptr;
+  GPtr<const SRec> sa_rec;
+  GPtr<const double> sa_val;
+  GPtr<const uint32_t> da_src;
+  GPtr<const double> da_val;
+  GPtr<int64_t> hs_ptr;
+  GPtr<uint32_t> hs_src;
+  GPtr<double> hs_val;
   // capped sliced-ELL copies of the column role (beta)
   int64_t nv_s, nv_d;
-  const int32_t *vs_cnt, *vd_cnt;
-  const int64_t *vs_start, *vd_start, *es_sl, *ed_sl;
-  const SRec* sb_rec;
-  const double* sb_val;
-  const uint32_t* db_src;
-  const double* db_val;
-  SRec* es_rec;
-  double* es_val;
-  uint32_t* ed_src;
-  double* ed_val;
+  GPtr<const int32_t> vs_cnt, vd_cnt;
+  GPtr<const int64_t> vs_start, vd_start, es_sl, ed_sl;
+  GPtr<const SRec> sb_rec;
+  GPtr<const double> sb_val;
+  GPtr<const uint32_t> db_src;
+  GPtr<const double> db_val;
+  GPtr<SRec> es_rec;
+  GPtr<double> es_val;
+  GPtr<uint32_t> ed_src;
+  GPtr<double> ed_val;
+  unsigned gx;
 };
 // D: blockIdx.y = 0 merged alpha CSR (one wavefront per row: rows of the Hartree-Fock neighbourhood hold hundreds
 // of links) | 1 beta singles' ELL (thread per virtual row) | 2 beta doubles' ELL
-__global__ void k_tables_ell(const EllArgs g) {
-  if (blockIdx.y == 0) {
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ inline void tables_ell_body(const EllArgs& g, unsigned bx, unsigned by) {
+  if (by == 0) {
+    const int64_t i = (int64_t)bx * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i > g.n_a) return;
     const int64_t o = g.sa_ptr[i] + g.da_ptr[i];
@@ -541,8 +606,8 @@ __global__ void k_tables_ell(const EllArgs g) {
     }
     return;
   }
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.y == 1) {
+  const int64_t v = (int64_t)bx * blockDim.x + threadIdx.x;
+  if (by == 1) {
     if (v >= g.nv_s) return;
     const int64_t base = g.es_sl[v >> 6] + (v & 63);
     const int64_t p0 = g.vs_start[v];
@@ -561,6 +626,12 @@ __global__ void k_tables_ell(const EllArgs g) {
       g.ed_val[base + (int64_t)k * 64] = g.db_val[p0 + k];
     }
   }
+}
+__global__ void k_tables_ell(const EllArgs g) { tables_ell_body(g, blockIdx.x, blockIdx.y); }
+__global__ void k_tables_ell_b(const EllArgs* __restrict__ gs) {
+  const EllArgs& g = gs[blockIdx.z];
+  if (blockIdx.x >= g.gx) return;
+  tables_ell_body(g, blockIdx.x, blockIdx.y);
 }
 
 // host side of the above: virtual-row descriptors from a CSR pointer array
@@ -813,50 +884,76 @@ static int validate_strings(const uint64_t* s, int64_t n, int norb, const char* 
   return SQD_OK;
 }
 
-int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0,
-                   int64_t row1) {
+// ---- the table build of ONE subspace, cut into phases so that the same code serves a single solve (every phase
+// launches its own kernels) and a batched solve (sqd_solve_batch: the phases of all subspaces run in lock-step and
+// each level's kernels of all of them go out as ONE launch, arguments in device memory).
+struct SubspaceBuild {
+  const uint64_t *sa = nullptr, *sb = nullptr;
+  int64_t na = 0, nb = 0, row0 = 0, row1 = 0, nrows = 0, maxn = 0;
+  int nocc[2] = {0, 0};
+  long long seq_ptrs = 0;
+  int64_t tot[4] = {0, 0, 0, 0};
+  CountArgs count;
+  DiagArgs diag;
+  FillArgs fill;
+  EllArgs ell;
+  JdsArgs jds;
+  bool have_fill = false, have_ell = false, have_jds = false;
+  unsigned ell_gx = 0;
+  struct Up {
+    DevBuf* buf;
+    const void* src;
+    size_t bytes;
+  };
+  std::vector<Up> ups;    // work-item sigma: descriptor arrays that travel in one blob
+  size_t blob_bytes = 0;
+};
+
+// phase 1: checks, buffers, arguments of launches A (counts + scans) and B (J tables, diagonal).  `strs_dev`: where
+// the na + nb strings will be in device memory (nullptr: the context's own buffer); the caller uploads them.
+static int subspace_phase1(sqd_ctx* c, SubspaceBuild& b, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb,
+                           int64_t row0, int64_t row1, uint64_t* strs_dev) {
   c->have_subspace = false;
   c->guess_x = nullptr;
   c->have_solution = false;
   if (row1 < 0) row1 = na;
+  if (na <= 0 || sa == nullptr) {
+    set_error("empty Spin-up string list");
+    return SQD_ERR_INVALID;
+  }
   if (row0 < 0 || row0 >= row1 || row1 > na) {
     set_error("alpha row range [row0, row1) must be non-empty and inside [0, na)");
     return SQD_ERR_INVALID;
   }
-  const int64_t nrows = row1 - row0;
-  int nocc[2];
-  SQD_TRY(validate_strings(sa, na, c->norb, "Spin-up", &nocc[0]));
-  SQD_TRY(validate_strings(sb, nb, c->norb, "Spin-down", &nocc[1]));
+  b.sa = sa;
+  b.sb = sb;
+  b.na = na;
+  b.nb = nb;
+  b.row0 = row0;
+  b.row1 = row1;
+  b.nrows = row1 - row0;
+  SQD_TRY(validate_strings(sa, na, c->norb, "Spin-up", &b.nocc[0]));
+  SQD_TRY(validate_strings(sb, nb, c->norb, "Spin-down", &b.nocc[1]));
   const int norb = c->norb, nnorb = c->nnorb;
-  hipStream_t st = c->stream;
-  SQD_TRY(stage_reset(c));
-  if (c->want_timing) SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
-
   const int64_t ns[2] = {na, nb};
-  int64_t maxn = na > nb ? na : nb;
+  const int64_t maxn = na > nb ? na : nb;
+  b.maxn = maxn;
   SQD_TRY(c->scratch.reserve((size_t)(4 * maxn + 4 * (maxn / 64 + 2) + 64) * 8));
   SQD_TRY(reserve_counters(c));
-  // both string lists in one device buffer: one staged upload
-  SQD_TRY(c->strs2.reserve((size_t)(na + nb) * 8));
-  {
-    void* h = nullptr;
-    SQD_TRY(stage_alloc(c, (size_t)(na + nb) * 8, &h));
-    std::memcpy(h, sa, (size_t)na * 8);
-    std::memcpy(static_cast<char*>(h) + (size_t)na * 8, sb, (size_t)nb * 8);
-    SQD_HIP_CHECK(hipMemcpyAsync(c->strs2.p, h, (size_t)(na + nb) * 8, hipMemcpyHostToDevice, st));
-  }
+  // both string lists in one device buffer
+  if (strs_dev) c->strs2.set_view(strs_dev);
+  else SQD_TRY(c->strs2.reserve((size_t)(na + nb) * 8));
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     t.n = ns[s];
-    t.nocc = nocc[s];
+    t.nocc = b.nocc[s];
     t.n_slices = (t.n + 63) / 64;
     t.strs.set_view(c->strs2.as<uint64_t>() + (s ? na : 0));
     SQD_TRY(t.e_str.reserve(t.n * 8));
   }
-  // launch A: counts + CSR pointers for both spins (+ per-string energies), one host sync for the totals.
-  // All four CSR pointer arrays live in one device buffer so that ONE copy brings them (and with them
-  // every total the host needs) back: the sigma work list (alpha) and the capped-ELL geometry (beta)
-  // are cut on the host from these pointers
+  // launch A: counts + CSR pointers for both spins (+ per-string energies).  All four CSR pointer arrays live in one
+  // device buffer with a host-visible twin: the sigma work list (alpha) and the capped-ELL geometry (beta) are cut on
+  // the host from these pointers
   const int64_t nptr = 2 * (na + 1) + 2 * (nb + 1);
   SQD_TRY(c->ptrs.reserve((size_t)nptr * 8));
   if (c->ptrs_map_cap < (size_t)nptr) {  // host-visible twin of the pointer block (grow-only)
@@ -868,7 +965,6 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_HIP_CHECK(hipHostGetDevicePointer((void**)&c->d_ptrs_map, c->h_ptrs_map, 0));
     c->ptrs_map_cap = want;
   }
-  long long seq_ptrs = 0;
   {
     int64_t* base = c->ptrs.as<int64_t>();
     c->sp[0].s_ptr.set_view(base);
@@ -878,41 +974,35 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   SpinLinkArgs2 la;  // both spins' arguments, filled in as the buffers come to exist
   std::memset(&la, 0, sizeof(la));
-  {
-    int64_t* d_cnt = c->scratch.as<int64_t>();  // [cnt_s_a | cnt_d_a | cnt_s_b | cnt_d_b], maxn each
-    ScanJobs jobs;
-    for (int s = 0; s < 2; ++s) {
-      SpinTables& t = c->sp[s];
-      int64_t* cnt_s = d_cnt + (2 * s) * maxn;
-      int64_t* cnt_d = d_cnt + (2 * s + 1) * maxn;
-      la.a[s].strs = t.strs.as<uint64_t>();
-      la.a[s].n = t.n;
-      la.a[s].cnt_s = cnt_s;
-      la.a[s].cnt_d = cnt_d;
-      la.a[s].s_ptr = t.s_ptr.as<int64_t>();
-      la.a[s].d_ptr = t.d_ptr.as<int64_t>();
-      la.a[s].e_str = t.e_str.as<double>();
-      jobs.in[2 * s] = cnt_s;
-      jobs.out[2 * s] = t.s_ptr.as<int64_t>();
-      jobs.n[2 * s] = t.n;
-      jobs.in[2 * s + 1] = cnt_d;
-      jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
-      jobs.n[2 * s + 1] = t.n;
-    }
-    jobs.dev_block = c->ptrs.as<int64_t>();
-    jobs.host_block = c->d_ptrs_map;
-    jobs.nptr = nptr;
-    jobs.seq = ++c->mail_seq;
-    jobs.seq_word = reinterpret_cast<long long*>(c->d_mail + 3 * 128 + 256);  // its own word of the mailbox page
-    seq_ptrs = jobs.seq;
-    hipLaunchKernelGGL(k_tables_count, dim3(nblk(maxn, 4), 4), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
-                       (const double*)c->jm.as<double>(), (const double*)c->km.as<double>(), norb, jobs, counter_ptr(c));
-    SQD_HIP_CHECK(hipGetLastError());
+  int64_t* d_cnt = c->scratch.as<int64_t>();  // [cnt_s_a | cnt_d_a | cnt_s_b | cnt_d_b], maxn each
+  ScanJobs jobs;
+  for (int s = 0; s < 2; ++s) {
+    SpinTables& t = c->sp[s];
+    int64_t* cnt_s = d_cnt + (2 * s) * maxn;
+    int64_t* cnt_d = d_cnt + (2 * s + 1) * maxn;
+    la.a[s].strs = t.strs.as<uint64_t>();
+    la.a[s].n = t.n;
+    la.a[s].cnt_s = cnt_s;
+    la.a[s].cnt_d = cnt_d;
+    la.a[s].s_ptr = t.s_ptr.as<int64_t>();
+    la.a[s].d_ptr = t.d_ptr.as<int64_t>();
+    la.a[s].e_str = t.e_str.as<double>();
+    jobs.in[2 * s] = cnt_s;
+    jobs.out[2 * s] = t.s_ptr.as<int64_t>();
+    jobs.n[2 * s] = t.n;
+    jobs.in[2 * s + 1] = cnt_d;
+    jobs.out[2 * s + 1] = t.d_ptr.as<int64_t>();
+    jobs.n[2 * s + 1] = t.n;
   }
-  // launch B -- everything else that needs only the strings -- is queued BEHIND the copy and runs while the
-  // host waits for the pointers and cuts the work lists: occupation (J) tables, the diagonal, the row minima
-  SQD_TRY(c->hdiag.reserve((size_t)nrows * nb * 8));
-  SQD_TRY(c->guess_min.reserve((size_t)nrows * 16));
+  jobs.dev_block = c->ptrs.as<int64_t>();
+  jobs.host_block = c->d_ptrs_map;
+  jobs.nptr = nptr;
+  jobs.seq = ++c->mail_seq;
+  jobs.seq_word = reinterpret_cast<long long*>(c->d_mail + 3 * 128 + 256);  // its own word of the mailbox page
+  b.seq_ptrs = jobs.seq;
+  // launch B -- everything else that needs only the strings: occupation (J) tables, the diagonal, the row minima
+  SQD_TRY(c->hdiag.reserve((size_t)b.nrows * nb * 8));
+  SQD_TRY(c->guess_min.reserve((size_t)b.nrows * 16));
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     DevBuf& jt = (s == 0) ? t.jrow : t.jT;  // alpha: J[I][pair] (row role); beta: transposed (column role)
@@ -920,22 +1010,58 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     la.a[s].jtab = jt.as<double>();
     la.a[s].transposed = s;
   }
-  {
-    const int64_t gx_j = (int64_t)nblk(maxn * nnorb, 256), gx_h = nrows < 65535 ? nrows : 65535;
-    const int tril_only = (nocc[0] == nocc[1] && na == nb) ? 1 : 0;
-    double* pmin = c->guess_min.as<double>();
-    hipLaunchKernelGGL(k_tables_diag, dim3((unsigned)(gx_j > gx_h ? gx_j : gx_h), 3), dim3(256), 0, st, la,
-                       (const double*)c->jm.as<double>(), (const double*)c->jdiag.as<double>(), norb, nnorb, row0, row1,
-                       nb, tril_only, c->hdiag.as<double>(), pmin, reinterpret_cast<int64_t*>(pmin + nrows));
-  }
-  SQD_HIP_CHECK(hipGetLastError());
-  // the scan of launch A posted the pointers to their host-visible twin: spin on its sequence word
-  SQD_TRY(spin_wait_word(c->h_mail + 3 * 128 + 256, seq_ptrs, st));
+  CountArgs& ca = b.count;
+  ca.p = la;
+  ca.h1 = c->h1.as<double>();
+  ca.jm = c->jm.as<double>();
+  ca.km = c->km.as<double>();
+  ca.norb = norb;
+  ca.jobs = jobs;
+  ca.counter = counter_ptr(c);
+  ca.gx = nblk(maxn, 4);
+  DiagArgs& da = b.diag;
+  const int64_t gx_j = (int64_t)nblk(maxn * nnorb, 256), gx_h = b.nrows < 65535 ? b.nrows : 65535;
+  double* pmin = c->guess_min.as<double>();
+  da.p = la;
+  da.jm = c->jm.as<double>();
+  da.jdiag = c->jdiag.as<double>();
+  da.norb = norb;
+  da.nnorb = nnorb;
+  da.row0 = row0;
+  da.row1 = row1;
+  da.nb = nb;
+  da.tril_only = (b.nocc[0] == b.nocc[1] && na == nb) ? 1 : 0;
+  da.hdiag = c->hdiag.as<double>();
+  da.pmin = pmin;
+  da.pidx = reinterpret_cast<int64_t*>(pmin + b.nrows);
+  da.gx = (unsigned)(gx_j > gx_h ? gx_j : gx_h);
+  return SQD_OK;
+}
+
+// between the phases: the scan of launch A posted the pointers to their host-visible twin -- spin on its sequence word
+static int subspace_wait_pointers(sqd_ctx* c, SubspaceBuild& b) {
+  const int64_t na = b.na, nb = b.nb;
+  SQD_TRY(spin_wait_word(c->h_mail + 3 * 128 + 256, b.seq_ptrs, c->stream));
   c->h_sptr = c->h_ptrs_map;
   c->h_dptr = c->h_sptr + (na + 1);
   c->h_sptr_b = c->h_dptr + (na + 1);
   c->h_dptr_b = c->h_sptr_b + (nb + 1);
-  const int64_t tot[4] = {c->h_sptr[na], c->h_dptr[na], c->h_sptr_b[nb], c->h_dptr_b[nb]};
+  b.tot[0] = c->h_sptr[na];
+  b.tot[1] = c->h_dptr[na];
+  b.tot[2] = c->h_sptr_b[nb];
+  b.tot[3] = c->h_dptr_b[nb];
+  return SQD_OK;
+}
+
+// phase 2, host planning: the sigma kernel of this subspace, the link arrays, the arguments of launch C (fill +
+// decorate + the start of the Davidson run) and -- for the work-item kernel -- the descriptors and the work list.
+// always_guess: prepare the Davidson run even when the subspace has no link at all (batched solves run launch C for
+// every subspace; a single solve skips the launch then and the solver starts itself).
+static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess) {
+  const int64_t na = b.na, nb = b.nb, row0 = b.row0, row1 = b.row1, nrows = b.nrows;
+  const int64_t* tot = b.tot;
+  const int* nocc = b.nocc;
+  const int nnorb = c->nnorb;
   // Ultra-sparse coupling (at most two links per string on average, either spin): sigma is the element-gather
   // kernel.  SQD_SIGMA_DIRECT=1 / 0 forces / forbids it (tests run both kernels on the same inputs).
   // Long rows with short, even lists (uniform-random sets beyond ~10^3 strings per spin): k_sigma_rows, R whole rows
@@ -964,6 +1090,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     c->sig_direct = direct || c->sig_rows > 0;
   }
   // launch C: fill + decorate
+  SpinLinkArgs2 la = b.count.p;
   for (int s = 0; s < 2; ++s) {
     SpinTables& t = c->sp[s];
     t.n_s = tot[2 * s];
@@ -975,6 +1102,8 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_TRY(t.d_row.reserve((size_t)t.n_d * 4));
     SQD_TRY(t.d_orb.reserve((size_t)t.n_d * 4));
     SQD_TRY(t.d_val.reserve((size_t)t.n_d * 8));
+    la.a[s].jtab = b.diag.p.a[s].jtab;
+    la.a[s].transposed = s;
     la.a[s].n_s = t.n_s;
     la.a[s].n_d = t.n_d;
     la.a[s].s_rec = t.s_rec.as<SRec>();
@@ -985,10 +1114,11 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     la.a[s].d_orb = t.d_orb.as<uint32_t>();
     la.a[s].d_val = t.d_val.as<double>();
   }
+  b.have_fill = false;
   {
     int64_t maxl = 0;
-    for (int64_t v : tot) maxl = v > maxl ? v : maxl;
-    if (maxl > 0) {
+    for (int k = 0; k < 4; ++k) maxl = tot[k] > maxl ? tot[k] : maxl;
+    if (maxl > 0 || always_guess) {
       GuessJob job;
       std::memset(&job, 0, sizeof(job));
       c->guess_x = nullptr;
@@ -1007,198 +1137,245 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
         job.counter = counter_ptr(c);
         c->guess_x = job.x;
       }
-      hipLaunchKernelGGL(k_tables_fill, dim3(nblk(maxn, 4), 2), dim3(256), 0, st, la, (const double*)c->h1.as<double>(),
-                         (const double*)c->eri4.as<double>(), norb, job);
-      SQD_HIP_CHECK(hipGetLastError());
+      FillArgs& fa = b.fill;
+      fa.p = la;
+      fa.h1 = c->h1.as<double>();
+      fa.eri4 = c->eri4.as<double>();
+      fa.norb = c->norb;
+      fa.job = job;
+      fa.gx = nblk(b.maxn, 4);
+      b.have_fill = true;
     }
   }
-  if (!c->sig_direct) {
-    SpinTables& t = c->sp[0];  // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY items
-    SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
-    SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
-    SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
-  }
+  c->na = na;
+  c->nb = nb;
+  c->row0 = row0;
+  c->row1 = row1;
+  c->D = na * nb;
+  c->nelec[0] = nocc[0];
+  c->nelec[1] = nocc[1];
+  b.have_ell = b.have_jds = false;
+  b.ups.clear();
+  b.blob_bytes = 0;
   if (c->sig_direct) {
     // the element-gather sigma kernel reads the CSR lists as they are: no work items, no ELL copies, no merged
     // same-spin list, no descriptor upload -- launch D does not exist
-    c->na = na;
-    c->nb = nb;
-    c->row0 = row0;
-    c->row1 = row1;
-    c->D = na * nb;
-    c->nelec[0] = nocc[0];
-    c->nelec[1] = nocc[1];
     c->n_items = c->n_multi = c->n_slots = 0;
     if (c->sig_rows) {
       SpinTables& t = c->sp[1];
       SQD_TRY(t.jd_src.reserve((size_t)t.n_d * 4));
       SQD_TRY(t.jd_val.reserve((size_t)t.n_d * 8));
       if (t.n_d > 0) {
-        hipLaunchKernelGGL(k_tables_jds, dim3(nblk((nb + 63) / 64, 4)), dim3(256), 0, st, nb,
-                           (const int64_t*)t.d_ptr.as<int64_t>(), (const uint32_t*)t.d_src.as<uint32_t>(),
-                           (const double*)t.d_val.as<double>(), t.jd_src.as<uint32_t>(), t.jd_val.as<double>());
-        SQD_HIP_CHECK(hipGetLastError());
+        JdsArgs& j = b.jds;
+        j.n = nb;
+        j.d_ptr = t.d_ptr.as<int64_t>();
+        j.d_src = t.d_src.as<uint32_t>();
+        j.d_val = t.d_val.as<double>();
+        j.jd_src = t.jd_src.as<uint32_t>();
+        j.jd_val = t.jd_val.as<double>();
+        j.gx = nblk((nb + 63) / 64, 4);
+        b.have_jds = true;
       }
     }
-  } else
-  // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
+    return SQD_OK;
+  }
   {
-    SpinTables& t = c->sp[1];
-    VRowsHost& vs = c->hv_s;  // context members: they must outlive the asynchronous uploads
-    VRowsHost& vd = c->hv_d;
-    int cap = 8;
-    if (const char* env = std::getenv("SQD_ELL_CAP")) {  // test hook: force tiny rows
-      const int v = std::atoi(env);
-      if (v >= 1) cap = v;
+    SpinTables& t = c->sp[0];  // merged same-spin CSR (singles then doubles of each row) for the row role's AXPY items
+    SQD_TRY(t.hs_ptr.reserve((t.n + 1) * 8));
+    SQD_TRY(t.hs_src.reserve((size_t)(t.n_s + t.n_d) * 4));
+    SQD_TRY(t.hs_val.reserve((size_t)(t.n_s + t.n_d) * 8));
+  }
+  // capped sliced-ELL copies for the column role (beta): descriptors on the host, fill on the device
+  SpinTables& t = c->sp[1];
+  VRowsHost& vs = c->hv_s;  // context members: they must outlive the asynchronous uploads
+  VRowsHost& vd = c->hv_d;
+  int cap = 8;
+  if (const char* env = std::getenv("SQD_ELL_CAP")) {  // test hook: force tiny rows
+    const int v = std::atoi(env);
+    if (v >= 1) cap = v;
+  }
+  // LDS plan of the sigma kernel: K staged C rows + K integral rows + the row partial sums of one
+  // column chunk.  Rows too long for that (nb beyond ~14 000) are not staged: the kernel then reads
+  // them from global memory (L2) and works on column chunks, whose partial sums may use the freed LDS.
+  const int cap0 = cap;
+  const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
+  const size_t w2_bytes = (size_t)((nnorb + 1) & ~1) * 8;
+  const size_t row_bytes = (size_t)((nb + 1) & ~int64_t(1)) * 8 + w2_bytes;
+  bool lds_rows = (row_bytes + 64 <= budget) && ((nb + 1023) / 1024 <= 16);
+  int64_t chunk_cols = nb;
+  int64_t forced = 0;
+  if (const char* env = std::getenv("SQD_SIGMA_GLOBAL_ROWS")) {  // test hook: chunk width, forces the fallback
+    forced = (std::atoll(env) / 64) * 64;
+    if (forced >= 64 && forced <= 1024) lds_rows = false;
+    else forced = 0;
+  }
+  int64_t forced_pass = 0;  // test hook: partial-sum capacity in virtual rows, forces the multi-pass walk
+  if (const char* env = std::getenv("SQD_SIGMA_PASS")) {
+    forced_pass = std::atoll(env);
+    if (forced_pass < 1 || !lds_rows) forced_pass = 0;
+  }
+  int64_t pass_s = 0, pass_d = 0;
+  for (;;) {
+    if (!lds_rows) chunk_cols = forced ? forced : 4096;
+    const size_t target = lds_rows ? 40 * 1024 : 120 * 1024;
+    for (cap = cap0;; cap *= 2) {
+      make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
+      make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
+      if ((size_t)(vs.nv_max + vd.nv_max) * 8 <= target || cap >= (1 << 20)) break;
     }
-    // LDS plan of the sigma kernel: K staged C rows + K integral rows + the row partial sums of one
-    // column chunk.  Rows too long for that (nb beyond ~14 000) are not staged: the kernel then reads
-    // them from global memory (L2) and works on column chunks, whose partial sums may use the freed LDS.
-    const int cap0 = cap;
-    const size_t budget = (size_t)c->lds_bytes - 8 * 1024;
-    const size_t w2_bytes = (size_t)((nnorb + 1) & ~1) * 8;
-    const size_t row_bytes = (size_t)((nb + 1) & ~int64_t(1)) * 8 + w2_bytes;
-    bool lds_rows = (row_bytes + 64 <= budget) && ((nb + 1023) / 1024 <= 16);
-    int64_t chunk_cols = nb;
-    int64_t forced = 0;
-    if (const char* env = std::getenv("SQD_SIGMA_GLOBAL_ROWS")) {  // test hook: chunk width, forces the fallback
-      forced = (std::atoll(env) / 64) * 64;
-      if (forced >= 64 && forced <= 1024) lds_rows = false;
-      else forced = 0;
-    }
-    int64_t forced_pass = 0;  // test hook: partial-sum capacity in virtual rows, forces the multi-pass walk
-    if (const char* env = std::getenv("SQD_SIGMA_PASS")) {
-      forced_pass = std::atoll(env);
-      if (forced_pass < 1 || !lds_rows) forced_pass = 0;
-    }
-    int64_t pass_s = 0, pass_d = 0;
-    for (;;) {
-      if (!lds_rows) chunk_cols = forced ? forced : 4096;
-      const size_t target = lds_rows ? 40 * 1024 : 120 * 1024;
-      for (cap = cap0;; cap *= 2) {
+    const size_t part_bytes = (size_t)(vs.nv_max + vd.nv_max) * 8 + 64;
+    pass_s = vs.nv_max;
+    pass_d = vd.nv_max;
+    if (lds_rows && (row_bytes + part_bytes > budget || forced_pass)) {
+      // The row fits but one partial sum per virtual row does not (at least one row per beta string with
+      // links: nb of ~8000 and more).  Keep the row in LDS -- a gather from LDS beats a gather from L2
+      // by far -- and walk the virtual rows in passes over a bounded partial-sum buffer.
+      size_t avail = (budget > row_bytes + 128) ? budget - row_bytes - 128 : 0;
+      if (std::getenv("SQD_SIGMA_NOPASS")) avail = 0;  // tuning hook: previous behaviour (global rows)
+      if (avail >= 24 * 1024 || forced_pass) {
+        cap = cap0 < 32 && !forced_pass ? 32 : cap0;  // moderate rows: balance without a row per 8 links
         make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
         make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
-        if ((size_t)(vs.nv_max + vd.nv_max) * 8 <= target || cap >= (1 << 20)) break;
+        const int64_t entries = (int64_t)(avail / 8);
+        pass_s = forced_pass ? forced_pass : entries / 4;
+        if (pass_s > vs.nv_max) pass_s = vs.nv_max;
+        if (pass_s < 1) pass_s = 1;
+        pass_d = forced_pass ? forced_pass : entries - ((pass_s + 1) & ~int64_t(1));
+        if (!forced_pass && pass_d >= 1024) pass_d &= ~int64_t(1023);  // whole strides of the workgroup
+        if (pass_d > vd.nv_max) pass_d = vd.nv_max;
+        if (pass_d < 1) pass_d = 1;
+        break;
       }
-      const size_t part_bytes = (size_t)(vs.nv_max + vd.nv_max) * 8 + 64;
-      pass_s = vs.nv_max;
-      pass_d = vd.nv_max;
-      if (lds_rows && (row_bytes + part_bytes > budget || forced_pass)) {
-        // The row fits but one partial sum per virtual row does not (at least one row per beta string with
-        // links: nb of ~8000 and more).  Keep the row in LDS -- a gather from LDS beats a gather from L2
-        // by far -- and walk the virtual rows in passes over a bounded partial-sum buffer.
-        size_t avail = (budget > row_bytes + 128) ? budget - row_bytes - 128 : 0;
-        if (std::getenv("SQD_SIGMA_NOPASS")) avail = 0;  // tuning hook: previous behaviour (global rows)
-        if (avail >= 24 * 1024 || forced_pass) {
-          cap = cap0 < 32 && !forced_pass ? 32 : cap0;  // moderate rows: balance without a row per 8 links
-          make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
-          make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
-          const int64_t entries = (int64_t)(avail / 8);
-          pass_s = forced_pass ? forced_pass : entries / 4;
-          if (pass_s > vs.nv_max) pass_s = vs.nv_max;
-          if (pass_s < 1) pass_s = 1;
-          pass_d = forced_pass ? forced_pass : entries - ((pass_s + 1) & ~int64_t(1));
-          if (!forced_pass && pass_d >= 1024) pass_d &= ~int64_t(1023);  // whole strides of the workgroup
-          if (pass_d > vd.nv_max) pass_d = vd.nv_max;
-          if (pass_d < 1) pass_d = 1;
-          break;
-        }
-        lds_rows = false;
-        continue;
-      }
-      if (!lds_rows && w2_bytes + part_bytes > budget) {
-        set_error("beta link lists of a " + std::to_string(chunk_cols) + "-column chunk exceed the LDS budget");
-        return SQD_ERR_LIMIT;
-      }
-      break;
+      lds_rows = false;
+      continue;
     }
-    c->sig_lds_rows = lds_rows;
-    c->sig_ps = pass_s;
-    c->sig_pd = pass_d;
-    c->sig_chunk = chunk_cols;
-    c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
-    c->sig_kmax = 4;
-    // The kernel lives on resident waves: a single workgroup per CU (rows of ~2000 strings and more) is
-    // the one case where a smaller batch pays (HF-centred 2000 x 2000: 2.3 ms -> 1.5 ms per sigma with 3
-    // links per batch instead of 4).  Finer searches over cap / batch size to gain a third or fourth
-    // resident workgroup were measured too and are a wash (+-10 % either way, profiles/r01 notes).
-    if (lds_rows)
-      while (c->sig_kmax > 2 && plan_sigma(c, nb, vs, vd, c->sig_kmax).wgs < 2) --c->sig_kmax;
-    t.cap = cap;
-    t.nv_s = vs.nv;
-    t.nv_d = vd.nv;
-    // the sigma work list is cut on the host from the same pointer arrays (no device dependency)
-    c->na = na;
-    c->nb = nb;
-    c->row0 = row0;
-    c->row1 = row1;
-    c->D = na * nb;
-    c->nelec[0] = nocc[0];
-    c->nelec[1] = nocc[1];
-    SQD_TRY(build_sigma_work(c));
-    // all descriptors and the work list travel in ONE host blob / ONE copy; the per-array DevBufs are views into it
-    struct Up { DevBuf* buf; const void* src; size_t bytes; };
-    const Up ups[] = {
-        {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_own, vs.own.data(), vs.own.size() * 4},
-        {&t.vs_start, vs.vstart.data(), vs.vstart.size() * 8}, {&t.es_sl, vs.sl.data(), vs.sl.size() * 8},
-        {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_own, vd.own.data(), vd.own.size() * 4},
-        {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
-        {&t.vs_chunk, vs.chunk.data(), vs.chunk.size() * 4}, {&t.vd_chunk, vd.chunk.data(), vd.chunk.size() * 4},
-        {&c->items, c->h_items.data(), c->h_items.size() * sizeof(WorkItem)},
-        {&c->multi, c->h_multi.data(), c->h_multi.size() * sizeof(MultiRow)},
-        {&c->rowinfo, c->h_rowinfo.data(), c->h_rowinfo.size() * 4},
-    };
-    size_t blob = 0;
-    for (const Up& u : ups) blob += (u.bytes + 15) & ~size_t(15);
+    if (!lds_rows && w2_bytes + part_bytes > budget) {
+      set_error("beta link lists of a " + std::to_string(chunk_cols) + "-column chunk exceed the LDS budget");
+      return SQD_ERR_LIMIT;
+    }
+    break;
+  }
+  c->sig_lds_rows = lds_rows;
+  c->sig_ps = pass_s;
+  c->sig_pd = pass_d;
+  c->sig_chunk = chunk_cols;
+  c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
+  c->sig_kmax = 4;
+  // The kernel lives on resident waves: a single workgroup per CU (rows of ~2000 strings and more) is
+  // the one case where a smaller batch pays (HF-centred 2000 x 2000: 2.3 ms -> 1.5 ms per sigma with 3
+  // links per batch instead of 4).  Finer searches over cap / batch size to gain a third or fourth
+  // resident workgroup were measured too and are a wash (+-10 % either way, profiles/r01 notes).
+  if (lds_rows)
+    while (c->sig_kmax > 2 && plan_sigma(c, nb, vs, vd, c->sig_kmax).wgs < 2) --c->sig_kmax;
+  t.cap = cap;
+  t.nv_s = vs.nv;
+  t.nv_d = vd.nv;
+  // the sigma work list is cut on the host from the same pointer arrays (no device dependency)
+  SQD_TRY(build_sigma_work(c));
+  // all descriptors and the work list travel in ONE host blob / ONE copy; the per-array DevBufs are views into it
+  b.ups = {
+      {&t.vs_cnt, vs.vcnt.data(), vs.vcnt.size() * 4},   {&t.vs_own, vs.own.data(), vs.own.size() * 4},
+      {&t.vs_start, vs.vstart.data(), vs.vstart.size() * 8}, {&t.es_sl, vs.sl.data(), vs.sl.size() * 8},
+      {&t.vd_cnt, vd.vcnt.data(), vd.vcnt.size() * 4},   {&t.vd_own, vd.own.data(), vd.own.size() * 4},
+      {&t.vd_start, vd.vstart.data(), vd.vstart.size() * 8}, {&t.ed_sl, vd.sl.data(), vd.sl.size() * 8},
+      {&t.vs_chunk, vs.chunk.data(), vs.chunk.size() * 4}, {&t.vd_chunk, vd.chunk.data(), vd.chunk.size() * 4},
+      {&c->items, c->h_items.data(), c->h_items.size() * sizeof(WorkItem)},
+      {&c->multi, c->h_multi.data(), c->h_multi.size() * sizeof(MultiRow)},
+      {&c->rowinfo, c->h_rowinfo.data(), c->h_rowinfo.size() * 4},
+  };
+  size_t blob = 0;
+  for (const auto& u : b.ups) blob += (u.bytes + 15) & ~size_t(15);
+  b.blob_bytes = blob + 16;
+  SQD_TRY(t.es_rec.reserve((size_t)vs.total * sizeof(SRec) + 8));
+  SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
+  SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
+  SQD_TRY(t.ed_val.reserve((size_t)vd.total * 8 + 8));
+  b.have_ell = true;
+  return SQD_OK;
+}
+
+// phase 2, placement: the descriptor blob into (h_blob, d_blob) -- pinned host memory and where it will be on the
+// device -- and the arguments of launch D (merged alpha CSR + both capped-ELL copies)
+static void subspace_phase2_place(sqd_ctx* c, SubspaceBuild& b, char* h_blob, char* d_blob) {
+  if (!b.have_ell) return;
+  size_t off = 0;
+  for (const auto& u : b.ups) {
+    if (u.bytes) std::memcpy(h_blob + off, u.src, u.bytes);
+    u.buf->set_view(d_blob + off);
+    off += (u.bytes + 15) & ~size_t(15);
+  }
+  const SpinTables& ta = c->sp[0];
+  const SpinTables& t = c->sp[1];
+  EllArgs& g = b.ell;
+  g.n_a = ta.n;
+  g.sa_ptr = ta.s_ptr.as<int64_t>();
+  g.da_ptr = ta.d_ptr.as<int64_t>();
+  g.sa_rec = ta.s_rec.as<SRec>();
+  g.sa_val = ta.s_val.as<double>();
+  g.da_src = ta.d_src.as<uint32_t>();
+  g.da_val = ta.d_val.as<double>();
+  g.hs_ptr = ta.hs_ptr.as<int64_t>();
+  g.hs_src = ta.hs_src.as<uint32_t>();
+  g.hs_val = ta.hs_val.as<double>();
+  g.nv_s = t.n_s > 0 ? c->hv_s.nv : 0;
+  g.nv_d = t.n_d > 0 ? c->hv_d.nv : 0;
+  g.vs_cnt = t.vs_cnt.as<int32_t>();
+  g.vd_cnt = t.vd_cnt.as<int32_t>();
+  g.vs_start = t.vs_start.as<int64_t>();
+  g.vd_start = t.vd_start.as<int64_t>();
+  g.es_sl = t.es_sl.as<int64_t>();
+  g.ed_sl = t.ed_sl.as<int64_t>();
+  g.sb_rec = t.s_rec.as<SRec>();
+  g.sb_val = t.s_val.as<double>();
+  g.db_src = t.d_src.as<uint32_t>();
+  g.db_val = t.d_val.as<double>();
+  g.es_rec = t.es_rec.as<SRec>();
+  g.es_val = t.es_val.as<double>();
+  g.ed_src = t.ed_src.as<uint32_t>();
+  g.ed_val = t.ed_val.as<double>();
+  const unsigned gx_m = nblk(ta.n + 1, 4), gx_s = nblk(g.nv_s, 256), gx_d = nblk(g.nv_d, 256);
+  unsigned gx = gx_m > gx_s ? gx_m : gx_s;
+  gx = gx > gx_d ? gx : gx_d;
+  g.gx = gx;
+}
+
+int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* sb, int64_t nb, int64_t row0,
+                   int64_t row1) {
+  hipStream_t st = c->stream;
+  SQD_TRY(stage_reset(c));
+  if (c->want_timing) SQD_HIP_CHECK(hipEventRecord(c->ev[0], st));
+  SubspaceBuild b;
+  SQD_TRY(subspace_phase1(c, b, sa, na, sb, nb, row0, row1, nullptr));
+  {
+    void* h = nullptr;  // both string lists: one staged upload
+    SQD_TRY(stage_alloc(c, (size_t)(na + nb) * 8, &h));
+    std::memcpy(h, sa, (size_t)na * 8);
+    std::memcpy(static_cast<char*>(h) + (size_t)na * 8, sb, (size_t)nb * 8);
+    SQD_HIP_CHECK(hipMemcpyAsync(c->strs2.p, h, (size_t)(na + nb) * 8, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(k_tables_count, dim3(b.count.gx, 4), dim3(256), 0, st, b.count);
+  SQD_HIP_CHECK(hipGetLastError());
+  // launch B is queued behind A and runs while the host waits for the pointers and cuts the work lists
+  hipLaunchKernelGGL(k_tables_diag, dim3(b.diag.gx, 3), dim3(256), 0, st, b.diag);
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_TRY(subspace_wait_pointers(c, b));
+  SQD_TRY(subspace_phase2_plan(c, b, /*always_guess=*/false));
+  if (b.have_fill) {
+    hipLaunchKernelGGL(k_tables_fill, dim3(b.fill.gx, 2), dim3(256), 0, st, b.fill);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (b.have_jds) {
+    hipLaunchKernelGGL(k_tables_jds, dim3(b.jds.gx), dim3(256), 0, st, b.jds);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (b.have_ell) {
     void* h_blob = nullptr;
-    SQD_TRY(stage_alloc(c, blob + 16, &h_blob));
-    SQD_TRY(c->d_blob.reserve(blob + 16));
-    size_t off = 0;
-    for (const Up& u : ups) {
-      if (u.bytes) std::memcpy(static_cast<char*>(h_blob) + off, u.src, u.bytes);
-      u.buf->set_view(static_cast<char*>(c->d_blob.p) + off);
-      off += (u.bytes + 15) & ~size_t(15);
-    }
-    if (blob) SQD_HIP_CHECK(hipMemcpyAsync(c->d_blob.p, h_blob, blob, hipMemcpyHostToDevice, st));
-    SQD_TRY(t.es_rec.reserve((size_t)vs.total * sizeof(SRec) + 8));
-    SQD_TRY(t.es_val.reserve((size_t)vs.total * 8 + 8));
-    SQD_TRY(t.ed_src.reserve((size_t)vd.total * 4 + 8));
-    SQD_TRY(t.ed_val.reserve((size_t)vd.total * 8 + 8));
-    {
-      // launch D: merged alpha CSR + both capped-ELL copies
-      const SpinTables& ta = c->sp[0];
-      EllArgs g;
-      g.n_a = ta.n;
-      g.sa_ptr = ta.s_ptr.as<int64_t>();
-      g.da_ptr = ta.d_ptr.as<int64_t>();
-      g.sa_rec = ta.s_rec.as<SRec>();
-      g.sa_val = ta.s_val.as<double>();
-      g.da_src = ta.d_src.as<uint32_t>();
-      g.da_val = ta.d_val.as<double>();
-      g.hs_ptr = ta.hs_ptr.as<int64_t>();
-      g.hs_src = ta.hs_src.as<uint32_t>();
-      g.hs_val = ta.hs_val.as<double>();
-      g.nv_s = t.n_s > 0 ? vs.nv : 0;
-      g.nv_d = t.n_d > 0 ? vd.nv : 0;
-      g.vs_cnt = t.vs_cnt.as<int32_t>();
-      g.vd_cnt = t.vd_cnt.as<int32_t>();
-      g.vs_start = t.vs_start.as<int64_t>();
-      g.vd_start = t.vd_start.as<int64_t>();
-      g.es_sl = t.es_sl.as<int64_t>();
-      g.ed_sl = t.ed_sl.as<int64_t>();
-      g.sb_rec = t.s_rec.as<SRec>();
-      g.sb_val = t.s_val.as<double>();
-      g.db_src = t.d_src.as<uint32_t>();
-      g.db_val = t.d_val.as<double>();
-      g.es_rec = t.es_rec.as<SRec>();
-      g.es_val = t.es_val.as<double>();
-      g.ed_src = t.ed_src.as<uint32_t>();
-      g.ed_val = t.ed_val.as<double>();
-      const unsigned gx_m = nblk(ta.n + 1, 4), gx_s = nblk(g.nv_s, 256), gx_d = nblk(g.nv_d, 256);
-      unsigned gx = gx_m > gx_s ? gx_m : gx_s;
-      gx = gx > gx_d ? gx : gx_d;
-      hipLaunchKernelGGL(k_tables_ell, dim3(gx, 3), dim3(256), 0, st, g);
-    }
+    SQD_TRY(stage_alloc(c, b.blob_bytes, &h_blob));
+    SQD_TRY(c->d_blob.reserve(b.blob_bytes));
+    subspace_phase2_place(c, b, static_cast<char*>(h_blob), static_cast<char*>(c->d_blob.p));
+    if (b.blob_bytes > 16)
+      SQD_HIP_CHECK(hipMemcpyAsync(c->d_blob.p, h_blob, b.blob_bytes - 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tables_ell, dim3(b.ell.gx, 3), dim3(256), 0, st, b.ell);
     SQD_HIP_CHECK(hipGetLastError());
   }
   // no synchronisation here: later calls use the same stream; ev[0]..ev[1] is read lazily
@@ -1206,6 +1383,132 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   c->stage_pending = true;
   c->ms_setup = c->want_timing ? -1.0 : 0.0;
   c->have_subspace = true;
+  return SQD_OK;
+}
+
+// ---- batched table build (sqd_solve_batch): the phases of all subspaces in lock-step; the kernels of one dependency
+// level of ALL subspaces go out as one launch (blockIdx.z = subspace), their arguments, the strings and the
+// descriptor blobs travel in ONE host-to-device copy per phase.  Per-subspace results are the single build's, bit
+// for bit: the same bodies on the same per-subspace grids.
+int BatchStage::reserve(size_t bytes) {
+  if (bytes <= cap) return SQD_OK;
+  if (host) SQD_HIP_CHECK(hipHostFree(host));
+  host = nullptr;
+  cap = 0;
+  const size_t want = bytes + bytes / 2 + 4096;
+  SQD_HIP_CHECK(hipHostMalloc((void**)&host, want, hipHostMallocDefault));
+  SQD_TRY(dev.reserve(want));
+  cap = want;
+  return SQD_OK;
+}
+void BatchStage::release() {
+  if (host) {
+    hipError_t e = hipHostFree(host);
+    (void)e;
+  }
+  host = nullptr;
+  cap = 0;
+  dev.release();
+}
+
+template <class T>
+static size_t stage_take(size_t& off, size_t count) {
+  off = (off + 63) & ~size_t(63);
+  const size_t at = off;
+  off += count * sizeof(T);
+  return at;
+}
+
+int build_subspace_batch(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const uint64_t* const* sa,
+                         const int64_t* na, const uint64_t* const* sb, const int64_t* nb) {
+  const int n = (int)subs.size();
+  hipStream_t st = parent->stream;
+  std::vector<SubspaceBuild> bs(n);
+  // ---- phase 1: [CountArgs[n] | DiagArgs[n] | strings of every subspace]
+  BatchStage& s1 = parent->bstage[0];
+  size_t off = 0;
+  const size_t o_count = stage_take<CountArgs>(off, n), o_diag = stage_take<DiagArgs>(off, n);
+  std::vector<size_t> o_str(n);
+  for (int p = 0; p < n; ++p) {
+    if (na[p] <= 0 || nb[p] <= 0 || !sa[p] || !sb[p]) {
+      set_error("empty CI string list in batch " + std::to_string(p));
+      return SQD_ERR_INVALID;
+    }
+    o_str[p] = stage_take<uint64_t>(off, (size_t)(na[p] + nb[p]));
+  }
+  SQD_TRY(s1.reserve(off));
+  char* d1 = static_cast<char*>(s1.dev.p);
+  unsigned gx_count = 0, gx_diag = 0;
+  for (int p = 0; p < n; ++p) {
+    sqd_ctx* c = subs[p];
+    c->want_timing = false;
+    SQD_TRY(subspace_phase1(c, bs[p], sa[p], na[p], sb[p], nb[p], 0, -1, reinterpret_cast<uint64_t*>(d1 + o_str[p])));
+    std::memcpy(s1.host + o_str[p], sa[p], (size_t)na[p] * 8);
+    std::memcpy(s1.host + o_str[p] + (size_t)na[p] * 8, sb[p], (size_t)nb[p] * 8);
+    reinterpret_cast<CountArgs*>(s1.host + o_count)[p] = bs[p].count;
+    reinterpret_cast<DiagArgs*>(s1.host + o_diag)[p] = bs[p].diag;
+    gx_count = bs[p].count.gx > gx_count ? bs[p].count.gx : gx_count;
+    gx_diag = bs[p].diag.gx > gx_diag ? bs[p].diag.gx : gx_diag;
+  }
+  SQD_HIP_CHECK(hipMemcpyAsync(d1, s1.host, off, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_tables_count_b, dim3(gx_count, 4, n), dim3(256), 0, st,
+                     reinterpret_cast<const CountArgs*>(d1 + o_count));
+  SQD_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(k_tables_diag_b, dim3(gx_diag, 3, n), dim3(256), 0, st,
+                     reinterpret_cast<const DiagArgs*>(d1 + o_diag));
+  SQD_HIP_CHECK(hipGetLastError());
+  // ---- phase 2: [FillArgs[n] | EllArgs[n_ell] | JdsArgs[n_jds] | descriptor blobs]
+  for (int p = 0; p < n; ++p) {
+    SQD_TRY(subspace_wait_pointers(subs[p], bs[p]));
+    SQD_TRY(subspace_phase2_plan(subs[p], bs[p], /*always_guess=*/true));
+  }
+  BatchStage& s2 = parent->bstage[1];
+  off = 0;
+  int n_ell = 0, n_jds = 0;
+  for (int p = 0; p < n; ++p) {
+    n_ell += bs[p].have_ell;
+    n_jds += bs[p].have_jds;
+  }
+  const size_t o_fill = stage_take<FillArgs>(off, n), o_ell = stage_take<EllArgs>(off, n_ell),
+               o_jds = stage_take<JdsArgs>(off, n_jds);
+  std::vector<size_t> o_blob(n, 0);
+  for (int p = 0; p < n; ++p)
+    if (bs[p].have_ell) o_blob[p] = stage_take<char>(off, bs[p].blob_bytes);
+  SQD_TRY(s2.reserve(off));
+  char* d2 = static_cast<char*>(s2.dev.p);
+  unsigned gx_fill = 0, gx_ell = 0, gx_jds = 0;
+  int i_ell = 0, i_jds = 0;
+  for (int p = 0; p < n; ++p) {
+    subspace_phase2_place(subs[p], bs[p], s2.host + o_blob[p], d2 + o_blob[p]);
+    reinterpret_cast<FillArgs*>(s2.host + o_fill)[p] = bs[p].fill;
+    gx_fill = bs[p].fill.gx > gx_fill ? bs[p].fill.gx : gx_fill;
+    if (bs[p].have_ell) {
+      reinterpret_cast<EllArgs*>(s2.host + o_ell)[i_ell++] = bs[p].ell;
+      gx_ell = bs[p].ell.gx > gx_ell ? bs[p].ell.gx : gx_ell;
+    }
+    if (bs[p].have_jds) {
+      reinterpret_cast<JdsArgs*>(s2.host + o_jds)[i_jds++] = bs[p].jds;
+      gx_jds = bs[p].jds.gx > gx_jds ? bs[p].jds.gx : gx_jds;
+    }
+  }
+  SQD_HIP_CHECK(hipMemcpyAsync(d2, s2.host, off, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_tables_fill_b, dim3(gx_fill, 2, n), dim3(256), 0, st,
+                     reinterpret_cast<const FillArgs*>(d2 + o_fill));
+  SQD_HIP_CHECK(hipGetLastError());
+  if (n_jds) {
+    hipLaunchKernelGGL(k_tables_jds_b, dim3(gx_jds, 1, n_jds), dim3(256), 0, st,
+                       reinterpret_cast<const JdsArgs*>(d2 + o_jds));
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (n_ell) {
+    hipLaunchKernelGGL(k_tables_ell_b, dim3(gx_ell, 3, n_ell), dim3(256), 0, st,
+                       reinterpret_cast<const EllArgs*>(d2 + o_ell));
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  for (int p = 0; p < n; ++p) {
+    subs[p]->ms_setup = 0.0;
+    subs[p]->have_subspace = true;
+  }
   return SQD_OK;
 }
 

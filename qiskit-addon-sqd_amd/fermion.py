@@ -37,35 +37,65 @@ _CTX_CACHE_MAX = 16
 
 
 _HASH_LOCK = threading.Lock()
-_HASH_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of an integral array -> (array, full hash)
+_HASH_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of a READ-ONLY integral array -> (array, full hash)
+_HASH_SMALL = 1 << 15  # elements: below this a full pass costs a few microseconds and is always made
+
+
+def _immutable(a: np.ndarray) -> bool:
+    """True when nobody can change the array's bytes through numpy: it is read-only and so is every array it is a
+    view of (a read-only view of a writeable base can still change through the base)."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None or isinstance(a, (bytes, memoryview)) and getattr(a, "readonly", True)
 
 
 def _full_hash(arr: np.ndarray) -> int:
-    """Hash of EVERY byte of an integral array, memoised by the array's identity (data pointer, size, a 64-value
-    strided sample as a cheap guard against in-place edits).  The SQD loop passes the same tensor objects on every
-    call, so the full pass (xxh3, ~1 ms for norb = 30) is paid once per tensor, not once per solve; the memo
-    keeps a reference to the array so that its address cannot be recycled by another array while it is cached.
-    Two tensors that differ anywhere get different hashes, hence different contexts."""
+    """Hash of EVERY byte of an integral array (xxh3).  Two tensors that differ anywhere get different hashes, hence
+    different solver contexts -- also after an IN-PLACE edit of a tensor that was used before: a writeable array is
+    hashed in full on every call (1 ms for the 6.5 MB of norb = 30; small tensors always are).  Only arrays that
+    cannot change -- read-only, ``arr.setflags(write=False)``, with no writeable base -- are memoised by identity, so
+    callers that solve many subspaces of one Hamiltonian freeze their integrals once (``freeze_integrals``; the SQD
+    loop of this package does) and pay the pass once.  The memo holds a reference to the array, so its address cannot be
+    recycled while it is cached; temporaries made here (non-contiguous / non-float64 input) are never cached."""
     a = np.asarray(arr)
-    if not a.flags.c_contiguous or a.dtype != np.float64:
+    own = a.flags.c_contiguous and a.dtype == np.float64
+    if not own:
         a = np.ascontiguousarray(a, dtype=np.float64)
     flat = a.reshape(-1)
-    ident = (a.__array_interface__["data"][0], a.size, flat[:: max(1, flat.size // 64)].tobytes())
-    with _HASH_LOCK:
-        hit = _HASH_MEMO.get(ident)
-        if hit is not None:
-            return hit[1]
+    ident = None
+    if own and a.size > _HASH_SMALL and _immutable(a):
+        ident = (id(a), a.__array_interface__["data"][0], a.size)
+        with _HASH_LOCK:
+            hit = _HASH_MEMO.get(ident)
+            if hit is not None and hit[0] is a:
+                return hit[1]
     try:
         import xxhash
 
         digest = xxhash.xxh3_64_intdigest(flat.data)
     except ImportError:  # pragma: no cover - xxhash ships with this image
         digest = zlib.crc32(flat.data) | (zlib.adler32(flat.data) << 32)
-    with _HASH_LOCK:
-        _HASH_MEMO[ident] = (a, digest)
-        while len(_HASH_MEMO) > 64:
-            _HASH_MEMO.popitem(last=False)
+    if ident is not None:
+        with _HASH_LOCK:
+            _HASH_MEMO[ident] = (a, digest)
+            while len(_HASH_MEMO) > 16:
+                _HASH_MEMO.popitem(last=False)
     return digest
+
+
+def freeze_integrals(hcore, eri) -> tuple[np.ndarray, np.ndarray]:
+    """Read-only float64 copies of the integral tensors: solver contexts are then found by identity instead of a
+    full hash of the tensors per call (see ``_full_hash``).  Arrays that are already immutable are returned as is."""
+    out = []
+    for t in (hcore, eri):
+        a = np.asarray(t)
+        if not (a.dtype == np.float64 and a.flags.c_contiguous and _immutable(a)):
+            a = np.array(a, dtype=np.float64, order="C", copy=True)
+            a.setflags(write=False)
+        out.append(a)
+    return out[0], out[1]
 
 
 def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
@@ -84,6 +114,7 @@ def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int 
         _CTX_CACHE[key] = ctx
         while len(_CTX_CACHE) > _CTX_CACHE_MAX:
             _, old = _CTX_CACHE.popitem(last=False)
+            _settle_deferred(old)
             old.close()
     return ctx
 
@@ -92,6 +123,7 @@ def clear_context_cache() -> None:
     with _CTX_LOCK:
         while _CTX_CACHE:
             _, old = _CTX_CACHE.popitem()
+            _settle_deferred(old)
             old.close()
 
 
@@ -101,6 +133,38 @@ def _state_context(norb: int, device: int = 0) -> _capi.Context:
 
 
 # --------------------------------------------------------------------------- result types
+class _DeferredAmplitudes:
+    """Amplitudes of one batch of a batched solve that are still on the device.  The SQD loop reads the state of the
+    lowest-energy batch only (reference ``fermion.py:577, :608-631``), so ``solve_sci_batch`` brings that one to the host
+    and leaves the others resident; ``SCIState.amplitudes`` fetches on first access.  Before the solver context is
+    re-used for another batched solve (or closed) every deferred state that is still referenced is fetched."""
+
+    __slots__ = ("ctx", "index", "shape", "value", "__weakref__")
+
+    def __init__(self, ctx, index, shape):
+        self.ctx, self.index, self.shape, self.value = ctx, int(index), tuple(shape), None
+
+    def fetch(self) -> np.ndarray:
+        if self.value is None:
+            ctx = self.ctx
+            if ctx is None:
+                raise RuntimeError("the solver context that held this state has been released")
+            self.value = ctx.batch_state(self.index)
+            self.ctx = None
+        return self.value
+
+
+def _settle_deferred(ctx) -> None:
+    """Fetch every still-referenced deferred state of the context's latest batched solve (called before the next)."""
+    refs = getattr(ctx, "_deferred", None)
+    if refs:
+        for r in refs:
+            d = r()
+            if d is not None and d.value is None:
+                d.fetch()
+    ctx._deferred = []
+
+
 @dataclass(frozen=True)
 class SCIState:
     """The amplitudes and determinants describing a quantum state (reference ``fermion.py:57-139``)."""
@@ -121,12 +185,25 @@ class SCIState:
     """The numbers of alpha and beta electrons."""
 
     def __post_init__(self):
-        object.__setattr__(self, "amplitudes", np.asarray(self.amplitudes))
-        if self.amplitudes.shape != (len(self.ci_strs_a), len(self.ci_strs_b)):
+        amps = object.__getattribute__(self, "amplitudes")
+        if isinstance(amps, _DeferredAmplitudes):
+            shape = amps.shape
+        else:
+            amps = np.asarray(amps)
+            object.__setattr__(self, "amplitudes", amps)
+            shape = amps.shape
+        if shape != (len(self.ci_strs_a), len(self.ci_strs_b)):
             raise ValueError(
                 f"'amplitudes' shape must be ({len(self.ci_strs_a)}, {len(self.ci_strs_b)}) "
-                f"but got {self.amplitudes.shape}"
+                f"but got {shape}"
             )
+
+    def __getattribute__(self, name):
+        value = object.__getattribute__(self, name)
+        if name == "amplitudes" and isinstance(value, _DeferredAmplitudes):
+            value = value.fetch()
+            object.__setattr__(self, "amplitudes", value)  # frozen dataclass: cache through object
+        return value
 
     def save(self, filename):
         """Save the SCIState object to an .npz file (same keys as the reference, ``fermion.py:90-99``)."""
@@ -348,6 +425,8 @@ def solve_sci_batch(
     sparse ones -- while every subspace stays below 4e6 determinants (26 resident vectors each), else one at a
     time.  The results do not depend on the concurrency.
     """
+    if concurrency is None and devices is None and _batched_ok(ci_strings, kwargs):
+        return _solve_sci_batched(ci_strings, one_body_tensor, two_body_tensor, nelec, spin_sq, kwargs)
     if concurrency is None:
         biggest = max((len(a) * len(b) for a, b in ci_strings), default=0)
         concurrency = min(4, len(ci_strings)) if 0 < biggest <= 4_000_000 else 1
@@ -374,6 +453,51 @@ def solve_sci_batch(
         for part in pool.map(work, range(len(devices))):
             results.update(part)
     return [results[i] for i in range(len(ci_strings))]
+
+
+def _batched_ok(ci_strings, kwargs) -> bool:
+    """The batched native solve serves the default call: several subspaces of up to 4e6 determinants each (26
+    resident vectors per subspace), pyscf's start vector, no per-round log, RDMs on demand."""
+    if len(ci_strings) < 2 or kwargs.get("ci0") is not None or kwargs.get("compute_rdms", "lazy") is True:
+        return False
+    verbose = kwargs.get("verbose")
+    if isinstance(verbose, int) and verbose >= 5:
+        return False
+    if _PROFILE["time_sigma_every"] or "device" in kwargs or "_slot" in kwargs:
+        return False
+    sizes = [len(a) * len(b) for a, b in ci_strings]
+    return 0 < min(sizes) and max(sizes) <= 4_000_000
+
+
+def _solve_sci_batched(ci_strings, one_body_tensor, two_body_tensor, nelec, spin_sq, kwargs) -> list[SCIResult]:
+    """``solve_sci`` of every subspace through ONE native call (``sqd_solve_batch``).  Results are those of the
+    one-by-one loop bit for bit; the states of all but the lowest-energy batch stay on the device until read."""
+    import weakref
+
+    kwargs = dict(kwargs)
+    compute_rdms = kwargs.pop("compute_rdms", "lazy")
+    dk = _davidson_kwargs(kwargs)
+    dk.pop("verbose", None)
+    one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
+    norb = one_body_tensor.shape[0]
+    ctx = _get_context(one_body_tensor, two_body_tensor, 0, slot="batch")
+    _settle_deferred(ctx)
+    out = ctx.solve_batch(ci_strings, spin_sq=spin_sq, shift=0.2, spin_square=False, fetch="best", **dk)
+    _TLS.stats = out["stats"][out["best"]]
+    _TLS.batch_stats = out["stats"]
+    want = tuple(int(x) for x in nelec)
+    results = []
+    for i, (strs_a, strs_b) in enumerate(ci_strings):
+        if out["nelec"][i] != want:
+            raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {out['nelec'][i]} of the CI strings")
+        amps = out["amps"][i]
+        if amps is None:
+            amps = _DeferredAmplitudes(ctx, i, (len(strs_a), len(strs_b)))
+            ctx._deferred.append(weakref.ref(amps))
+        state = SCIState(amplitudes=amps, ci_strs_a=np.asarray(strs_a), ci_strs_b=np.asarray(strs_b), norb=norb, nelec=want)
+        results.append(SCIResult(float(out["energy"][i]), state, orbital_occupancies=(out["occ_a"][i], out["occ_b"][i]),
+                                 _lazy_rdms=(compute_rdms == "lazy")))
+    return results
 
 
 def solve_sci(

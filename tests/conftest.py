@@ -22,8 +22,7 @@ def pytest_configure(config):
 def _build_emu() -> Path:
     """g++ build of the UNMODIFIED kernel sources against tests/emu/hip/hip_runtime.h (logic checks only)."""
     srcs = [CSRC / s for s in HIP_SOURCES]
-    deps = srcs + [CSRC / "sqd_common.h", CSRC / "sqd_device.h", ROOT / "include" / "sqd_hip.h",
-                   EMU_DIR / "hip" / "hip_runtime.h"]
+    deps = srcs + sorted(CSRC.glob("*.h")) + [ROOT / "include" / "sqd_hip.h", EMU_DIR / "hip" / "hip_runtime.h"]
     if EMU_LIB.exists() and all(d.stat().st_mtime <= EMU_LIB.stat().st_mtime for d in deps):
         return EMU_LIB
     EMU_LIB.parent.mkdir(exist_ok=True)

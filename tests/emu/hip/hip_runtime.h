@@ -182,14 +182,15 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
   blk.waves.resize((T + 63) / 64);
   cur_block() = &blk;
   s.body = [&] { kernel(args...); };
-  for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
-      for (int t = 0; t < T; ++t) {
-        fiber_prepare(s.fib[t]);
-        s.fib[t].tl = TL{dim3(t, 0, 0), dim3(bx, by, 0), block, grid};
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        for (int t = 0; t < T; ++t) {
+          fiber_prepare(s.fib[t]);
+          s.fib[t].tl = TL{dim3(t, 0, 0), dim3(bx, by, bz), block, grid};
+        }
+        run_block(T);
       }
-      run_block(T);
-    }
   s.body = nullptr;
   cur_block() = nullptr;
 }

@@ -328,7 +328,7 @@ def test_n2_uniform_solve_vs_reference_flow(hip_lib):
 
 def test_config3_eight_batches_one_gpu(hip_lib):
     """BASELINE config 3 on one GPU: 8 independent 317 x 317 subsample batches of the N2-sized problem through
-    (i) ``solve_sci_batch`` with batches in flight concurrently and (ii) the collective ``solve_sci_batch_distributed``
+    (i) ``solve_sci_batch`` -- the batched native solve and the threads-x-streams path -- and (ii) the collective ``solve_sci_batch_distributed``
     on an RCCL ("nccl") process group of world size 1 -- all-reduce of the (E, occ) records and winner broadcast
     included -- against the one-at-a-time run, bit for bit."""
     import socket
@@ -344,7 +344,8 @@ def test_config3_eight_batches_one_gpu(hip_lib):
     batches = [(O.random_strings(norb, 8, 317, 100 + i), O.random_strings(norb, 8, 317, 200 + i)) for i in range(7)]
     batches.append((O.hf_centred_strings(norb, 8, 317, 1), O.hf_centred_strings(norb, 8, 317, 2)))
     serial = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False, concurrency=1)
-    par = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False)
+    par = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False)  # (the batched native solve)
+    thr = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=False, concurrency=4)  # (threads x streams)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -358,8 +359,8 @@ def test_config3_eight_batches_one_gpu(hip_lib):
         dist.destroy_process_group()
     best = int(np.argmin([r.energy for r in serial]))
     assert best == 7  # the HF-centred batch contains the aufbau determinant
-    for i, (s0, p, c) in enumerate(zip(serial, par, coll)):
-        for r in (p, c):
+    for i, (s0, p, t, c) in enumerate(zip(serial, par, thr, coll)):
+        for r in (p, t, c):
             assert r.energy == s0.energy, i
             assert np.array_equal(r.orbital_occupancies[0], s0.orbital_occupancies[0])
             assert np.array_equal(r.orbital_occupancies[1], s0.orbital_occupancies[1])
