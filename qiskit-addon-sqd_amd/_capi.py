@@ -600,6 +600,19 @@ class Context:
             "generation": self._batch_gen,
         }
 
+    def batch_sub(self, index: int) -> "Context":
+        """Borrowed handle on the sub-context that holds batch ``index`` of the latest ``solve_batch`` (tables + resident
+        solution): ``link_counts``, ``sigma_kernel``, ``sigma_bytes``, RDMs ... until the next batched solve."""
+        sub = object.__new__(Context)
+        sub._lib, sub._h, sub.norb, sub.device = self._lib, _ctxp(), self.norb, self.device
+        self._check(self._lib.sqd_batch_ctx(self._h, int(index), C.byref(sub._h)))
+        sub.na, sub.nb = self._batch_shapes[index]
+        sub.rows = (0, sub.na)
+        sub.nelec = (0, 0)
+        sub._owner = self       # keeps the parent alive
+        sub.close = lambda: None  # owned by the parent context
+        return sub
+
     def batch_state(self, index: int) -> np.ndarray:
         """Amplitudes of batch ``index`` of the latest ``solve_batch`` from their device-resident copy."""
         sh = self._batch_shapes[index]

@@ -793,24 +793,24 @@ struct DavBatchArgs {
 };
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_dots_eig_b(const DavBatchArgs* __restrict__ as) {
-  const DavBatchArgs& a = as[blockIdx.z];
+  const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   dots_eig_body<MV>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
-  const DavBatchArgs& a = as[blockIdx.z];
+  const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   residual_precond_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.hdiag, a.pd, a.part_res, a.width, blockIdx.x, a.gb);
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_orth_dev_b(const DavBatchArgs* __restrict__ as, long long seq) {
-  const DavBatchArgs& a = as[blockIdx.z];
+  const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   orth_dev_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.prm, a.part_res, (int)a.gb, a.width, a.mail, seq, blockIdx.x, a.gb);
 }
 __global__ void k_solution_b(const DavBatchArgs* __restrict__ as) {
-  const DavBatchArgs& a = as[blockIdx.z];
+  const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   solution_body(a.n, a.X, a.n, a.st, a.sol, a.res, blockIdx.x, a.gb);
 }

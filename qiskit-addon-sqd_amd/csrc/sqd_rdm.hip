@@ -447,7 +447,7 @@ __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned 
 __global__ void k_observables(const ObsArgs g) { observables_body(g, blockIdx.x, gridDim.x); }
 // batched (sqd_solve_batch): blockIdx.z = subspace, every subspace on the grid a single solve would give it
 __global__ void k_observables_b(const ObsArgs* __restrict__ gs) {
-  const ObsArgs& g = gs[blockIdx.z];
+  const ObsArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx) return;
   observables_body(g, blockIdx.x, g.gx);
 }

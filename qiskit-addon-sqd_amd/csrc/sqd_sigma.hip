@@ -485,7 +485,7 @@ __global__ __launch_bounds__(1024) void k_sigma(const SigmaArgs g) {
 template <int R, bool SPIN, bool LDSROW, bool PASS>
 __global__ __launch_bounds__(1024) void k_sigma_b(const SigmaArgs* __restrict__ gs) {
   HIP_DYNAMIC_SHARED(double, smem)
-  const SigmaArgs& g = gs[blockIdx.z];
+  const SigmaArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx || blockIdx.y >= g.gy) return;
   sigma_body<R, SPIN, LDSROW, PASS>(g, smem, blockIdx.x, blockIdx.y);
 }
@@ -515,7 +515,7 @@ __global__ void k_sigma_direct(const DirectArgs g) {
 }
 template <bool SPIN>
 __global__ void k_sigma_direct_b(const DirectArgs* __restrict__ gs) {
-  const DirectArgs& g = gs[blockIdx.z];
+  const DirectArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx) return;
   sigma_direct_body<SPIN>(g, blockIdx.x, g.gx);
 }
@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(1024) k_sigma_rows(const DirectArgs g) {
 template <int R, bool SPIN>
 __global__ void __launch_bounds__(1024) k_sigma_rows_b(const DirectArgs* __restrict__ gs) {
   HIP_DYNAMIC_SHARED(double, srow)
-  const DirectArgs& g = gs[blockIdx.z];
+  const DirectArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx) return;
   sigma_rows_body<R, SPIN>(g, srow, blockIdx.x);
 }
@@ -768,7 +768,7 @@ __device__ inline void sigma_reduce_body(const ReduceArgs& g, unsigned bx, unsig
 }
 __global__ void k_sigma_reduce(const ReduceArgs g) { sigma_reduce_body(g, blockIdx.x, blockIdx.y); }
 __global__ void k_sigma_reduce_b(const ReduceArgs* __restrict__ gs) {
-  const ReduceArgs& g = gs[blockIdx.z];
+  const ReduceArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx || blockIdx.y >= g.gy) return;
   sigma_reduce_body(g, blockIdx.x, blockIdx.y);
 }

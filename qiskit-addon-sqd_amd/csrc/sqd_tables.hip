@@ -323,7 +323,7 @@ __device__ inline void tables_count_body(const CountArgs& g, unsigned bx, unsign
 __global__ void k_tables_count(const CountArgs g) { tables_count_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
 // batched: blockIdx.z = problem; the arguments of every problem live in device memory (uniform address: scalar loads)
 __global__ void k_tables_count_b(const CountArgs* __restrict__ gs) {
-  const CountArgs& g = gs[blockIdx.z];
+  const CountArgs& g = gs[blockIdx.z];  // (by reference: the bodies index into the record dynamically)
   if (blockIdx.x >= g.gx) return;
   tables_count_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
@@ -391,7 +391,7 @@ __device__ inline void tables_diag_body(const DiagArgs& g, unsigned bx, unsigned
 }
 __global__ void k_tables_diag(const DiagArgs g) { tables_diag_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
 __global__ void k_tables_diag_b(const DiagArgs* __restrict__ gs) {
-  const DiagArgs& g = gs[blockIdx.z];
+  const DiagArgs& g = gs[blockIdx.z];  // (by reference: the bodies index into the record dynamically)
   if (blockIdx.x >= g.gx) return;
   tables_diag_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
@@ -430,7 +430,7 @@ __device__ inline void tables_fill_body(const FillArgs& g, unsigned bx, unsigned
 }
 __global__ void k_tables_fill(const FillArgs g) { tables_fill_body(g, blockIdx.x, blockIdx.y, gridDim.x); }
 __global__ void k_tables_fill_b(const FillArgs* __restrict__ gs) {
-  const FillArgs& g = gs[blockIdx.z];
+  const FillArgs& g = gs[blockIdx.z];  // (by reference: the bodies index into the record dynamically)
   if (blockIdx.x >= g.gx) return;
   tables_fill_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
@@ -545,7 +545,7 @@ __global__ void k_tables_jds(const JdsArgs g) {
   tables_jds_body(g.n, g.d_ptr, g.d_src, g.d_val, g.jd_src, g.jd_val, blockIdx.x);
 }
 __global__ void k_tables_jds_b(const JdsArgs* __restrict__ gs) {
-  const JdsArgs& g = gs[blockIdx.z];
+  const JdsArgs& g = gs[blockIdx.z];  // (by reference: the bodies index into the record dynamically)
   if (blockIdx.x >= g.gx) return;
   tables_jds_body(g.n, g.d_ptr, g.d_src, g.d_val, g.jd_src, g.jd_val, blockIdx.x);
 }
@@ -629,7 +629,7 @@ __device__ inline void tables_ell_body(const EllArgs& g, unsigned bx, unsigned b
 }
 __global__ void k_tables_ell(const EllArgs g) { tables_ell_body(g, blockIdx.x, blockIdx.y); }
 __global__ void k_tables_ell_b(const EllArgs* __restrict__ gs) {
-  const EllArgs& g = gs[blockIdx.z];
+  const EllArgs& g = gs[blockIdx.z];  // (by reference: the bodies index into the record dynamically)
   if (blockIdx.x >= g.gx) return;
   tables_ell_body(g, blockIdx.x, blockIdx.y);
 }

@@ -20,7 +20,7 @@ from typing import Callable
 import numpy as np
 
 from .counts import bitstring_matrix_to_integers
-from .fermion import SCIResult, solve_sci_batch
+from .fermion import SCIResult, freeze_integrals, solve_sci_batch
 from .sampling import bit_array_to_arrays, postselect_by_hamming_right_and_left, recover_configurations, subsample
 
 
@@ -73,6 +73,10 @@ def _carryover(result: SCIResult, threshold: float, symmetrize_spin: bool):
 # ---- SPMD plumbing (reference ``processes.py:100-134``: ``is_control_process`` / pickle ``broadcast`` over MPI;
 # here the process group is torch.distributed's -- "nccl" = RCCL on MI355X, "gloo" on CPU)
 def _process_group():
+    import sys
+
+    if "torch" not in sys.modules:  # a process group cannot exist without torch: no multi-second import for nothing
+        return None
     try:
         import torch.distributed as dist
     except ImportError:  # pragma: no cover - torch is part of the image
@@ -86,13 +90,37 @@ def _is_control_process(dist) -> bool:
     return dist is None or dist.get_rank() == 0
 
 
+class _ControlError:
+    """An exception raised on the control process, shipped in place of the broadcast's payload so that EVERY rank
+    raises it (the reference leaves the other ranks blocked in the collective until their timeout)."""
+
+    def __init__(self, exc: BaseException):
+        self.kind, self.text = type(exc).__name__, str(exc)
+
+
 def _broadcast(dist, obj):
     """Pickle broadcast from the control process (rank 0); a pass-through outside distributed mode."""
     if dist is None:
+        if isinstance(obj, _ControlError):
+            raise obj.exc
         return obj
     box = [obj]
     dist.broadcast_object_list(box, src=0)
+    if isinstance(box[0], _ControlError):
+        if isinstance(obj, _ControlError) and getattr(obj, "exc", None) is not None:
+            raise obj.exc  # the control process re-raises the original exception
+        raise RuntimeError(f"control process failed: {box[0].kind}: {box[0].text}")
     return box[0]
+
+
+def _guarded(dist, fn):
+    """Run a control-process section; an exception becomes a `_ControlError` payload for the broadcast that follows."""
+    try:
+        return fn()
+    except Exception as exc:  # noqa: BLE001 - shipped to every rank by _broadcast
+        err = _ControlError(exc)
+        err.exc = exc
+        return err
 
 
 def diagonalize_fermionic_hamiltonian(
@@ -151,10 +179,14 @@ def diagonalize_fermionic_hamiltonian(
     rng = np.random.default_rng(seed) if control else None
     if sci_solver is not None:
         solver = sci_solver
-    elif dist is not None:
-        from .distributed import solve_sci_batch_distributed as solver
     else:
-        solver = solve_sci_batch
+        # the integrals are constant over the loop: read-only copies let this package's solvers find their device
+        # context by identity instead of hashing 8 norb^4 bytes on every call (fermion._full_hash)
+        one_body_tensor, two_body_tensor = freeze_integrals(one_body_tensor, two_body_tensor)
+        if dist is not None:
+            from .distributed import solve_sci_batch_distributed as solver
+        else:
+            solver = solve_sci_batch
     raw_bitstrings, raw_probs = bit_array_to_arrays(bit_array)
 
     occupancies = initial_occupancies
@@ -165,7 +197,8 @@ def diagonalize_fermionic_hamiltonian(
     for _ in range(max_iterations):
         # ---- configurations for this iteration (control process only)
         ci_strings = None
-        if control:
+
+        def _prepare():
             if occupancies is None:
                 bitstrings, probs = postselect_by_hamming_right_and_left(
                     raw_bitstrings, raw_probs, hamming_right=n_alpha, hamming_left=n_beta
@@ -179,20 +212,24 @@ def diagonalize_fermionic_hamiltonian(
             else:
                 bitstrings, probs = recover_configurations(raw_bitstrings, raw_probs, occupancies, n_alpha, n_beta, rand_seed=rng)
             batches = subsample(bitstrings, probs, samples_per_batch=samples_per_batch, num_batches=num_batches, rand_seed=rng)
-            ci_strings = [
+            return [
                 _batch_strings(b, norb, symmetrize_spin, include_a, include_b, carry_a, carry_b, max_dim_a, max_dim_b)
                 for b in batches
             ]
+
+        if control:
+            ci_strings = _guarded(dist, _prepare)
         ci_strings = _broadcast(dist, ci_strings)
 
         # ---- the seam (reference fermion.py:432): the only collective step
         results = solver(ci_strings, one_body_tensor, two_body_tensor, norb, nelec)
-        if callback is not None and control:
-            callback(results)
 
         # ---- bookkeeping (control process), then the iteration state to every rank (reference :436-451)
         state = None
-        if control:
+
+        def _bookkeeping():
+            if callback is not None:
+                callback(results)
             winner = min(results, key=lambda r: r.energy)
             new_best = winner if best is None or winner.energy < best.energy else best
             converged = (
@@ -201,7 +238,10 @@ def diagonalize_fermionic_hamiltonian(
                 and np.linalg.norm(np.ravel(occupancies) - np.ravel(winner.orbital_occupancies), ord=np.inf) < occupancies_tol
             )
             carry = (carry_a, carry_b) if converged else _carryover(winner, carryover_threshold, symmetrize_spin)
-            state = (new_best, winner, bool(converged), carry)
+            return (new_best, winner, bool(converged), carry)
+
+        if control:
+            state = _guarded(dist, _bookkeeping)
         best, winner, converged, (carry_a, carry_b) = _broadcast(dist, state)
         if converged:
             break

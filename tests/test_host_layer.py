@@ -56,7 +56,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _capi.load_library()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.sqd_abi_version() == 2
+    assert lib.sqd_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
