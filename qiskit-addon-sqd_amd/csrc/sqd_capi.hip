@@ -219,7 +219,8 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   for (auto& bs : c->bstage) bs.release();
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
-                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo};
+                    &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo,
+                    &c->hdense_a, &c->hdense_b, &c->gdense};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();
@@ -920,7 +921,7 @@ SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
 SQD_API int sqd_sigma_kernel(sqd_ctx* c, int* kind, int* rows_per_workgroup) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
-  if (kind) *kind = c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : 0);
+  if (kind) *kind = c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_dense ? 3 : 0));
   if (rows_per_workgroup) *rows_per_workgroup = c->sig_rows;
   return SQD_OK;
 }

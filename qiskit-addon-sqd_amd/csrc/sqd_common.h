@@ -230,6 +230,13 @@ struct sqd_ctx {
   int sig_rows = 0;              // > 0: k_sigma_rows with this many rows of C per workgroup (implies sig_direct's
                                  // table layout: CSR lists only)
   bool sig_direct = false;       // ultra-sparse coupling: the element-gather kernel k_sigma_direct, no work items
+  // well-connected string sets (same-spin blocks >= ~8 % dense: what the SQD loop's carry-over produces, 20-22 %
+  // measured, profiles/r03/loop_subspaces_probe.txt): the same-spin part H_a C + C H_b runs on the f64 matrix cores
+  // (k_same_spin_mfma) from dense, zero-padded copies of the two symmetric blocks; the work items keep the
+  // opposite-spin terms
+  bool sig_dense = false;
+  int dense_pa = 0, dense_pb = 0;        // padded orders (multiples of 64) = leading dimensions
+  sqd::DevBuf hdense_a, hdense_b, gdense;  // f64[pa*pa], f64[pb*pb], f64[rows*nb] (the product, added by the own-row items)
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
   // LDS capacity (in virtual rows) of the singles' / doubles' partial-sum arrays; a chunk with more

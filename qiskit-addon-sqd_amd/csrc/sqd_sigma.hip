@@ -28,6 +28,11 @@
 
 namespace sqd {
 
+// dense same-spin mode: the matrix-core product is cut into this many partial products over disjoint k ranges (one
+// workgroup each per 64 x 64 tile): a workgroup's chain of dependent loads is 4 x shorter and a single subspace of
+// batch size (25 tiles at 317 x 317) still gives every CU work.  Fixed => the same bits in single and batched solves.
+constexpr int DENSE_SPLIT = 4;
+
 struct SigmaArgs {
   GPtr<const double> c;
   GPtr<double> sigma;
@@ -76,6 +81,11 @@ struct SigmaArgs {
   // input is c + (*vec_index - 1) * c_stride and the output sigma + (*vec_index - 1) * s_stride.
   GPtr<const int> vec_index;
   int64_t c_stride, s_stride;
+  // dense same-spin mode (sqd_ctx::sig_dense): the matrix-core product H_a C + C H_b of this vector, row-major like
+  // sigma, as DENSE_SPLIT partial products over disjoint k ranges (gdense[s * gdense_stride + ...]); the own-row items
+  // add them in order s = 0, 1, ... and carry no same-spin link of their own.  nullptr: sparse same-spin links.
+  GPtr<const double> gdense;
+  int64_t gdense_stride;
   // launch geometry of THIS subspace: threads that work (a batched launch uses the largest workgroup of its class; the
   // surplus threads of a smaller subspace idle), work items, column chunks
   int T;
@@ -128,7 +138,10 @@ __device__ inline double axpy_chunk(const double* __restrict__ C, const uint32_t
 // of a round are issued back to back and waited for once (predicated per-link blocks make the compiler wait
 // for each pair of LDS reads separately -- measured as the pace of the whole kernel).
 // singles on the own row: sum (value + sign * W[pair]) * Crow[src]
-__device__ inline double vrow_singles_own(const SigmaArgs& g, int64_t v, const double* Crow, const double* W2) {
+// (same_spin == false -- dense same-spin mode: the links' own values are in the matrix-core product, only the
+// alpha-occupation term sign * W[pair] is left)
+__device__ inline double vrow_singles_own(const SigmaArgs& g, int64_t v, const double* Crow, const double* W2,
+                                          bool same_spin) {
   const int64_t base = g.esb_sl[v >> 6] + (v & 63);
   const int cnt = g.vs_cnt[v];
   constexpr int PF = 8;
@@ -142,7 +155,7 @@ __device__ inline double vrow_singles_own(const SigmaArgs& g, int64_t v, const d
       vals[u] = 0.0;
       if (k0 + u < cnt) {
         recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
-        vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
+        if (same_spin) vals[u] = g.esb_val[base + (int64_t)(k0 + u) * 64];
       }
     }
     double w[PF], x[PF];
@@ -326,11 +339,12 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
     const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
     const int d1 = (vd0 + g.nvd_max < vd1) ? vd0 + g.nvd_max : vd1;
     if (g.mode == 0) {
+      const bool ssl = (g.gdense == nullptr);
       if (LDSROW) {
-        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, Crow, W2);
+        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, Crow, W2, ssl);
         for (int v = vd0 + tid; v < d1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, Crow);
       } else {
-        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, crow0, W2);
+        for (int v = vs0 + tid; v < s1; v += T) part_s[v - vs0] = vrow_singles_own(g, v, crow0, W2, ssl);
         for (int v = vd0 + tid; v < d1; v += T) part_d[v - vd0] = vrow_doubles_own(g, v, crow0);
       }
     }
@@ -353,6 +367,14 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
           a += own_rows_sum(g.vd_own, B, part_d, vd0, d1);
           // first same-spin alpha links of this row: unit-stride row reads
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
+          // dense same-spin mode: the whole same-spin part of this element, from the matrix-core product
+          if (g.gdense) {
+            double gp[DENSE_SPLIT];
+#pragma unroll
+            for (int sp = 0; sp < DENSE_SPLIT; ++sp) gp[sp] = g.gdense[sp * g.gdense_stride + (A - g.row0) * nb + B];
+#pragma unroll
+            for (int sp = 0; sp < DENSE_SPLIT; ++sp) a += gp[sp];
+          }
         }
         acc[r] = a;
       }
@@ -456,7 +478,7 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
       const int d0 = vd0 + ps * g.nvd_max, d1 = (d0 + g.nvd_max < vd1) ? d0 + g.nvd_max : vd1;
       __syncthreads();  // the previous pass's sums have been consumed
       if (own) {
-        for (int v = s0 + tid; v < s1; v += T) part_s[v - s0] = vrow_singles_own(g, v, Crow, W2);
+        for (int v = s0 + tid; v < s1; v += T) part_s[v - s0] = vrow_singles_own(g, v, Crow, W2, g.gdense == nullptr);
         for (int v = d0 + tid; v < d1; v += T) part_d[v - d0] = vrow_doubles_own(g, v, Crow);
       } else {
         for (int v = s0 + tid; v < s1; v += T)
@@ -735,6 +757,133 @@ __global__ void __launch_bounds__(1024) k_sigma_rows_b(const DirectArgs* __restr
 // sigma[A,:] = sum over the partial rows of A (fixed order) for rows that were split into several items.
 // Workgroup = 64 columns x SL slot lanes: lane sl adds slots sl, sl+SL, ... (independent loads), the SL
 // partial sums meet in LDS and are added in slot-lane order => bitwise reproducible.
+// ---- same-spin part on the f64 matrix cores (dense same-spin mode):  G = H_a C + C H_b  with H_a (na x na), H_b
+// (nb x nb) the dense, zero-padded, SYMMETRIC same-spin blocks (k_tables_dense) and C the na x nb vector.  MFMA is used
+// here because the blocks of the sets the SQD loop produces are 20-22 % dense: enumerating the links costs two LDS
+// gathers per multiply-add, the dense product none, and 5 x the flops on v_mfma_f64_16x16x4_f64 are cheaper.
+// One workgroup (4 wavefronts) = one 64 x 64 tile of G; wavefront w owns the 32 x 32 quadrant (w / 2, w % 2) as 2 x 2
+// MFMA tiles (16 f64 accumulators per lane).  Both products run through the same loop over chunks of DK = 32 k: the 64 x 32
+// operand tiles are staged in LDS k-major -- H_a[i][k] is read as H_a[k][i] (symmetric: coalesced), the rows of C for
+// the second product are transposed on the way in (pitch 65) -- so every fragment read is 16 consecutive doubles.
+// Register-staged double buffering: the global loads of chunk c + 1 are in flight while chunk c is multiplied.
+// Fixed order of accumulation: the same bits on every run, and in a batched launch.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+struct DenseArgs {
+  GPtr<const double> c;   // the vector(s): na x nb, row-major
+  GPtr<double> g;         // the product, na x nb
+  GPtr<const double> ha, hb;
+  int64_t na, nb;
+  int pa, pb;             // leading dimensions (multiples of 64)
+  GPtr<const int> stop, vec_index;
+  int64_t c_stride;
+  unsigned tj;            // tiles along B
+  unsigned gx;            // tiles of this subspace (x DENSE_SPLIT workgroups: blockIdx.y = k range)
+};
+constexpr int DT = 64, DK = 32, DPITCH = DT + 1, DU = DT * DK / 256;  // DU: elements per thread and operand tile
+__device__ inline void same_spin_mfma_body(const DenseArgs& g, double* smem, unsigned bx, unsigned by) {
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  const double* __restrict__ Ha = g.ha;
+  const double* __restrict__ Hb = g.hb;
+  const int64_t na = g.na, nb = g.nb;
+  const int pa = g.pa, pb = g.pb;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int wi = wv >> 1, wj = wv & 1;
+  const int64_t i0 = (int64_t)(bx / g.tj) * DT, j0 = (int64_t)(bx % g.tj) * DT;
+  double* sA[2] = {smem, smem + 2 * DK * DPITCH};
+  double* sB[2] = {smem + DK * DPITCH, smem + 3 * DK * DPITCH};
+  // chunk list: product 1 over k in [0, na16), then product 2 over k in [0, nb16)
+  const int n1 = (int)((na + DK - 1) / DK), n2 = (int)((nb + DK - 1) / DK), nch = n1 + n2;
+  double ra[DU], rb[DU];
+  auto fetch = [&](int ch) {  // this thread's 4 + 4 elements of chunk ch's operand tiles, into registers
+    if (ch < n1) {
+      const int64_t k0 = (int64_t)ch * DK;
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int e = t + 256 * u, kk = e >> 6, cc = e & 63;
+        ra[u] = Ha[(k0 + kk) * pa + i0 + cc];                                  // H_a[i0+cc][k0+kk] (symmetric)
+        const int64_t kr = k0 + kk, jc = j0 + cc;
+        rb[u] = (kr < na && jc < nb) ? C[kr * nb + jc] : 0.0;                  // C[k0+kk][j0+cc]
+      }
+    } else {
+      const int64_t k0 = (int64_t)(ch - n1) * DK;
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int e = t + 256 * u;
+        const int ii = e / DK, k2 = e % DK;                                    // DK consecutive k of one row of C
+        const int64_t ir = i0 + ii, kc = k0 + k2;
+        ra[u] = (ir < na && kc < nb) ? C[ir * nb + kc] : 0.0;                  // C[i0+ii][k0+k2]
+        const int kk = e >> 6, cc = e & 63;
+        rb[u] = Hb[(k0 + kk) * pb + j0 + cc];                                  // H_b[k0+kk][j0+cc]
+      }
+    }
+  };
+  auto park = [&](int ch, int buf) {  // registers -> LDS, k-major
+    double* a = sA[buf];
+    double* b = sB[buf];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int e = t + 256 * u;
+      if (ch < n1) a[(e >> 6) * DPITCH + (e & 63)] = ra[u];
+      else a[(e % DK) * DPITCH + (e / DK)] = ra[u];
+      b[(e >> 6) * DPITCH + (e & 63)] = rb[u];
+    }
+  };
+  mfma_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  // this workgroup's share of the chunk list (by = which of the DENSE_SPLIT partial products)
+  const int ch0 = (int)((int64_t)nch * by / DENSE_SPLIT), ch1 = (int)((int64_t)nch * (by + 1) / DENSE_SPLIT);
+  if (ch0 < ch1) {
+    fetch(ch0);
+    park(ch0, ch0 & 1);
+  }
+  __syncthreads();
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < ch1) fetch(ch + 1);
+    const double* a = sA[buf];
+    const double* b = sB[buf];
+#pragma unroll
+    for (int k4 = 0; k4 < DK / 4; ++k4) {
+      const int kr = (k4 * 4 + lk) * DPITCH;
+      const double a0 = a[kr + wi * 32 + li], a1 = a[kr + wi * 32 + 16 + li];
+      const double b0 = b[kr + wj * 32 + li], b1 = b[kr + wj * 32 + 16 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (ch + 1 < ch1) park(ch + 1, buf ^ 1);
+    __syncthreads();
+  }
+  double* __restrict__ G = g.g + (int64_t)by * na * nb;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = i0 + wi * 32 + a * 16 + lk + 4 * r, col = j0 + wj * 32 + b * 16 + li;
+        if (row < na && col < nb) G[row * nb + col] = acc[a][b][r];
+      }
+}
+constexpr size_t DENSE_SHMEM = (size_t)4 * DK * DPITCH * 8;  // two buffers x two operand tiles
+__global__ void __launch_bounds__(256) k_same_spin_mfma(const DenseArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  same_spin_mfma_body(g, smem, blockIdx.x, blockIdx.y);
+}
+__global__ void __launch_bounds__(256) k_same_spin_mfma_b(const DenseArgs* __restrict__ gs) {
+  HIP_DYNAMIC_SHARED(double, smem)
+  const DenseArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
+  if (blockIdx.x >= g.gx) return;
+  same_spin_mfma_body(g, smem, blockIdx.x, blockIdx.y);
+}
+
 struct ReduceArgs {
   GPtr<const MultiRow> rows;
   GPtr<const double> partial;
@@ -991,6 +1140,38 @@ static void fill_sigma_args(sqd_ctx* c, const double* d_c, double* d_sigma, int 
   g.T = c->sig_T;
   g.gx = (unsigned)c->n_items;
   g.gy = (unsigned)c->sig_nchunks;
+  g.gdense = (c->sig_dense && mode == 0) ? c->gdense.as<double>() : nullptr;
+  g.gdense_stride = c->na * c->nb;
+}
+// the product kernels' dynamic LDS is beyond the 64 KB a kernel gets without asking: once per device
+static int grant_dense_shmem(sqd_ctx* c) {
+  static std::atomic<int> granted[64];
+  const int dev = c->device & 63;
+  if (!granted[dev].load(std::memory_order_relaxed)) {
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_same_spin_mfma),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_SHMEM));
+    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_same_spin_mfma_b),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_SHMEM));
+    granted[dev].store(1, std::memory_order_relaxed);
+  }
+  return SQD_OK;
+}
+// arguments of the matrix-core same-spin product for the vector the work items of the same sigma build will read
+static void fill_dense_args(sqd_ctx* c, const double* d_c, int64_t in_stride, DenseArgs* dp) {
+  DenseArgs& d = *dp;
+  d.c = d_c;
+  d.g = c->gdense.as<double>();
+  d.ha = c->hdense_a.as<double>();
+  d.hb = c->hdense_b.as<double>();
+  d.na = c->na;
+  d.nb = c->nb;
+  d.pa = c->dense_pa;
+  d.pb = c->dense_pb;
+  d.stop = c->sigma_stop;
+  d.vec_index = (c->sigma_index && in_stride) ? c->sigma_index : nullptr;
+  d.c_stride = in_stride;
+  d.tj = (unsigned)((c->nb + DT - 1) / DT);
+  d.gx = d.tj * (unsigned)((c->na + DT - 1) / DT);
 }
 // does a work-item sigma build of this subspace need the k_sigma_reduce launch behind it?  (Inside a Davidson run the
 // first reader of the new vector adds the partial rows instead.)
@@ -1019,6 +1200,13 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   SigmaArgs g;
   fill_sigma_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);
+  if (g.gdense) {
+    DenseArgs d;
+    fill_dense_args(c, d_c, in_stride, &d);
+    SQD_TRY(grant_dense_shmem(c));
+    hipLaunchKernelGGL(k_same_spin_mfma, dim3(d.gx, DENSE_SPLIT), dim3(256), DENSE_SHMEM, c->stream, d);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
   const int R = c->sig_R;
   int rc;
   if (!c->sig_lds_rows) rc = (R <= 1) ? launch_sigma_g<1>(c, g) : launch_sigma_g<4>(c, g);
@@ -1055,7 +1243,7 @@ static int work_item_R(const sqd_ctx* c) {
   return R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : R <= 8 ? 8 : 16;
 }
 size_t sigma_batch_bytes(size_t nsub) {
-  return nsub * (sizeof(SigmaArgs) + sizeof(DirectArgs) + sizeof(ReduceArgs) + 3 * 64) + 256;
+  return nsub * (sizeof(SigmaArgs) + sizeof(DirectArgs) + sizeof(ReduceArgs) + sizeof(DenseArgs) + 4 * 64) + 256;
 }
 int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const double*>& d_c,
                      const std::vector<double*>& d_sigma, int mode, bool spin, double ss, double shift,
@@ -1093,6 +1281,32 @@ int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const 
         fill_direct_args(c, d_c[idx[k]], d_sigma[idx[k]], mode, spin, ss, shift, st, st, &g);
         reinterpret_cast<DirectArgs*>(h + at)[k] = g;
         L.gx = g.gx > L.gx ? g.gx : L.gx;
+      }
+      plan->launches.push_back(L);
+    }
+  }
+  // the matrix-core same-spin products of the subspaces in dense mode (in front of their work items)
+  if (mode == 0) {
+    std::vector<int> idx;
+    for (int p = 0; p < n; ++p)
+      if (!subs[p]->sig_direct && subs[p]->sig_dense) idx.push_back(p);
+    if (!idx.empty()) {
+      const size_t at = take(idx.size() * sizeof(DenseArgs));
+      SigmaBatchPlan::Launch L;
+      L.kind = 4;
+      L.R = 0;
+      L.spin = false;
+      L.T = 256;
+      L.shmem = 0;
+      L.gx = L.gy = 1;
+      L.n = (int)idx.size();
+      L.args = d + at;
+      for (size_t k = 0; k < idx.size(); ++k) {
+        sqd_ctx* c = subs[idx[k]];
+        DenseArgs da;
+        fill_dense_args(c, d_c[idx[k]], stride_scale ? c->D : 0, &da);
+        reinterpret_cast<DenseArgs*>(h + at)[k] = da;
+        L.gx = da.gx > L.gx ? da.gx : L.gx;
       }
       plan->launches.push_back(L);
     }
@@ -1182,6 +1396,10 @@ int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan) {
       else
         hipLaunchKernelGGL((k_sigma_direct_b<false>), dim3(L.gx, 1, (unsigned)L.n), dim3(256), 0, parent->stream,
                            reinterpret_cast<const DirectArgs*>(L.args));
+    } else if (L.kind == 4) {
+      SQD_TRY(grant_dense_shmem(parent));
+      hipLaunchKernelGGL(k_same_spin_mfma_b, dim3(L.gx, DENSE_SPLIT, (unsigned)L.n), dim3(256), DENSE_SHMEM, parent->stream,
+                         reinterpret_cast<const DenseArgs*>(L.args));
     } else if (L.kind == 3) {
       hipLaunchKernelGGL(k_sigma_reduce_b, dim3(L.gx, L.gy, (unsigned)L.n), dim3(512), 0, parent->stream,
                          reinterpret_cast<const ReduceArgs*>(L.args));

@@ -550,6 +550,37 @@ __global__ void k_tables_jds_b(const JdsArgs* __restrict__ gs) {
   tables_jds_body(g.n, g.d_ptr, g.d_src, g.d_val, g.jd_src, g.jd_val, blockIdx.x);
 }
 
+// Dense, zero-padded copy of one spin's same-spin block (singles' same-spin value + doubles), row `bx`: the operand of
+// k_same_spin_mfma.  The block is symmetric and every row's CSR lists hold all of its sources, so a workgroup writes
+// its row alone: zero, barrier, scatter.  by = spin.
+struct DenseFillArgs {
+  int64_t n[2];
+  int P[2];
+  GPtr<const int64_t> s_ptr[2], d_ptr[2];
+  GPtr<const SRec> s_rec[2];
+  GPtr<const double> s_val[2], d_val[2];
+  GPtr<const uint32_t> d_src[2];
+  GPtr<double> out[2];
+  unsigned gx;
+};
+__device__ inline void tables_dense_body(const DenseFillArgs& g, unsigned bx, unsigned by) {
+  const int P = g.P[by];
+  if ((int)bx >= P) return;
+  double* __restrict__ row = g.out[by] + (int64_t)bx * P;
+  for (int j = threadIdx.x; j < P; j += blockDim.x) row[j] = 0.0;
+  __syncthreads();
+  if ((int64_t)bx >= g.n[by]) return;
+  const int64_t s0 = g.s_ptr[by][bx], s1 = g.s_ptr[by][bx + 1], d0 = g.d_ptr[by][bx], d1 = g.d_ptr[by][bx + 1];
+  for (int64_t l = s0 + threadIdx.x; l < s1; l += blockDim.x) row[g.s_rec[by][l].src] = g.s_val[by][l];
+  for (int64_t l = d0 + threadIdx.x; l < d1; l += blockDim.x) row[g.d_src[by][l]] = g.d_val[by][l];
+}
+__global__ void k_tables_dense(const DenseFillArgs g) { tables_dense_body(g, blockIdx.x, blockIdx.y); }
+__global__ void k_tables_dense_b(const DenseFillArgs* __restrict__ gs) {
+  const DenseFillArgs& g = gs[blockIdx.z];  // (by reference: indexed dynamically)
+  if (blockIdx.x >= g.gx) return;
+  tables_dense_body(g, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------ capped sliced ELL (column role)
 // Lanes of the sigma kernel would map to beta strings, so one string with hundreds of links (the
 // Hartree-Fock neighbourhood) would stall its whole wavefront and leave the LDS pipe running mostly
@@ -798,12 +829,14 @@ static int build_sigma_work(sqd_ctx* c) {
     row.clear();
     const int64_t s0 = c->h_sptr[A], s1 = c->h_sptr[A + 1];
     const int64_t h0 = s0 + c->h_dptr[A], h1 = s1 + c->h_dptr[A + 1];
-    WorkItem own{h0, (uint32_t)A, 0, (uint16_t)((h1 - h0 < L0) ? (h1 - h0) : L0), -1, 0};
+    // (dense same-spin blocks: the alpha links are in the matrix-core product, no AXPY work in any item)
+    WorkItem own{h0, (uint32_t)A, 0, (uint16_t)(c->sig_dense ? 0 : ((h1 - h0 < L0) ? (h1 - h0) : L0)), -1, 0};
     row.push_back(own);
     for (int64_t l = s0; l < s1; l += K)
       row.push_back(WorkItem{l, (uint32_t)A, 1, (uint16_t)((s1 - l < K) ? (s1 - l) : K), -1, 0});
-    for (int64_t l = h0 + L0; l < h1; l += L)
-      row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
+    if (!c->sig_dense)
+      for (int64_t l = h0 + L0; l < h1; l += L)
+        row.push_back(WorkItem{l, (uint32_t)A, 2, (uint16_t)((h1 - l < L) ? (h1 - l) : L), -1, 0});
     if (row.size() > 1) {  // several items: partial rows + fixed-order reduce
       multi.push_back(MultiRow{(uint32_t)A, nslots, (int32_t)row.size()});
       c->h_rowinfo[2 * (A - c->row0)] = nslots;
@@ -898,7 +931,9 @@ struct SubspaceBuild {
   FillArgs fill;
   EllArgs ell;
   JdsArgs jds;
-  bool have_fill = false, have_ell = false, have_jds = false;
+  DenseFillArgs dense;
+  bool have_fill = false, have_ell = false, have_jds = false, have_dense = false;
+  std::vector<int64_t> zero_ptr;  // dense same-spin blocks: the beta doubles leave the work items (empty lists)
   unsigned ell_gx = 0;
   struct Up {
     DevBuf* buf;
@@ -1154,9 +1189,42 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
   c->D = na * nb;
   c->nelec[0] = nocc[0];
   c->nelec[1] = nocc[1];
-  b.have_ell = b.have_jds = false;
+  b.have_ell = b.have_jds = b.have_dense = false;
   b.ups.clear();
   b.blob_bytes = 0;
+  // Dense same-spin blocks on the matrix cores: connected sets of batch size (the SQD loop's carry-over sets are 20-22 %
+  // dense in both spins at 200-550 strings per spin; HF-centred synthetic sets 22-26 %).  Below ~8 % the sparse work
+  // items do less work than the padded dense product; SQD_SIGMA_DENSE=1 / 0 forces / forbids (tests run both).
+  {
+    bool dense = !c->sig_direct && row0 == 0 && row1 == na && na <= 4096 && nb <= 4096 &&
+                 (double)(tot[0] + tot[1]) >= 0.08 * (double)na * (double)na &&
+                 (double)(tot[2] + tot[3]) >= 0.08 * (double)nb * (double)nb;
+    if (const char* env = std::getenv("SQD_SIGMA_DENSE"))
+      dense = std::atoi(env) != 0 && !c->sig_direct && row0 == 0 && row1 == na && na <= 4096 && nb <= 4096;
+    c->sig_dense = dense;
+    if (dense) {
+      c->dense_pa = (int)((na + 63) / 64 * 64);
+      c->dense_pb = (int)((nb + 63) / 64 * 64);
+      SQD_TRY(c->hdense_a.reserve((size_t)c->dense_pa * c->dense_pa * 8));
+      SQD_TRY(c->hdense_b.reserve((size_t)c->dense_pb * c->dense_pb * 8));
+      SQD_TRY(c->gdense.reserve((size_t)4 * na * nb * 8));  // DENSE_SPLIT partial products (sqd_sigma.hip)
+      DenseFillArgs& d = b.dense;
+      for (int s = 0; s < 2; ++s) {
+        const SpinTables& t = c->sp[s];
+        d.n[s] = t.n;
+        d.P[s] = s ? c->dense_pb : c->dense_pa;
+        d.s_ptr[s] = t.s_ptr.as<int64_t>();
+        d.d_ptr[s] = t.d_ptr.as<int64_t>();
+        d.s_rec[s] = t.s_rec.as<SRec>();
+        d.s_val[s] = t.s_val.as<double>();
+        d.d_val[s] = t.d_val.as<double>();
+        d.d_src[s] = t.d_src.as<uint32_t>();
+        d.out[s] = (s ? c->hdense_b : c->hdense_a).as<double>();
+      }
+      d.gx = (unsigned)(c->dense_pa > c->dense_pb ? c->dense_pa : c->dense_pb);
+      b.have_dense = true;
+    }
+  }
   if (c->sig_direct) {
     // the element-gather sigma kernel reads the CSR lists as they are: no work items, no ELL copies, no merged
     // same-spin list, no descriptor upload -- launch D does not exist
@@ -1215,12 +1283,17 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
     if (forced_pass < 1 || !lds_rows) forced_pass = 0;
   }
   int64_t pass_s = 0, pass_d = 0;
+  const int64_t* dptr_b = c->h_dptr_b;
+  if (c->sig_dense) {  // the beta doubles are in the dense block: empty lists for the work items
+    b.zero_ptr.assign((size_t)nb + 1, 0);
+    dptr_b = b.zero_ptr.data();
+  }
   for (;;) {
     if (!lds_rows) chunk_cols = forced ? forced : 4096;
     const size_t target = lds_rows ? 40 * 1024 : 120 * 1024;
     for (cap = cap0;; cap *= 2) {
       make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
-      make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
+      make_vrows(dptr_b, nb, cap, chunk_cols, vd);
       if ((size_t)(vs.nv_max + vd.nv_max) * 8 <= target || cap >= (1 << 20)) break;
     }
     const size_t part_bytes = (size_t)(vs.nv_max + vd.nv_max) * 8 + 64;
@@ -1235,7 +1308,7 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
       if (avail >= 24 * 1024 || forced_pass) {
         cap = cap0 < 32 && !forced_pass ? 32 : cap0;  // moderate rows: balance without a row per 8 links
         make_vrows(c->h_sptr_b, nb, cap, chunk_cols, vs);
-        make_vrows(c->h_dptr_b, nb, cap, chunk_cols, vd);
+        make_vrows(dptr_b, nb, cap, chunk_cols, vd);
         const int64_t entries = (int64_t)(avail / 8);
         pass_s = forced_pass ? forced_pass : entries / 4;
         if (pass_s > vs.nv_max) pass_s = vs.nv_max;
@@ -1258,6 +1331,10 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
   c->sig_lds_rows = lds_rows;
   c->sig_ps = pass_s;
   c->sig_pd = pass_d;
+  if (c->sig_dense && vd.total != 0) {
+    set_error("internal: dense same-spin mode with beta doubles left in the work items");
+    return SQD_ERR_STATE;
+  }
   c->sig_chunk = chunk_cols;
   c->sig_nchunks = (int)((nb + chunk_cols - 1) / chunk_cols);
   c->sig_kmax = 4;
@@ -1318,7 +1395,7 @@ static void subspace_phase2_place(sqd_ctx* c, SubspaceBuild& b, char* h_blob, ch
   g.hs_src = ta.hs_src.as<uint32_t>();
   g.hs_val = ta.hs_val.as<double>();
   g.nv_s = t.n_s > 0 ? c->hv_s.nv : 0;
-  g.nv_d = t.n_d > 0 ? c->hv_d.nv : 0;
+  g.nv_d = (t.n_d > 0 && !c->sig_dense) ? c->hv_d.nv : 0;
   g.vs_cnt = t.vs_cnt.as<int32_t>();
   g.vd_cnt = t.vd_cnt.as<int32_t>();
   g.vs_start = t.vs_start.as<int64_t>();
@@ -1366,6 +1443,10 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   if (b.have_jds) {
     hipLaunchKernelGGL(k_tables_jds, dim3(b.jds.gx), dim3(256), 0, st, b.jds);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (b.have_dense) {
+    hipLaunchKernelGGL(k_tables_dense, dim3(b.dense.gx, 2), dim3(256), 0, st, b.dense);
     SQD_HIP_CHECK(hipGetLastError());
   }
   if (b.have_ell) {
@@ -1464,20 +1545,21 @@ int build_subspace_batch(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, con
   }
   BatchStage& s2 = parent->bstage[1];
   off = 0;
-  int n_ell = 0, n_jds = 0;
+  int n_ell = 0, n_jds = 0, n_dense = 0;
   for (int p = 0; p < n; ++p) {
     n_ell += bs[p].have_ell;
     n_jds += bs[p].have_jds;
+    n_dense += bs[p].have_dense;
   }
   const size_t o_fill = stage_take<FillArgs>(off, n), o_ell = stage_take<EllArgs>(off, n_ell),
-               o_jds = stage_take<JdsArgs>(off, n_jds);
+               o_jds = stage_take<JdsArgs>(off, n_jds), o_dense = stage_take<DenseFillArgs>(off, n_dense);
   std::vector<size_t> o_blob(n, 0);
   for (int p = 0; p < n; ++p)
     if (bs[p].have_ell) o_blob[p] = stage_take<char>(off, bs[p].blob_bytes);
   SQD_TRY(s2.reserve(off));
   char* d2 = static_cast<char*>(s2.dev.p);
-  unsigned gx_fill = 0, gx_ell = 0, gx_jds = 0;
-  int i_ell = 0, i_jds = 0;
+  unsigned gx_fill = 0, gx_ell = 0, gx_jds = 0, gx_dense = 0;
+  int i_ell = 0, i_jds = 0, i_dense = 0;
   for (int p = 0; p < n; ++p) {
     subspace_phase2_place(subs[p], bs[p], s2.host + o_blob[p], d2 + o_blob[p]);
     reinterpret_cast<FillArgs*>(s2.host + o_fill)[p] = bs[p].fill;
@@ -1490,6 +1572,10 @@ int build_subspace_batch(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, con
       reinterpret_cast<JdsArgs*>(s2.host + o_jds)[i_jds++] = bs[p].jds;
       gx_jds = bs[p].jds.gx > gx_jds ? bs[p].jds.gx : gx_jds;
     }
+    if (bs[p].have_dense) {
+      reinterpret_cast<DenseFillArgs*>(s2.host + o_dense)[i_dense++] = bs[p].dense;
+      gx_dense = bs[p].dense.gx > gx_dense ? bs[p].dense.gx : gx_dense;
+    }
   }
   SQD_HIP_CHECK(hipMemcpyAsync(d2, s2.host, off, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_tables_fill_b, dim3(gx_fill, 2, n), dim3(256), 0, st,
@@ -1498,6 +1584,11 @@ int build_subspace_batch(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, con
   if (n_jds) {
     hipLaunchKernelGGL(k_tables_jds_b, dim3(gx_jds, 1, n_jds), dim3(256), 0, st,
                        reinterpret_cast<const JdsArgs*>(d2 + o_jds));
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (n_dense) {
+    hipLaunchKernelGGL(k_tables_dense_b, dim3(gx_dense, 2, n_dense), dim3(256), 0, st,
+                       reinterpret_cast<const DenseFillArgs*>(d2 + o_dense));
     SQD_HIP_CHECK(hipGetLastError());
   }
   if (n_ell) {

@@ -256,6 +256,19 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
   return emu_exchange(v, (lane / width) * width + (src % width));
 }
 inline int __builtin_amdgcn_readlane(int v, int src) { return emu_exchange(v, src); }
+// v_mfma_f64_16x16x4_f64: D (16 x 16) = A (16 x 4) B (4 x 16) + C.  Lane l = (lk = l / 16, li = l % 16) holds A[li][lk],
+// B[lk][li] and the four elements D[lk + 4 r][li], r = 0..3 (the layout the product kernels are written for).
+#define ext_vector_type(n) vector_size(8 * (n))
+typedef double emu_d4 __attribute__((vector_size(32)));
+inline emu_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_d4 c, int, int, int) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  emu_d4 d = c;
+  for (int k = 0; k < 4; ++k) {
+    const double bk = emu_exchange(b, k * 16 + li);
+    for (int r = 0; r < 4; ++r) d[r] += emu_exchange(a, k * 16 + lk + 4 * r) * bk;
+  }
+  return d;
+}
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -27,6 +27,7 @@ def test_emu_full_parity(emu_lib, norb, nelec, na, nb, seed, hf):
 def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
     # SQD_ELL_CAP=3 cuts the beta link lists into many overflow chunks (virtual rows): the partial sums
     # that travel through LDS must reproduce the same sigma / ground state
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
     run_operator_parity(emu_lib, 6, (2, 3), 9, 14, 5, False)
@@ -35,6 +36,7 @@ def test_emu_capped_ell_overflow_rows(emu_lib, monkeypatch):
 def test_emu_many_axpy_items(emu_lib, monkeypatch):
     # SQD_SIGMA_L=2 cuts the same-spin alpha links into many 2-link AXPY items per row (partial rows + the
     # fixed-order reduce with many slots per row)
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_L", "2")
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
@@ -69,6 +71,7 @@ def test_emu_global_row_fallback(emu_lib, monkeypatch):
     # SQD_SIGMA_GLOBAL_ROWS=64 forces the path taken when a C row does not fit LDS: rows are read in
     # place, one alpha link per batch, and the beta side is cut into 64-column chunks (here 2 chunks,
     # the second ragged) with their own virtual-row ranges
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
     run_full_parity(emu_lib, 8, (3, 4), 12, 70, 23, False, variants=False)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
@@ -79,6 +82,7 @@ def test_emu_multi_pass_partial_sums(emu_lib, monkeypatch):
     # SQD_SIGMA_PASS=5 leaves LDS room for only 5 partial sums per list: the virtual rows of the staged
     # row are walked in several passes (the layout of rows with ~10^4 strings), singles and doubles needing
     # different numbers of passes
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_PASS", "5")
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
     # 420 / 840 virtual rows in passes of 40, two column strides per thread (64 threads: the emulator's
@@ -166,3 +170,23 @@ def test_emu_invalid_inputs(emu_lib):
             ctx.set_subspace(np.array([], dtype=np.int64), sb)
         with pytest.raises(_capi.SQDNativeError, match="no subspace"):
             ctx.hdiag()
+
+
+def test_emu_dense_same_spin_mfma(emu_lib, monkeypatch):
+    # SQD_SIGMA_DENSE=1 forces the mode connected string sets take by default (same-spin blocks >= 8 % dense): the
+    # same-spin part H_a C + C H_b as one dense product on the f64 matrix cores (v_mfma_f64_16x16x4_f64, emulated
+    # lane for lane here), the work items keeping the opposite-spin terms.  Ragged tiles (70 and 20 against 64), all
+    # operator forms, Davidson, RDMs
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "1")
+    monkeypatch.setenv("SQD_SIGMA_DIRECT", "0")
+    h1, eri, sa, sb = make_problem(7, (3, 3), 20, 20, 7, True)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_same_spin_mfma+k_sigma"
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
+    run_operator_parity(emu_lib, 9, (4, 2), 70, 30, 31, True)
+    monkeypatch.delenv("SQD_SIGMA_DENSE")
+    monkeypatch.delenv("SQD_SIGMA_DIRECT")
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:  # default selection: 20 HF-centred strings of 7 orbitals are dense
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_same_spin_mfma+k_sigma"

@@ -128,6 +128,7 @@ def test_rows_sigma_kernel_ragged_against_work_items(hip_lib, monkeypatch, na, n
 
 
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
     run_full_parity(hip_lib, 7, (3, 3), 20, 20, 7, True)
     run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
@@ -135,6 +136,7 @@ def test_capped_ell_overflow_rows(hip_lib, monkeypatch):
 
 def test_many_axpy_items_forced(hip_lib, monkeypatch):
     # many small AXPY items per row: partial rows + the fixed-order reduce with many slots per row
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_L", "2")
     run_full_parity(hip_lib, 10, (5, 5), 40, 37, 11, True)
     run_full_parity(hip_lib, 8, (4, 4), 70, 70, 17, False, variants=False)
@@ -142,6 +144,7 @@ def test_many_axpy_items_forced(hip_lib, monkeypatch):
 
 def test_global_row_fallback_forced(hip_lib, monkeypatch):
     # the path for rows that do not fit LDS, forced at a size the oracle can check (3 column chunks)
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_GLOBAL_ROWS", "64")
     run_full_parity(hip_lib, 10, (5, 5), 40, 150, 31, True)
     run_full_parity(hip_lib, 12, (2, 6), 3, 924, 19, False)
@@ -149,6 +152,7 @@ def test_global_row_fallback_forced(hip_lib, monkeypatch):
 
 def test_multi_pass_partial_sums_forced(hip_lib, monkeypatch):
     # LDS room for 48 partial sums per list: the staged row's virtual rows are walked in many passes
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (the sparse same-spin work items are what this test is about)
     monkeypatch.setenv("SQD_SIGMA_PASS", "48")
     run_full_parity(hip_lib, 10, (5, 5), 40, 150, 31, True)
     monkeypatch.setenv("SQD_ELL_CAP", "3")
@@ -246,7 +250,7 @@ def test_n2_headline_properties(hip_lib, hf):
         assert s2 > -1e-9
 
 
-def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8):
+def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8, kernel=None):
     """sigma, hdiag, E0, occupancies and the state itself at a BASELINE size against the oracles:
     O1s = string-space evaluation of the decomposition that ``build_php`` forms densely (numpy, independent of
     the J-table / hdiag split of the kernels), O2 = the C restatement of pyscf's contract_2e.  Tolerances:
@@ -259,6 +263,8 @@ def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8):
     x = np.random.default_rng(7).standard_normal((n, n))
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
+        if kernel is not None:
+            assert ctx.sigma_kernel() == kernel
         hd = ctx.hdiag()
         s_gpu = ctx.sigma(x)
         x0 = ctx.init_guess()
@@ -287,17 +293,26 @@ def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8):
     return e, e_ref
 
 
-@pytest.mark.parametrize("hf", [False, True])
-def test_n2_full_size_against_oracles(hip_lib, hf):
+@pytest.mark.parametrize("hf,dense", [(False, None), (True, "1"), (True, "0")])
+def test_n2_full_size_against_oracles(hip_lib, monkeypatch, hf, dense):
     """BASELINE headline size, N2 (16e,30o) 317 x 317 = 100 489 determinants, both string generators: the full
-    sigma vector against O1s and O2, E0 / occupancies / state against the oracle's own Davidson."""
-    _full_size_checks(hip_lib, 30, 8, 317, hf, (1, 2), with_o2=True)
+    sigma vector against O1s and O2, E0 / occupancies / state against the oracle's own Davidson.  The HF-centred set
+    (same-spin blocks 22-26 % dense) selects the matrix-core same-spin product by default; it is run in that mode and
+    with the sparse same-spin work items (SQD_SIGMA_DENSE=0)."""
+    kernel = "k_sigma_direct"
+    if hf:
+        if dense == "0":
+            monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
+        kernel = "k_same_spin_mfma+k_sigma" if dense == "1" else "k_sigma"
+    _full_size_checks(hip_lib, 30, 8, 317, hf, (1, 2), with_o2=True, kernel=kernel)
 
 
-@pytest.mark.parametrize("hf", [False, True])
-def test_fes_full_size_against_oracle(hip_lib, hf):
+@pytest.mark.parametrize("hf,dense", [(False, None), (True, "1"), (True, "0")])
+def test_fes_full_size_against_oracle(hip_lib, monkeypatch, hf, dense):
     """BASELINE config 4's size, (30e,40o) 707 x 707 = 499 849 determinants: full sigma, E0, occupancies against
     O1s (O2's dense formulation needs 1.3e14 flop per sigma at this size -- minutes -- and is left out)."""
+    if dense == "0":
+        monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
     _full_size_checks(hip_lib, 40, 15, 707, hf, (5, 6), with_o2=False)
 
 
