@@ -60,6 +60,14 @@ int sqd_ctx_destroy(sqd_ctx* ctx);
  * outlive the context; call between solves (the previous stream is drained first).  No counterpart in
  * the reference: pyscf is host code. */
 int sqd_ctx_use_stream(sqd_ctx* ctx, void* stream);
+/* From now on every sqd_solve / sqd_solve_strings / sqd_solve_batch of this context ALSO leaves the raw record of its
+ * observables in device memory at d_record (batch p of sqd_solve_batch: d_record + p * stride doubles):
+ *   {e_davidson, c.Hc (0 here), c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}  -- 5 + 2 norb doubles, un-normalised;
+ * energy = e_davidson - shift * penalty, occupancies = occ / c.c exactly as the call's host outputs are formed.
+ * Written by the observables kernel itself, so a collective on the same stream (sqd_ctx_use_stream) -- the RCCL
+ * all-reduce that makes every rank know every batch's record after the reference's collective step, fermion.py:432,
+ * :577-605 -- needs no host-to-device copy and no host wait in between.  NULL switches it off (the default). */
+int sqd_ctx_set_record_out(sqd_ctx* ctx, double* d_record, int64_t stride);
 
 /* Define the subspace.  strs_a / strs_b must be strictly ascending with a constant
  * popcount per spin (the post-condition of reference _check_ci_strs, fermion.py:1075-1097);
@@ -87,6 +95,9 @@ int sqd_ctx_sync(sqd_ctx* ctx);
  * sqd_set_subspace on this context.  For collectives that ship the winning state between GPUs without a detour through
  * the host (the broadcast after the reference's batch loop, fermion.py:432 / :608-631). */
 int sqd_solution_device_ptr(sqd_ctx* ctx, const double** d_ptr);
+/* Copy the resident solution of the latest sqd_davidson / sqd_solve (called with amps == NULL) to `amps`
+ * (na*nb doubles): the state on demand, for callers that leave it on the device by default. */
+int sqd_solution_copy(sqd_ctx* ctx, double* amps);
 /* on != 0: bracket every following sqd_set_subspace and Davidson run of this context with HIP events, so that
  * sqd_davidson_stats::ms_setup / ms_total are filled.  Off by default: each event record is a bubble in a stream of
  * ~5 us kernels (four records cost ~40 us of a 0.2 ms solve).  The sigma-launch sampling of time_sigma_every is

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "sqd_ctx_create",
     "sqd_ctx_destroy",
     "sqd_ctx_use_stream",
+    "sqd_ctx_set_record_out",
     "sqd_set_subspace",
     "sqd_set_subspace_rows",
     "sqd_sigma_rows_dev",
@@ -34,6 +35,7 @@ EXPORTED_SYMBOLS = (
     "sqd_hdiag_rows_dev",
     "sqd_ctx_sync",
     "sqd_solution_device_ptr",
+    "sqd_solution_copy",
     "sqd_ctx_set_phase_timing",
     "sqd_get_dims",
     "sqd_link_counts",
@@ -121,6 +123,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_ctx_create.argtypes = [C.c_int, C.c_int, _dp, _dp, C.POINTER(_ctxp)]
     lib.sqd_ctx_destroy.argtypes = [_ctxp]
     lib.sqd_ctx_use_stream.argtypes = [_ctxp, C.c_void_p]
+    lib.sqd_ctx_set_record_out.argtypes = [_ctxp, C.c_void_p, C.c_int64]
     lib.sqd_set_subspace.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64]
     lib.sqd_set_subspace_rows.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64, C.c_int64, C.c_int64]
     lib.sqd_sigma_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
@@ -128,6 +131,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_hdiag_rows_dev.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_sync.argtypes = [_ctxp]
     lib.sqd_solution_device_ptr.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
+    lib.sqd_solution_copy.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_set_phase_timing.argtypes = [_ctxp, C.c_int]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
@@ -295,6 +299,31 @@ def strings_to_u64(strs) -> np.ndarray:
     return np.ascontiguousarray(arr)
 
 
+def record_width(norb: int) -> int:
+    """Doubles in the raw observables record of ``Context.set_record_out``."""
+    return 5 + 2 * int(norb)
+
+
+def results_from_record(rec: np.ndarray, norb: int, spin_sq: float | None, shift: float, nelec) -> tuple:
+    """(energy, occ_a, occ_b) from a raw observables record, with the arithmetic -- operation for operation -- of the
+    native ``solve_collect`` (sqd_capi.hip), so that a record that travelled through a collective gives the bits the
+    solving rank got from its own call."""
+    e_dav, cs2c, cc, tt_raw = float(rec[0]), float(rec[2]), float(rec[3]), float(rec[4 + 2 * norb])
+    form = 0
+    if spin_sq is not None:
+        szh = 0.5 * abs(int(nelec[0]) - int(nelec[1]))
+        form = 1 if float(spin_sq) < szh * (szh + 1.0) + 0.1 else 2
+    ct, tt = cs2c / cc, tt_raw / cc
+    penalty = 0.0
+    if form == 1:
+        penalty = ct - float(spin_sq)
+    elif form == 2:
+        ss = float(spin_sq)
+        penalty = tt - 2.0 * ss * ct + ss * ss
+    energy = e_dav - (float(shift) * penalty if form else 0.0)
+    return energy, rec[4 : 4 + norb] / cc, rec[4 + norb : 4 + 2 * norb] / cc
+
+
 class Context:
     """RAII wrapper of one ``sqd_ctx`` (one device, one stream, one Hamiltonian)."""
 
@@ -326,6 +355,12 @@ class Context:
         """Enqueue all further work of this context on a caller-owned HIP stream (``hipStream_t`` as an integer,
         e.g. ``torch.cuda.Stream().cuda_stream``); the stream must outlive the context."""
         self._check(self._lib.sqd_ctx_use_stream(self._h, C.c_void_p(int(stream_handle))))
+
+    def set_record_out(self, device_ptr: int | None, stride: int = 0):
+        """Device address (``tensor.data_ptr()``) where the following solves also leave their raw observables record
+        ``{e_davidson, c.Hc, c.S2c, c.c, occ_a, occ_b, |S2 c|^2}`` (``record_width(norb)`` doubles; batch p of
+        ``solve_batch`` at ``device_ptr + 8 * p * stride``); ``None`` switches it off."""
+        self._check(self._lib.sqd_ctx_set_record_out(self._h, C.c_void_p(int(device_ptr) if device_ptr else None), int(stride)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -379,6 +414,16 @@ class Context:
 
     def hdiag_rows_dev(self, out_rows_ptr: int):
         self._check(self._lib.sqd_hdiag_rows_dev(self._h, C.c_void_p(int(out_rows_ptr))))
+
+    def fetch_solution(self) -> np.ndarray:
+        """The resident Davidson solution of the latest solve on this context, copied to a page-locked host array."""
+        import ctypes as _C
+
+        out = pinned_empty((self.na, self.nb))
+        load_library()
+        # (hipMemcpy through the library's own runtime: sqd_batch_state serves sub-contexts, this the context itself)
+        self._check(self._lib.sqd_solution_copy(self._h, _addr(out)))
+        return out
 
     def solution_device_ptr(self) -> int:
         """Device address of the resident Davidson solution (valid until the next solve on this context)."""
@@ -503,7 +548,7 @@ class Context:
     def solve(self, strs_a, strs_b, ci0=None, *, tol: float = 1e-9, tol_residual: float | None = None,
               lindep: float = 1e-14, max_cycle: int = 100, max_space: int = 12, spin_sq: float | None = None,
               shift: float = 0.2, verbose: int = 0, time_sigma_every: int = 0, spin_square: bool = True,
-              pageable_result: bool = False):
+              pageable_result: bool = False, fetch: bool = True):
         """``set_subspace`` + ``davidson(observables=True)`` in one native call (``sqd_solve_strings``).
         Returns (amps, stats, (energy, spin_square | None, occ_a, occ_b))."""
         a = strings_to_u64(strs_a)
@@ -519,7 +564,8 @@ class Context:
         stats = DavidsonStats()
         # (pageable_result: an ordinary numpy buffer for the state, the way a C caller without sqd_host_alloc would
         # pass it -- the copy-stream path of sqd_solve instead of the kernel-written one; tests compare the two)
-        amps = np.empty((a.size, b.size)) if pageable_result else pinned_empty((a.size, b.size))
+        # (fetch=False: the state stays on the device -- solution_device_ptr() / a later davidson-free copy)
+        amps = None if not fetch else (np.empty((a.size, b.size)) if pageable_result else pinned_empty((a.size, b.size)))
         ci0p = None
         if ci0 is not None:
             ci0 = _as_f64(ci0).reshape(a.size, b.size)
@@ -531,7 +577,7 @@ class Context:
         base = _addr(occ)
         self._check(
             self._lib.sqd_solve_strings(self._h, _addr(a), a.size, _addr(b), b.size, C.byref(opts), ci0p,
-                                        _addr(amps), C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,
+                                        _addr(amps) if amps is not None else None, C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,
                                         base, base + 8 * self.norb, C.byref(ea), C.byref(eb))
         )
         self.na, self.nb = int(a.size), int(b.size)

@@ -321,6 +321,24 @@ SQD_API int sqd_solution_device_ptr(sqd_ctx* c, const double** d_ptr) {
   *d_ptr = c->sol.as<double>();
   return SQD_OK;
 }
+SQD_API int sqd_solution_copy(sqd_ctx* c, double* amps) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  if (!amps) return SQD_ERR_INVALID;
+  if (!c->have_solution) {
+    set_error("no resident solution: run sqd_davidson / sqd_solve first");
+    return SQD_ERR_STATE;
+  }
+  SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, (size_t)c->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_TRY(spin_stream_sync(c->stream));
+  return SQD_OK;
+}
+SQD_API int sqd_ctx_set_record_out(sqd_ctx* c, double* d_record, int64_t stride) {
+  if (!c) return SQD_ERR_INVALID;
+  c->record_out = d_record;
+  c->record_stride = stride;
+  return SQD_OK;
+}
 SQD_API int sqd_ctx_set_phase_timing(sqd_ctx* c, int on) {
   if (!c) return SQD_ERR_INVALID;
   c->phase_timing = on != 0;
@@ -731,9 +749,12 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
     c->subs.push_back(sub);
   }
   std::vector<sqd_ctx*> subs(c->subs.begin(), c->subs.begin() + nbatch);
-  for (sqd_ctx* sub : subs) {
+  for (int p = 0; p < nbatch; ++p) {
+    sqd_ctx* sub = subs[p];
     sub->stream = c->stream;
     sub->want_timing = false;
+    sub->record_out = c->record_out ? c->record_out + (int64_t)p * c->record_stride : nullptr;
+    sub->record_stride = 0;
   }
   hipStream_t st = c->stream;
   // ---- tables of every subspace: 2 copies + 4-5 launches for the whole batch

@@ -277,6 +277,11 @@ struct sqd_ctx {
   // ---- batched solves (sqd_solve_batch).  A parent context owns one sub-context per subspace of the batch: the
   // per-subspace state (tables, Davidson workspace, state block, mailbox) in the same struct a single solve uses, on
   // the PARENT's stream and with views of the parent's integral tables.
+  // device address where the observables kernel of a solve also leaves its RAW record {e_davidson, c.Hc, c.S2c, c.c,
+  // occ_a[norb], occ_b[norb], |S2 c|^2} (sqd_ctx_set_record_out): the input of a collective exchange that follows on
+  // the same stream, no copy in between.  Batch p of sqd_solve_batch: record_out + p * record_stride.
+  double* record_out = nullptr;
+  int64_t record_stride = 0;
   sqd_ctx* parent = nullptr;        // set on a sub-context
   std::vector<sqd_ctx*> subs;       // grow-only; subs[i] serves batch i of the latest sqd_solve_batch
   int batch_n = 0;                  // subspaces of the latest sqd_solve_batch (0: none)

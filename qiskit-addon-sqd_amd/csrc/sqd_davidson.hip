@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig_b(const DavBatchArgs* __rest
   dots_eig_body<MV>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
 }
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
+__global__ void __launch_bounds__(RED_T, 4) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
   const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   residual_precond_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.hdiag, a.pd, a.part_res, a.width, blockIdx.x, a.gb);

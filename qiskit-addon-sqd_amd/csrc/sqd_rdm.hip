@@ -12,6 +12,7 @@
 #include "sqd_common.h"
 #include "sqd_device.h"
 #include "sqd_direct.h"
+#include "sqd_davstate.h"
 
 namespace sqd {
 
@@ -283,6 +284,10 @@ struct ObsArgs {
   long long seq;
   int s2_inline;
   DirectArgs dg;
+  // optional device-side copy of the results, led by the Davidson eigenvalue (sqd_ctx::record_out): what a collective
+  // exchange on the same stream reads
+  GPtr<double> record;
+  GPtr<const DavState> st;
 };
 __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned nbx) {
   __shared__ double red[1024];
@@ -434,6 +439,13 @@ __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned 
   __syncthreads();
   // results leave the chip from consecutive lanes: a few full-line writes over PCIe instead of one per result
   if ((int)threadIdx.x < nres) mail_store(&out[threadIdx.x], red[512 + threadIdx.x]);
+  if (g.record) {
+    if ((int)threadIdx.x < nres) g.record[1 + threadIdx.x] = red[512 + threadIdx.x];
+    if (threadIdx.x == 0) {
+      const DavState* st = g.st;
+      g.record[0] = st ? st->e : 0.0;
+    }
+  }
   // sequence word behind the results: the host waits for it by reading memory instead of polling hipStreamQuery (whose
   // runtime lock other contexts' host threads need for their launches: 16 concurrent 317 x 317 solves ran 15-25 %
   // faster once the waiting threads stopped hammering it)
@@ -503,6 +515,8 @@ static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const 
   g.seq_word = reinterpret_cast<long long*>(c->d_mail + OBS_SEQ);
   g.seq = (long long)c->obs_seq;
   g.s2_inline = s2_inline ? 1 : 0;
+  g.record = c->record_out;
+  g.st = (c->record_out && c->have_solution) ? static_cast<const DavState*>(dav_state_ptr(c)) : nullptr;
   return SQD_OK;
 }
 static bool obs_s2_inline(const sqd_ctx* c, bool with_s2) {

@@ -4,11 +4,20 @@ RCCL over xGMI on MI355X, "gloo" for CPU tests).
 The reference's SQD loop hands a list of independent subspaces to ``sci_solver`` and documents that
 call as its only collective step (``qiskit_addon_sqd/fermion.py:316-333``, ``:432``;
 ``docs/guides/hpc_acceleration.rst:52-57``); its default solver runs them serially (:670-681).
-Here batch ``i`` is solved by rank ``i % world`` with no communication during the solve.  Afterwards
-ONE all-reduce (sum of a table whose rows are zero except on the owning rank -- i.e. a gather) makes
-every batch's ``[E, occ_a, occ_b]`` record known everywhere (``(1 + 2 norb) * 8`` bytes per batch:
-latency-bound, xGMI bandwidth irrelevant), and the winner's amplitude matrix -- the only large object
-the loop consumes (``fermion.py:608-631``) -- is broadcast from its owner.
+Here batch ``i`` is solved by rank ``i % world`` -- all of a rank's batches in ONE batched native solve
+(``sqd_solve_batch``) -- with no communication during the solve.  Afterwards ONE all-reduce (sum of a
+table whose rows are zero except on the owning rank -- i.e. a gather) makes every batch's raw observables
+record known everywhere (``(5 + 2 norb) * 8`` bytes per batch: latency-bound, xGMI bandwidth irrelevant).
+
+Round-3 exchange: the record of a batch is written INTO THE COLLECTIVE'S DEVICE BUFFER by the observables
+kernel of its solve (``sqd_ctx_set_record_out``), the solver runs on torch's current stream, and the
+all-reduce is enqueued behind it on the same stream -- no host-to-device copy, no host wait between solve and
+exchange.  Energies and occupancies of every batch are then formed from the reduced records on every rank with
+the arithmetic of the native call (``_capi.results_from_record``): the same bits everywhere.  The winner's
+amplitude matrix -- the only large object the loop consumes (``fermion.py:608-631``), and only on the control
+process (rank 0 does the carry-over, ``:436-451``) -- travels from its owner to rank 0 alone; nothing is
+broadcast.  ``states="all"`` gathers every batch's state on rank 0 (one grouped send / receive), for callbacks
+that read them (``fermion.py:435-436``).
 
 Reference semantics (v0.13) = argmin over energies, take that batch's occupancies (``fermion.py:577,
 :604-605``): ``occupancy_reduce="best"``.  ``"mean"`` replaces every result's occupancies by the batch
@@ -17,11 +26,13 @@ average (the older tutorial workflow / BASELINE north_star wording), computed fr
 
 from __future__ import annotations
 
+import time
 from typing import Callable, Sequence
 
 import numpy as np
 
-from .fermion import SCIResult, SCIState, solve_sci
+from . import _capi
+from .fermion import SCIResult, SCIState, _DeferredAmplitudes, _davidson_kwargs, _get_context, _settle_deferred, solve_sci
 
 
 def _dist():
@@ -34,14 +45,20 @@ def _dist():
 
 _XBUF: dict = {}
 _GROUPS: dict = {}
-_VIEWS: dict = {}
+last_exchange_ms: float | None = None
+"""Wall clock of the latest call's exchange on this rank: from the return of the local solve(s) to the reduced table
+on the host, plus the winner's transfer (benchmark hook; ``bench.py`` reports it as ``exchange_ms``)."""
 
 
 def _wait_stream(stream) -> None:
-    """Wait for ``stream`` by polling: ``hipStreamSynchronize`` parks the thread and costs ~10-20 us to wake up, a
-    query loop returns within a microsecond of completion (the waits here cover a 488-byte collective)."""
+    """Wait for ``stream``: a short polling spin (``hipStreamSynchronize`` parks the thread and wakes up 10-20 us
+    late; the waits here cover a 500-byte collective), then the blocking call -- a long wait must not burn a core
+    and hold the GIL."""
+    t0 = time.perf_counter()
     while not stream.query():
-        pass
+        if time.perf_counter() - t0 > 2e-4:
+            stream.synchronize()
+            return
 
 
 def _group_info(dist, group):
@@ -72,38 +89,25 @@ def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
     return hit
 
 
-class _DeviceView:
-    """Zero-copy handle on device memory for ``torch.as_tensor`` (``__cuda_array_interface__``, version 2)."""
-
-    def __init__(self, ptr: int, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def _resident_solution(one_body_tensor, two_body_tensor, device, shape, tdev):
-    """The Davidson solution still resident in this rank's solver context as a torch tensor, or None."""
-    import torch
-
-    from .fermion import _get_context
-
-    try:
-        ctx = _get_context(np.asarray(one_body_tensor, dtype=np.float64), two_body_tensor, device)
-        if (ctx.na, ctx.nb) != tuple(shape):
-            return None
-        key = (ctx.solution_device_ptr(), tuple(shape), str(tdev))
-        view = _VIEWS.get(key)
-        if view is None:  # the address is stable while the context keeps its capacity: wrap it once
-            view = _VIEWS[key] = torch.as_tensor(_DeviceView(key[0], shape), device=tdev)
-            while len(_VIEWS) > 8:
-                _VIEWS.pop(next(iter(_VIEWS)))
-        return view
-    except Exception:  # any doubt: take the host path
-        return None
-
-
 def shard_indices(num_batches: int, rank: int, world: int) -> list[int]:
     """Batches owned by ``rank``: round-robin, ``i % world == rank``."""
     return list(range(rank, num_batches, world))
+
+
+class _RemoteAmplitudes(_DeferredAmplitudes):
+    """Placeholder for the state of a batch another rank solved and that was not shipped (``states="winner"``)."""
+
+    __slots__ = ("owner",)
+
+    def __init__(self, index, shape, owner):
+        super().__init__(None, index, shape)
+        self.owner = owner
+
+    def fetch(self):
+        raise RuntimeError(
+            f"the state of batch {self.index} lives on rank {self.owner}: only the lowest-energy batch is shipped to "
+            "the control process; call solve_sci_batch_distributed(..., states='all') to gather every state on rank 0"
+        )
 
 
 def solve_sci_batch_distributed(
@@ -117,18 +121,23 @@ def solve_sci_batch_distributed(
     group=None,
     device: int | None = None,
     occupancy_reduce: str = "best",
+    states: str = "winner",
     local_solver: Callable[..., SCIResult] | None = None,
     **kwargs,
 ) -> list[SCIResult]:
     """Collective drop-in for ``solve_sci_batch`` (same positional signature, so it can be passed as
     ``sci_solver=`` to the SQD loop on every rank).
 
-    Returns one ``SCIResult`` per batch on every rank.  ``energy`` and ``orbital_occupancies`` are
-    populated for all batches; ``sci_state`` is populated for the batches this rank solved and for the
-    lowest-energy batch (broadcast), ``None`` otherwise; ``rdm1``/``rdm2`` only for local batches.
+    Returns one ``SCIResult`` per batch on every rank.  ``energy`` and ``orbital_occupancies`` are populated for all
+    batches.  ``sci_state``: the batches this rank solved; on the control process (group rank 0) also the
+    lowest-energy batch, or every batch with ``states="all"``; every other state is a placeholder that raises when
+    its amplitudes are read.  ``rdm1``/``rdm2`` (lazy) only where the state is present.
     """
+    global last_exchange_ms
     if occupancy_reduce not in ("best", "mean"):
         raise ValueError("occupancy_reduce must be 'best' or 'mean'")
+    if states not in ("winner", "all"):
+        raise ValueError("states must be 'winner' or 'all'")
     import torch
 
     dist = _dist()
@@ -136,86 +145,169 @@ def solve_sci_batch_distributed(
     if device is None:
         device = torch.cuda.current_device() if on_gpu else 0
     tdev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
-    solver = local_solver or solve_sci
-    norb = int(np.asarray(one_body_tensor).shape[0])
+    one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
+    norb = int(one_body_tensor.shape[0])
     nb = len(ci_strings)
-    width = 1 + 2 * norb
+    width = _capi.record_width(norb)
+    nelec = tuple(int(x) for x in nelec)
+    mine = shard_indices(nb, rank, world)
+    compute_rdms = kwargs.pop("compute_rdms", "lazy")
+    shift = 0.2  # pyscf fix_spin_ default, as solve_sci (reference fermion.py:715)
 
-    # ---- independent solves, no communication.  The records go straight into the (cached, pinned) exchange buffer.
-    local: dict[int, SCIResult] = {}
     dev_table, host_table = _exchange_buffers(group, tdev, nb, width, on_gpu)
     table = host_table.numpy()
-    table[:] = 0.0
-    for i in shard_indices(nb, rank, world):
-        res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
-                     device=device, **kwargs)  # fmt: skip
-        local[i] = res
-        table[i, 0] = res.energy
-        table[i, 1 : 1 + norb] = res.orbital_occupancies[0]
-        table[i, 1 + norb :] = res.orbital_occupancies[1]
+    local: dict[int, SCIResult] = {}
+    resident = None  # (context, position of each local batch in its batched solve)
 
-    # ---- the path's single exchange: all-reduce(sum) of the per-batch records.  Device and pinned host buffers
-    # are cached per (group, shape): the record table is 61 doubles per batch at norb = 30, so everything but the
-    # collective itself is overhead worth removing (allocation, pageable copies)
+    # ---- independent solves, no communication.  Their records land in the collective's buffer by themselves.
+    if local_solver is None and compute_rdms is not True and kwargs.get("ci0") is None:
+        ctx = _get_context(one_body_tensor, two_body_tensor, device, slot="dist")
+        _settle_deferred(ctx)
+        if on_gpu:
+            stream = torch.cuda.current_stream(tdev)
+            if getattr(ctx, "_on_stream", None) != stream.cuda_stream:
+                ctx.use_stream(stream.cuda_stream)  # solver kernels and the collective on ONE stream
+                ctx._on_stream = stream.cuda_stream
+        dev_table.zero_()
+        if mine:
+            import weakref
+
+            from . import fermion as _F
+
+            ctx.set_record_out(dev_table.data_ptr() + 8 * rank * width, world * width)
+            dk = _davidson_kwargs(kwargs)
+            dk.pop("verbose", None)
+            dk.pop("ci0", None)
+            try:
+                if len(mine) == 1:
+                    # one batch per rank (BASELINE config 3: 8 batches over 8 GPUs): the single solve.  The control
+                    # process takes the state with the call (written by the observables kernel into page-locked memory);
+                    # elsewhere it stays on the device -- it only ever leaves for rank 0, GPU to GPU
+                    sa, sb = ci_strings[mine[0]]
+                    amps1, st1, (e1, _s2, oa1, ob1) = ctx.solve(sa, sb, spin_sq=spin_sq, shift=shift, spin_square=False,
+                                                                fetch=(rank == 0), **dk)
+                    out = {"nelec": [ctx.nelec], "energy": [e1], "occ_a": [oa1], "occ_b": [ob1], "stats": [st1],
+                           "amps": [amps1]}
+                else:
+                    out = ctx.solve_batch([ci_strings[i] for i in mine], spin_sq=spin_sq, shift=shift, spin_square=False,
+                                          fetch="none", **dk)
+            finally:
+                ctx.set_record_out(None)
+            resident = (ctx, {i: k for k, i in enumerate(mine)}, len(mine) == 1)
+            _F._TLS.stats, _F._TLS.batch_stats = out["stats"][0], out["stats"]
+            for k, i in enumerate(mine):
+                if out["nelec"][k] != nelec:
+                    raise ValueError(f"nelec={nelec} does not match the Hamming weights {out['nelec'][k]} of the CI strings")
+                sa, sb = ci_strings[i]
+                amps = out["amps"][k]
+                if amps is None:
+                    amps = _DeferredAmplitudes(ctx, k, (len(sa), len(sb)))
+                    if len(mine) == 1:
+                        amps.single = True
+                    ctx._deferred.append(weakref.ref(amps))
+                state = SCIState(amps, np.asarray(sa), np.asarray(sb), norb=norb, nelec=nelec)
+                local[i] = SCIResult(float(out["energy"][k]), state, (out["occ_a"][k], out["occ_b"][k]),
+                                     _lazy_rdms=(compute_rdms == "lazy"))
+    else:
+        # a caller-supplied solver (or eager RDMs / a start vector): the records are formed on the host
+        solver = local_solver or solve_sci
+        table[:] = 0.0
+        for i in mine:
+            res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
+                         device=device, compute_rdms=compute_rdms, **kwargs)  # fmt: skip
+            local[i] = res
+            # a record that results_from_record maps back to exactly these numbers: c.c = 1, no penalty left to apply
+            table[i, 0] = res.energy
+            table[i, 3] = 1.0
+            table[i, 4 : 4 + norb] = res.orbital_occupancies[0]
+            table[i, 4 + norb : 4 + 2 * norb] = res.orbital_occupancies[1]
+        if on_gpu:
+            dev_table.copy_(host_table, non_blocking=True)
+    host_formed = resident is None
+
+    # ---- the path's single exchange: all-reduce(sum) of the per-batch records, enqueued behind the solves
+    t_x = time.perf_counter()
     if on_gpu:
-        dev_table.copy_(host_table, non_blocking=True)
         dist.all_reduce(dev_table, op=dist.ReduceOp.SUM, group=group)
         host_table.copy_(dev_table, non_blocking=True)
         _wait_stream(torch.cuda.current_stream(tdev))
     else:
         dist.all_reduce(host_table, op=dist.ReduceOp.SUM, group=group)
     table = table.copy()
-    best = int(np.argmin(table[:, 0]))
-    owner = best % world
+    energies = np.empty(nb)
+    occs = []
+    for i in range(nb):
+        e, oa, ob = _capi.results_from_record(table[i], norb, None if host_formed else spin_sq, shift, nelec)
+        energies[i] = e
+        occs.append((oa, ob))
+    best = int(np.argmin(energies))
 
-    # ---- winner's state to every rank (the loop's control process needs it for the carry-over, reference
-    # fermion.py:608-631; the reference ships it inside the pickled iteration state)
-    sa, sb = ci_strings[best]
-    if world > 1 or on_gpu:  # (also on a one-rank RCCL group: the collective path is the tested path)
-        src = dist.get_global_rank(group, owner) if group is not None else owner
-        dev_view = None
-        if rank == owner:
-            amps = local[best].sci_state.amplitudes
-            if on_gpu and local_solver is None and shard_indices(nb, rank, world)[-1] == best:
-                # the winner is this rank's LAST solve: its state is still resident in the solver context -- ship it
-                # from there, no host-to-device copy
-                dev_view = _resident_solution(one_body_tensor, two_body_tensor, device, amps.shape, tdev)
-            if dev_view is not None:
-                ta = dev_view
-            else:
-                a = np.ascontiguousarray(amps, dtype=np.float64)
-                ta = torch.from_numpy(a).to(tdev, non_blocking=True) if on_gpu else torch.from_numpy(a)
-        else:
-            ta = torch.empty((len(sa), len(sb)), dtype=torch.float64, device=tdev)
-        dist.broadcast(ta, src=src, group=group)
-        if rank == owner:
+    # ---- states to the control process (group rank 0): the winner's, or all of them
+    wanted = list(range(nb)) if states == "all" else [best]
+    shipped: dict[int, np.ndarray] = {}
+    moves = [(i, i % world) for i in wanted if i % world != 0]
+    if moves and world > 1:
+        ops, bufs = [], {}
+        g0 = dist.get_global_rank(group, 0) if group is not None else 0
+        for i, owner in moves:
+            shape = (len(ci_strings[i][0]), len(ci_strings[i][1]))
+            if rank == owner:
+                if resident is not None and on_gpu:
+                    holder = resident[0] if resident[2] else resident[0].batch_sub(resident[1][i])
+                    sub_ptr = holder.solution_device_ptr()
+                    ta = torch.as_tensor(_DeviceView(sub_ptr, shape), device=tdev)
+                else:
+                    ta = torch.from_numpy(np.ascontiguousarray(local[i].sci_state.amplitudes, dtype=np.float64))
+                    if on_gpu:
+                        ta = ta.to(tdev, non_blocking=True)
+                ops.append(dist.P2POp(dist.isend, ta, g0, group=group))
+                bufs[i] = ta
+            elif rank == 0:
+                gsrc = dist.get_global_rank(group, owner) if group is not None else owner
+                ta = torch.empty(shape, dtype=torch.float64, device=tdev)
+                ops.append(dist.P2POp(dist.irecv, ta, gsrc, group=group))
+                bufs[i] = ta
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
             if on_gpu:
-                _wait_stream(torch.cuda.current_stream(tdev))  # the resident buffer is free again for the next solve
-        elif on_gpu:
-            from ._capi import pinned_empty
-
-            amps = pinned_empty(tuple(ta.shape))
-            torch.from_numpy(amps).copy_(ta, non_blocking=True)
-            _wait_stream(torch.cuda.current_stream(tdev))
-        else:
-            amps = ta.numpy()
-    else:
-        amps = local[best].sci_state.amplitudes
+                _wait_stream(torch.cuda.current_stream(tdev))
+            if rank == 0:
+                for i, ta in bufs.items():
+                    if on_gpu:
+                        amps = _capi.pinned_empty(tuple(ta.shape))
+                        torch.from_numpy(amps).copy_(ta, non_blocking=True)
+                        shipped[i] = amps
+                    else:
+                        shipped[i] = ta.numpy()
+                if on_gpu:
+                    _wait_stream(torch.cuda.current_stream(tdev))
+    last_exchange_ms = 1e3 * (time.perf_counter() - t_x)
 
     if occupancy_reduce == "mean":
-        mean_occ = (table[:, 1 : 1 + norb].mean(axis=0), table[:, 1 + norb :].mean(axis=0))
-    out: list[SCIResult] = []
+        mean_occ = (np.mean([o[0] for o in occs], axis=0), np.mean([o[1] for o in occs], axis=0))
+    out_list: list[SCIResult] = []
     for i in range(nb):
-        # (views of this call's private copy of the table)
-        occ = mean_occ if occupancy_reduce == "mean" else (table[i, 1 : 1 + norb], table[i, 1 + norb :])
+        occ = mean_occ if occupancy_reduce == "mean" else occs[i]
+        sa, sb = ci_strings[i]
         if i in local:
             r = local[i]
             raw = lambda name: object.__getattribute__(r, name)  # noqa: E731  (do not trigger lazy RDMs)
-            out.append(SCIResult(float(table[i, 0]), r.sci_state, occ, rdm1=raw("rdm1"), rdm2=raw("rdm2"),
-                                 _lazy_rdms=raw("_lazy_rdms")))
-        elif i == best:
-            state = SCIState(amps, np.asarray(sa), np.asarray(sb), norb=norb, nelec=tuple(int(x) for x in nelec))
-            out.append(SCIResult(float(table[i, 0]), state, occ, _lazy_rdms=True))
+            out_list.append(SCIResult(float(energies[i]), r.sci_state, occ, rdm1=raw("rdm1"), rdm2=raw("rdm2"),
+                                      _lazy_rdms=raw("_lazy_rdms")))
+        elif i in shipped:
+            state = SCIState(shipped[i], np.asarray(sa), np.asarray(sb), norb=norb, nelec=nelec)
+            out_list.append(SCIResult(float(energies[i]), state, occ, _lazy_rdms=True))
         else:
-            out.append(SCIResult(float(table[i, 0]), None, occ))  # type: ignore[arg-type]
-    return out
+            state = SCIState(_RemoteAmplitudes(i, (len(sa), len(sb)), i % world), np.asarray(sa), np.asarray(sb),
+                             norb=norb, nelec=nelec)
+            out_list.append(SCIResult(float(energies[i]), state, occ))
+    return out_list
+
+
+class _DeviceView:
+    """Zero-copy handle on device memory for ``torch.as_tensor`` (``__cuda_array_interface__``, version 2)."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}

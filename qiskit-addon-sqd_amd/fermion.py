@@ -139,17 +139,21 @@ class _DeferredAmplitudes:
     and leaves the others resident; ``SCIState.amplitudes`` fetches on first access.  Before the solver context is
     re-used for another batched solve (or closed) every deferred state that is still referenced is fetched."""
 
-    __slots__ = ("ctx", "index", "shape", "value", "__weakref__")
+    __slots__ = ("ctx", "index", "shape", "value", "single", "__weakref__")
 
     def __init__(self, ctx, index, shape):
         self.ctx, self.index, self.shape, self.value = ctx, int(index), tuple(shape), None
+        self.single = False  # True: the resident solution of a single solve on ctx (not a batch of a batched solve)
+
+    def __reduce__(self):  # pickled (the SPMD loop broadcasts its iteration state): as the array itself
+        return (np.array, (self.fetch(),))
 
     def fetch(self) -> np.ndarray:
         if self.value is None:
             ctx = self.ctx
             if ctx is None:
                 raise RuntimeError("the solver context that held this state has been released")
-            self.value = ctx.batch_state(self.index)
+            self.value = ctx.fetch_solution() if self.single else ctx.batch_state(self.index)
             self.ctx = None
         return self.value
 

@@ -26,7 +26,7 @@ def _build_emu() -> Path:
     if EMU_LIB.exists() and all(d.stat().st_mtime <= EMU_LIB.stat().st_mtime for d in deps):
         return EMU_LIB
     EMU_LIB.parent.mkdir(exist_ok=True)
-    cmd = ["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", f"-I{EMU_DIR}", f"-I{ROOT / 'include'}",
+    cmd = ["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-psabi", f"-I{EMU_DIR}", f"-I{ROOT / 'include'}",
            f"-I{CSRC}", "-x", "c++", *map(str, srcs), "-o", str(EMU_LIB)]
     subprocess.run(cmd, check=True)
     return EMU_LIB

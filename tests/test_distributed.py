@@ -52,7 +52,9 @@ def test_two_rank_gloo_whole_loop_unseeded(emu_lib):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("kernel_env", [{}, {"SQD_SIGMA_ROWS": "2"}, {"SQD_SIGMA_DIRECT": "1"}],
+# (SQD_SIGMA_DENSE=0: a row shard always runs the sparse same-spin work items, and the bit-for-bit comparison below is
+# against the whole-subspace sigma of the SAME kernels)
+@pytest.mark.parametrize("kernel_env", [{"SQD_SIGMA_DENSE": "0"}, {"SQD_SIGMA_ROWS": "2"}, {"SQD_SIGMA_DIRECT": "1"}],
                          ids=["work-items", "rows", "direct"])
 def test_two_rank_gloo_row_sharded_sigma_and_solve(emu_lib, kernel_env):
     """one subspace split by alpha rows over two ranks -- all-gather of the vector, sigma rows per rank

@@ -572,11 +572,12 @@ def test_context_on_caller_stream(hip_lib):
     assert float(x) == 8.0
 
 
-def test_row_sharded_sigma_on_gpu(hip_lib):
+def test_row_sharded_sigma_on_gpu(hip_lib, monkeypatch):
     """SURVEY 8f-3 on the real kernels: a context that owns alpha rows [row0, row1) of the N2-sized 317 x 317 problem
-    must reproduce exactly those rows of the whole-subspace sigma (same work items, same order: bit for bit), for H,
-    for the spin-penalised operator and for S^2; and the collective solver on an RCCL group of world size 1 must
-    agree with the single-GPU solver."""
+    must reproduce the ORACLE's sigma rows (string-space operator, numpy) and exactly those rows of the whole-subspace
+    sigma of the same kernels (same work items, same order: bit for bit), for H, for the spin-penalised operator and
+    for S^2; and the collective solver on an RCCL group of world size 1 must agree with the single-GPU solver."""
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")  # (a row shard runs the sparse same-spin work items: compare like with like)
     import socket
 
     import torch
@@ -590,6 +591,8 @@ def test_row_sharded_sigma_on_gpu(hip_lib):
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
         s_full, p_full, ss_full, hd_full = ctx.sigma(x), ctx.sigma(x, 1, 0.0, 0.25), ctx.contract_ss(x), ctx.hdiag()
+        s_oracle = O.sigma_string_space(h1, eri, sa, sb, x, norb)  # the oracle, not the product's own whole-subspace sigma
+        scale = np.abs(hd_full).max()
         xd = torch.from_numpy(x).cuda()
         for lo, hi in ((0, 317), (100, 250), (316, 317)):
             ctx.set_subspace_rows(sa, sb, lo, hi)
@@ -597,6 +600,7 @@ def test_row_sharded_sigma_on_gpu(hip_lib):
             torch.cuda.synchronize()
             ctx.sigma_rows_dev(xd.data_ptr(), out.data_ptr())
             ctx.sync()
+            assert np.abs(out.cpu().numpy() - s_oracle[lo:hi]).max() < 1e-11 * scale
             assert np.array_equal(out.cpu().numpy(), s_full[lo:hi])
             ctx.sigma_rows_dev(xd.data_ptr(), out.data_ptr(), 1, 0.0, 0.25)
             ctx.sync()
