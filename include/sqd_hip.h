@@ -221,8 +221,8 @@ int sqd_solve_strings(sqd_ctx* ctx, const uint64_t* strs_a, int64_t na, const ui
  *   amplitudes -- written by the observables kernel itself when it came from sqd_host_alloc.
  *   best_amps (may be NULL): room for the largest subspace; receives the amplitudes of the lowest-energy batch --
  *   the only state the reference's loop consumes (fermion.py:577, :608-631) -- and *best its index.  Every other
- *   state stays resident until the next sqd_solve_batch / sqd_ctx_destroy on this context: sqd_batch_state copies one
- *   out on demand.
+ *   state stays resident for this and the NEXT sqd_solve_batch on this context: sqd_batch_state copies one out on
+ *   demand.
  * opts->verbose and opts->time_sigma_every are ignored; ci0 is not available (pyscf's start vector is used).
  * Subspaces outside the batched launch classes (rows too long for LDS staging, the (S^2-ss)^2 penalty form) are
  * solved one by one inside the same call. */
@@ -230,8 +230,10 @@ int sqd_solve_batch(sqd_ctx* ctx, int nbatch, const uint64_t* const* strs_a, con
                     const uint64_t* const* strs_b, const int64_t* nb, const sqd_davidson_opts* opts,
                     double* const* amps, double* best_amps, int* best, sqd_davidson_stats* stats, double* e, double* s2,
                     double* occ_a, double* occ_b, int* nelec_a, int* nelec_b);
-/* amplitudes of batch `index` of the latest sqd_solve_batch (na*nb doubles) from their device-resident copy */
-int sqd_batch_state(sqd_ctx* ctx, int index, double* amps);
+/* amplitudes of batch `index` (na*nb doubles) from their device-resident copy: age 0 = of the latest sqd_solve_batch,
+ * age 1 = of the one before it (each subspace slot keeps two solutions, so the results of call N stay readable while
+ * and after call N + 1 runs -- the `results = solver(...)` loop of the reference, fermion.py:432) */
+int sqd_batch_state(sqd_ctx* ctx, int index, int age, double* amps);
 /* the sub-context that holds batch `index` of the latest sqd_solve_batch (tables + resident solution): usable with the
  * observables / RDM entry points (amps = NULL: the resident solution) until the next sqd_solve_batch.  Owned by ctx. */
 int sqd_batch_ctx(sqd_ctx* ctx, int index, sqd_ctx** sub);

@@ -22,6 +22,27 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
+# ---- sigma kernels of a kernel trace with the EARLY-EXIT launches split out: the host keeps one sigma build enqueued
+# ahead of the Davidson round it has seen finish, so every solve ends with one or more launches that find the stop flag
+# raised and return at once (< 1.5 us); averaged in, they flatter the kernel
+for d in glob.glob(os.path.join(src, "prof_*")):
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        real, early = defaultdict(list), defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            name = short(r["Kernel_Name"])
+            if "k_sigma" not in name and "k_same_spin" not in name:
+                continue
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            if dur < 1.5:
+                early[name] += 1
+            else:
+                real[name].append(dur)
+        if real:
+            out = {k: {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v),
+                       "early_exit_launches_excluded": early.get(k, 0)} for k, v in real.items()}
+            json.dump(out, open(os.path.join(dst, "final_" + os.path.basename(d)[5:] + "_sigma_launches.json"), "w"), indent=1)
+
+
 for wl in ("uniform317", "hf317", "big"):
     out = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):

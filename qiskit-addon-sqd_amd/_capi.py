@@ -153,7 +153,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                       C.POINTER(DavidsonStats), _dp, _dp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_solve_batch.argtypes = [_ctxp, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(DavidsonOpts), _vp, _vp,
                                     C.POINTER(C.c_int), _vp, _vp, _vp, _vp, _vp, _vp, _vp]
-    lib.sqd_batch_state.argtypes = [_ctxp, C.c_int, _vp]
+    lib.sqd_batch_state.argtypes = [_ctxp, C.c_int, C.c_int, _vp]
     lib.sqd_batch_ctx.argtypes = [_ctxp, C.c_int, C.POINTER(_ctxp)]
     lib.sqd_energy.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_spin_square.argtypes = [_ctxp, _dp, _dp]
@@ -633,6 +633,7 @@ class Context:
                                       C.addressof(stats), _addr(e), _addr(s2) if s2 is not None else None, _addr(occ[0]),
                                       _addr(occ[1]), C.addressof(ea), C.addressof(eb))
         )
+        self._batch_shapes_prev = getattr(self, "_batch_shapes", [])
         self._batch_shapes = [(a_arr[i].size, b_arr[i].size) for i in range(n)]
         if best_buf is not None:
             w = int(best.value)
@@ -659,11 +660,15 @@ class Context:
         sub.close = lambda: None  # owned by the parent context
         return sub
 
-    def batch_state(self, index: int) -> np.ndarray:
-        """Amplitudes of batch ``index`` of the latest ``solve_batch`` from their device-resident copy."""
-        sh = self._batch_shapes[index]
+    def batch_state(self, index: int, generation: int | None = None) -> np.ndarray:
+        """Amplitudes of batch ``index`` of a ``solve_batch`` from their device-resident copy: of the latest call, or
+        (``generation`` = that call's ``"generation"``) of the one before it -- a slot keeps two solutions."""
+        age = 0 if generation is None else self._batch_gen - int(generation)
+        if age not in (0, 1):
+            raise SQDNativeError("that batched solve's states are no longer resident on the device")
+        sh = (self._batch_shapes if age == 0 else self._batch_shapes_prev)[index]
         out = pinned_empty(sh)
-        self._check(self._lib.sqd_batch_state(self._h, int(index), _addr(out)))
+        self._check(self._lib.sqd_batch_state(self._h, int(index), age, _addr(out)))
         return out
 
     # -- observables (amps=None -> resident Davidson solution)

@@ -1,9 +1,11 @@
 // extern "C" boundary of libsqd_hip.so (declared in include/sqd_hip.h).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "sqd_common.h"
 
@@ -13,7 +15,17 @@ void set_error(const std::string& msg) { g_err = msg; }
 }  // namespace sqd
 
 namespace sqd {
+// Host waits.  Everything on the solve path of a batch-sized subspace is sub-millisecond, and a blocking runtime wait
+// wakes up 10-20 us late, so a wait first SPINS -- on the memory word the awaited kernel writes, or on the stream's
+// status -- but only for SPIN_US: a solve of 1e7-1e8 determinants waits for milliseconds to seconds per round, and a
+// thread that spins through that burns a core and starves the launches of the other solver threads.  Past the budget
+// the wait sleeps in short naps (word waits) or hands over to the runtime's blocking call.
+static inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+constexpr double SPIN_US = 300.0;
 int spin_stream_sync(hipStream_t s) {
+  const double t0 = now_us();
   for (long spin = 0;; ++spin) {
     const hipError_t e = hipStreamQuery(s);
     if (e == hipSuccess) return SQD_OK;
@@ -21,7 +33,7 @@ int spin_stream_sync(hipStream_t s) {
       set_error(std::string("hipStreamQuery: ") + hipGetErrorString(e));
       return SQD_ERR_HIP;
     }
-    if (spin > 1000000L) break;  // ~2 s of polling: something is badly wrong, let the runtime wait (and report)
+    if ((spin & 15) == 15 && now_us() - t0 > SPIN_US) break;
     // (hipStreamQuery takes a runtime lock that other host threads need for their launches: ~1 us between polls)
     for (int p = 0; p < 64; ++p) __builtin_ia32_pause();
   }
@@ -30,12 +42,31 @@ int spin_stream_sync(hipStream_t s) {
 }
 int spin_wait_word(const void* word, long long seq, hipStream_t s) {
   volatile const long long* flag = reinterpret_cast<volatile const long long*>(word);
-  for (long spin = 0; spin < 20000000L; ++spin) {
+  const double t0 = now_us();
+  for (long spin = 0;; ++spin) {
     if (*flag >= seq) {  // sequence numbers only grow on a context: a later post implies this one
       std::atomic_thread_fence(std::memory_order_acquire);
       return SQD_OK;
     }
     __builtin_ia32_pause();
+    if ((spin & 255) == 255 && now_us() - t0 > SPIN_US) break;
+  }
+  // long wait: nap between looks at the word; the stream's status tells a kernel that died from one still running
+  for (long nap = 0;; ++nap) {
+    if (*flag >= seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return SQD_OK;
+    }
+    if ((nap & 7) == 7) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) break;  // everything enqueued has run: the word is there now, or never will be
+      if (e != hipErrorNotReady) {
+        set_error(std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        return SQD_ERR_HIP;
+      }
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+    if (now_us() - t0 > 120e6) break;  // two minutes: let the runtime report what is wrong
   }
   SQD_TRY(spin_stream_sync(s));  // also surfaces asynchronous kernel errors
   if (*flag < seq) {
@@ -46,6 +77,7 @@ int spin_wait_word(const void* word, long long seq, hipStream_t s) {
   return SQD_OK;
 }
 int spin_event_sync(hipEvent_t ev) {
+  const double t0 = now_us();
   for (long spin = 0;; ++spin) {
     const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) return SQD_OK;
@@ -53,7 +85,7 @@ int spin_event_sync(hipEvent_t ev) {
       set_error(std::string("hipEventQuery: ") + hipGetErrorString(e));
       return SQD_ERR_HIP;
     }
-    if (spin > 4000000L) break;
+    if ((spin & 15) == 15 && now_us() - t0 > SPIN_US) break;
     __builtin_ia32_pause();
   }
   SQD_HIP_CHECK(hipEventSynchronize(ev));
@@ -220,7 +252,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
                     &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo,
-                    &c->hdense_a, &c->hdense_b, &c->gdense};
+                    &c->hdense_a, &c->hdense_b, &c->gdense, &c->sol_prev};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();
@@ -749,6 +781,13 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
     c->subs.push_back(sub);
   }
   std::vector<sqd_ctx*> subs(c->subs.begin(), c->subs.begin() + nbatch);
+  for (size_t p = 0; p < c->subs.size(); ++p) {  // the latest solutions become the previous ones
+    sqd_ctx* sub = c->subs[p];
+    const bool had = (int)p < c->batch_n_prev_valid && sub->have_solution;
+    std::swap(sub->sol, sub->sol_prev);
+    sub->D_prev = had ? sub->D : 0;
+    sub->have_solution = false;
+  }
   for (int p = 0; p < nbatch; ++p) {
     sqd_ctx* sub = subs[p];
     sub->stream = c->stream;
@@ -817,6 +856,7 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
     if (e) e[p] = e_p;
   }
   c->batch_n = nbatch;
+  c->batch_n_prev_valid = nbatch;
   if (best || best_amps) {
     int w = 0;
     for (int p = 1; p < nbatch; ++p)
@@ -844,18 +884,27 @@ SQD_API int sqd_batch_ctx(sqd_ctx* c, int index, sqd_ctx** sub) {
   return SQD_OK;
 }
 
-SQD_API int sqd_batch_state(sqd_ctx* c, int index, double* amps) {
+SQD_API int sqd_batch_state(sqd_ctx* c, int index, int age, double* amps) {
   CTX_ENTER(c);
-  if (!amps || index < 0 || index >= c->batch_n) {
-    set_error("sqd_batch_state: no such batch in the latest sqd_solve_batch");
+  if (!amps || index < 0 || index >= (int)c->subs.size() || age < 0 || age > 1) {
+    set_error("sqd_batch_state: no such batch");
     return SQD_ERR_INVALID;
   }
   sqd_ctx* sub = c->subs[index];
-  if (!sub->have_solution) {
-    set_error("sqd_batch_state: no resident solution");
+  const void* src = nullptr;
+  size_t bytes = 0;
+  if (age == 0 && index < c->batch_n && sub->have_solution) {
+    src = sub->sol.p;
+    bytes = (size_t)sub->D * 8;
+  } else if (age == 1 && sub->D_prev > 0 && sub->sol_prev.p) {
+    src = sub->sol_prev.p;
+    bytes = (size_t)sub->D_prev * 8;
+  }
+  if (!src) {
+    set_error("sqd_batch_state: that solution is no longer resident");
     return SQD_ERR_STATE;
   }
-  SQD_HIP_CHECK(hipMemcpyAsync(amps, sub->sol.p, (size_t)sub->D * 8, hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(amps, src, bytes, hipMemcpyDeviceToHost, c->stream));
   SQD_TRY(spin_stream_sync(c->stream));
   return SQD_OK;
 }

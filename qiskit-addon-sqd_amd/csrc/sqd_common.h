@@ -246,6 +246,11 @@ struct sqd_ctx {
   sqd::DevBuf X, AX;        // (max_space+1) * D each
   sqd::DevBuf sol;          // f64[D] resident solution
   bool have_solution = false;
+  // batched solves keep the PREVIOUS call's solution of each sub-context as well (sol and sol_prev swap at the start
+  // of sqd_solve_batch): a caller that still holds the results of call N while call N + 1 runs -- `results =
+  // solver(...)` in a loop -- can read their states afterwards without every one of them being copied out first
+  sqd::DevBuf sol_prev;
+  int64_t D_prev = 0;
   sqd::DevBuf tmp1, tmp2;   // f64[D] scratch vectors
   sqd::DevBuf io_in, io_out;  // staging of host vectors crossing the C ABI
   sqd::DevBuf partial;      // reduction partials
@@ -285,6 +290,7 @@ struct sqd_ctx {
   sqd_ctx* parent = nullptr;        // set on a sub-context
   std::vector<sqd_ctx*> subs;       // grow-only; subs[i] serves batch i of the latest sqd_solve_batch
   int batch_n = 0;                  // subspaces of the latest sqd_solve_batch (0: none)
+  int batch_n_prev_valid = 0;       // ... of the latest one that completed (their solutions are resident)
   sqd::BatchStage bstage[3];        // [0] table build phase 1, [1] phase 2, [2] solver (sigma / Davidson / observables)
 };
 

@@ -201,7 +201,7 @@ def solve_sci_batch_distributed(
                 sa, sb = ci_strings[i]
                 amps = out["amps"][k]
                 if amps is None:
-                    amps = _DeferredAmplitudes(ctx, k, (len(sa), len(sb)))
+                    amps = _DeferredAmplitudes(ctx, k, (len(sa), len(sb)), out.get("generation"))
                     if len(mine) == 1:
                         amps.single = True
                     ctx._deferred.append(weakref.ref(amps))

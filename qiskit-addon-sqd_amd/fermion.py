@@ -114,7 +114,7 @@ def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int 
         _CTX_CACHE[key] = ctx
         while len(_CTX_CACHE) > _CTX_CACHE_MAX:
             _, old = _CTX_CACHE.popitem(last=False)
-            _settle_deferred(old)
+            _settle_deferred(old, final=True)
             old.close()
     return ctx
 
@@ -123,7 +123,7 @@ def clear_context_cache() -> None:
     with _CTX_LOCK:
         while _CTX_CACHE:
             _, old = _CTX_CACHE.popitem()
-            _settle_deferred(old)
+            _settle_deferred(old, final=True)
             old.close()
 
 
@@ -139,11 +139,12 @@ class _DeferredAmplitudes:
     and leaves the others resident; ``SCIState.amplitudes`` fetches on first access.  Before the solver context is
     re-used for another batched solve (or closed) every deferred state that is still referenced is fetched."""
 
-    __slots__ = ("ctx", "index", "shape", "value", "single", "__weakref__")
+    __slots__ = ("ctx", "index", "shape", "value", "single", "generation", "__weakref__")
 
-    def __init__(self, ctx, index, shape):
+    def __init__(self, ctx, index, shape, generation=None):
         self.ctx, self.index, self.shape, self.value = ctx, int(index), tuple(shape), None
         self.single = False  # True: the resident solution of a single solve on ctx (not a batch of a batched solve)
+        self.generation = generation  # the batched solve it belongs to (a slot keeps this and the next call's solutions)
 
     def __reduce__(self):  # pickled (the SPMD loop broadcasts its iteration state): as the array itself
         return (np.array, (self.fetch(),))
@@ -153,20 +154,28 @@ class _DeferredAmplitudes:
             ctx = self.ctx
             if ctx is None:
                 raise RuntimeError("the solver context that held this state has been released")
-            self.value = ctx.fetch_solution() if self.single else ctx.batch_state(self.index)
+            self.value = ctx.fetch_solution() if self.single else ctx.batch_state(self.index, self.generation)
             self.ctx = None
         return self.value
 
 
-def _settle_deferred(ctx) -> None:
-    """Fetch every still-referenced deferred state of the context's latest batched solve (called before the next)."""
-    refs = getattr(ctx, "_deferred", None)
-    if refs:
-        for r in refs:
-            d = r()
-            if d is not None and d.value is None:
-                d.fetch()
-    ctx._deferred = []
+def _settle_deferred(ctx, final: bool = False) -> None:
+    """Called before the context runs its next batched solve (``final``: before it is closed): fetch the deferred
+    states that would no longer be resident afterwards and are still referenced.  A slot keeps the latest and the
+    previous call's solutions, so the results of call N survive call N + 1 untouched -- the ``results = solver(...)``
+    loop of the reference (``fermion.py:432``) never pays for states it does not read."""
+    refs = getattr(ctx, "_deferred", None) or []
+    gen_now = getattr(ctx, "_batch_gen", 0)
+    keep = []
+    for r in refs:
+        d = r()
+        if d is None or d.value is not None:
+            continue
+        if final or d.single or d.generation is None or d.generation < gen_now:
+            d.fetch()
+        else:
+            keep.append(r)
+    ctx._deferred = keep
 
 
 @dataclass(frozen=True)
@@ -496,7 +505,7 @@ def _solve_sci_batched(ci_strings, one_body_tensor, two_body_tensor, nelec, spin
             raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {out['nelec'][i]} of the CI strings")
         amps = out["amps"][i]
         if amps is None:
-            amps = _DeferredAmplitudes(ctx, i, (len(strs_a), len(strs_b)))
+            amps = _DeferredAmplitudes(ctx, i, (len(strs_a), len(strs_b)), out["generation"])
             ctx._deferred.append(weakref.ref(amps))
         state = SCIState(amplitudes=amps, ci_strs_a=np.asarray(strs_a), ci_strs_b=np.asarray(strs_b), norb=norb, nelec=want)
         results.append(SCIResult(float(out["energy"][i]), state, orbital_occupancies=(out["occ_a"][i], out["occ_b"][i]),

@@ -23,6 +23,14 @@ Native side: ``sqd_set_subspace_rows`` (link tables for all strings, hdiag / sig
 host-controlled pyscf flow (the single-GPU solver's device-controlled loop needs its reductions in
 one device's memory), with the vectors as torch tensors on the rank's GPU: torch is the plumbing for device memory
 and the collectives, the sigma kernels are the library's.
+
+Round 3: the basis lives in two persistent ``[max_space + 1, rows, nb]`` tensors (sigma writes its output in place:
+no allocation per build); an iteration makes TWO host reads instead of five or more -- the new column of the
+projected matrix (one matrix-vector product + one all-reduce), and ``{|r|^2, |t|^2, X_v . t}`` in one all-reduce --
+everything else (Ritz vector, residual, preconditioner, Gram-Schmidt) is a handful of device-side matrix-vector
+products with the coefficients uploaded once; the correction is orthogonalised with the known norm ``1 - sum g^2`` as
+the single-GPU solver does; the solver context is cached per (Hamiltonian, group); the squared spin penalty is applied
+through two gathers.  Still host-controlled, and the all-gather is not overlapped with the beta-side work.
 """
 
 from __future__ import annotations
@@ -48,6 +56,24 @@ def row_range(na: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_CTX_CACHE: dict = {}
+
+
+def _cached_context(one_body_tensor, two_body_tensor, device, group, lib):
+    """One solver context per (Hamiltonian, device, group): integral upload and packing once, arenas reused."""
+    from .fermion import _ham_key
+
+    if lib is not None:  # (tests drive a specific library object: no sharing)
+        return _capi.Context(one_body_tensor, two_body_tensor, device=device, lib=lib), False
+    key = _ham_key(one_body_tensor, two_body_tensor, device) + (id(group),)
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None:
+        ctx = _CTX_CACHE[key] = _capi.Context(one_body_tensor, two_body_tensor, device=device)
+        while len(_CTX_CACHE) > 4:
+            _CTX_CACHE.pop(next(iter(_CTX_CACHE))).close()
+    return ctx, True
+
+
 class ShardedSubspace:
     """The rank-local part of one subspace: tables on this rank's GPU, sigma for its rows, collectives."""
 
@@ -69,9 +95,13 @@ class ShardedSubspace:
         self.row0, self.row1 = row_range(self.na, self.rank, self.world)
         self.nrows = self.row1 - self.row0
         self.norb = int(np.asarray(one_body_tensor).shape[0])
-        self.ctx = _capi.Context(one_body_tensor, two_body_tensor, device=device, lib=lib)
+        self.ctx, self._shared_ctx = _cached_context(np.asarray(one_body_tensor, dtype=np.float64), two_body_tensor, device,
+                                                      group, lib)
         if self.on_gpu:  # library kernels and torch ops / collectives on ONE stream: ordering without events
-            self.ctx.use_stream(torch.cuda.current_stream(self.tdev).cuda_stream)
+            h = torch.cuda.current_stream(self.tdev).cuda_stream
+            if getattr(self.ctx, "_on_stream", None) != h:
+                self.ctx.use_stream(h)
+                self.ctx._on_stream = h
         self.ctx.set_subspace_rows(self.strs_a, self.strs_b, self.row0, self.row1)
         self.nelec = self.ctx.nelec
         self.hdiag = torch.empty((self.nrows, self.nb), dtype=torch.float64, device=self.tdev)
@@ -85,7 +115,8 @@ class ShardedSubspace:
         self.ctx.sync()  # (CPU / emulator: no-op; GPU: the shared stream)
 
     def close(self):
-        self.ctx.close()
+        if not self._shared_ctx:
+            self.ctx.close()
 
     # -- collectives
     def gather_rows(self, shard):
@@ -123,14 +154,32 @@ class ShardedSubspace:
         return float(self.allreduce(torch.sum(x * y).reshape(1))[0])
 
     # -- operators on shards
-    def sigma(self, shard, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0):
-        """Rows [row0, row1) of (P H P (+ penalty)) c for the row-sharded vector ``shard``: one all-gather + local kernels."""
+    def sigma(self, shard, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0, out=None):
+        """Rows [row0, row1) of (P H P (+ penalty)) c for the row-sharded vector ``shard``: one all-gather + local
+        kernels, enqueued on the shared stream (no host wait).  ``use_spin``: 0 none, 1 ``shift (S^2 - ss)``,
+        2 ``shift (S^2 - ss)^2`` -- pyscf's second form, which chains S^2 through an intermediate FULL vector: a second
+        all-gather.  ``out``: where the rows go (a contiguous ``[rows, nb]`` tensor), else a fresh one."""
         import torch
 
+        if out is None:
+            out = torch.empty((self.nrows, self.nb), dtype=torch.float64, device=self.tdev)
         full = self.gather_rows(shard)
-        out = torch.empty((self.nrows, self.nb), dtype=torch.float64, device=self.tdev)
-        self.ctx.sigma_rows_dev(full.data_ptr(), out.data_ptr(), use_spin, ss, shift)
-        self._sync()
+        if use_spin != 2:
+            self.ctx.sigma_rows_dev(full.data_ptr(), out.data_ptr(), use_spin, ss, shift)
+            if not self.on_gpu:
+                self._sync()
+            return out
+        t1 = torch.empty_like(out)
+        self.ctx.sigma_rows_dev(full.data_ptr(), out.data_ptr(), 0, 0.0, 0.0)        # H c
+        self.ctx.contract_ss_rows_dev(full.data_ptr(), t1.data_ptr())              # S^2 c
+        t1.sub_(shard, alpha=ss)                                                    # (S^2 - ss) c, owned rows
+        full = self.gather_rows(t1)                                                 # second gather
+        t2 = torch.empty_like(out)
+        self.ctx.contract_ss_rows_dev(full.data_ptr(), t2.data_ptr())
+        t2.sub_(t1, alpha=ss)                                                       # (S^2 - ss)^2 c
+        out.add_(t2, alpha=shift)
+        if not self.on_gpu:
+            self._sync()
         return out
 
     def contract_ss(self, shard):
@@ -192,9 +241,7 @@ def solve_sci_sharded(
         use_spin, ss = 0, 0.0
         if spin_sq is not None:
             sz = 0.5 * abs(sub.nelec[0] - sub.nelec[1])
-            if not spin_sq < sz * (sz + 1.0) + 0.1:
-                raise NotImplementedError("the squared spin penalty (spin_sq above sz(sz+1)) is not available sharded")
-            use_spin, ss = 1, float(spin_sq)
+            use_spin, ss = (1 if spin_sq < sz * (sz + 1.0) + 0.1 else 2), float(spin_sq)
         toloose = tol_residual if tol_residual else np.sqrt(tol) / 32.0
         hd = sub.hdiag
         # ---- pyscf get_init_guess on the sharded diagonal: global argmin (lower triangle when the sectors match)
@@ -211,8 +258,14 @@ def solve_sci_sharded(
         else:
             allc = [cand]
         best = min(((float(c[0]), int(c[1])) for c in allc))  # ties: lowest flat index
-        x = torch.zeros((sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
-        flat = x.reshape(-1)
+        # ---- persistent basis: X[v], AX[v] = rows of basis vector v and of its sigma (flat views for the products)
+        nvec = max_space + 1
+        Dl = sub.nrows * sub.nb
+        X = torch.zeros((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
+        AX = torch.empty((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
+        Xf, AXf = X.view(nvec, Dl), AX.view(nvec, Dl)
+        hdf = hd.reshape(Dl)
+        flat = Xf[0]
         lo, hi = sub.row0 * sub.nb, sub.row1 * sub.nb
         if lo <= best[1] < hi:
             flat[best[1] - lo] = 1.0
@@ -220,55 +273,73 @@ def solve_sci_sharded(
             flat[0] += 1e-5
         if hi == sub.na * sub.nb:
             flat[-1] -= 1e-5
-        x = x / np.sqrt(sub.dot(x, x))
+        # closed-form norm of the start vector (no reduction): 1 at the minimum, +-1e-5 on the first / last element
+        f = {0: 1e-5, sub.na * sub.nb - 1: -1e-5}
+        f[best[1]] = f.get(best[1], 0.0) + 1.0
+        flat.mul_(1.0 / np.sqrt(sum(v * v for v in f.values())))
 
-        xs, axs = [], []
-        e, conv, nsig = 0.0, False, 0
-        xt = x
-        heff = np.zeros((max_space + 1, max_space + 1))
+        def host(t):  # ONE all-reduce + ONE device-to-host read of a small vector
+            return sub.allreduce(t).cpu().numpy()
+
+        e, conv, nsig, m = 0.0, False, 0, 1
+        heff = np.zeros((nvec, nvec))
+        v0 = np.ones(1)
+        xr = axr = None
         for _ in range(max_cycle):
-            xs.append(xt)
-            axs.append(sub.sigma(xt, use_spin, ss, shift))
+            sub.sigma(X[m - 1], use_spin, ss, shift, out=AX[m - 1])
             nsig += 1
-            m = len(xs)
-            # new row / column of the projected matrix: m local dots, one all-reduce
-            col = torch.stack([torch.sum(xi * axs[-1]) for xi in xs])
-            col = sub.allreduce(col).cpu().numpy()
+            # new column of the projected matrix: ONE matrix-vector product over the local rows, one all-reduce
+            col = host(torch.mv(Xf[:m], AXf[m - 1]))
             heff[:m, m - 1] = heff[m - 1, :m] = col
             w, v = np.linalg.eigh(heff[:m, :m])
             elast, e = e, float(w[0])
             v0 = v[:, 0]
-            xr = sum(float(c) * xi for c, xi in zip(v0, xs))
-            axr = sum(float(c) * ai for c, ai in zip(v0, axs))
-            r = axr - e * xr
+            coef = torch.from_numpy(np.ascontiguousarray(v0)).to(sub.tdev)
+            xr = torch.mv(Xf[:m].t(), coef)       # Ritz vector and A * Ritz: two matrix-vector products
+            axr = torch.mv(AXf[:m].t(), coef)
+            r = torch.sub(axr, xr, alpha=e)
+            t = r / (hdf - e + 1e-4)
+            # {|r|^2, |t|^2, X_v . t}: one all-reduce, one host read -- the stop rule and the Gram-Schmidt coefficients
+            red = host(torch.cat([torch.stack([torch.dot(r, r), torch.dot(t, t)]), torch.mv(Xf[:m], t)]))
+            rn2, tt = float(red[0]), float(red[1])
             de = e - elast if nsig > 1 else e
-            rn2 = sub.dot(r, r)
             if abs(de) < tol and rn2 < toloose**2:
                 conv = True
                 break
-            if rn2 <= lindep:
+            if rn2 <= lindep or not tt > 0.0:
                 conv = rn2 < toloose**2
                 break
-            t = r / (hd - e + 1e-4)
-            t = t / np.sqrt(sub.dot(t, t))
-            ov = sub.allreduce(torch.stack([torch.sum(xi * t) for xi in xs]))
-            for c, xi in zip(ov.cpu().numpy(), xs):
-                t = t - float(c) * xi
-            tn2 = sub.dot(t, t)
-            if tn2 <= lindep:
+            g = red[2:] / np.sqrt(tt)              # overlaps of the normalised correction with the (orthonormal) basis
+            c2 = float(g @ g)
+            if 1.0 - c2 <= lindep:
                 conv = rn2 < toloose**2
                 break
-            xt = t / np.sqrt(tn2)
-            if m + 1 > max_space:  # restart: {Ritz vector, correction}, A*Ritz by combination (no sigma build)
-                xs, axs = [xr], [axr]
+            # t <- (t / |t| - sum_v g_v X_v) / sqrt(1 - c2): the norm after Gram-Schmidt is known before it is done
+            inv = 1.0 / np.sqrt(1.0 - c2)
+            gdev = torch.from_numpy(np.ascontiguousarray(g * inv)).to(sub.tdev)
+            restart = m + 1 > max_space
+            tgt = Xf[1] if restart else Xf[m]
+            proj = torch.mv(Xf[:m].t(), gdev)  # (before the target is written: at a restart it is one of the X_v)
+            torch.mul(t, inv / np.sqrt(tt), out=tgt)
+            tgt.sub_(proj)
+            if restart:  # {Ritz vector, correction}, A * Ritz by combination (no sigma build)
+                Xf[0].copy_(xr)
+                AXf[0].copy_(axr)
                 heff[:] = 0.0
                 heff[0, 0] = e
+                m = 2
+            else:
+                m += 1
+        xr = xr.view(sub.nrows, sub.nb)
         c_loc = xr / np.sqrt(sub.dot(xr, xr))
         # ---- observables (reference fermion.py:725-742): <c|H|c> without the penalty, occupancies
         e_dav = e
-        if use_spin:
+        if use_spin == 1:
             s2c = sub.contract_ss(c_loc)
             energy = e_dav - shift * (sub.dot(c_loc, s2c) - ss)
+        elif use_spin == 2:  # <(S^2 - ss)^2> = |S^2 c - ss c|^2
+            pc = sub.contract_ss(c_loc) - ss * c_loc
+            energy = e_dav - shift * sub.dot(pc, pc)
         else:
             energy = e_dav
         occ_a, occ_b = sub.occupancies(c_loc)

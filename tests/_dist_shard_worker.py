@@ -59,9 +59,16 @@ def main():
     sub.close()
 
     # (iii) the collective solver against dense diagonalisation, without and with the spin penalty
-    for spin_sq in (None, 0.0):
+    sz = 0.5 * abs(nelec[0] - nelec[1])
+    for spin_sq in (None, 0.0, sz * (sz + 1.0) + 2.0):  # no penalty, pyscf's first form, the squared form (two gathers)
         res = solve_sci_sharded((sa, sb), h1, eri, norb, nelec, spin_sq=spin_sq, lib=emu)
-        Heff = H if spin_sq is None else H + 0.2 * (S2 - spin_sq * np.eye(len(H)))
+        if spin_sq is None:
+            Heff = H
+        elif spin_sq < sz * (sz + 1.0) + 0.1:
+            Heff = H + 0.2 * (S2 - spin_sq * np.eye(len(H)))
+        else:
+            P = S2 - spin_sq * np.eye(len(H))
+            Heff = H + 0.2 * (P @ P)
         w, v = np.linalg.eigh(Heff)
         e_ref = float(v[:, 0] @ H @ v[:, 0])
         st = res._sharded_stats

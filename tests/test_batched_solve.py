@@ -68,8 +68,18 @@ def test_batched_solve_settles_deferred_states(emu_backend):
     b2 = _batches(norb, nelec, [(8, 8), (9, 5), (4, 4)], hf=False)
     first = solve_sci_batch(b1, h1, eri, norb, nelec)
     ref = [solve_sci(b, h1, eri, norb, nelec) for b in b1]
+    ref2 = [solve_sci(b, h1, eri, norb, nelec) for b in b2]
     second = solve_sci_batch(b2, h1, eri, norb, nelec)
+    # a slot keeps the latest and the previous call's solutions: nothing of `first` has been copied out yet ...
+    lazy = [r for r in first if isinstance(object.__getattribute__(r.sci_state, "amplitudes"), fermion._DeferredAmplitudes)]
+    assert len(lazy) == 1 and lazy[0].sci_state.amplitudes.shape == lazy[0].sci_state.amplitudes.shape
     for r, s in zip(first, ref):
+        assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
+    # ... and a third call fetches what is still referenced of the second before its slots are reused
+    third = solve_sci_batch(b1, h1, eri, norb, nelec)
+    for r, s in zip(second, ref2):
+        assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
+    for r, s in zip(third, ref):
         assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
     assert len(second) == 3
 

@@ -100,6 +100,10 @@ def test_rows_sigma_kernel_default_selection(hip_lib, monkeypatch):
             out[forced] = (ctx.sigma(x), ctx.contract_ss(x), ctx.sigma(x, 1, 0.0, 0.3), st["e_davidson"], st["converged"])
     a, b = out[None], out["0"]
     scale = np.abs(b[0]).max()
+    # the default-selected rows kernel against the ORACLE (O1s: string-space operator in numpy, ~20 s at this size),
+    # not only against the product's other kernel
+    hd_max = np.abs(O.make_hdiag(h1, eri, sa, sb, 30)).max()
+    assert np.abs(a[0] - O.sigma_string_space(h1, eri, sa, sb, x, 30)).max() < 1e-11 * hd_max
     assert np.abs(a[0] - b[0]).max() < 1e-12 * scale
     assert np.abs(a[1] - b[1]).max() < 1e-12 * np.abs(b[1]).max()
     assert np.abs(a[2] - b[2]).max() < 1e-12 * scale
@@ -125,6 +129,25 @@ def test_rows_sigma_kernel_ragged_against_work_items(hip_lib, monkeypatch, na, n
             out[forced] = (ctx.sigma(x), ctx.contract_ss(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.sigma(x, 2, 0.75, 0.3))
     for a, b in zip(out[rows], out["0"]):
         assert np.abs(a - b).max() < 1e-12 * max(1.0, np.abs(b).max())
+
+
+def test_long_rows_kernel_selection_and_oracle(hip_lib):
+    """256 x 10 000 uniform strings (the 1e4-column regime of BASELINE config 2 read literally, at a row count the
+    oracle finishes in seconds): the default selection must be k_sigma_rows<2>, its sigma must match the oracle (O1s)
+    and be Hermitian on a pair of vectors."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, 256, 41), S.uniform_strings(30, 8, 10000, 42)
+    rng = np.random.default_rng(9)
+    x, y = rng.standard_normal((256, 10000)), rng.standard_normal((256, 10000))
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_sigma_rows<2>"
+        sx, sy = ctx.sigma(x), ctx.sigma(y)
+    hd_max = np.abs(O.make_hdiag(h1, eri, sa, sb, 30)).max()
+    assert np.abs(sx - O.sigma_string_space(h1, eri, sa, sb, x, 30)).max() < 1e-11 * hd_max
+    assert abs(np.vdot(y, sx) - np.vdot(sy, x)) < 1e-9 * abs(np.vdot(y, sx))
 
 
 def test_capped_ell_overflow_rows(hip_lib, monkeypatch):

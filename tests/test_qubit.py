@@ -118,6 +118,34 @@ def test_gpu_large_random_2local(hip_lib):
     assert abs(op - op.getH()).max() < 1e-12  # Hermitian
 
 
+@pytest.mark.gpu
+def test_gpu_config5_full_size(hip_lib):
+    """BASELINE config 5 at its full size: 40 qubits, 1e5 sampled bitstrings (sorted, unique), a random 2-local
+    Hamiltonian of 60 terms, the projected operator against the numpy restatement -- CSR bit for bit in its structure."""
+    rng = np.random.default_rng(15)
+    nq, d = 40, 100_000
+    mat = rng.integers(2, size=(d, nq)).astype(bool)
+    flips = np.zeros((400, nq), dtype=bool)
+    for f in flips:
+        f[rng.choice(nq, 2, replace=False)] = True
+    extra = mat[rng.integers(d, size=20000)] ^ flips[rng.integers(400, size=20000)]  # partners, so that terms connect
+    mat = Q.sort_and_remove_duplicates(np.concatenate([mat, extra]))[:d]
+    assert mat.shape[0] == d
+    labels, coeffs = [], []
+    for _ in range(60):
+        i, j = rng.choice(nq, 2, replace=False)
+        lab = ["I"] * nq
+        lab[i], lab[j] = rng.choice(list("XYZ")), rng.choice(list("XYZ"))
+        labels.append("".join(lab)); coeffs.append(float(rng.standard_normal()))
+    ham = Q.PauliSum.from_list(list(zip(labels, coeffs)))
+    op = Q.project_operator_to_subspace(mat, ham)
+    ref = QO.project_operator_to_subspace(mat, [(*_term(l), c) for l, c in zip(labels, coeffs)]).tocsr()
+    ref.sum_duplicates(); ref.eliminate_zeros(); ref.sort_indices()
+    assert op.shape == ref.shape == (d, d) and op.nnz == ref.nnz
+    assert np.array_equal(op.indptr, ref.indptr) and np.array_equal(op.indices, ref.indices)
+    assert np.allclose(op.data, ref.data, atol=1e-12)
+
+
 def _check_large_scan_path():
     # d > 16384 rows exercises the three-phase (tile sums / scan / tile scan) CSR pointer construction
     rng = np.random.default_rng(11)
