@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(1024) k_sigma_rows_b(const DirectArgs* __restr
 // here because the blocks of the sets the SQD loop produces are 20-22 % dense: enumerating the links costs two LDS
 // gathers per multiply-add, the dense product none, and 5 x the flops on v_mfma_f64_16x16x4_f64 are cheaper.
 // One workgroup (4 wavefronts) = one 64 x 64 tile of G; wavefront w owns the 32 x 32 quadrant (w / 2, w % 2) as 2 x 2
-// MFMA tiles (16 f64 accumulators per lane).  Both products run through the same loop over chunks of DK = 32 k: the 64 x 32
+// MFMA tiles (16 f64 accumulators per lane).  Both products run through the same loop over chunks of DK = 16 k: the 64 x 16
 // operand tiles are staged in LDS k-major -- H_a[i][k] is read as H_a[k][i] (symmetric: coalesced), the rows of C for
 // the second product are transposed on the way in (pitch 65) -- so every fragment read is 16 consecutive doubles.
 // Register-staged double buffering: the global loads of chunk c + 1 are in flight while chunk c is multiplied.
@@ -779,56 +779,64 @@ struct DenseArgs {
   unsigned tj;            // tiles along B
   unsigned gx;            // tiles of this subspace (x DENSE_SPLIT workgroups: blockIdx.y = k range)
 };
-constexpr int DT = 64, DK = 32, DPITCH = DT + 1, DU = DT * DK / 256;  // DU: elements per thread and operand tile
-__device__ inline void same_spin_mfma_body(const DenseArgs& g, double* smem, unsigned bx, unsigned by) {
+constexpr int DT = 64, DK = 16, DU = DT * DK / 256;  // DU: elements per thread and operand tile
+// LDS layouts, chosen so that every fragment read (ds_read_b64: lane groups {0-31}, {32-63}, bank = word mod 64) and every
+// staging write is conflict-free: k-major tiles [k][64] at a pitch of 80 doubles (the two k rows of a lane group start
+// 32 banks apart), the rows of C of product 2 as they are, [i][16 k] at a pitch of 18 doubles (16 rows x 36 words
+// are 16 distinct multiples of 4 mod 64; the group's second k sits 2 banks further)
+constexpr int DPITCH = 80, DPITCH2 = DK + 2, DTILE = DK * DPITCH;  // DTILE doubles per staged tile (>= 64 * DPITCH2)
+__device__ inline void same_spin_mfma_body(const DenseArgs& g, unsigned bx, unsigned by) {
+  // (declared HERE and addressed by integer offsets: through a `double*` parameter or an array of buffer pointers the
+  // compiler loses the address space and emits flat_load / flat_store for the tiles, and a flat access waits on the
+  // vector-memory counter too -- the prefetch of the next chunk was waited for before the MFMAs it should hide behind)
+  __shared__ double smem[4 * DTILE];
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   const double* __restrict__ Ha = g.ha;
   const double* __restrict__ Hb = g.hb;
-  const int64_t na = g.na, nb = g.nb;
-  const int pa = g.pa, pb = g.pb;
+  // (orders up to 4096: every element offset fits 32 bits)
+  const int na = (int)g.na, nb = (int)g.nb, pa = g.pa, pb = g.pb;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int wi = wv >> 1, wj = wv & 1;
-  const int64_t i0 = (int64_t)(bx / g.tj) * DT, j0 = (int64_t)(bx % g.tj) * DT;
-  double* sA[2] = {smem, smem + 2 * DK * DPITCH};
-  double* sB[2] = {smem + DK * DPITCH, smem + 3 * DK * DPITCH};
-  // chunk list: product 1 over k in [0, na16), then product 2 over k in [0, nb16)
-  const int n1 = (int)((na + DK - 1) / DK), n2 = (int)((nb + DK - 1) / DK), nch = n1 + n2;
+  const int i0 = (int)(bx / g.tj) * DT, j0 = (int)(bx % g.tj) * DT;
+  // buffer `buf`: operand tile A at 2 buf DTILE, operand tile B at (2 buf + 1) DTILE
+  // chunk list: product 1 over k in [0, na16), then product 2 over k in [0, nb16); this workgroup's share of it
+  // (by = which of the DENSE_SPLIT partial products)
+  const int n1 = (na + DK - 1) / DK, n2 = (nb + DK - 1) / DK, nch = n1 + n2;
+  const int ch0 = (int)((int64_t)nch * by / DENSE_SPLIT), ch1 = (int)((int64_t)nch * (by + 1) / DENSE_SPLIT);
+  // this thread's DU + DU elements of a chunk's operand tiles: tile element e = t + 256 u is (kk, cc) = (e / 64, e % 64)
+  // for the k-major reads, (ii, k2) = (e / DK, e % DK) for the rows of C of product 2
+  const int kk0 = t >> 6, cc = t & 63, ii0 = t / DK, k2 = t % DK;
+  const bool col_ok = j0 + cc < nb;
   double ra[DU], rb[DU];
-  auto fetch = [&](int ch) {  // this thread's 4 + 4 elements of chunk ch's operand tiles, into registers
+  auto fetch = [&](int ch) {
     if (ch < n1) {
-      const int64_t k0 = (int64_t)ch * DK;
+      const int k0 = ch * DK;
 #pragma unroll
       for (int u = 0; u < DU; ++u) {
-        const int e = t + 256 * u, kk = e >> 6, cc = e & 63;
-        ra[u] = Ha[(k0 + kk) * pa + i0 + cc];                                  // H_a[i0+cc][k0+kk] (symmetric)
-        const int64_t kr = k0 + kk, jc = j0 + cc;
-        rb[u] = (kr < na && jc < nb) ? C[kr * nb + jc] : 0.0;                  // C[k0+kk][j0+cc]
+        const int kr = k0 + kk0 + (256 / 64) * u;
+        ra[u] = Ha[kr * pa + i0 + cc];                                   // H_a[i0+cc][kr] (symmetric: read k-major)
+        rb[u] = (kr < na && col_ok) ? C[kr * nb + j0 + cc] : 0.0;        // C[kr][j0+cc]
       }
     } else {
-      const int64_t k0 = (int64_t)(ch - n1) * DK;
+      const int k0 = (ch - n1) * DK;
 #pragma unroll
       for (int u = 0; u < DU; ++u) {
-        const int e = t + 256 * u;
-        const int ii = e / DK, k2 = e % DK;                                    // DK consecutive k of one row of C
-        const int64_t ir = i0 + ii, kc = k0 + k2;
-        ra[u] = (ir < na && kc < nb) ? C[ir * nb + kc] : 0.0;                  // C[i0+ii][k0+k2]
-        const int kk = e >> 6, cc = e & 63;
-        rb[u] = Hb[(k0 + kk) * pb + j0 + cc];                                  // H_b[k0+kk][j0+cc]
+        const int ir = i0 + ii0 + (256 / DK) * u, kc = k0 + k2;
+        ra[u] = (ir < na && kc < nb) ? C[ir * nb + kc] : 0.0;            // C[i0+ii][k0+k2]
+        rb[u] = Hb[(k0 + kk0 + (256 / 64) * u) * pb + j0 + cc];          // H_b[kr][j0+cc]
       }
     }
   };
-  auto park = [&](int ch, int buf) {  // registers -> LDS, k-major
-    double* a = sA[buf];
-    double* b = sB[buf];
+  auto park = [&](int ch, int buf) {  // registers -> LDS
+    const int oa = 2 * buf * DTILE, ob = oa + DTILE;
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const int e = t + 256 * u;
-      if (ch < n1) a[(e >> 6) * DPITCH + (e & 63)] = ra[u];
-      else a[(e % DK) * DPITCH + (e / DK)] = ra[u];
-      b[(e >> 6) * DPITCH + (e & 63)] = rb[u];
+      if (ch < n1) smem[oa + (kk0 + (256 / 64) * u) * DPITCH + cc] = ra[u];      // k-major
+      else smem[oa + (ii0 + (256 / DK) * u) * DPITCH2 + k2] = ra[u];             // rows of C as they are
+      smem[ob + (kk0 + (256 / 64) * u) * DPITCH + cc] = rb[u];
     }
   };
   mfma_d4 acc[2][2];
@@ -836,23 +844,22 @@ __device__ inline void same_spin_mfma_body(const DenseArgs& g, double* smem, uns
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-  // this workgroup's share of the chunk list (by = which of the DENSE_SPLIT partial products)
-  const int ch0 = (int)((int64_t)nch * by / DENSE_SPLIT), ch1 = (int)((int64_t)nch * (by + 1) / DENSE_SPLIT);
   if (ch0 < ch1) {
     fetch(ch0);
     park(ch0, ch0 & 1);
   }
   __syncthreads();
+  const int fa1 = lk * DPITCH + wi * 32 + li, fa2 = (wi * 32 + li) * DPITCH2 + lk, fb = lk * DPITCH + wj * 32 + li;
   for (int ch = ch0; ch < ch1; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < ch1) fetch(ch + 1);
-    const double* a = sA[buf];
-    const double* b = sB[buf];
+    const bool p1 = ch < n1;
+    const int oa = 2 * buf * DTILE + (p1 ? fa1 : fa2), ob = (2 * buf + 1) * DTILE + fb;
+    const int ak = p1 ? 4 * DPITCH : 4, a16 = p1 ? 16 : 16 * DPITCH2;  // fragment strides: next k4 step, next 16 rows
 #pragma unroll
     for (int k4 = 0; k4 < DK / 4; ++k4) {
-      const int kr = (k4 * 4 + lk) * DPITCH;
-      const double a0 = a[kr + wi * 32 + li], a1 = a[kr + wi * 32 + 16 + li];
-      const double b0 = b[kr + wj * 32 + li], b1 = b[kr + wj * 32 + 16 + li];
+      const double a0 = smem[oa + k4 * ak], a1 = smem[oa + k4 * ak + a16];
+      const double b0 = smem[ob + k4 * 4 * DPITCH], b1 = smem[ob + k4 * 4 * DPITCH + 16];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
@@ -861,27 +868,26 @@ __device__ inline void same_spin_mfma_body(const DenseArgs& g, double* smem, uns
     if (ch + 1 < ch1) park(ch + 1, buf ^ 1);
     __syncthreads();
   }
-  double* __restrict__ G = g.g + (int64_t)by * na * nb;
+  double* __restrict__ G = g.g + (int64_t)by * g.na * g.nb;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = i0 + wi * 32 + a * 16 + lk + 4 * r, col = j0 + wj * 32 + b * 16 + li;
+        const int row = i0 + wi * 32 + a * 16 + lk + 4 * r, col = j0 + wj * 32 + b * 16 + li;
         if (row < na && col < nb) G[row * nb + col] = acc[a][b][r];
       }
 }
-constexpr size_t DENSE_SHMEM = (size_t)4 * DK * DPITCH * 8;  // two buffers x two operand tiles
-__global__ void __launch_bounds__(256) k_same_spin_mfma(const DenseArgs g) {
-  HIP_DYNAMIC_SHARED(double, smem)
-  same_spin_mfma_body(g, smem, blockIdx.x, blockIdx.y);
+// (40 KB of LDS and at most 128 VGPRs: three to four workgroups per CU, so that one workgroup's loads hide behind the
+// others' MFMAs)
+__global__ void __launch_bounds__(256, 4) k_same_spin_mfma(const DenseArgs g) {
+  same_spin_mfma_body(g, blockIdx.x, blockIdx.y);
 }
-__global__ void __launch_bounds__(256) k_same_spin_mfma_b(const DenseArgs* __restrict__ gs) {
-  HIP_DYNAMIC_SHARED(double, smem)
+__global__ void __launch_bounds__(256, 4) k_same_spin_mfma_b(const DenseArgs* __restrict__ gs) {
   const DenseArgs g = gs[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= g.gx) return;
-  same_spin_mfma_body(g, smem, blockIdx.x, blockIdx.y);
+  same_spin_mfma_body(g, blockIdx.x, blockIdx.y);
 }
 
 struct ReduceArgs {
@@ -1143,19 +1149,6 @@ static void fill_sigma_args(sqd_ctx* c, const double* d_c, double* d_sigma, int 
   g.gdense = (c->sig_dense && mode == 0) ? c->gdense.as<double>() : nullptr;
   g.gdense_stride = c->na * c->nb;
 }
-// the product kernels' dynamic LDS is beyond the 64 KB a kernel gets without asking: once per device
-static int grant_dense_shmem(sqd_ctx* c) {
-  static std::atomic<int> granted[64];
-  const int dev = c->device & 63;
-  if (!granted[dev].load(std::memory_order_relaxed)) {
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_same_spin_mfma),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_SHMEM));
-    SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_same_spin_mfma_b),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_SHMEM));
-    granted[dev].store(1, std::memory_order_relaxed);
-  }
-  return SQD_OK;
-}
 // arguments of the matrix-core same-spin product for the vector the work items of the same sigma build will read
 static void fill_dense_args(sqd_ctx* c, const double* d_c, int64_t in_stride, DenseArgs* dp) {
   DenseArgs& d = *dp;
@@ -1203,8 +1196,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (g.gdense) {
     DenseArgs d;
     fill_dense_args(c, d_c, in_stride, &d);
-    SQD_TRY(grant_dense_shmem(c));
-    hipLaunchKernelGGL(k_same_spin_mfma, dim3(d.gx, DENSE_SPLIT), dim3(256), DENSE_SHMEM, c->stream, d);
+    hipLaunchKernelGGL(k_same_spin_mfma, dim3(d.gx, DENSE_SPLIT), dim3(256), 0, c->stream, d);
     SQD_HIP_CHECK(hipGetLastError());
   }
   const int R = c->sig_R;
@@ -1397,8 +1389,7 @@ int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan) {
         hipLaunchKernelGGL((k_sigma_direct_b<false>), dim3(L.gx, 1, (unsigned)L.n), dim3(256), 0, parent->stream,
                            reinterpret_cast<const DirectArgs*>(L.args));
     } else if (L.kind == 4) {
-      SQD_TRY(grant_dense_shmem(parent));
-      hipLaunchKernelGGL(k_same_spin_mfma_b, dim3(L.gx, DENSE_SPLIT, (unsigned)L.n), dim3(256), DENSE_SHMEM, parent->stream,
+      hipLaunchKernelGGL(k_same_spin_mfma_b, dim3(L.gx, DENSE_SPLIT, (unsigned)L.n), dim3(256), 0, parent->stream,
                          reinterpret_cast<const DenseArgs*>(L.args));
     } else if (L.kind == 3) {
       hipLaunchKernelGGL(k_sigma_reduce_b, dim3(L.gx, L.gy, (unsigned)L.n), dim3(512), 0, parent->stream,
