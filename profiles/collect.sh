@@ -1,42 +1,41 @@
 #!/bin/bash
 # Collects the measurements that DESIGN.md section 8 and profiles/rNN/ quote.  Run on the GPU box:
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r02'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
 # Everything lands under gpurun_out/<round>/; profiles/summarize.py then writes the tracked summaries.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $ROOT
-python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1
+F='grep -v -e amdgpu.ids -e RCCL -e "HIP version" -e "ROCm version" -e Hostname -e Librccl -e socket.cpp'
+python -m pytest tests -m gpu -q 2>&1 | eval $F | tail -5 > $OUT/gpu_tests.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_uniform317.json 2> $OUT/bench_uniform317.err  # the driver's command line
 python bench.py --strings hf --skip-cpu --skip-secondary > $OUT/bench_hf317.json 2>/dev/null
+SQD_SIGMA_DENSE=0 python bench.py --strings hf --skip-cpu --skip-secondary > $OUT/bench_hf317_sparse_same_spin.json 2>/dev/null
 python bench.py --strings hf --spin-sq 0 --skip-cpu --skip-secondary > $OUT/bench_hf317_spin0.json 2>/dev/null
 python bench.py --skip-cpu --skip-secondary --extra > $OUT/bench_extra_ladder.json 2>/dev/null
 python bench.py --norb 40 --nelec 15 --na 707 --nb 707 --skip-cpu --skip-secondary > $OUT/bench_fes_uniform707.json 2>/dev/null
 python bench.py --norb 40 --nelec 15 --na 707 --nb 707 --strings hf --skip-cpu --skip-secondary --steps 5 --warmup 1 > $OUT/bench_fes_hf707.json 2>/dev/null
 SQD_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --skip-cpu --skip-secondary > $OUT/bench_forced_dist_1gpu.json 2> $OUT/bench_forced_dist_1gpu.err
 python bench_pauli.py > $OUT/bench_pauli.json 2>/dev/null
-python profiles/probes/_phase_probe2.py 2>&1 | grep -v amdgpu.ids > $OUT/phase_probe.txt
-python profiles/probes/_jitter_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/jitter_probe.txt
-python profiles/probes/_concurrency_probe2.py 2>&1 | grep -v amdgpu.ids > $OUT/concurrency_probe.txt
-python profiles/probes/_loop_probe.py > $OUT/loop_probe.txt 2>&1
-python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/big_sigma_probe.txt
-# sigma of uniform n x n sets with the work-item kernel (SQD_SIGMA_ROWS=0) and with the default selection
-: > $OUT/sigma_ladder.txt
-for n in 1000 2000 3000 4000 6000 8000 10000 14000; do
-  SQD_SIGMA_ROWS=0 N=$n python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/sigma_ladder.txt
-  N=$n python profiles/probes/_big_sigma_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/sigma_ladder.txt
-done
-python profiles/probes/_eig_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/eig_probe.txt
-python profiles/probes/_bench_gap_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/bench_gap_probe.txt
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29551 profiles/probes/_exchange_probe2.py 2>&1 | grep -v -e amdgpu.ids -e socket.cpp > $OUT/exchange_probe.txt
+python profiles/probes/_batch_probe.py 2>&1 | eval $F > $OUT/batch_probe.txt
+SQD_SIGMA_DENSE=0 python profiles/probes/_batch_probe.py 2>&1 | eval $F | grep hf > $OUT/batch_sparse_same_spin_probe.txt
+python profiles/probes/_loop_probe2.py 2>&1 | eval $F > $OUT/loop_subspaces_probe.txt
+MODE=4 python profiles/probes/_loop_probe2.py 2>&1 | eval $F > $OUT/loop_subspaces_4streams_probe.txt
+python profiles/probes/_sharded_probe.py 2>&1 | eval $F > $OUT/sharded_probe.txt
+python profiles/probes/_phase_probe2.py 2>&1 | eval $F > $OUT/phase_probe.txt
+python profiles/probes/_jitter_probe.py 2>&1 | eval $F > $OUT/jitter_probe.txt
+python profiles/probes/_big_sigma_probe.py 2>&1 | eval $F > $OUT/big_sigma_probe.txt
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-# kernel traces of the SAME commands as the bench lines
+# kernel traces of the SAME commands as the bench lines, and of the batched solves
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_uniform317 -o p -- python $ROOT/bench.py --skip-cpu --skip-secondary > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_hf317 -o p -- python $ROOT/bench.py --strings hf --skip-cpu --skip-secondary > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fes_hf707 -o p -- python $ROOT/bench.py --norb 40 --nelec 15 --na 707 --nb 707 --strings hf --skip-cpu --skip-secondary --steps 5 --warmup 1 > /dev/null 2>&1
+CASE=uniform8 REPS=20 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_batch_uniform8 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
+CASE=hf16 REPS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_batch_hf16 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_loop -o p -- python $ROOT/profiles/probes/_loop_probe2.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_big_sigma -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 # HBM traffic counters: separate passes, nothing else enabled (MI355X_MICROARCH.md, HBM / rocprofv3 section)
 for wl in uniform317 hf317; do
@@ -44,9 +43,16 @@ for wl in uniform317 hf317; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$wl -o p -- python $ROOT/bench.py $S --skip-cpu --skip-secondary --steps 5 --warmup 1 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$wl -o p -- python $ROOT/bench.py $S --skip-cpu --skip-secondary --steps 5 --warmup 1 > /dev/null 2>&1
 done
+for c in uniform8 hf16; do
+  CASE=$c REPS=3 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_batch_$c -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
+  CASE=$c REPS=3 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_batch_$c -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
+done
+# matrix-core utilisation of the dense same-spin product: busy cycles of the MFMA pipe against the kernel's cycles
+CASE=hf16 REPS=3 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_batch_hf16 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
+CASE=hf16 REPS=3 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_mfma2_batch_hf16 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 # keep only what travels back comfortably (the merge limit is 64 MiB)
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+find $OUT -name "*kernel_trace.csv" -size +12M -delete
 find $OUT -name "*.db" -delete
-ls -la $OUT
+du -sh $OUT

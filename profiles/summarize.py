@@ -5,7 +5,7 @@ profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traf
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
@@ -43,7 +43,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
             json.dump(out, open(os.path.join(dst, "final_" + os.path.basename(d)[5:] + "_sigma_launches.json"), "w"), indent=1)
 
 
-for wl in ("uniform317", "hf317", "big"):
+for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16"):
     out = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
         acc = defaultdict(list)
@@ -62,4 +62,18 @@ for wl in ("uniform317", "hf317", "big"):
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{name}_pmc_summary.json"), "w"), indent=1)
         top = sorted(hbm.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]
         print(wl, [(k, round(v["hbm_bytes_per_launch"] / 1e6, 3), v["dispatches"]) for k, v in top])
+# ---- matrix-core utilisation of the dense same-spin product (batched HF-centred solves): MFMA-pipe busy cycles over the
+# kernel's busy cycles, per kernel, straight from the counters
+for sub in ("pmc_mfma_batch_hf16", "pmc_mfma2_batch_hf16"):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if acc:
+        out = {k: {c: {"dispatches": len(v), "avg": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items()}
+        for k, d in out.items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]["avg"] > 0:
+                d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / d["SQ_BUSY_CYCLES"]["avg"]
+        json.dump(out, open(os.path.join(dst, "pmc", f"final_{sub[4:]}_summary.json"), "w"), indent=1)
+        print(sub, {k: {c: (round(v["avg"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in d.items()} for k, d in out.items() if "mfma" in k or "sigma" in k})
 print("written to", dst)

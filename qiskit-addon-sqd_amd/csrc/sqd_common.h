@@ -90,6 +90,11 @@ struct GPtr {
 #endif
 };
 
+// dense same-spin mode: the matrix-core product is cut into this many partial products over disjoint k ranges (one
+// workgroup each per 64 x 64 tile): a workgroup's chain of dependent loads is that much shorter and a single subspace of
+// batch size (25 tiles at 317 x 317) still gives every CU work.  Fixed => the same bits in single and batched solves.
+constexpr int DENSE_SPLIT = 8;
+
 // ---- link record encodings ----------------------------------------------------
 // single-excitation record: {src address, meta}
 //   meta bits  0..12 : widx = 2*pair + dir   (pair = tril index of (cre,des); dir = cre > des)

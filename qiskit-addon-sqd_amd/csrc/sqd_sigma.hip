@@ -28,11 +28,6 @@
 
 namespace sqd {
 
-// dense same-spin mode: the matrix-core product is cut into this many partial products over disjoint k ranges (one
-// workgroup each per 64 x 64 tile): a workgroup's chain of dependent loads is 4 x shorter and a single subspace of
-// batch size (25 tiles at 317 x 317) still gives every CU work.  Fixed => the same bits in single and batched solves.
-constexpr int DENSE_SPLIT = 4;
-
 struct SigmaArgs {
   GPtr<const double> c;
   GPtr<double> sigma;
@@ -224,11 +219,31 @@ __device__ inline int npasses(int ns, int cs, int nd, int cd) {
 // SPIN: the S^2 operator couples alpha link j (cre a, des b) to the one beta link with the same orbital
 // pair and the opposite direction (cre b, des a); penw[j] is that beta link's widx (-1 for an empty slot),
 // pen the coefficient.
+// One virtual row's header and first round of records, requested EARLY: a work item's chain of dependent loads is
+// item -> alpha records -> rows -> (barrier) -> virtual-row header -> beta records -> ...; the last two depend on
+// nothing before them, so they are put in flight beside the first two and are in registers when the staging is done
+// (six round trips per workgroup become four -- the kernel lives on resident workgroups x their latency).
+struct VRowPre {
+  int cnt;
+  int64_t base;
+  SRec recs[8];
+};
+__device__ inline void vrow_header(const SigmaArgs& g, int64_t v, bool on, VRowPre& p) {
+  p.cnt = on ? g.vs_cnt[v] : 0;
+  p.base = on ? g.esb_sl[v >> 6] + (v & 63) : 0;
+}
+__device__ inline void vrow_records(const SigmaArgs& g, VRowPre& p) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    p.recs[u] = SRec{0u, 0u};
+    if (u < p.cnt) p.recs[u] = g.esb_rec[p.base + (int64_t)u * 64];
+  }
+}
 template <bool SPIN, int KT>
 __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const double* Crow, const double* W, int ws,
-                                            const int* penw, double pen) {
-  const int64_t base = g.esb_sl[v >> 6] + (v & 63);
-  const int cnt = g.vs_cnt[v];
+                                            const int* penw, double pen, const VRowPre& pre, bool use_pre) {
+  const int64_t base = use_pre ? pre.base : g.esb_sl[v >> 6] + (v & 63);
+  const int cnt = use_pre ? pre.cnt : g.vs_cnt[v];
   constexpr int PF = 8;
   int pw[KT];
 #pragma unroll
@@ -238,8 +253,12 @@ __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const
     SRec recs[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      recs[u] = SRec{0u, 0u};
-      if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+      if (use_pre && k0 == 0) {
+        recs[u] = pre.recs[u];
+      } else {
+        recs[u] = SRec{0u, 0u};
+        if (k0 + u < cnt) recs[u] = g.esb_rec[base + (int64_t)(k0 + u) * 64];
+      }
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -268,12 +287,12 @@ __device__ inline double vrow_singles_batch(const SigmaArgs& g, int64_t v, const
 // dispatch on the batch capacity of this launch (uniform)
 template <bool SPIN>
 __device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t v, const double* Crow, const double* W,
-                                              int ws, const int* penw, double pen) {
+                                              int ws, const int* penw, double pen, const VRowPre& pre, bool use_pre) {
   switch (K) {
-    case 1: return vrow_singles_batch<SPIN, 1>(g, v, Crow, W, ws, penw, pen);
-    case 2: return vrow_singles_batch<SPIN, 2>(g, v, Crow, W, ws, penw, pen);
-    case 3: return vrow_singles_batch<SPIN, 3>(g, v, Crow, W, ws, penw, pen);
-    default: return vrow_singles_batch<SPIN, 4>(g, v, Crow, W, ws, penw, pen);
+    case 1: return vrow_singles_batch<SPIN, 1>(g, v, Crow, W, ws, penw, pen, pre, use_pre);
+    case 2: return vrow_singles_batch<SPIN, 2>(g, v, Crow, W, ws, penw, pen, pre, use_pre);
+    case 3: return vrow_singles_batch<SPIN, 3>(g, v, Crow, W, ws, penw, pen, pre, use_pre);
+    default: return vrow_singles_batch<SPIN, 4>(g, v, Crow, W, ws, penw, pen, pre, use_pre);
   }
 }
 
@@ -312,6 +331,11 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ sigma_out = g.sigma + vsel * g.s_stride;
+  // this thread's first virtual row of the beta singles: header now, records as soon as the header is there
+  VRowPre pre;
+  // (not conditional on the item's type: that would put the header one round trip behind the item record)
+  const bool pre_on = LDSROW && vs0 + tid < ((vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1);
+  vrow_header(g, vs0 + (pre_on ? tid : 0), pre_on, pre);
   double acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -395,6 +419,7 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
     SRec recs[KM];
 #pragma unroll
     for (int j = 0; j < KM; ++j) recs[j] = g.sa_rec[it.begin + (j < kb ? j : 0)];
+    if (LDSROW) vrow_records(g, pre);  // (in flight with the rows and the integral rows)
     if (tid == 0) {
 #pragma unroll
       for (int j = 0; j < KM; ++j)
@@ -422,10 +447,10 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
     const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
     if (LDSROW) {
       for (int v = vs0 + tid; v < s1; v += T)
-        part_s[v - vs0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen);
+        part_s[v - vs0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen, pre, v == vs0 + tid);
     } else {
       for (int v = vs0 + tid; v < s1; v += T)
-        part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN, 1>(g, v, srow0, W2, w2s, penw, pen);
+        part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN, 1>(g, v, srow0, W2, w2s, penw, pen, pre, false);
     }
     __syncthreads();
 #pragma unroll
@@ -482,7 +507,7 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
         for (int v = d0 + tid; v < d1; v += T) part_d[v - d0] = vrow_doubles_own(g, v, Crow);
       } else {
         for (int v = s0 + tid; v < s1; v += T)
-          part_s[v - s0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen);
+          part_s[v - s0] = vrow_singles_batch_k<SPIN>(g, g.K, v, Crow, W2, w2s, penw, pen, pre, false);
       }
       __syncthreads();
 #pragma nounroll

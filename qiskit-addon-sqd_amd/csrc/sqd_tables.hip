@@ -1207,7 +1207,7 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
       c->dense_pb = (int)((nb + 63) / 64 * 64);
       SQD_TRY(c->hdense_a.reserve((size_t)c->dense_pa * c->dense_pa * 8));
       SQD_TRY(c->hdense_b.reserve((size_t)c->dense_pb * c->dense_pb * 8));
-      SQD_TRY(c->gdense.reserve((size_t)4 * na * nb * 8));  // DENSE_SPLIT partial products (sqd_sigma.hip)
+      SQD_TRY(c->gdense.reserve((size_t)DENSE_SPLIT * na * nb * 8));  // the partial products
       DenseFillArgs& d = b.dense;
       for (int s = 0; s < 2; ++s) {
         const SpinTables& t = c->sp[s];
