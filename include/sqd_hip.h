@@ -184,6 +184,28 @@ void sqd_davidson_default_opts(sqd_davidson_opts* o);
 int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0, double* amps,
                  sqd_davidson_stats* stats);
 
+/* The Davidson of a row-sharded subspace, stage by stage.  Every rank runs the SAME device-resident state machine as
+ * sqd_davidson (projected matrix, lowest eigenpair, restart, stop rule: pyscf lib.davidson1 as called at reference
+ * fermion.py:721-723) on its rows; the reductions are cut where a number crosses ranks -- each stage that needs one
+ * leaves its LOCAL totals in a small device buffer and returns its address and length, the caller all-reduces (sum) that
+ * buffer on the context's stream (sqd_ctx_use_stream; RCCL in qiskit_addon_sqd_amd.sharded) and calls the next stage.
+ * One iteration:  pick (rows of the newest basis vector -> send buffer; the caller all-gathers it into the full vector)
+ * -> sigma (rows of H c from the full vector) -> dots -> [all-reduce] -> residual (eigenproblem, residual,
+ * preconditioner) -> [all-reduce] -> orth (stop rule, Gram-Schmidt, restart collapse; returns a ticket).  No stage waits
+ * for the device: every kernel reads "which vector / whether to stop" from the state block, so the caller may enqueue
+ * iteration k + 1 before sqd_shard_dav_wait(ticket of k) -- the one host wait -- tells it whether the run has stopped
+ * (stages enqueued behind a stop return at once).  begin returns where the rows of the (normalised) start vector go; end returns where
+ * the rows of the solution are.  The squared spin penalty (use_spin = 2) is refused: it chains S^2 through a second
+ * gathered vector per sigma build (qiskit_addon_sqd_amd.sharded keeps a torch-level driver for it). */
+int sqd_shard_dav_begin(sqd_ctx* ctx, const sqd_davidson_opts* opts, double** d_x0_rows);
+int sqd_shard_dav_pick(sqd_ctx* ctx, double** d_send_rows);
+int sqd_shard_dav_sigma(sqd_ctx* ctx, const double* d_c_full);
+int sqd_shard_dav_dots(sqd_ctx* ctx, double** d_totals, int* count);
+int sqd_shard_dav_residual(sqd_ctx* ctx, double** d_totals, int* count);
+int sqd_shard_dav_orth(sqd_ctx* ctx, long long* ticket);
+int sqd_shard_dav_wait(sqd_ctx* ctx, long long ticket, int* stopped, double* e, double* rnorm2, int* basis_size);
+int sqd_shard_dav_end(sqd_ctx* ctx, double** d_solution_rows, sqd_davidson_stats* stats);
+
 /* Observables of a state.  amps == NULL means "the resident Davidson solution".
  * sqd_energy: <c|H|c> without penalty (what the reference recomputes from RDMs, fermion.py:730-732,:827).
  * sqd_spin_square: <c|S^2|c> (pyscf spin_square, fermion.py:830,:133).

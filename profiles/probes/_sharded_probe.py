@@ -32,6 +32,12 @@ n_ref = F.last_solve_stats()['n_sigma']
 t_sh, res = timed(lambda: solve_sci_sharded((sa, sb), h1, eri, 30, (8, 8), gather_state=False))
 st = res._sharded_stats
 print(f"solve_sci            : {t_ref:8.3f} ms, {n_ref} sigma builds, E = {ref.energy:.10f}")
+os.environ["SQD_SHARD_FORCE_COLLECTIVES"] = "1"
+t_f, res_f = timed(lambda: solve_sci_sharded((sa, sb), h1, eri, 30, (8, 8), gather_state=False))
+del os.environ["SQD_SHARD_FORCE_COLLECTIVES"]
+t_t, res_t = timed(lambda: solve_sci_sharded((sa, sb), h1, eri, 30, (8, 8), gather_state=False, driver="torch"))
+print(f"solve_sci_sharded ws=1, collectives really issued (all-gather + 2 all-reduces per iteration on the 1-rank group): {t_f:8.3f} ms (ratio {t_f / t_ref:.2f})")
+print(f"solve_sci_sharded ws=1, torch-level driver (round 2 structure, two host reads per iteration): {t_t:8.3f} ms (ratio {t_t / t_ref:.2f})")
 print(f"solve_sci_sharded ws=1: {t_sh:8.3f} ms, {st['n_sigma']} sigma builds, E = {res.energy:.10f}  (ratio {t_sh / t_ref:.2f}, "
       f"per iteration {1e3 * t_sh / st['n_sigma']:.1f} us vs {1e3 * t_ref / n_ref:.1f} us)")
 dist.destroy_process_group()

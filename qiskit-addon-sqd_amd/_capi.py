@@ -34,6 +34,14 @@ EXPORTED_SYMBOLS = (
     "sqd_contract_ss_rows_dev",
     "sqd_hdiag_rows_dev",
     "sqd_ctx_sync",
+    "sqd_shard_dav_begin",
+    "sqd_shard_dav_pick",
+    "sqd_shard_dav_sigma",
+    "sqd_shard_dav_dots",
+    "sqd_shard_dav_residual",
+    "sqd_shard_dav_orth",
+    "sqd_shard_dav_wait",
+    "sqd_shard_dav_end",
     "sqd_solution_device_ptr",
     "sqd_solution_copy",
     "sqd_ctx_set_phase_timing",
@@ -130,6 +138,14 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_contract_ss_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p]
     lib.sqd_hdiag_rows_dev.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_sync.argtypes = [_ctxp]
+    lib.sqd_shard_dav_begin.argtypes = [_ctxp, C.POINTER(DavidsonOpts), C.POINTER(C.c_void_p)]
+    lib.sqd_shard_dav_pick.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
+    lib.sqd_shard_dav_sigma.argtypes = [_ctxp, C.c_void_p]
+    lib.sqd_shard_dav_dots.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.sqd_shard_dav_residual.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    lib.sqd_shard_dav_orth.argtypes = [_ctxp, C.POINTER(C.c_longlong)]
+    lib.sqd_shard_dav_wait.argtypes = [_ctxp, C.c_longlong, C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_int)]
+    lib.sqd_shard_dav_end.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(DavidsonStats)]
     lib.sqd_solution_device_ptr.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
     lib.sqd_solution_copy.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_set_phase_timing.argtypes = [_ctxp, C.c_int]
@@ -424,6 +440,55 @@ class Context:
         # (hipMemcpy through the library's own runtime: sqd_batch_state serves sub-contexts, this the context itself)
         self._check(self._lib.sqd_solution_copy(self._h, _addr(out)))
         return out
+
+    # -- row-sharded Davidson, stage by stage (device addresses in and out; the caller owns the collectives)
+    def shard_dav_begin(self, *, tol=1e-9, tol_residual=None, lindep=1e-14, max_cycle=100, max_space=12, spin_sq=None,
+                        shift=0.2) -> int:
+        opts = DavidsonOpts()
+        self._lib.sqd_davidson_default_opts(C.byref(opts))
+        opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
+        opts.tol_residual = float(tol_residual) if tol_residual else 0.0
+        if spin_sq is not None:
+            opts.use_spin, opts.ss, opts.shift = 3, float(spin_sq), float(shift)
+        out = C.c_void_p()
+        self._check(self._lib.sqd_shard_dav_begin(self._h, C.byref(opts), C.byref(out)))
+        return int(out.value)
+
+    def shard_dav_pick(self) -> int:
+        out = C.c_void_p()
+        self._check(self._lib.sqd_shard_dav_pick(self._h, C.byref(out)))
+        return int(out.value)
+
+    def shard_dav_sigma(self, full_ptr: int):
+        self._check(self._lib.sqd_shard_dav_sigma(self._h, C.c_void_p(int(full_ptr))))
+
+    def shard_dav_dots(self):
+        out, n = C.c_void_p(), C.c_int()
+        self._check(self._lib.sqd_shard_dav_dots(self._h, C.byref(out), C.byref(n)))
+        return int(out.value), int(n.value)
+
+    def shard_dav_residual(self):
+        out, n = C.c_void_p(), C.c_int()
+        self._check(self._lib.sqd_shard_dav_residual(self._h, C.byref(out), C.byref(n)))
+        return int(out.value), int(n.value)
+
+    def shard_dav_orth(self) -> int:
+        """Enqueue the last stage of an iteration; returns the ticket ``shard_dav_wait`` takes."""
+        t = C.c_longlong()
+        self._check(self._lib.sqd_shard_dav_orth(self._h, C.byref(t)))
+        return int(t.value)
+
+    def shard_dav_wait(self, ticket: int):
+        stop, m = C.c_int(), C.c_int()
+        e, rr = C.c_double(), C.c_double()
+        self._check(self._lib.sqd_shard_dav_wait(self._h, int(ticket), C.byref(stop), C.byref(e), C.byref(rr), C.byref(m)))
+        return bool(stop.value), float(e.value), float(rr.value), int(m.value)
+
+    def shard_dav_end(self):
+        out = C.c_void_p()
+        stats = DavidsonStats()
+        self._check(self._lib.sqd_shard_dav_end(self._h, C.byref(out), C.byref(stats)))
+        return int(out.value), {f[0]: getattr(stats, f[0]) for f in DavidsonStats._fields_}
 
     def solution_device_ptr(self) -> int:
         """Device address of the resident Davidson solution (valid until the next solve on this context)."""

@@ -252,7 +252,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
                     &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo,
-                    &c->hdense_a, &c->hdense_b, &c->gdense, &c->sol_prev};
+                    &c->hdense_a, &c->hdense_b, &c->gdense, &c->sol_prev, &c->shard_tot};
   for (DevBuf* b : bufs) b->release();
   c->sp[0].release();
   c->sp[1].release();
@@ -352,6 +352,50 @@ SQD_API int sqd_solution_device_ptr(sqd_ctx* c, const double** d_ptr) {
   }
   *d_ptr = c->sol.as<double>();
   return SQD_OK;
+}
+// ---- row-sharded Davidson (include/sqd_hip.h)
+SQD_API int sqd_shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* opts, double** d_x0_rows) {
+  CTX_ENTER(c);
+  if (!d_x0_rows) return SQD_ERR_INVALID;
+  sqd_davidson_opts o;
+  if (opts) o = *opts; else sqd_davidson_default_opts(&o);
+  if (o.tol <= 0 || o.max_cycle < 1) {
+    set_error("bad Davidson options");
+    return SQD_ERR_INVALID;
+  }
+  return shard_dav_begin(c, &o, d_x0_rows);
+}
+SQD_API int sqd_shard_dav_pick(sqd_ctx* c, double** d_send_rows) {
+  CTX_ENTER(c);
+  if (!d_send_rows) return SQD_ERR_INVALID;
+  return shard_dav_pick(c, d_send_rows);
+}
+SQD_API int sqd_shard_dav_sigma(sqd_ctx* c, const double* d_c_full) {
+  CTX_ENTER(c);
+  if (!d_c_full) return SQD_ERR_INVALID;
+  return shard_dav_sigma(c, d_c_full);
+}
+SQD_API int sqd_shard_dav_dots(sqd_ctx* c, double** d_totals, int* count) {
+  CTX_ENTER(c);
+  if (!d_totals || !count) return SQD_ERR_INVALID;
+  return shard_dav_dots(c, d_totals, count);
+}
+SQD_API int sqd_shard_dav_residual(sqd_ctx* c, double** d_totals, int* count) {
+  CTX_ENTER(c);
+  if (!d_totals || !count) return SQD_ERR_INVALID;
+  return shard_dav_residual(c, d_totals, count);
+}
+SQD_API int sqd_shard_dav_orth(sqd_ctx* c, long long* ticket) {
+  CTX_ENTER(c);
+  return shard_dav_orth(c, ticket);
+}
+SQD_API int sqd_shard_dav_wait(sqd_ctx* c, long long ticket, int* stopped, double* e, double* rnorm2, int* basis_size) {
+  CTX_ENTER(c);
+  return shard_dav_wait(c, ticket, stopped, e, rnorm2, basis_size);
+}
+SQD_API int sqd_shard_dav_end(sqd_ctx* c, double** d_solution_rows, sqd_davidson_stats* stats) {
+  CTX_ENTER(c);
+  return shard_dav_end(c, d_solution_rows, stats);
 }
 SQD_API int sqd_solution_copy(sqd_ctx* c, double* amps) {
   CTX_ENTER(c);

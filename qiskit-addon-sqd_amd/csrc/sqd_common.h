@@ -284,6 +284,12 @@ struct sqd_ctx {
   size_t h_amps_cap = 0;
   bool dav_timed = false;  // the latest Davidson run recorded its start / end events
   int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)
+  // ---- row-sharded Davidson in progress (sqd_shard_dav_*): constants of the run, the all-reduce buffers
+  bool shard_active = false;
+  int shard_max_space = 12, shard_form = 0;
+  double shard_prm_tol = 1e-9, shard_prm_tol2 = 0.0, shard_prm_lindep = 1e-14, shard_ss = 0.0, shard_shift = 0.0;
+  int64_t shard_Dl = 0;
+  sqd::DevBuf shard_tot;
   // ---- batched solves (sqd_solve_batch).  A parent context owns one sub-context per subspace of the batch: the
   // per-subspace state (tables, Davidson workspace, state block, mailbox) in the same struct a single solve uses, on
   // the PARENT's stream and with views of the parent's integral tables.
@@ -341,6 +347,15 @@ int enqueue_init_guess(sqd_ctx* c, double* d_x);  // pyscf get_init_guess into d
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync = false);
 int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st);
+// row-sharded Davidson, stage by stage (sqd_shard_dav_* of the C ABI)
+int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0);
+int shard_dav_pick(sqd_ctx* c, double** d_send);
+int shard_dav_sigma(sqd_ctx* c, const double* d_full);
+int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count);
+int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count);
+int shard_dav_orth(sqd_ctx* c, long long* seq_out);
+int shard_dav_wait(sqd_ctx* c, long long seq, int* stopped, double* e, double* rnorm2, int* m_cur);
+int shard_dav_end(sqd_ctx* c, double** d_solution_rows, sqd_davidson_stats* st);
 // batched Davidson (sqd_solve_batch): prepare writes the per-subspace argument records (and the sigma plan) into the
 // staging blob at *off_io; run enqueues rounds until every subspace has stopped, then the solutions
 struct DavBatchPlan {

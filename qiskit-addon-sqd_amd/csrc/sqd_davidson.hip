@@ -624,7 +624,10 @@ __device__ inline void post_progress(double* mail, long long seq, const DavState
 template <int MV>
 __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                                      const DavParams& prm, const double* __restrict__ partial, int nblocks, int width,
-                                     double* mail, long long seq, unsigned bx, unsigned nbx) {
+                                     double* mail, long long seq, unsigned bx, unsigned nbx,
+                                     const double* __restrict__ tot_in = nullptr) {
+  // tot_in != nullptr (row-sharded solves): the totals {|r|^2, |t|^2, X_v . t} are already folded AND all-reduced
+  // over the ranks; every workgroup of every rank reads the same numbers and takes the same decisions
   __shared__ double red[16 * (MV + 2)];
   __shared__ double tot[MV + 2];
   __shared__ double g[MV + 2];
@@ -642,7 +645,9 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   const int nvec = st->m_cur;
   const int restart = st->restart;
   const int nv = nvec + 2;
-  {
+  if (tot_in) {
+    if ((int)threadIdx.x < nv) tot[threadIdx.x] = tot_in[threadIdx.x];
+  } else {
     double vals[MV + 2];
 #pragma unroll
     for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
@@ -770,6 +775,91 @@ __device__ inline void solution_body(int64_t n, const double* __restrict__ X, in
 __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
                            double* __restrict__ out, double* res) {
   solution_body(n, X, stride, st, out, res, blockIdx.x, gridDim.x);
+}
+
+// ---- row-sharded solves (reference docs/guides/hpc_acceleration.rst:52-57: a collective sci_solver).  Every
+// rank holds the rows [row0, row1) of all Davidson vectors and the SAME state block: the reductions are cut where a
+// number has to cross ranks -- local totals to a device buffer, an all-reduce by the caller on the same stream, the rest
+// of the iteration from the reduced totals -- so that the state machine (projected matrix, eigenpair, restart, stop
+// rule) is this file's, device-resident, and evolves bit-identically on every rank.
+__global__ void k_shard_pick(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
+                             double* __restrict__ send) {
+  if (st->stop) return;
+  const double* __restrict__ x = X + (int64_t)(st->m_next - 1) * stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) send[i] = x[i];
+}
+// local totals {|X_{m-1}|^2, X_v . A X_{m-1}} over this rank's rows into tot_out[0 .. MAXB] (zero beyond m)
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_shard_dots(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
+                                                      int64_t stride, double* __restrict__ partial, int width, unsigned* counter,
+                                                      const DavState* __restrict__ st, double* __restrict__ tot_out) {
+  __shared__ double red[16 * (MV + 1)];
+  if (st->stop) return;
+  const int nvec = st->m_next;
+  const double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
+  double acc[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double yv = y[i];
+    double xv[MV];
+    load_vectors<MV>(X, stride, nvec, i, xv);
+#pragma unroll
+    for (int v = 0; v < MV; ++v) {
+      acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
+      acc[0] += (v == nvec - 1) ? xv[v] * xv[v] : 0.0;
+    }
+  }
+  block_sum_multi<MV + 1>(acc, nvec + 1, red);
+  if ((int)threadIdx.x < nvec + 1)
+    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
+  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+  double vals[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) vals[v] = 0.0;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+    double p[MV + 1];
+    load_partials<MV + 1, true>(partial, (int64_t)b * width, nvec + 1, p);
+#pragma unroll
+    for (int v = 0; v < MV + 1; ++v) vals[v] += (v < nvec + 1) ? p[v] : 0.0;
+  }
+  block_sum_multi<MV + 1>(vals, nvec + 1, red);
+  if ((int)threadIdx.x <= MAXB) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 1) ? block_sum_multi_get<MV + 1>(red, threadIdx.x) : 0.0;
+}
+// the projected eigenproblem from the all-reduced totals: one wavefront
+template <int MV>
+__global__ void __launch_bounds__(64) k_shard_eig(DavState* st, const double* __restrict__ tot_in, const DavParams prm) {
+  __shared__ double tot[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  if (st->stop) return;
+  if ((int)threadIdx.x < MV + 1) tot[threadIdx.x] = tot_in[threadIdx.x];
+  wave_sync();
+  wave_eig_step<MV>(st, tot, prm, sA, sM, sv_eig);
+}
+// local totals of the residual kernel's partials {|r|^2, |t|^2, X_v . t}, folded exactly as k_orth_dev folds them
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_shard_fold(const double* __restrict__ partial, int nblocks, int width,
+                                                      const DavState* __restrict__ st, double* __restrict__ tot_out) {
+  __shared__ double red[16 * (MV + 2)];
+  if (st->stop) return;
+  const int nv = st->m_cur + 2;
+  double vals[MV + 2];
+#pragma unroll
+  for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    double p[MV + 2];
+    load_partials<MV + 2, false>(partial, (int64_t)b * width, nv, p);
+#pragma unroll
+    for (int v = 0; v < MV + 2; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
+  }
+  block_sum_multi<MV + 2>(vals, nv, red);
+  if ((int)threadIdx.x <= MAXB + 1) tot_out[threadIdx.x] = ((int)threadIdx.x < nv) ? block_sum_multi_get<MV + 2>(red, threadIdx.x) : 0.0;
+}
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_shard_orth(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+                                                      DavState* st, const DavParams prm, const double* __restrict__ tot_in,
+                                                      double* mail, long long seq) {
+  orth_dev_body<MV>(n, X, AX, stride, st, prm, nullptr, 0, 0, mail, seq, blockIdx.x, gridDim.x, tot_in);
 }
 
 // ---- batched forms (sqd_solve_batch): blockIdx.z = subspace, one argument record per subspace in device memory.
@@ -1258,6 +1348,192 @@ int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const
   hipLaunchKernelGGL(k_solution_b, grid, dim3(RED_T), 0, s, args);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
+}
+
+// ---- host side of the row-sharded Davidson: one call per stage of an iteration; the caller (sharded.py) puts its
+// collectives between them on the same stream.  No host wait except in shard_dav_orth (the stop decision).
+static int shard_check(sqd_ctx* c) {
+  if (!c->have_subspace) {
+    set_error("no subspace set");
+    return SQD_ERR_STATE;
+  }
+  if (!c->shard_active) {
+    set_error("no row-sharded Davidson run in progress (sqd_shard_dav_begin)");
+    return SQD_ERR_STATE;
+  }
+  return SQD_OK;
+}
+int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0) {
+  if (!c->have_subspace) {
+    set_error("no subspace set");
+    return SQD_ERR_STATE;
+  }
+  int max_space = o->max_space;
+  if (max_space < 2) max_space = 2;
+  if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
+  int form = o->use_spin;
+  const double szh = 0.5 * std::abs(c->nelec[0] - c->nelec[1]);
+  if (form == 3) form = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
+  if (form == 2) {
+    set_error("the squared spin penalty needs a second all-gather per sigma build: not available in the native sharded run");
+    return SQD_ERR_INVALID;
+  }
+  const int64_t Dl = (c->row1 - c->row0) * c->nb;
+  const int nvecs = max_space + 1;
+  SQD_TRY(c->X.reserve((size_t)nvecs * Dl * 8));
+  SQD_TRY(c->AX.reserve((size_t)nvecs * Dl * 8));
+  SQD_TRY(c->sol.reserve((size_t)Dl * 8));
+  SQD_TRY(c->tmp1.reserve((size_t)Dl * 8));  // the send buffer of the all-gather
+  SQD_TRY(reserve_reduction_buffers(c));
+  SQD_TRY(c->shard_tot.reserve((size_t)2 * (MAXB + 2) * 8));
+  c->guess_x = nullptr;
+  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
+  c->shard_prm_tol = o->tol;
+  c->shard_prm_tol2 = toloose * toloose;
+  c->shard_prm_lindep = o->lindep;
+  c->shard_max_space = max_space;
+  c->shard_form = form;
+  c->shard_ss = o->ss;
+  c->shard_shift = o->shift;
+  c->shard_Dl = Dl;
+  c->shard_active = true;
+  c->have_solution = false;
+  hipLaunchKernelGGL(k_dav_init, dim3(1), dim3(256), 0, c->stream, state_ptr_dev(c), counter_ptr(c));
+  SQD_HIP_CHECK(hipGetLastError());
+  *d_x0 = c->X.as<double>();
+  return SQD_OK;
+}
+static DavParams shard_params(const sqd_ctx* c) {
+  DavParams prm;
+  prm.tol = c->shard_prm_tol;
+  prm.tol2 = c->shard_prm_tol2;
+  prm.lindep = c->shard_prm_lindep;
+  prm.max_space = c->shard_max_space;
+  return prm;
+}
+int shard_dav_pick(sqd_ctx* c, double** d_send) {
+  SQD_TRY(shard_check(c));
+  const int64_t Dl = c->shard_Dl;
+  hipLaunchKernelGGL(k_shard_pick, dim3(red_blocks(Dl)), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(), Dl,
+                     (const DavState*)state_ptr_dev(c), c->tmp1.as<double>());
+  SQD_HIP_CHECK(hipGetLastError());
+  *d_send = c->tmp1.as<double>();
+  return SQD_OK;
+}
+int shard_dav_sigma(sqd_ctx* c, const double* d_full) {
+  SQD_TRY(shard_check(c));
+  DavState* dst = state_ptr_dev(c);
+  c->sigma_stop = &dst->stop;
+  c->sigma_index = &dst->m_next;
+  c->sigma_defer_reduce = false;
+  const int rc = apply_h(c, d_full, c->AX.as<double>(), c->shard_form, c->shard_ss, c->shard_shift, 0, c->shard_Dl);
+  c->sigma_stop = nullptr;
+  c->sigma_index = nullptr;
+  return rc;
+}
+int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count) {
+  SQD_TRY(shard_check(c));
+  const int64_t Dl = c->shard_Dl;
+  const unsigned gb = red_blocks(Dl);
+  const int width = SQD_MAX_SPACE + 4;
+  double* tot = c->shard_tot.as<double>();
+  if (c->shard_max_space <= 12)
+    hipLaunchKernelGGL((k_shard_dots<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
+                       (const double*)c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c),
+                       (const DavState*)state_ptr_dev(c), tot);
+  else
+    hipLaunchKernelGGL((k_shard_dots<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
+                       (const double*)c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c),
+                       (const DavState*)state_ptr_dev(c), tot);
+  SQD_HIP_CHECK(hipGetLastError());
+  *d_tot = tot;
+  *count = MAXB + 1;
+  return SQD_OK;
+}
+int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count) {
+  SQD_TRY(shard_check(c));
+  const int64_t Dl = c->shard_Dl;
+  const unsigned gb = red_blocks(Dl);
+  const int width = SQD_MAX_SPACE + 4;
+  DavState* dst = state_ptr_dev(c);
+  const DavParams prm = shard_params(c);
+  double* tot = c->shard_tot.as<double>();
+  double* tot2 = tot + (MAXB + 2);
+  double* part_res = c->partial.as<double>() + (size_t)RED_BLOCKS * width;
+  PenaltyDiag pd;
+  {
+    const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+    pd.form = c->shard_form;
+    pd.shift = c->shard_shift;
+    pd.ss = c->shard_ss;
+    pd.szterm = sz * (sz + 1.0);
+    pd.sa = c->sp[0].strs.as<uint64_t>() + c->row0;  // (element i of the shard lies in row row0 + i / nb)
+    pd.sb = c->sp[1].strs.as<uint64_t>();
+    pd.nb = c->nb;
+  }
+  if (c->shard_max_space <= 12) {
+    hipLaunchKernelGGL((k_shard_eig<13>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
+    hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
+                       (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
+                       part_res, width);
+    hipLaunchKernelGGL((k_shard_fold<13>), dim3(1), dim3(RED_T), 0, c->stream, (const double*)part_res, (int)gb, width,
+                       (const DavState*)dst, tot2);
+  } else {
+    hipLaunchKernelGGL((k_shard_eig<MAXB>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
+    hipLaunchKernelGGL((k_residual_precond<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
+                       (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
+                       part_res, width);
+    hipLaunchKernelGGL((k_shard_fold<MAXB>), dim3(1), dim3(RED_T), 0, c->stream, (const double*)part_res, (int)gb, width,
+                       (const DavState*)dst, tot2);
+  }
+  SQD_HIP_CHECK(hipGetLastError());
+  *d_tot2 = tot2;
+  *count = MAXB + 2;
+  return SQD_OK;
+}
+int shard_dav_orth(sqd_ctx* c, long long* seq_out) {
+  SQD_TRY(shard_check(c));
+  const int64_t Dl = c->shard_Dl;
+  const unsigned gb = red_blocks(Dl);
+  DavState* dst = state_ptr_dev(c);
+  const DavParams prm = shard_params(c);
+  const double* tot2 = c->shard_tot.as<double>() + (MAXB + 2);
+  const long long seq = ++c->mail_seq;
+  double* mail_prog = c->d_mail + MAIL_SLOT;
+  if (c->shard_max_space <= 12)
+    hipLaunchKernelGGL((k_shard_orth<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(), c->AX.as<double>(), Dl,
+                       dst, prm, tot2, mail_prog, seq);
+  else
+    hipLaunchKernelGGL((k_shard_orth<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(), c->AX.as<double>(), Dl,
+                       dst, prm, tot2, mail_prog, seq);
+  SQD_HIP_CHECK(hipGetLastError());
+  if (seq_out) *seq_out = seq;
+  return SQD_OK;
+}
+// the progress record of the iteration whose orth stage returned `seq` (or of a later one: the stop flag only rises)
+int shard_dav_wait(sqd_ctx* c, long long seq, int* stopped, double* e, double* rnorm2, int* m_cur) {
+  SQD_TRY(shard_check(c));
+  SQD_TRY(wait_mail(c, 1, seq));
+  const double* h_prog = c->h_mail + MAIL_SLOT;
+  if (stopped) *stopped = h_prog[MAIL_PAYLOAD + 1] != 0.0;
+  if (e) *e = h_prog[MAIL_PAYLOAD + 2];
+  if (rnorm2) *rnorm2 = h_prog[MAIL_PAYLOAD + 4];
+  if (m_cur) *m_cur = (int)h_prog[MAIL_PAYLOAD + 5];
+  return SQD_OK;
+}
+int shard_dav_end(sqd_ctx* c, double** d_solution_rows, sqd_davidson_stats* st) {
+  SQD_TRY(shard_check(c));
+  const int64_t Dl = c->shard_Dl;
+  hipLaunchKernelGGL(k_solution, dim3(red_blocks(Dl)), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(), Dl,
+                     (const DavState*)state_ptr_dev(c), c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_STREAM_SYNC(c->stream);
+  c->shard_active = false;
+  c->have_solution = true;
+  c->dav_timed = false;
+  c->dav_nev = 0;
+  if (d_solution_rows) *d_solution_rows = c->sol.as<double>();
+  return davidson_collect(c, st);
 }
 
 // outcome and event timings of the latest run (the stream must have been synchronised since)

@@ -59,6 +59,27 @@ def row_range(na: int, rank: int, world: int) -> tuple[int, int]:
 _CTX_CACHE: dict = {}
 
 
+class _DeviceView:
+    """Zero-copy handle on device memory for ``torch.as_tensor`` (``__cuda_array_interface__``, version 2)."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _view(ptr: int, shape, tdev):
+    """A torch tensor over memory the library owns (device memory on a GPU; host memory under the CPU emulator)."""
+    import ctypes
+
+    import torch
+
+    if tdev.type == "cuda":
+        return torch.as_tensor(_DeviceView(ptr, shape), device=tdev)
+    n = int(np.prod(shape))
+    buf = (ctypes.c_double * n).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape))
+
+
 def _cached_context(one_body_tensor, two_body_tensor, device, group, lib):
     """One solver context per (Hamiltonian, device, group): integral upload and packing once, arenas reused."""
     from .fermion import _ham_key
@@ -109,6 +130,11 @@ class ShardedSubspace:
         self._full = torch.empty((self.na, self.nb), dtype=torch.float64, device=self.tdev)  # the gathered vector
         self._sizes = [row_range(self.na, r, self.world) for r in range(self.world)]
         self.n_allgather = 0
+        # SQD_SHARD_FORCE_COLLECTIVES=1 (probes): call the collectives on a group of ONE rank too, to measure what they
+        # cost when there is nothing to exchange
+        import os
+
+        self._force = bool(os.environ.get("SQD_SHARD_FORCE_COLLECTIVES")) and self.on_gpu
         self._sync()
 
     def _sync(self):
@@ -125,7 +151,7 @@ class ShardedSubspace:
 
         dist = _dist()
         self.n_allgather += 1
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             self._full.copy_(shard)
             return self._full
         equal = all(hi - lo == self.nrows for lo, hi in self._sizes)
@@ -144,7 +170,7 @@ class ShardedSubspace:
         return self._full
 
     def allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self._force:
             _dist().all_reduce(t, group=self.group)
         return t
 
@@ -223,6 +249,7 @@ def solve_sci_sharded(
     group=None,
     device=None,
     gather_state: bool = True,
+    driver: str = "native",
     lib=None,
 ) -> SCIResult:
     """Collective counterpart of ``solve_sci`` (reference ``fermion.py:684-742``) for ONE subspace spread over the
@@ -231,6 +258,13 @@ def solve_sci_sharded(
 
     Davidson: pyscf's single-root flow -- start vector of ``get_init_guess`` (lower-triangle rule), residual
     threshold ``sqrt(tol)/32`` as in the single-GPU solver (``tol_residual`` overrides), restart at ``max_space``.
+
+    ``driver="native"`` (default): the library's device-resident state machine on every rank (``sqd_shard_dav_*``) --
+    projected matrix, eigenpair, restart and stop rule live on the GPU exactly as in the single-GPU solver; per iteration
+    this function only enqueues the stages and three collectives (all-gather of the newest vector's rows, two all-reduces
+    of ~32 doubles) on the shared stream and makes ONE host read (the stop decision).  ``driver="torch"``: the same flow
+    with torch tensor operations (two host reads per iteration); it also serves the squared spin penalty, which needs a
+    second all-gather inside every sigma build.
     """
     import torch
 
@@ -258,79 +292,125 @@ def solve_sci_sharded(
         else:
             allc = [cand]
         best = min(((float(c[0]), int(c[1])) for c in allc))  # ties: lowest flat index
-        # ---- persistent basis: X[v], AX[v] = rows of basis vector v and of its sigma (flat views for the products)
-        nvec = max_space + 1
-        Dl = sub.nrows * sub.nb
-        X = torch.zeros((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
-        AX = torch.empty((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
-        Xf, AXf = X.view(nvec, Dl), AX.view(nvec, Dl)
-        hdf = hd.reshape(Dl)
-        flat = Xf[0]
-        lo, hi = sub.row0 * sub.nb, sub.row1 * sub.nb
-        if lo <= best[1] < hi:
-            flat[best[1] - lo] = 1.0
-        if lo == 0:
-            flat[0] += 1e-5
-        if hi == sub.na * sub.nb:
-            flat[-1] -= 1e-5
-        # closed-form norm of the start vector (no reduction): 1 at the minimum, +-1e-5 on the first / last element
-        f = {0: 1e-5, sub.na * sub.nb - 1: -1e-5}
-        f[best[1]] = f.get(best[1], 0.0) + 1.0
-        flat.mul_(1.0 / np.sqrt(sum(v * v for v in f.values())))
+        native = driver == "native" and use_spin != 2
+        if native:
+            # ---- the library's state machine; this loop only strings stages and collectives together
+            x0 = _view(sub.ctx.shard_dav_begin(tol=tol, tol_residual=tol_residual, lindep=lindep, max_cycle=max_cycle,
+                                               max_space=max_space, spin_sq=spin_sq, shift=shift), (sub.nrows * sub.nb,), sub.tdev)
+            x0.zero_()
+            lo, hi = sub.row0 * sub.nb, sub.row1 * sub.nb
+            f = {0: 1e-5, sub.na * sub.nb - 1: -1e-5}
+            f[best[1]] = f.get(best[1], 0.0) + 1.0
+            inv0 = 1.0 / np.sqrt(sum(v * v for v in f.values()))
+            for idx, val in f.items():  # pyscf's start vector, normalised in closed form
+                if lo <= idx < hi:
+                    x0[idx - lo] = val * inv0
+            e, conv, nsig = 0.0, False, 0
+            views: dict = {}  # the library hands out the same buffers every iteration: wrap each address once
 
-        def host(t):  # ONE all-reduce + ONE device-to-host read of a small vector
-            return sub.allreduce(t).cpu().numpy()
+            def view(ptr, shape):
+                v = views.get(ptr)
+                if v is None:
+                    v = views[ptr] = _view(ptr, shape, sub.tdev)
+                return v
 
-        e, conv, nsig, m = 0.0, False, 0, 1
-        heff = np.zeros((nvec, nvec))
-        v0 = np.ones(1)
-        xr = axr = None
-        for _ in range(max_cycle):
-            sub.sigma(X[m - 1], use_spin, ss, shift, out=AX[m - 1])
-            nsig += 1
-            # new column of the projected matrix: ONE matrix-vector product over the local rows, one all-reduce
-            col = host(torch.mv(Xf[:m], AXf[m - 1]))
-            heff[:m, m - 1] = heff[m - 1, :m] = col
-            w, v = np.linalg.eigh(heff[:m, :m])
-            elast, e = e, float(w[0])
-            v0 = v[:, 0]
-            coef = torch.from_numpy(np.ascontiguousarray(v0)).to(sub.tdev)
-            xr = torch.mv(Xf[:m].t(), coef)       # Ritz vector and A * Ritz: two matrix-vector products
-            axr = torch.mv(AXf[:m].t(), coef)
-            r = torch.sub(axr, xr, alpha=e)
-            t = r / (hdf - e + 1e-4)
-            # {|r|^2, |t|^2, X_v . t}: one all-reduce, one host read -- the stop rule and the Gram-Schmidt coefficients
-            red = host(torch.cat([torch.stack([torch.dot(r, r), torch.dot(t, t)]), torch.mv(Xf[:m], t)]))
-            rn2, tt = float(red[0]), float(red[1])
-            de = e - elast if nsig > 1 else e
-            if abs(de) < tol and rn2 < toloose**2:
-                conv = True
-                break
-            if rn2 <= lindep or not tt > 0.0:
-                conv = rn2 < toloose**2
-                break
-            g = red[2:] / np.sqrt(tt)              # overlaps of the normalised correction with the (orthonormal) basis
-            c2 = float(g @ g)
-            if 1.0 - c2 <= lindep:
-                conv = rn2 < toloose**2
-                break
-            # t <- (t / |t| - sum_v g_v X_v) / sqrt(1 - c2): the norm after Gram-Schmidt is known before it is done
-            inv = 1.0 / np.sqrt(1.0 - c2)
-            gdev = torch.from_numpy(np.ascontiguousarray(g * inv)).to(sub.tdev)
-            restart = m + 1 > max_space
-            tgt = Xf[1] if restart else Xf[m]
-            proj = torch.mv(Xf[:m].t(), gdev)  # (before the target is written: at a restart it is one of the X_v)
-            torch.mul(t, inv / np.sqrt(tt), out=tgt)
-            tgt.sub_(proj)
-            if restart:  # {Ritz vector, correction}, A * Ritz by combination (no sigma build)
-                Xf[0].copy_(xr)
-                AXf[0].copy_(axr)
-                heff[:] = 0.0
-                heff[0, 0] = e
-                m = 2
-            else:
-                m += 1
-        xr = xr.view(sub.nrows, sub.nb)
+            def enqueue_iteration() -> int:
+                full = sub.gather_rows(view(sub.ctx.shard_dav_pick(), (sub.nrows, sub.nb)))
+                sub.ctx.shard_dav_sigma(full.data_ptr())
+                p, n = sub.ctx.shard_dav_dots()
+                sub.allreduce(view(p, (n,)))
+                p, n = sub.ctx.shard_dav_residual()
+                sub.allreduce(view(p, (n,)))
+                return sub.ctx.shard_dav_orth()
+
+            # one iteration is kept enqueued ahead of the one whose progress record is waited for: the device decides
+            # everything (stages behind a stop return at once; their collectives still run, on every rank alike)
+            tickets = [enqueue_iteration()]
+            for it in range(max_cycle):
+                if it + 1 < max_cycle:
+                    tickets.append(enqueue_iteration())
+                stopped, e, rn2, _m = sub.ctx.shard_dav_wait(tickets[it])
+                if stopped:
+                    break
+            sol_ptr, st_native = sub.ctx.shard_dav_end()
+            conv, nsig = bool(st_native["converged"]), int(st_native["n_sigma"])
+            e = float(st_native["e_davidson"])
+            xr = _view(sol_ptr, (sub.nrows, sub.nb), sub.tdev).clone()
+        else:
+            # ---- persistent basis: X[v], AX[v] = rows of basis vector v and of its sigma (flat views for the products)
+            nvec = max_space + 1
+            Dl = sub.nrows * sub.nb
+            X = torch.zeros((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
+            AX = torch.empty((nvec, sub.nrows, sub.nb), dtype=torch.float64, device=sub.tdev)
+            Xf, AXf = X.view(nvec, Dl), AX.view(nvec, Dl)
+            hdf = hd.reshape(Dl)
+            flat = Xf[0]
+            lo, hi = sub.row0 * sub.nb, sub.row1 * sub.nb
+            if lo <= best[1] < hi:
+                flat[best[1] - lo] = 1.0
+            if lo == 0:
+                flat[0] += 1e-5
+            if hi == sub.na * sub.nb:
+                flat[-1] -= 1e-5
+            # closed-form norm of the start vector (no reduction): 1 at the minimum, +-1e-5 on the first / last element
+            f = {0: 1e-5, sub.na * sub.nb - 1: -1e-5}
+            f[best[1]] = f.get(best[1], 0.0) + 1.0
+            flat.mul_(1.0 / np.sqrt(sum(v * v for v in f.values())))
+
+            def host(t):  # ONE all-reduce + ONE device-to-host read of a small vector
+                return sub.allreduce(t).cpu().numpy()
+
+            e, conv, nsig, m = 0.0, False, 0, 1
+            heff = np.zeros((nvec, nvec))
+            v0 = np.ones(1)
+            xr = axr = None
+            for _ in range(max_cycle):
+                sub.sigma(X[m - 1], use_spin, ss, shift, out=AX[m - 1])
+                nsig += 1
+                # new column of the projected matrix: ONE matrix-vector product over the local rows, one all-reduce
+                col = host(torch.mv(Xf[:m], AXf[m - 1]))
+                heff[:m, m - 1] = heff[m - 1, :m] = col
+                w, v = np.linalg.eigh(heff[:m, :m])
+                elast, e = e, float(w[0])
+                v0 = v[:, 0]
+                coef = torch.from_numpy(np.ascontiguousarray(v0)).to(sub.tdev)
+                xr = torch.mv(Xf[:m].t(), coef)       # Ritz vector and A * Ritz: two matrix-vector products
+                axr = torch.mv(AXf[:m].t(), coef)
+                r = torch.sub(axr, xr, alpha=e)
+                t = r / (hdf - e + 1e-4)
+                # {|r|^2, |t|^2, X_v . t}: one all-reduce, one host read -- the stop rule and the Gram-Schmidt coefficients
+                red = host(torch.cat([torch.stack([torch.dot(r, r), torch.dot(t, t)]), torch.mv(Xf[:m], t)]))
+                rn2, tt = float(red[0]), float(red[1])
+                de = e - elast if nsig > 1 else e
+                if abs(de) < tol and rn2 < toloose**2:
+                    conv = True
+                    break
+                if rn2 <= lindep or not tt > 0.0:
+                    conv = rn2 < toloose**2
+                    break
+                g = red[2:] / np.sqrt(tt)              # overlaps of the normalised correction with the (orthonormal) basis
+                c2 = float(g @ g)
+                if 1.0 - c2 <= lindep:
+                    conv = rn2 < toloose**2
+                    break
+                # t <- (t / |t| - sum_v g_v X_v) / sqrt(1 - c2): the norm after Gram-Schmidt is known before it is done
+                inv = 1.0 / np.sqrt(1.0 - c2)
+                gdev = torch.from_numpy(np.ascontiguousarray(g * inv)).to(sub.tdev)
+                restart = m + 1 > max_space
+                tgt = Xf[1] if restart else Xf[m]
+                proj = torch.mv(Xf[:m].t(), gdev)  # (before the target is written: at a restart it is one of the X_v)
+                torch.mul(t, inv / np.sqrt(tt), out=tgt)
+                tgt.sub_(proj)
+                if restart:  # {Ritz vector, correction}, A * Ritz by combination (no sigma build)
+                    Xf[0].copy_(xr)
+                    AXf[0].copy_(axr)
+                    heff[:] = 0.0
+                    heff[0, 0] = e
+                    m = 2
+                else:
+                    m += 1
+            xr = xr.view(sub.nrows, sub.nb)
+
         c_loc = xr / np.sqrt(sub.dot(xr, xr))
         # ---- observables (reference fermion.py:725-742): <c|H|c> without the penalty, occupancies
         e_dav = e
