@@ -27,16 +27,22 @@ def short(name):
 # raised and return at once (< 1.5 us); averaged in, they flatter the kernel
 for d in glob.glob(os.path.join(src, "prof_*")):
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-        real, early = defaultdict(list), defaultdict(int)
+        real, early, alld = defaultdict(list), defaultdict(int), defaultdict(list)
         for r in csv.DictReader(open(f)):
             name = short(r["Kernel_Name"])
             if "k_sigma" not in name and "k_same_spin" not in name:
                 continue
-            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            if dur < 1.5:
-                early[name] += 1
-            else:
-                real[name].append(dur)
+            alld[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for name, ds in alld.items():
+            # an early-exit launch still pays for dispatching its grid (0.8 us for 400 workgroups, ~4.5 us for the
+            # thousands of a work-item or batched launch): cut at a third of the kernel's median, at least 1.5 us
+            med = sorted(ds)[len(ds) // 2]
+            cut = max(1.5, med / 3.0)
+            for dur in ds:
+                if dur < cut:
+                    early[name] += 1
+                else:
+                    real[name].append(dur)
         if real:
             out = {k: {"launches": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v),
                        "early_exit_launches_excluded": early.get(k, 0)} for k, v in real.items()}
