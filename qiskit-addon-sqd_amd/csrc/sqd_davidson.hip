@@ -29,6 +29,20 @@
 
 namespace sqd {
 
+// ---- phase clocks (probe builds only: -DSQD_PHASE_CLOCK; profiles/probes/_phase_clock.py).  Slots accumulate the
+// 100 MHz wall clock over the launches since the last reset; the LAST workgroup of a launch (its critical path) writes.
+#ifdef SQD_PHASE_CLOCK
+__device__ unsigned long long sqd_clk[64 + 1024];  // [64 + 2 b], [65 + 2 b]: start / hand-over of workgroup b of k_dots_eig in iteration 10
+#define CLK(var) const unsigned long long var = wall_clock64()
+#define CLK_ACC(slot, a, b) do { if (threadIdx.x == 0) atomicAdd(&sqd_clk[slot], (unsigned long long)((b) - (a))); } while (0)
+#define CLK_FIRST(slot, t) do { if (threadIdx.x == 0) atomicMin(&sqd_clk[slot], t); } while (0)
+#else
+#define CLK(var)
+#define CLK_ACC(slot, a, b)
+#define CLK_FIRST(slot, t)
+#endif
+
+
 constexpr int NV = 16;       // vectors per fused reduction launch (stand-alone dots)
 constexpr int RED_BLOCKS = 512;
 constexpr int RED_T = 512;    // 8 waves per workgroup: half as many partials to fold as with 256
@@ -52,6 +66,44 @@ __device__ inline void load_partials(const double* partial, int64_t row_offset, 
     const double* p = &partial[row_offset + (v < nv ? v : 0)];
     out[v] = COHERENT ? coherent_load(p) : *p;
   }
+}
+
+// Column sums of a [nblocks][width] partial-sum array by a whole workgroup, out[v] (LDS) = sum_b partial[b][v], v < nv:
+// wavefront w takes the columns w, w + W, ... (W = wavefronts of the workgroup), two of them per pass; lane l adds the
+// rows l, l + 64, ... (four rows in flight), a DPP tree adds the lanes.  One memory round trip, one barrier -- the
+// thread-per-row form before it cost 3-4.6 us per call (a DPP tree over all nv columns in every wavefront, a cross-wave
+// stage in LDS, two barriers).  Fixed order => bitwise reproducible.  Ends with a barrier: out[] may be read at once.
+template <bool COHERENT>
+__device__ inline void fold_partials(const double* partial, int nblocks, int width, int nv, double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int v = wave; v < nv; v += 2 * nw) {
+    const bool two = v + nw < nv;
+    const int v2 = two ? v + nw : v;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b0 = lane; b0 < nblocks; b0 += 256) {
+      double p1[4], p2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 64 * u < nblocks ? b0 + 64 * u : b0;
+        const double* q = &partial[(int64_t)b * width];
+        p1[u] = COHERENT ? coherent_load(q + v) : q[v];
+        p2[u] = COHERENT ? coherent_load(q + v2) : q[v2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool on = b0 + 64 * u < nblocks;
+        s1 += on ? p1[u] : 0.0;
+        s2 += on ? p2[u] : 0.0;
+      }
+    }
+    s1 = wave_sum_lane63(s1);
+    s2 = wave_sum_lane63(s2);
+    if (lane == 63) {
+      out[v] = s1;
+      if (two) out[v2] = s2;
+    }
+  }
+  __syncthreads();
 }
 
 // partial[block*NV + v] = sum_i X[v*stride + i] * y[i]   (v < nvec <= NV)
@@ -171,9 +223,13 @@ __global__ void __launch_bounds__(128) k_reduce_to_mail(const double* __restrict
 // all the same, the acceptance rule rejects the result and the Jacobi fallback takes over -- speed, never
 // correctness, is what the missing pivoting can cost.
 // a[j] = A[lane][j]; xi: previous Ritz vector component of this lane in, new one out.
-template <int MV>
-__device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double& xi_io, double e_old, double* e_out,
+// N: the order n as a compile-time constant (0: run-time n).  The loops below are unrolled to MV with a guard `j < n`
+// per step; with a run-time n every guard is a scalar branch that fences the schedule (the phase clocks showed 9.5 us
+// per call at a mean order of 6.5), with N the guards fold away and the body is straight-line code of exactly n steps.
+template <int MV, int N>
+__device__ inline bool wave_lowest_eig_rqi(int n_rt, const double (&a)[MV], double& xi_io, double e_old, double* e_out,
                                            int* n_solves) {
+  const int n = N ? N : n_rt;
   const int lane = threadIdx.x & 63;
   const bool act = lane < n;
   double xi = (act && lane < n - 1) ? xi_io : 0.0;
@@ -209,6 +265,7 @@ __device__ inline bool wave_lowest_eig_rqi(int n, const double (&a)[MV], double&
   };
   double yi = matvec(xi);
   double theta = wave_sum(xi * yi);
+#pragma nounroll
   for (int it = 0; it < 6; ++it) {
     const double res = wave_sum(act ? (yi - theta * xi) * (yi - theta * xi) : 0.0);
     // accepted at 1e-11 |A| (the residual of the small eigenpair, not of the big one): the Ritz value is second order
@@ -327,65 +384,128 @@ __device__ inline double wave_lowest_eig_jacobi(int n, int ld, double* A, double
   return w0;
 }
 
+// ---- LDS working copy of the state block.  The state lives in global memory (every kernel of an iteration reads it);
+// the one wavefront that solves the projected problem used to read it field by field -- three dependent round trips, 2.6 us
+// (phase clocks) -- so the workgroups of k_dots_eig now request it when they start, beside the vector loads of their main
+// loop (nobody writes the block during that kernel before the last workgroup has arrived), and the eigen step works on
+// the copy and stores the head back in one go.  Head = every field before `heff`; the projected matrix is kept compact
+// (MV x MV) in LDS and written through.
+constexpr int DAV_HEAD_WORDS = (int)(offsetof(DavState, heff) / 8);
+static_assert(offsetof(DavState, heff) % 8 == 0, "the head of the state block is copied as 8-byte words");
+template <int MV>
+__device__ inline void dav_state_prefetch(const DavState* st, unsigned long long* s_head, double* s_heff) {
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(st);
+  for (int i = threadIdx.x; i < DAV_HEAD_WORDS; i += blockDim.x) s_head[i] = src[i];
+  for (int i = threadIdx.x; i < MV * MV; i += blockDim.x) s_heff[i] = st->heff[(i / MV) * MAXB + (i % MV)];
+}
+
+template <int MV, int N>
+__device__ inline bool rqi_case(int m, const double (&a)[MV], double& ci, double e_old, double* e_new, int* n_solves, bool& done) {
+  if (m != N) return false;
+  done = wave_lowest_eig_rqi<MV, N>(m, a, ci, e_old, e_new, n_solves);
+  return true;
+}
+// the order as a compile-time constant for the sizes of the default run (max_space 12), the run-time form beyond
+template <int MV>
+__device__ inline bool rqi_dispatch(int m, const double (&a)[MV], double& ci, double e_old, double* e_new, int* n_solves) {
+  bool done = false;
+  if (rqi_case<MV, 3>(m, a, ci, e_old, e_new, n_solves, done) || rqi_case<MV, 4>(m, a, ci, e_old, e_new, n_solves, done) ||
+      rqi_case<MV, 5>(m, a, ci, e_old, e_new, n_solves, done) || rqi_case<MV, 6>(m, a, ci, e_old, e_new, n_solves, done) ||
+      rqi_case<MV, 7>(m, a, ci, e_old, e_new, n_solves, done) || rqi_case<MV, 8>(m, a, ci, e_old, e_new, n_solves, done) ||
+      rqi_case<MV, 9>(m, a, ci, e_old, e_new, n_solves, done) || rqi_case<MV, 10>(m, a, ci, e_old, e_new, n_solves, done) ||
+      rqi_case<MV, 11>(m, a, ci, e_old, e_new, n_solves, done) || rqi_case<MV, 12>(m, a, ci, e_old, e_new, n_solves, done) ||
+      rqi_case<MV, 13>(m, a, ci, e_old, e_new, n_solves, done))
+    return done;
+  return wave_lowest_eig_rqi<MV, 0>(m, a, ci, e_old, e_new, n_solves);
+}
+
 // One wavefront of the LAST workgroup of k_dots_eig: the new column of the projected matrix from the folded
 // dot products, the linear-dependence test, the lowest eigenpair, the Ritz coefficients, the restart decision.
-// tot[0] = |X_{m-1}|^2, tot[1+v] = X_v . A X_{m-1}.
+// tot[0] = |X_{m-1}|^2, tot[1+v] = X_v . A X_{m-1}.  w / wh: the LDS working copy (dav_state_prefetch).
 template <int MV>
-__device__ inline void wave_eig_step(DavState* st, const double* tot, const DavParams prm, double* sA, double* sM,
-                                     double* sv_eig) {
+__device__ inline void wave_eig_step(DavState* st, unsigned long long* s_head, double* wh, const double* tot, const DavParams prm,
+                                     double* sA, double* sM, double* sv_eig) {
   const int lane = threadIdx.x & 63;
-  const int m = st->m_next;
-  constexpr int LD = MV;
-  if (st->restart) {  // the previous iteration collapsed the basis: X0 = Ritz vector (unit norm), A X0 by combination
+  DavState* w = reinterpret_cast<DavState*>(s_head);  // (head fields only)
+  CLK(e0);
+  auto flush = [&]() {  // the head back to global memory: independent stores, one round trip
     wave_sync();
-    for (int i = lane; i < MAXB * MAXB; i += 64) st->heff[i] = 0.0;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(st);
+    for (int i = lane; i < DAV_HEAD_WORDS; i += 64) dst[i] = s_head[i];
+  };
+  const int m = w->m_next;
+  constexpr int LD = MV;
+  if (w->restart) {  // the previous iteration collapsed the basis: X0 = Ritz vector (unit norm), A X0 by combination
+    wave_sync();
+    for (int i = lane; i < MV * MV; i += 64) {
+      wh[i] = 0.0;
+      st->heff[(i / MV) * MAXB + (i % MV)] = 0.0;
+    }
     wave_sync();
     if (lane == 0) {
-      st->heff[0] = st->e;
-      st->sv[0] = 1.0;
-      st->restart = 0;
-      st->m_eig = -1;
+      wh[0] = w->e;
+      st->heff[0] = w->e;
+      w->sv[0] = 1.0;
+      w->restart = 0;
+      w->m_eig = -1;
     }
     wave_sync();
   }
   const double nrm2 = tot[0];
-  if (st->it == 0 && !(nrm2 > 0.0)) {
+  if (w->it == 0 && !(nrm2 > 0.0)) {
+    wave_sync();
     if (lane == 0) {
-      st->err = 1;
-      st->stop = 1;
+      w->err = 1;
+      w->stop = 1;
     }
+    flush();
     return;
   }
   if (!(nrm2 > prm.lindep)) {
     // the last correction vector was linearly dependent on the basis: stop with the Ritz vector of the
     // previous projected problem (pyscf: 'Linear dependency in trial subspace'); this sigma is not counted
+    wave_sync();
     if (lane == 0) {
-      st->conv = (st->rnorm2 < prm.tol2) ? 1 : 0;
-      st->stop = 1;
+      w->conv = (w->rnorm2 < prm.tol2) ? 1 : 0;
+      w->stop = 1;
     }
+    flush();
     return;
   }
   const double svm = 1.0 / sqrt(nrm2);
-  const double svi = (lane < m) ? ((lane == m - 1) ? svm : st->sv[lane]) : 0.0;
+  const double svi = (lane < m) ? ((lane == m - 1) ? svm : w->sv[lane]) : 0.0;
+  const double e_old = w->e;
+  const int m_eig = w->m_eig, first = w->first;
   // row `lane` of the projected matrix in registers: the old block from the state, the new row / column from tot
   double a[MV];
+  {
+    const double tl = (lane < m) ? tot[1 + lane] : 0.0;
+    const int row = lane < MV ? lane : 0;
 #pragma unroll
-  for (int j = 0; j < MV; ++j) {
-    double v = 0.0;
-    if (lane < m && j < m) {
-      if (lane == m - 1) v = tot[1 + j] * ((j == m - 1) ? svm : st->sv[j]) * svm;
-      else if (j == m - 1) v = tot[1 + lane] * svi * svm;
-      else v = st->heff[lane * MAXB + j];
+    for (int j = 0; j < MV; ++j) {
+      double v = 0.0;
+      if (lane < m && j < m) {
+        if (lane == m - 1) v = tot[1 + j] * ((j == m - 1) ? svm : w->sv[j]) * svm;
+        else if (j == m - 1) v = tl * svi * svm;
+        else v = wh[row * MV + j];
+      }
+      a[j] = v;
     }
-    a[j] = v;
-  }
-  if (lane < m) {
-    st->heff[lane * MAXB + (m - 1)] = tot[1 + lane] * svi * svm;
-    st->heff[(m - 1) * MAXB + lane] = tot[1 + lane] * svi * svm;
+    if (lane < m) {
+      const double hv = tl * svi * svm;
+      wh[lane * MV + (m - 1)] = hv;
+      wh[(m - 1) * MV + lane] = hv;
+      st->heff[lane * MAXB + (m - 1)] = hv;
+      st->heff[(m - 1) * MAXB + lane] = hv;
+    }
   }
   double e_new = 0.0;
   double ci = 0.0;  // this lane's component of the lowest eigenvector
   bool done = false;
+#ifdef SQD_PHASE_CLOCK
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  CLK(e1);
   if (m == 1) {
     e_new = wave_bcast(a[0], 0);
     ci = (lane == 0) ? 1.0 : 0.0;
@@ -413,13 +533,13 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
     const double sgn = (v0 < 0.0) ? -1.0 : 1.0;  // orientation: positive weight on the older vector
     ci = (lane == 0) ? sgn * v0 / nn : ((lane == 1) ? sgn * v1 / nn : 0.0);
     done = true;
-  } else if (m == st->m_eig + 1 && !st->first) {
-    ci = (lane < m - 1) ? st->coef[lane] : 0.0;  // previous Ritz vector as the warm start
-    done = wave_lowest_eig_rqi<MV>(m, a, ci, st->e, &e_new, &st->n_rqi);
+  } else if (m == m_eig + 1 && !first) {
+    ci = (lane < m - 1) ? w->coef[lane] : 0.0;  // previous Ritz vector as the warm start
+    done = rqi_dispatch<MV>(m, a, ci, e_old, &e_new, &w->n_rqi);
     if (!done) ci = 0.0;
   }
   if (!done) {  // fallback: cyclic Jacobi on an LDS copy
-    if (lane == 0) st->n_jacobi += 1;
+    if (lane == 0) w->n_jacobi += 1;
     wave_sync();
     if (lane < m) {
 #pragma unroll
@@ -431,28 +551,31 @@ __device__ inline void wave_eig_step(DavState* st, const double* tot, const DavP
     ci = (lane < m) ? sv_eig[lane] : 0.0;
   }
   // the Ritz coefficients of this projected problem
+  CLK(e2);
+  CLK_ACC(7, e0, e1);   // state + projected matrix
+  CLK_ACC(8, e1, e2);   // eigenpair
   const double cn = wave_sum(ci * ci);
   wave_sync();
   if (lane < m) {
-    st->coef[lane] = ci;
-    st->raw[lane] = ci * svi;
-    st->sol_coef[lane] = (cn > 0.0 ? ci / sqrt(cn) : ci) * svi;
-    if (lane == m - 1) st->sv[lane] = svm;
+    w->coef[lane] = ci;
+    w->raw[lane] = ci * svi;
+    w->sol_coef[lane] = (cn > 0.0 ? ci / sqrt(cn) : ci) * svi;
+    if (lane == m - 1) w->sv[lane] = svm;
   }
   if (lane == 0) {
-    const double elast = st->e;
-    st->e = e_new;
-    st->de = st->first ? e_new : e_new - elast;
-    st->first = 0;
-    st->m_eig = m;
-    st->m_cur = m;
-    st->sol_m = m;
-    st->nsig += 1;
-    st->it += 1;
+    w->e = e_new;
+    w->de = first ? e_new : e_new - e_old;
+    w->first = 0;
+    w->m_eig = m;
+    w->m_cur = m;
+    w->sol_m = m;
+    w->nsig += 1;
+    w->it += 1;
     const int restart = (m + 1 > prm.max_space) ? 1 : 0;
-    st->restart = restart;
-    st->m_next = restart ? 2 : m + 1;
+    w->restart = restart;
+    w->m_next = restart ? 2 : m + 1;
   }
+  flush();
 }
 
 // sums[0] = |X_{m-1}|^2, sums[1+v] = X_v . y  (v < m <= MV), y = A X_{m-1}, m = st->m_next; the workgroup that
@@ -468,25 +591,41 @@ struct SplitRows {
 };
 // (bx, nbx): this workgroup's index in ITS subspace's grid and that grid's size -- the whole launch for the single
 // kernels, one z-slice for the batched ones (sqd_solve_batch)
-template <int MV>
+// FUSED: the workgroup that arrives last goes on to fold the partials and solve the projected problem (single solves:
+// one launch less on a latency-bound chain).  !FUSED: the dot products only -- the eigen step's 232 VGPRs would hold this
+// kernel to one workgroup per CU, and a batched launch is 16 x 197 workgroups of bandwidth-bound work; k_eig_b follows.
+// Either way the partials, their fold (fold_partials in a RED_T-thread workgroup) and the eigen step are the same code:
+// the same bits.
+template <int MV, bool FUSED>
 __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                                      double* __restrict__ partial, int width, unsigned* counter, DavState* st,
                                      const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx) {
   __shared__ double red[16 * (MV + 1)];
-  __shared__ double tot[MV + 1];
-  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  __shared__ double tot[FUSED ? MV + 1 : 1];
+  __shared__ double sA[FUSED ? MV * MV : 1], sM[FUSED ? MV * MV : 1], sv_eig[FUSED ? MV + 1 : 1];
+  __shared__ unsigned long long s_head[FUSED ? DAV_HEAD_WORDS : 1];
+  __shared__ double s_heff[FUSED ? MV * MV : 1];
+  CLK(c0);
+  CLK_FIRST(63, c0);
   if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
                          // kernel before every workgroup has arrived)
   const int nvec = st->m_next;
+  if (FUSED) dav_state_prefetch<MV>(st, s_head, s_heff);  // (for the workgroup that turns out to be the last one)
   double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
   double acc[MV + 1];
 #pragma unroll
   for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
   for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
-    double yv;
+    // every request that does not depend on another one first: the basis vectors, y, the row's split record -- the
+    // partial rows of a split row are the only second round trip (they were the third)
+    double xv[MV];
+    load_vectors<MV>(X, stride, nvec, i, xv);
+    double yv = y[i];
     if (split.rowinfo) {
-      const int64_t A = i / split.nb, B = i - A * split.nb;
-      const int slot0 = split.rowinfo[2 * A], ns = split.rowinfo[2 * A + 1];
+      const int64_t A = (n < (int64_t)1 << 31) ? (int64_t)((unsigned)i / (unsigned)split.nb) : i / split.nb;
+      const int64_t B = i - A * split.nb;
+      const int2 info = *reinterpret_cast<const int2*>(&split.rowinfo[2 * A]);
+      const int slot0 = info.x, ns = info.y;
       if (ns > 0) {
         double sacc = 0.0;
         for (int j0 = 0; j0 < ns; j0 += 8) {  // eight partial rows in flight per round, added in slot order
@@ -498,14 +637,8 @@ __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, do
         }
         yv = sacc;
         y[i] = sacc;
-      } else {
-        yv = y[i];
       }
-    } else {
-      yv = y[i];
     }
-    double xv[MV];
-    load_vectors<MV>(X, stride, nvec, i, xv);
 #pragma unroll
     for (int v = 0; v < MV; ++v) {
       acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
@@ -513,29 +646,45 @@ __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, do
     }
   }
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
+  if constexpr (!FUSED) {
+    if ((int)threadIdx.x < nvec + 1) partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
+    return;
+  }
   if ((int)threadIdx.x < nvec + 1)
     coherent_store(&partial[(int64_t)bx * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
-  if (!arrive_last(counter, bx, nbx)) return;
-  double vals[MV + 1];
-#pragma unroll
-  for (int v = 0; v < MV + 1; ++v) vals[v] = 0.0;
-  for (int b = threadIdx.x; b < (int)nbx; b += blockDim.x) {
-    double p[MV + 1];
-    load_partials<MV + 1, true>(partial, (int64_t)b * width, nvec + 1, p);  // all requests in flight together
-#pragma unroll
-    for (int v = 0; v < MV + 1; ++v) vals[v] += (v < nvec + 1) ? p[v] : 0.0;
+  CLK(c1);
+#ifdef SQD_PHASE_CLOCK
+  if (threadIdx.x == 0 && st->it == 10 && bx < 512) {
+    sqd_clk[64 + 2 * bx] = c0;
+    sqd_clk[65 + 2 * bx] = c1;
   }
-  block_sum_multi<MV + 1>(vals, nvec + 1, red);
-  if ((int)threadIdx.x < nvec + 1) tot[threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
-  __syncthreads();
+#endif
+  if (!arrive_last(counter, bx, nbx)) return;
+  CLK(c2);
+  fold_partials<true>(partial, (int)nbx, width, nvec + 1, tot);
   if (threadIdx.x >= 64) return;
-  wave_eig_step<MV>(st, tot, prm, sA, sM, sv_eig);
+  CLK(c3);
+  wave_eig_step<MV>(st, s_head, s_heff, tot, prm, sA, sM, sv_eig);
+#ifdef SQD_PHASE_CLOCK
+  __builtin_amdgcn_s_waitcnt(0);
+  CLK(c4);
+  if (threadIdx.x == 0) {
+    const unsigned long long first = atomicExch(&sqd_clk[63], ~0ull);
+    atomicAdd(&sqd_clk[0], 1ull);          // launches
+    atomicAdd(&sqd_clk[1], c0 - first);    // first workgroup's start -> last workgroup's start
+    atomicAdd(&sqd_clk[2], c1 - c0);       // main loop + block sum + partial store (last workgroup)
+    atomicAdd(&sqd_clk[3], c2 - c1);       // arrival
+    atomicAdd(&sqd_clk[4], c3 - c2);       // fold
+    atomicAdd(&sqd_clk[5], c4 - c3);       // eig step
+    atomicAdd(&sqd_clk[6], (unsigned long long)st->m_cur);
+  }
+#endif
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                            double* __restrict__ partial, int width, unsigned* counter, DavState* st,
                            const DavParams prm, const SplitRows split) {
-  dots_eig_body<MV>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
+  dots_eig_body<MV, true>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
 }
 
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
@@ -548,11 +697,13 @@ __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, 
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   __shared__ double s_raw[MV];
+  CLK(r0);
   if (st->stop) return;
   const int nvec = st->m_cur;
   const double e = st->e;
   if ((int)threadIdx.x < MV) s_raw[threadIdx.x] = ((int)threadIdx.x < nvec) ? st->raw[threadIdx.x] : 0.0;
   __syncthreads();
+  CLK(r1);
   double* __restrict__ out = X + (int64_t)nvec * stride;
   double vals[MV + 2];
 #pragma unroll
@@ -583,9 +734,20 @@ __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, 
 #pragma unroll
     for (int v = 0; v < MV; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
   }
+  CLK(r2);
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   if ((int)threadIdx.x < nvec + 2)
     partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+#ifdef SQD_PHASE_CLOCK
+  __builtin_amdgcn_s_waitcnt(0);
+  CLK(r3);
+  if (bx == 0 && threadIdx.x == 0) {
+    atomicAdd(&sqd_clk[10], 1ull);
+    atomicAdd(&sqd_clk[11], r1 - r0);  // state loads
+    atomicAdd(&sqd_clk[12], r2 - r1);  // main loop
+    atomicAdd(&sqd_clk[13], r3 - r2);  // block sum + store
+  }
+#endif
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
@@ -636,6 +798,7 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   __shared__ int s_stop, s_was_stopped;
   // (workgroup 0 raises st->stop further down while other workgroups may still be starting: the flag is
   // sampled once per workgroup so that all its threads take the same path)
+  CLK(o0);
   if (threadIdx.x == 0) s_was_stopped = st->stop;
   __syncthreads();
   if (s_was_stopped) {
@@ -648,49 +811,47 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   if (tot_in) {
     if ((int)threadIdx.x < nv) tot[threadIdx.x] = tot_in[threadIdx.x];
   } else {
-    double vals[MV + 2];
-#pragma unroll
-    for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-      double p[MV + 2];
-      load_partials<MV + 2, false>(partial, (int64_t)b * width, nv, p);
-#pragma unroll
-      for (int v = 0; v < MV + 2; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
-    }
-    block_sum_multi<MV + 2>(vals, nv, red);
-    if ((int)threadIdx.x < nv) tot[threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
+    fold_partials<false>(partial, nblocks, width, nv, tot);
   }
   __syncthreads();
+  CLK(o1);
   const double rr = tot[0], tt = tot[1];
-  if ((int)threadIdx.x < MV) {
+  // one wavefront, lane v = basis vector v: its state words are requested together (thread 0 alone used to walk the
+  // basis twice with a global load per step: 4.6 us of every workgroup's life, phase clocks of round 3)
+  if (threadIdx.x < 64) {
     const int v = threadIdx.x;
-    g[v] = (v < nvec && tt > 0.0) ? st->sv[v] * tot[2 + v] / sqrt(tt) : 0.0;
-    s_raw[v] = (v < nvec) ? st->raw[v] : 0.0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double c2 = 0.0;
-    for (int v = 0; v < nvec; ++v) c2 += g[v] * g[v];
+    const bool on = v < nvec && v < MV;
+    const double svv = on ? st->sv[v] : 0.0, rawv = on ? st->raw[v] : 0.0;
+    const double de = st->de;
+    const double gv = (on && tt > 0.0) ? svv * tot[2 + v] / sqrt(tt) : 0.0;
+    const double c2 = wave_sum(gv * gv);
     const double inv = (1.0 - c2 > 1e-3) ? 1.0 / sqrt(1.0 - c2) : 1.0;
-    s_scale = (tt > 0.0) ? inv / sqrt(tt) : 0.0;
-    for (int v = 0; v < nvec; ++v) g[v] *= inv * st->sv[v];
-    const int de_small = fabs(st->de) < prm.tol;
-    s_stop = ((de_small && rr < prm.tol2) || !(rr > prm.lindep) || !(tt > 0.0)) ? 1 : 0;
-    if (bx == 0) {
-      st->rnorm2 = rr;
-      if (s_stop) {
-        st->conv = (rr < prm.tol2) ? 1 : 0;
-        st->stop = 1;
-      } else if (restart) {
-        // from here on the solution is X0 alone (the collapse below), should the run end before the next
-        // projected problem is solved
-        st->sol_coef[0] = 1.0;
-        st->sol_m = 1;
+    if (v < MV) {
+      g[v] = gv * inv * svv;
+      s_raw[v] = rawv;
+    }
+    if (v == 0) {
+      s_scale = (tt > 0.0) ? inv / sqrt(tt) : 0.0;
+      const int de_small = fabs(de) < prm.tol;
+      s_stop = ((de_small && rr < prm.tol2) || !(rr > prm.lindep) || !(tt > 0.0)) ? 1 : 0;
+      if (bx == 0) {
+        st->rnorm2 = rr;
+        if (s_stop) {
+          st->conv = (rr < prm.tol2) ? 1 : 0;
+          st->stop = 1;
+        } else if (restart) {
+          // from here on the solution is X0 alone (the collapse below), should the run end before the next
+          // projected problem is solved
+          st->sol_coef[0] = 1.0;
+          st->sol_m = 1;
+        }
       }
-      post_progress(mail, seq, st, s_stop, rr);
     }
   }
   __syncthreads();
+  CLK(o2);
+  // the iteration's progress record for the host: by the LAST wavefront of workgroup 0, beside the others' main loop
+  if (bx == 0 && threadIdx.x == blockDim.x - 64) post_progress(mail, seq, st, s_stop, rr);
   if (s_stop) return;  // the correction is not needed (and may be 0/0)
   const double scale = s_scale;
   double* __restrict__ t = X + (int64_t)nvec * stride;
@@ -706,6 +867,17 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
       }
       t[i] = s;
     }
+#ifdef SQD_PHASE_CLOCK
+    __builtin_amdgcn_s_waitcnt(0);
+    CLK(o3);
+    if (bx == 0 && threadIdx.x == 0) {
+      atomicAdd(&sqd_clk[20], 1ull);
+      atomicAdd(&sqd_clk[21], o1 - o0);  // stop flag + fold of the residual kernel's partials
+      atomicAdd(&sqd_clk[22], o2 - o1);  // coefficients, stop rule
+      atomicAdd(&sqd_clk[23], o3 - o2);  // main loop
+    }
+    if (bx == 0 && threadIdx.x == blockDim.x - 64) atomicAdd(&sqd_clk[24], o3 - o2);  // progress record + main loop (the posting wavefront)
+#endif
     return;
   }
   // restart: the same pass also forms the Ritz vector and A * Ritz, in place, element by element
@@ -814,46 +986,32 @@ __global__ void __launch_bounds__(RED_T) k_shard_dots(int64_t n, const double* _
   if ((int)threadIdx.x < nvec + 1)
     coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
   if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
-  double vals[MV + 1];
-#pragma unroll
-  for (int v = 0; v < MV + 1; ++v) vals[v] = 0.0;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
-    double p[MV + 1];
-    load_partials<MV + 1, true>(partial, (int64_t)b * width, nvec + 1, p);
-#pragma unroll
-    for (int v = 0; v < MV + 1; ++v) vals[v] += (v < nvec + 1) ? p[v] : 0.0;
-  }
-  block_sum_multi<MV + 1>(vals, nvec + 1, red);
-  if ((int)threadIdx.x <= MAXB) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 1) ? block_sum_multi_get<MV + 1>(red, threadIdx.x) : 0.0;
+  __shared__ double s_tot[MV + 1];
+  fold_partials<true>(partial, (int)gridDim.x, width, nvec + 1, s_tot);
+  if ((int)threadIdx.x <= MAXB) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 1) ? s_tot[threadIdx.x] : 0.0;
 }
 // the projected eigenproblem from the all-reduced totals: one wavefront
 template <int MV>
 __global__ void __launch_bounds__(64) k_shard_eig(DavState* st, const double* __restrict__ tot_in, const DavParams prm) {
   __shared__ double tot[MV + 1];
   __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  __shared__ unsigned long long s_head[DAV_HEAD_WORDS];
+  __shared__ double s_heff[MV * MV];
   if (st->stop) return;
+  dav_state_prefetch<MV>(st, s_head, s_heff);
   if ((int)threadIdx.x < MV + 1) tot[threadIdx.x] = tot_in[threadIdx.x];
   wave_sync();
-  wave_eig_step<MV>(st, tot, prm, sA, sM, sv_eig);
+  wave_eig_step<MV>(st, s_head, s_heff, tot, prm, sA, sM, sv_eig);
 }
 // local totals of the residual kernel's partials {|r|^2, |t|^2, X_v . t}, folded exactly as k_orth_dev folds them
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_shard_fold(const double* __restrict__ partial, int nblocks, int width,
                                                       const DavState* __restrict__ st, double* __restrict__ tot_out) {
-  __shared__ double red[16 * (MV + 2)];
+  __shared__ double s_tot[MV + 2];
   if (st->stop) return;
   const int nv = st->m_cur + 2;
-  double vals[MV + 2];
-#pragma unroll
-  for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    double p[MV + 2];
-    load_partials<MV + 2, false>(partial, (int64_t)b * width, nv, p);
-#pragma unroll
-    for (int v = 0; v < MV + 2; ++v) vals[v] += (v < nv) ? p[v] : 0.0;
-  }
-  block_sum_multi<MV + 2>(vals, nv, red);
-  if ((int)threadIdx.x <= MAXB + 1) tot_out[threadIdx.x] = ((int)threadIdx.x < nv) ? block_sum_multi_get<MV + 2>(red, threadIdx.x) : 0.0;
+  fold_partials<false>(partial, nblocks, width, nv, s_tot);
+  if ((int)threadIdx.x <= MAXB + 1) tot_out[threadIdx.x] = ((int)threadIdx.x < nv) ? s_tot[threadIdx.x] : 0.0;
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_shard_orth(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride,
@@ -882,10 +1040,26 @@ struct DavBatchArgs {
   GPtr<double> res;  // the run's outcome (host-visible)
 };
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_dots_eig_b(const DavBatchArgs* __restrict__ as) {
+__global__ void __launch_bounds__(RED_T, 4) k_dots_b(const DavBatchArgs* __restrict__ as) {
   const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
-  dots_eig_body<MV>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
+  dots_eig_body<MV, false>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
+}
+// the eigen step of every subspace of the batch: one workgroup each (fold of the partials k_dots_b left, then one wavefront)
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_eig_b(const DavBatchArgs* __restrict__ as) {
+  __shared__ double tot[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  __shared__ unsigned long long s_head[DAV_HEAD_WORDS];
+  __shared__ double s_heff[MV * MV];
+  const DavBatchArgs a = as[blockIdx.x];
+  DavState* st = a.st;
+  if (st->stop) return;
+  const int nvec = st->m_next;
+  dav_state_prefetch<MV>(st, s_head, s_heff);
+  fold_partials<false>(a.partial, (int)a.gb, a.width, nvec + 1, tot);
+  if (threadIdx.x >= 64) return;
+  wave_eig_step<MV>(st, s_head, s_heff, tot, a.prm, sA, sM, sv_eig);
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T, 4) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
@@ -1309,11 +1483,13 @@ int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const
     const long long seq = common_seq(subs);
     seq_of[round & 3] = seq;
     if (plan.max_space <= 12) {
-      hipLaunchKernelGGL((k_dots_eig_b<13>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_dots_b<13>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_eig_b<13>), dim3(grid.z), dim3(RED_T), 0, s, args);
       hipLaunchKernelGGL((k_residual_precond_b<13>), grid, dim3(RED_T), 0, s, args);
       hipLaunchKernelGGL((k_orth_dev_b<13>), grid, dim3(RED_T), 0, s, args, seq);
     } else {
-      hipLaunchKernelGGL((k_dots_eig_b<MAXB>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_dots_b<MAXB>), grid, dim3(RED_T), 0, s, args);
+      hipLaunchKernelGGL((k_eig_b<MAXB>), dim3(grid.z), dim3(RED_T), 0, s, args);
       hipLaunchKernelGGL((k_residual_precond_b<MAXB>), grid, dim3(RED_T), 0, s, args);
       hipLaunchKernelGGL((k_orth_dev_b<MAXB>), grid, dim3(RED_T), 0, s, args, seq);
     }
@@ -1584,3 +1760,15 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st) {
 }
 
 }  // namespace sqd
+
+#ifdef SQD_PHASE_CLOCK
+extern "C" __attribute__((visibility("default"))) int sqd_probe_clk(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sqd::sqd_clk), sizeof(unsigned long long) * (64 + 1024)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[64] = {};
+    z[63] = ~0ull;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sqd::sqd_clk), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

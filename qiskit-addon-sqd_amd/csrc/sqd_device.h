@@ -6,13 +6,51 @@
 
 namespace sqd {
 
+// ---- wave64 reductions on the DPP path.  `__shfl_down` of a double is two ds_bpermute_b32 -- an LDS-crossbar round
+// trip of ~120 clocks per step, seven dependent steps per reduction: the phase clocks of round 3 (profiles/probes/
+// _phase_clock.py) put 3-4 us of a 9 us BLAS-1 kernel into its block reduction and a third of the projected eigenproblem
+// into its dot products.  v_mov_b32_dpp moves a lane's register to a neighbour inside the VALU (no LDS): row_shr 1, 2, 4,
+// 8 leave the sum of a row of 16 lanes in its lane 15, row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) carry
+// the row totals up, and lane 63 holds the sum of the wavefront.  Lanes without a source take `fill`.  One fixed tree
+// => bitwise reproducible.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_take(double v, double fill) {
+  int w[2], f[2];
+  __builtin_memcpy(w, &v, 8);
+  __builtin_memcpy(f, &fill, 8);
+  w[0] = __builtin_amdgcn_update_dpp(f[0], w[0], CTRL, ROW_MASK, 0xf, false);
+  w[1] = __builtin_amdgcn_update_dpp(f[1], w[1], CTRL, ROW_MASK, 0xf, false);
+  double r;
+  __builtin_memcpy(&r, w, 8);
+  return r;
+}
+__device__ inline double wave_sum_lane63(double v) {  // the total on lane 63 (other lanes: partial sums)
+  v += dpp_take<0x111, 0xf>(v, 0.0);
+  v += dpp_take<0x112, 0xf>(v, 0.0);
+  v += dpp_take<0x114, 0xf>(v, 0.0);
+  v += dpp_take<0x118, 0xf>(v, 0.0);
+  v += dpp_take<0x142, 0xa>(v, 0.0);
+  v += dpp_take<0x143, 0xc>(v, 0.0);
+  return v;
+}
+__device__ inline double wave_max_lane63(double v) {
+  double o;
+  o = dpp_take<0x111, 0xf>(v, v), v = o > v ? o : v;
+  o = dpp_take<0x112, 0xf>(v, v), v = o > v ? o : v;
+  o = dpp_take<0x114, 0xf>(v, v), v = o > v ? o : v;
+  o = dpp_take<0x118, 0xf>(v, v), v = o > v ? o : v;
+  o = dpp_take<0x142, 0xa>(v, v), v = o > v ? o : v;
+  o = dpp_take<0x143, 0xc>(v, v), v = o > v ? o : v;
+  return v;
+}
+
 // Sum over the workgroup; result valid on thread 0.  `red` = >= 16 doubles of LDS.
-// Fixed shuffle tree + fixed wave order => bitwise reproducible.
+// Fixed tree + fixed wave order => bitwise reproducible.
 __device__ inline double block_sum(double v, double* red) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  v = wave_sum_lane63(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
-  if (lane == 0) red[wave] = v;
+  if (lane == 63) red[wave] = v;
   __syncthreads();
   double s = 0.0;
   if (threadIdx.x == 0) {
@@ -22,19 +60,20 @@ __device__ inline double block_sum(double v, double* red) {
   return s;
 }
 
-// Sum N per-thread values over the workgroup with ONE barrier: shuffle tree inside each wave, lane 0
-// parks the wave totals in LDS (red[wave*N + v]), thread v adds the waves in order.  Thread v (< n)
-// returns the total of value v in `vals[0]`... callers read it through `block_sum_multi_get`.
+// Sum N per-thread values over the workgroup with ONE barrier: DPP tree inside each wave (all N values, branch-free:
+// N independent chains that the scheduler interleaves -- a branch per value made them N chains in sequence), lane 63
+// parks the wave totals in LDS (red[wave*N + v]), thread v adds the waves in order: `block_sum_multi_get`.
+// Values at or past n must be zero (or are never read).
 template <int N>
 __device__ inline void block_sum_multi(double (&vals)[N], int n, double* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)n;
 #pragma unroll
-  for (int v = 0; v < N; ++v)
-    if (v < n) {
-      double x = vals[v];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-      if (lane == 0) red[wave * N + v] = x;
-    }
+  for (int v = 0; v < N; ++v) {
+    const double x = wave_sum_lane63(vals[v]);
+    if (lane == 63) red[wave * N + v] = x;
+    if (v % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // four chains interleaved at a time (registers)
+  }
   __syncthreads();
 }
 // after block_sum_multi: total of value v (any thread may call; v < n)
@@ -109,18 +148,12 @@ __device__ inline void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ inline double wave_sum(double v) {  // fixed tree => bitwise reproducible; result on every lane
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return __shfl(v, 0);
-}
-__device__ inline double wave_max(double v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(v, off);
-    v = o > v ? o : v;
-  }
-  return __shfl(v, 0);
-}
 // value of lane `src` (uniform over the wave) on every lane: v_readlane_b32 x2, no LDS crossbar
+__device__ inline double wave_bcast(double v, int src);
+__device__ inline double wave_sum(double v) {  // fixed tree => bitwise reproducible; result on every lane
+  return wave_bcast(wave_sum_lane63(v), 63);
+}
+__device__ inline double wave_max(double v) { return wave_bcast(wave_max_lane63(v), 63); }
 __device__ inline double wave_bcast(double v, int src) {
   int w[2];
   __builtin_memcpy(w, &v, 8);

@@ -31,6 +31,7 @@ struct dim3 {
   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
 struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
 struct double2 { double x, y; };
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 
@@ -256,6 +257,29 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
   return emu_exchange(v, (lane / width) * width + (src % width));
 }
 inline int __builtin_amdgcn_readlane(int v, int src) { return emu_exchange(v, src); }
+// v_mov_b32_dpp for the controls the kernels use: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
+// A lane whose row is enabled by row_mask and whose source lane exists takes the source's value; every other lane
+// keeps `old` (bound_ctrl = false).  bank_mask must be 0xf.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = threadIdx.x & 63, row = lane >> 4;
+  int from = -1;
+  if (ctrl > 0x110 && ctrl <= 0x11f) {
+    const int n = ctrl - 0x110;
+    if ((lane & 15) >= n) from = lane - n;
+  } else if (ctrl == 0x142) {
+    if (row >= 1) from = row * 16 - 1;
+  } else if (ctrl == 0x143) {
+    if (row >= 2) from = 31;
+  } else {
+    std::fprintf(stderr, "emu: DPP control 0x%x not implemented\n", ctrl);
+    std::abort();
+  }
+  if (bank_mask != 0xf) std::abort();
+  const int got = emu_exchange(src, from >= 0 ? from : lane);
+  const bool enabled = (row_mask >> row) & 1;
+  if (enabled && from >= 0) return got;
+  return (enabled && bound_ctrl) ? 0 : old;
+}
 // v_mfma_f64_16x16x4_f64: D (16 x 16) = A (16 x 4) B (4 x 16) + C.  Lane l = (lk = l / 16, li = l % 16) holds A[li][lk],
 // B[lk][li] and the four elements D[lk + 4 r][li], r = 0..3 (the layout the product kernels are written for).
 #define ext_vector_type(n) vector_size(8 * (n))
@@ -289,6 +313,7 @@ template <class T> inline T atomicExch(T* p, T v) {
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
 inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __builtin_amdgcn_wave_barrier() { emu::fiber_yield(emu::FIBER_AT_WAVE_BARRIER); }
 template <class T> inline T atomicMax(T* p, T v) {
