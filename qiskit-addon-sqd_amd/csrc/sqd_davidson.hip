@@ -628,12 +628,19 @@ __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, do
       const int slot0 = info.x, ns = info.y;
       if (ns > 0) {
         double sacc = 0.0;
-        for (int j0 = 0; j0 < ns; j0 += 8) {  // eight partial rows in flight per round, added in slot order
-          double pv[8];
+        for (int j0 = 0; j0 < ns; j0 += 16) {  // eight or sixteen partial rows in flight per round, added in slot order
+          double pv[16];
 #pragma unroll
           for (int u = 0; u < 8; ++u) pv[u] = split.partial[(int64_t)(slot0 + (j0 + u < ns ? j0 + u : j0)) * split.nb + B];
+          if (j0 + 8 < ns) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) sacc += (j0 + u < ns) ? pv[u] : 0.0;
+            for (int u = 8; u < 16; ++u) pv[u] = split.partial[(int64_t)(slot0 + (j0 + u < ns ? j0 + u : j0)) * split.nb + B];
+          } else {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) pv[u] = 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sacc += (j0 + u < ns) ? pv[u] : 0.0;
         }
         yv = sacc;
         y[i] = sacc;

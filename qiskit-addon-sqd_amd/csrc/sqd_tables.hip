@@ -745,11 +745,15 @@ struct SigmaPlan {
 static SigmaPlan plan_sigma(const sqd_ctx* c, int64_t nb, const VRowsHost& vs, const VRowsHost& vd, int kmax) {
   SigmaPlan p;
   // threads per workgroup (measured on MI355X, profiles/r01/sigma_geometry_sweep.txt): 512 up to
-  // nb = 2048, 1024 beyond; never more than the row or the virtual-row lists can occupy
+  // nb = 2048, 1024 beyond; never more than the row or the virtual-row lists can occupy.  Round 3, rows of up to 384
+  // strings: 256 threads with two columns and two virtual rows each -- twice the workgroups in flight per CU for items
+  // whose time is their chain of dependent loads (16 x HF-centred 317^2: 1.20 -> 1.09 ms per batch, single solve 3.00 ->
+  // 2.96; the loop's 200-300-string subspaces 5.6 -> 5.2 and 7.9 -> 7.5 ms per iteration; equal from ~430 strings on and
+  // worse at 707: 6.4 -> 7.3 ms)
   const int64_t nvmax = vs.nv > vd.nv ? vs.nv : vd.nv;
   const int64_t want = nb > nvmax ? nb : nvmax;
   int T = (int)(((want + 63) / 64) * 64);
-  const int tmax = (nb <= 2048) ? 512 : 1024;
+  const int tmax = (nb <= 384) ? 256 : (nb <= 2048) ? 512 : 1024;
   if (T > tmax) T = tmax;
   if (T < 64) T = 64;
   if (const char* env = std::getenv("SQD_SIGMA_T")) {  // tuning hook
