@@ -232,6 +232,11 @@ def roofline_entry(ctx, t_bracket_ms, t_apply_ms, n_timed, traffic=None, source=
 
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line.  Libraries loaded below write banners to file descriptor 1 (RCCL prints its version
+    # block there when the process group comes up), so everything but that line goes to stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -439,7 +444,7 @@ def main():
                                        "sample": f"failed: {exc!r}"}
         if args.extra and world == 1:
             out["extra"] = extra_measurements(args, ctx)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

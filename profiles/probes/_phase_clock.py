@@ -1,6 +1,7 @@
 """GPU probe (not a test): where a Davidson iteration's BLAS-1 kernels spend their time.  Needs the probe build of the
 library (-DSQD_PHASE_CLOCK -> profiles/probes/_build/libsqd_hip_clk.so; the product library carries none of this):
-the kernels add 100 MHz wall-clock deltas of their critical path into a device array, read here after N solves."""
+the kernels add 100 MHz wall-clock deltas of their critical path into a device array, read here after N solves.
+The marks wait for outstanding stores (s_waitcnt) where the product kernels do not: a phase reads up to ~1 us longer here."""
 import ctypes as C, os, sys, time
 from pathlib import Path
 ROOT = Path(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
@@ -29,7 +30,7 @@ for name, gen in (('hf', S.hf_centred_strings), ('uniform', S.uniform_strings)):
     us = lambda slot, cnt: c[slot] / max(cnt, 1) / 100.0
     nd, nr, no = c[0], c[10], c[20]
     print(f'{name} 317^2: {wall:.3f} ms per solve, {nd / n:.1f} k_dots_eig launches per solve, mean m {c[6] / max(nd, 1):.1f}')
-    print(f'  k_dots_eig (last workgroup): skew first->last start {us(1, nd):.2f} us | loop+sum+store {us(2, nd):.2f} | arrival {us(3, nd):.2f} | '
+    print(f'  k_dots_eig (the workgroup that arrives last): loop+sum+store {us(2, nd):.2f} us | arrival {us(3, nd):.2f} | '
           f'fold {us(4, nd):.2f} | eig step {us(5, nd):.2f} (state + matrix {us(7, nd):.2f}, eigenpair {us(8, nd):.2f})')
     print(f'  k_residual_precond (workgroup 0): state {us(11, nr):.2f} | loop {us(12, nr):.2f} | sum+store {us(13, nr):.2f}')
     if name == 'hf':
