@@ -29,6 +29,7 @@ python profiles/probes/_jitter_probe.py 2>&1 | eval $F > $OUT/jitter_probe.txt
 python profiles/probes/_big_sigma_probe.py 2>&1 | eval $F > $OUT/big_sigma_probe.txt
 # phase clocks of the Davidson BLAS-1 kernels (probe build of the library: hipcc ... -DSQD_PHASE_CLOCK, see the probe's header)
 [ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_phase_clock.py 2>&1 | eval $F > $OUT/phase_clock_probe.txt
+[ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_sigma_clock.py 2>&1 | eval $F > $OUT/sigma_clock_probe.txt
 [ -x profiles/probes/anyorder/anyorder_probe ] && ./profiles/probes/anyorder/anyorder_probe > $OUT/anyorder_probe.txt 2>&1
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp

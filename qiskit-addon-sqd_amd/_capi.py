@@ -484,6 +484,47 @@ class Context:
         self._check(self._lib.sqd_shard_dav_wait(self._h, int(ticket), C.byref(stop), C.byref(e), C.byref(rr), C.byref(m)))
         return bool(stop.value), float(e.value), float(rr.value), int(m.value)
 
+    def shard_dav_stages(self):
+        """The five per-iteration stage calls with their ctypes arguments built once (``pick() -> ptr``, ``sigma(ptr)``,
+        ``dots() -> (ptr, n)``, ``residual() -> (ptr, n)``, ``orth() -> ticket``): an iteration of the row-sharded solver
+        is ~85 us of kernels at batch size, and the generic wrappers above cost the host more than that per iteration."""
+        lib, h, check = self._lib, self._h, self._check
+        out, n, t = C.c_void_p(), C.c_int(), C.c_longlong()
+        r_out, r_n, r_t = C.byref(out), C.byref(n), C.byref(t)
+        f_pick, f_sigma, f_dots, f_res, f_orth = (lib.sqd_shard_dav_pick, lib.sqd_shard_dav_sigma, lib.sqd_shard_dav_dots,
+                                                  lib.sqd_shard_dav_residual, lib.sqd_shard_dav_orth)
+
+        def pick():
+            rc = f_pick(h, r_out)
+            if rc:
+                check(rc)
+            return out.value
+
+        def sigma(ptr):
+            rc = f_sigma(h, ptr)
+            if rc:
+                check(rc)
+
+        def dots():
+            rc = f_dots(h, r_out, r_n)
+            if rc:
+                check(rc)
+            return out.value, n.value
+
+        def residual():
+            rc = f_res(h, r_out, r_n)
+            if rc:
+                check(rc)
+            return out.value, n.value
+
+        def orth():
+            rc = f_orth(h, r_t)
+            if rc:
+                check(rc)
+            return t.value
+
+        return pick, sigma, dots, residual, orth
+
     def shard_dav_end(self):
         out = C.c_void_p()
         stats = DavidsonStats()

@@ -286,6 +286,7 @@ struct sqd_ctx {
   int dav_nev = 0;  // timed sigma launches of the latest Davidson run (stats are collected after the sync)
   // ---- row-sharded Davidson in progress (sqd_shard_dav_*): constants of the run, the all-reduce buffers
   bool shard_active = false;
+  bool shard_send_fresh = false;  // the send buffer holds the vector the next sigma build reads (left there by the orth stage)
   int shard_max_space = 12, shard_form = 0;
   double shard_prm_tol = 1e-9, shard_prm_tol2 = 0.0, shard_prm_lindep = 1e-14, shard_ss = 0.0, shard_shift = 0.0;
   int64_t shard_Dl = 0;

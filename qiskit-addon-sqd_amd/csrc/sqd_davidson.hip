@@ -596,10 +596,13 @@ struct SplitRows {
 // kernel to one workgroup per CU, and a batched launch is 16 x 197 workgroups of bandwidth-bound work; k_eig_b follows.
 // Either way the partials, their fold (fold_partials in a RED_T-thread workgroup) and the eigen step are the same code:
 // the same bits.
-template <int MV, bool FUSED>
+// (TOTALS -- row-sharded solves: the workgroup that arrives last folds the partials into tot_out, which the caller
+// all-reduces over the ranks before k_shard_eig; FUSED must be false)
+template <int MV, bool FUSED, bool TOTALS = false>
 __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                                      double* __restrict__ partial, int width, unsigned* counter, DavState* st,
-                                     const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx) {
+                                     const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx,
+                                     double* __restrict__ tot_out = nullptr) {
   __shared__ double red[16 * (MV + 1)];
   __shared__ double tot[FUSED ? MV + 1 : 1];
   __shared__ double sA[FUSED ? MV * MV : 1], sM[FUSED ? MV * MV : 1], sv_eig[FUSED ? MV + 1 : 1];
@@ -653,8 +656,17 @@ __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, do
     }
   }
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
-  if constexpr (!FUSED) {
+  if constexpr (!FUSED && !TOTALS) {
     if ((int)threadIdx.x < nvec + 1) partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
+    return;
+  }
+  if constexpr (TOTALS) {
+    __shared__ double s_tot[MV + 1];
+    if ((int)threadIdx.x < nvec + 1)
+      coherent_store(&partial[(int64_t)bx * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
+    if (!arrive_last(counter, bx, nbx)) return;
+    fold_partials<true>(partial, (int)nbx, width, nvec + 1, s_tot);
+    if ((int)threadIdx.x <= MAXB) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 1) ? s_tot[threadIdx.x] : 0.0;
     return;
   }
   if ((int)threadIdx.x < nvec + 1)
@@ -696,11 +708,14 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
 
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
 // partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]; k_orth_dev (next in the stream) folds them.
-template <int MV>
+// FOLD (row-sharded solves): the workgroup that arrives last folds the partials into tot_out (what the all-reduce over
+// the ranks reads) -- the single solver leaves the fold to every workgroup of k_orth_dev, which a collective in between
+// rules out, and a one-workgroup fold launch cost a dispatch and 3-4 us per iteration
+template <int MV, bool FOLD = false>
 __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
                                              const DavState* __restrict__ st, const double* __restrict__ hdiag,
                                              const PenaltyDiag& pd, double* __restrict__ partial, int width, unsigned bx,
-                                             unsigned nbx) {
+                                             unsigned nbx, unsigned* counter = nullptr, double* __restrict__ tot_out = nullptr) {
   // vals[0] = |r|^2, vals[1] = |t|^2, vals[2+v] = X_v . t ; MV bounds the basis size (registers)
   __shared__ double red[16 * (MV + 2)];
   __shared__ double s_raw[MV];
@@ -743,6 +758,15 @@ __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, 
   }
   CLK(r2);
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
+  if constexpr (FOLD) {
+    __shared__ double s_tot[MV + 2];
+    if ((int)threadIdx.x < nvec + 2)
+      coherent_store(&partial[(int64_t)bx * width + threadIdx.x], block_sum_multi_get<MV + 2>(red, threadIdx.x));
+    if (!arrive_last(counter, bx, nbx)) return;
+    fold_partials<true>(partial, (int)nbx, width, nvec + 2, s_tot);
+    if ((int)threadIdx.x <= MAXB + 1) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 2) ? s_tot[threadIdx.x] : 0.0;
+    return;
+  }
   if ((int)threadIdx.x < nvec + 2)
     partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 2>(red, threadIdx.x);
 #ifdef SQD_PHASE_CLOCK
@@ -794,7 +818,9 @@ template <int MV>
 __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                                      const DavParams& prm, const double* __restrict__ partial, int nblocks, int width,
                                      double* mail, long long seq, unsigned bx, unsigned nbx,
-                                     const double* __restrict__ tot_in = nullptr) {
+                                     const double* __restrict__ tot_in = nullptr, double* __restrict__ send = nullptr) {
+  // send != nullptr (row-sharded solves): the new vector is also written to the buffer the next iteration's all-gather
+  // reads -- the k_shard_pick launch that copied it there is needed for the start vector only
   // tot_in != nullptr (row-sharded solves): the totals {|r|^2, |t|^2, X_v . t} are already folded AND all-reduced
   // over the ranks; every workgroup of every rank reads the same numbers and takes the same decisions
   __shared__ double red[16 * (MV + 2)];
@@ -873,6 +899,7 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
         for (int u = 0; u < 8; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
       }
       t[i] = s;
+      if (send) send[i] = s;
     }
 #ifdef SQD_PHASE_CLOCK
     __builtin_amdgcn_s_waitcnt(0);
@@ -911,6 +938,7 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
     X[i] = x0;
     AX[i] = ax0;
     X[stride + i] = s;
+    if (send) send[i] = s;
   }
 }
 template <int MV>
@@ -967,35 +995,13 @@ __global__ void k_shard_pick(int64_t n, const double* __restrict__ X, int64_t st
   const double* __restrict__ x = X + (int64_t)(st->m_next - 1) * stride;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) send[i] = x[i];
 }
-// local totals {|X_{m-1}|^2, X_v . A X_{m-1}} over this rank's rows into tot_out[0 .. MAXB] (zero beyond m)
+// local totals {|X_{m-1}|^2, X_v . A X_{m-1}} over this rank's rows into tot_out[0 .. MAXB] (zero beyond m): the dot-product
+// pass of the single solver (split rows of the new sigma vector added on the way, as there)
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_shard_dots(int64_t n, const double* __restrict__ X, const double* __restrict__ AX,
+__global__ void __launch_bounds__(RED_T) k_shard_dots(int64_t n, const double* __restrict__ X, double* __restrict__ AX,
                                                       int64_t stride, double* __restrict__ partial, int width, unsigned* counter,
-                                                      const DavState* __restrict__ st, double* __restrict__ tot_out) {
-  __shared__ double red[16 * (MV + 1)];
-  if (st->stop) return;
-  const int nvec = st->m_next;
-  const double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
-  double acc[MV + 1];
-#pragma unroll
-  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double yv = y[i];
-    double xv[MV];
-    load_vectors<MV>(X, stride, nvec, i, xv);
-#pragma unroll
-    for (int v = 0; v < MV; ++v) {
-      acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
-      acc[0] += (v == nvec - 1) ? xv[v] * xv[v] : 0.0;
-    }
-  }
-  block_sum_multi<MV + 1>(acc, nvec + 1, red);
-  if ((int)threadIdx.x < nvec + 1)
-    coherent_store(&partial[(int64_t)blockIdx.x * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
-  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
-  __shared__ double s_tot[MV + 1];
-  fold_partials<true>(partial, (int)gridDim.x, width, nvec + 1, s_tot);
-  if ((int)threadIdx.x <= MAXB) tot_out[threadIdx.x] = ((int)threadIdx.x < nvec + 1) ? s_tot[threadIdx.x] : 0.0;
+                                                      DavState* st, const SplitRows split, double* __restrict__ tot_out) {
+  dots_eig_body<MV, false, true>(n, X, AX, stride, partial, width, counter, st, DavParams{}, split, blockIdx.x, gridDim.x, tot_out);
 }
 // the projected eigenproblem from the all-reduced totals: one wavefront
 template <int MV>
@@ -1010,21 +1016,21 @@ __global__ void __launch_bounds__(64) k_shard_eig(DavState* st, const double* __
   wave_sync();
   wave_eig_step<MV>(st, s_head, s_heff, tot, prm, sA, sM, sv_eig);
 }
-// local totals of the residual kernel's partials {|r|^2, |t|^2, X_v . t}, folded exactly as k_orth_dev folds them
+// the residual / correction pass of a row-sharded solve: k_residual_precond's body, the local totals {|r|^2, |t|^2,
+// X_v . t} folded by the workgroup that arrives last (fold_partials: the arithmetic of k_orth_dev's own fold)
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_shard_fold(const double* __restrict__ partial, int nblocks, int width,
-                                                      const DavState* __restrict__ st, double* __restrict__ tot_out) {
-  __shared__ double s_tot[MV + 2];
-  if (st->stop) return;
-  const int nv = st->m_cur + 2;
-  fold_partials<false>(partial, nblocks, width, nv, s_tot);
-  if ((int)threadIdx.x <= MAXB + 1) tot_out[threadIdx.x] = ((int)threadIdx.x < nv) ? s_tot[threadIdx.x] : 0.0;
+__global__ void __launch_bounds__(RED_T) k_shard_residual(int64_t n, double* __restrict__ X, const double* __restrict__ AX,
+                                                          int64_t stride, const DavState* __restrict__ st,
+                                                          const double* __restrict__ hdiag, const PenaltyDiag pd,
+                                                          double* __restrict__ partial, int width, unsigned* counter,
+                                                          double* __restrict__ tot_out) {
+  residual_precond_body<MV, true>(n, X, AX, stride, st, hdiag, pd, partial, width, blockIdx.x, gridDim.x, counter, tot_out);
 }
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_shard_orth(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride,
                                                       DavState* st, const DavParams prm, const double* __restrict__ tot_in,
-                                                      double* mail, long long seq) {
-  orth_dev_body<MV>(n, X, AX, stride, st, prm, nullptr, 0, 0, mail, seq, blockIdx.x, gridDim.x, tot_in);
+                                                      double* mail, long long seq, double* __restrict__ send) {
+  orth_dev_body<MV>(n, X, AX, stride, st, prm, nullptr, 0, 0, mail, seq, blockIdx.x, gridDim.x, tot_in, send);
 }
 
 // ---- batched forms (sqd_solve_batch): blockIdx.z = subspace, one argument record per subspace in device memory.
@@ -1580,6 +1586,7 @@ int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0) {
   c->shard_shift = o->shift;
   c->shard_Dl = Dl;
   c->shard_active = true;
+  c->shard_send_fresh = false;
   c->have_solution = false;
   hipLaunchKernelGGL(k_dav_init, dim3(1), dim3(256), 0, c->stream, state_ptr_dev(c), counter_ptr(c));
   SQD_HIP_CHECK(hipGetLastError());
@@ -1597,21 +1604,28 @@ static DavParams shard_params(const sqd_ctx* c) {
 int shard_dav_pick(sqd_ctx* c, double** d_send) {
   SQD_TRY(shard_check(c));
   const int64_t Dl = c->shard_Dl;
-  hipLaunchKernelGGL(k_shard_pick, dim3(red_blocks(Dl)), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(), Dl,
-                     (const DavState*)state_ptr_dev(c), c->tmp1.as<double>());
-  SQD_HIP_CHECK(hipGetLastError());
+  if (!c->shard_send_fresh) {  // the start vector; every later one is put there by the orth stage that forms it
+    hipLaunchKernelGGL(k_shard_pick, dim3(red_blocks(Dl)), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(), Dl,
+                       (const DavState*)state_ptr_dev(c), c->tmp1.as<double>());
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  c->shard_send_fresh = false;
   *d_send = c->tmp1.as<double>();
   return SQD_OK;
 }
+// split rows of the sigma vector are summed by the dots stage (as in the single solver: no k_sigma_reduce launch) unless the
+// squared-penalty form chains several sigma launches through scratch vectors
+static bool shard_defers_reduce(const sqd_ctx* c) { return c->n_multi > 0 && c->shard_form != 2 && !c->sig_direct && c->sig_rows == 0; }
 int shard_dav_sigma(sqd_ctx* c, const double* d_full) {
   SQD_TRY(shard_check(c));
   DavState* dst = state_ptr_dev(c);
   c->sigma_stop = &dst->stop;
   c->sigma_index = &dst->m_next;
-  c->sigma_defer_reduce = false;
+  c->sigma_defer_reduce = shard_defers_reduce(c);
   const int rc = apply_h(c, d_full, c->AX.as<double>(), c->shard_form, c->shard_ss, c->shard_shift, 0, c->shard_Dl);
   c->sigma_stop = nullptr;
   c->sigma_index = nullptr;
+  c->sigma_defer_reduce = false;
   return rc;
 }
 int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count) {
@@ -1620,14 +1634,17 @@ int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count) {
   const unsigned gb = red_blocks(Dl);
   const int width = SQD_MAX_SPACE + 4;
   double* tot = c->shard_tot.as<double>();
+  SplitRows split{nullptr, nullptr, c->nb};
+  if (shard_defers_reduce(c)) {  // (the sigma stage left split rows in pieces: this pass adds them, as k_dots_eig does)
+    split.rowinfo = c->rowinfo.as<int32_t>();
+    split.partial = c->sig_partial.as<double>();
+  }
   if (c->shard_max_space <= 12)
     hipLaunchKernelGGL((k_shard_dots<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
-                       (const double*)c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c),
-                       (const DavState*)state_ptr_dev(c), tot);
+                       c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c), state_ptr_dev(c), split, tot);
   else
     hipLaunchKernelGGL((k_shard_dots<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
-                       (const double*)c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c),
-                       (const DavState*)state_ptr_dev(c), tot);
+                       c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c), state_ptr_dev(c), split, tot);
   SQD_HIP_CHECK(hipGetLastError());
   *d_tot = tot;
   *count = MAXB + 1;
@@ -1656,18 +1673,14 @@ int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count) {
   }
   if (c->shard_max_space <= 12) {
     hipLaunchKernelGGL((k_shard_eig<13>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
-    hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
+    hipLaunchKernelGGL((k_shard_residual<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
                        (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
-                       part_res, width);
-    hipLaunchKernelGGL((k_shard_fold<13>), dim3(1), dim3(RED_T), 0, c->stream, (const double*)part_res, (int)gb, width,
-                       (const DavState*)dst, tot2);
+                       part_res, width, counter_ptr(c), tot2);
   } else {
     hipLaunchKernelGGL((k_shard_eig<MAXB>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
-    hipLaunchKernelGGL((k_residual_precond<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
+    hipLaunchKernelGGL((k_shard_residual<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
                        (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
-                       part_res, width);
-    hipLaunchKernelGGL((k_shard_fold<MAXB>), dim3(1), dim3(RED_T), 0, c->stream, (const double*)part_res, (int)gb, width,
-                       (const DavState*)dst, tot2);
+                       part_res, width, counter_ptr(c), tot2);
   }
   SQD_HIP_CHECK(hipGetLastError());
   *d_tot2 = tot2;
@@ -1685,11 +1698,12 @@ int shard_dav_orth(sqd_ctx* c, long long* seq_out) {
   double* mail_prog = c->d_mail + MAIL_SLOT;
   if (c->shard_max_space <= 12)
     hipLaunchKernelGGL((k_shard_orth<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(), c->AX.as<double>(), Dl,
-                       dst, prm, tot2, mail_prog, seq);
+                       dst, prm, tot2, mail_prog, seq, c->tmp1.as<double>());
   else
     hipLaunchKernelGGL((k_shard_orth<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(), c->AX.as<double>(), Dl,
-                       dst, prm, tot2, mail_prog, seq);
+                       dst, prm, tot2, mail_prog, seq, c->tmp1.as<double>());
   SQD_HIP_CHECK(hipGetLastError());
+  c->shard_send_fresh = true;  // (the orth stage left the next vector in the send buffer)
   if (seq_out) *seq_out = seq;
   return SQD_OK;
 }

@@ -296,6 +296,21 @@ __device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t
   }
 }
 
+// ---- phase clocks (probe builds only: -DSQD_PHASE_CLOCK; profiles/probes/_sigma_clock.py): thread 0 of every workgroup
+// adds the 100 MHz wall-clock deltas of its item's phases into ITS OWN row of a device array (plain stores: atomics on
+// shared counters serialised the 1300 workgroups of a launch and were most of what they measured); the host sums the rows
+#ifdef SQD_PHASE_CLOCK
+constexpr int SCLK_ROWS = 65536, SCLK_COLS = 16;
+__device__ unsigned long long sqd_clk_sigma[SCLK_ROWS * SCLK_COLS];
+__device__ inline unsigned sclk_row() {
+  return ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % SCLK_ROWS;
+}
+#define SCLK(var) __builtin_amdgcn_s_waitcnt(0); const unsigned long long var = wall_clock64()
+#define SCLK_ADD(slot, a, b) do { if (threadIdx.x == 0) sqd_clk_sigma[sclk_row() * SCLK_COLS + ((slot) % 10) + ((slot) >= 10 ? 8 : 0)] += (unsigned long long)((b) - (a)); } while (0)
+#else
+#define SCLK(var)
+#define SCLK_ADD(slot, a, b)
+#endif
 // LDSROW: the C rows of an item are staged in LDS (the tuned path).  !LDSROW: rows too long for LDS are
 // read in place (global memory / L2), one alpha link per batch; everything else is unchanged.
 // PASS: the beta lists outgrow the LDS partial-sum arrays and continue in extra passes (staged rows of ~10^4
@@ -306,6 +321,7 @@ __device__ inline double vrow_singles_batch_k(const SigmaArgs& g, int K, int64_t
 template <int R, bool SPIN, bool LDSROW, bool PASS>
 __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx, unsigned by) {
   if (g.stop && *g.stop) return;  // uniform over the subspace
+  SCLK(k0);
   const int T = g.T, tid = ((int)threadIdx.x < T) ? (int)threadIdx.x : (1 << 30);
   const WorkItem it = g.items[bx];
   const int64_t A = it.A;
@@ -339,6 +355,9 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
   double acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.0;
+#ifdef SQD_PHASE_CLOCK
+  unsigned long long sclk_mid = 0;
+#endif
 
   if (!((g.type_mask >> it.type) & 1)) {
     // profiling hook only: skipped item classes write zeros
@@ -356,6 +375,8 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
         W2[i] = g.ja_row[A * nnorb + i];
       }
     __syncthreads();
+    SCLK(k1);
+    SCLK_ADD(1, k0, k1);  // type 0: item record, own row + J row staged
     // every virtual row of the beta lists, by whichever thread comes next; partial sums through LDS.
     // One pass unless the lists outgrow the partial-sum arrays (long rows, see build_subspace).
     // (the first nvs_max / nvd_max of them here; lists that outgrow the partial-sum arrays -- long rows, see
@@ -373,6 +394,12 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
       }
     }
     __syncthreads();
+#ifdef SQD_PHASE_CLOCK
+    SCLK(k2);
+    SCLK_ADD(2, k1, k2);  // type 0: virtual rows
+    if (threadIdx.x == 0) sqd_clk_sigma[sclk_row() * SCLK_COLS + 0] += 1ull;
+    sclk_mid = k2;
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t B = B0 + tid + (int64_t)r * T;
@@ -419,6 +446,8 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
     SRec recs[KM];
 #pragma unroll
     for (int j = 0; j < KM; ++j) recs[j] = g.sa_rec[it.begin + (j < kb ? j : 0)];
+    SCLK(k1);
+    SCLK_ADD(11, k0, k1);  // type 1: item record -> alpha records (+ virtual-row header)
     if (LDSROW) vrow_records(g, pre);  // (in flight with the rows and the integral rows)
     if (tid == 0) {
 #pragma unroll
@@ -444,6 +473,8 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
         if (j < kslots) W2[(int64_t)j * w2s + i] = (j < kb && g.mode == 0) ? w[j] : 0.0;
     }
     __syncthreads();
+    SCLK(k2);
+    SCLK_ADD(12, k1, k2);  // type 1: rows + integral rows + beta records staged
     const int s1 = (vs0 + g.nvs_max < vs1) ? vs0 + g.nvs_max : vs1;
     if (LDSROW) {
       for (int v = vs0 + tid; v < s1; v += T)
@@ -453,6 +484,12 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
         part_s[v - vs0] = sg0 * vrow_singles_batch<SPIN, 1>(g, v, srow0, W2, w2s, penw, pen, pre, false);
     }
     __syncthreads();
+#ifdef SQD_PHASE_CLOCK
+    SCLK(k3);
+    SCLK_ADD(13, k2, k3);  // type 1: virtual rows (LDS gathers)
+    if (threadIdx.x == 0) sqd_clk_sigma[sclk_row() * SCLK_COLS + 8] += 1ull;
+    sclk_mid = k3;
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t B = B0 + tid + (int64_t)r * T;
@@ -488,6 +525,15 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
     const int64_t B = B0 + tid + (int64_t)r * T;
     if (B < Bend) __builtin_nontemporal_store(acc[r], &out[B]);
   }
+#ifdef SQD_PHASE_CLOCK
+  {
+    SCLK(k9);
+    if (it.type == 0) SCLK_ADD(3, sclk_mid, k9);        // type 0: diagonal, sums of the virtual rows, (dense partials,) store
+    else if (it.type == 1) SCLK_ADD(14, sclk_mid, k9);  // type 1: beta-occupation term, sums, store
+    if (it.type == 0) SCLK_ADD(4, k0, k9);
+    else if (it.type == 1) SCLK_ADD(15, k0, k9);
+  }
+#endif
   // ---- extra passes (staged rows of ~10^4 strings: one partial sum per virtual row does not fit beside
   // the row).  The staged rows are still in LDS; every further pass evaluates the next nvs_max / nvd_max
   // virtual rows and each thread adds its strings' share to the element it has just written (same thread,
@@ -1471,3 +1517,21 @@ int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double
 }
 
 }  // namespace sqd
+
+#ifdef SQD_PHASE_CLOCK
+// out[16]: the column sums over the workgroups' rows ([0..7] own-row items, [8..15] alpha-single batch items)
+extern "C" __attribute__((visibility("default"))) int sqd_probe_clk_sigma(unsigned long long* out, int reset) {
+  static std::vector<unsigned long long> h((size_t)sqd::SCLK_ROWS * sqd::SCLK_COLS);
+  if (out) {
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sqd::sqd_clk_sigma), h.size() * 8) != hipSuccess) return -1;
+    for (int k = 0; k < sqd::SCLK_COLS; ++k) out[k] = 0;
+    for (size_t r = 0; r < (size_t)sqd::SCLK_ROWS; ++r)
+      for (int k = 0; k < sqd::SCLK_COLS; ++k) out[k] += h[r * sqd::SCLK_COLS + k];
+  }
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sqd::sqd_clk_sigma), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

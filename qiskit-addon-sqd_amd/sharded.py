@@ -152,8 +152,7 @@ class ShardedSubspace:
         dist = _dist()
         self.n_allgather += 1
         if self.world == 1 and not self._force:
-            self._full.copy_(shard)
-            return self._full
+            return shard  # (an all-gather over one rank is the identity: the sigma build reads the shard where it lies)
         equal = all(hi - lo == self.nrows for lo, hi in self._sizes)
         if self.on_gpu and equal:
             dist.all_gather_into_tensor(self._full, shard.contiguous(), group=self.group)
@@ -314,14 +313,24 @@ def solve_sci_sharded(
                     v = views[ptr] = _view(ptr, shape, sub.tdev)
                 return v
 
+            st_pick, st_sigma, st_dots, st_residual, st_orth = sub.ctx.shard_dav_stages()
+            alone = sub.world == 1 and not sub._force  # a group of one: every collective is the identity
+
             def enqueue_iteration() -> int:
-                full = sub.gather_rows(view(sub.ctx.shard_dav_pick(), (sub.nrows, sub.nb)))
-                sub.ctx.shard_dav_sigma(full.data_ptr())
-                p, n = sub.ctx.shard_dav_dots()
+                p = st_pick()
+                if alone:
+                    sub.n_allgather += 1  # (counted as the collective it stands for)
+                    st_sigma(p)
+                    st_dots()
+                    st_residual()
+                    return st_orth()
+                full = sub.gather_rows(view(p, (sub.nrows, sub.nb)))
+                st_sigma(full.data_ptr())
+                p, n = st_dots()
                 sub.allreduce(view(p, (n,)))
-                p, n = sub.ctx.shard_dav_residual()
+                p, n = st_residual()
                 sub.allreduce(view(p, (n,)))
-                return sub.ctx.shard_dav_orth()
+                return st_orth()
 
             # one iteration is kept enqueued ahead of the one whose progress record is waited for: the device decides
             # everything (stages behind a stop return at once; their collectives still run, on every rank alike)
