@@ -68,6 +68,13 @@ int sqd_ctx_use_stream(sqd_ctx* ctx, void* stream);
  * all-reduce that makes every rank know every batch's record after the reference's collective step, fermion.py:432,
  * :577-605 -- needs no host-to-device copy and no host wait in between.  NULL switches it off (the default). */
 int sqd_ctx_set_record_out(sqd_ctx* ctx, double* d_record, int64_t stride);
+/* A function the solve calls of this context (sqd_solve / sqd_solve_strings / sqd_solve_batch) call ONCE per call, on the
+ * calling thread, when their last kernel has been enqueued and before they wait for it: whatever the hook enqueues on the
+ * context's stream -- the collective that follows the reference's batch loop (fermion.py:432), the copy of its result --
+ * runs right behind the solve instead of one host wait and one enqueue later (the exchange of the N > 1 path: 15-20 us
+ * of idle stream per step).  The hook must not call into this context.  NULL removes it (the default). */
+typedef void (*sqd_enqueue_hook)(void* user);
+int sqd_ctx_set_enqueue_hook(sqd_ctx* ctx, sqd_enqueue_hook hook, void* user);
 
 /* Define the subspace.  strs_a / strs_b must be strictly ascending with a constant
  * popcount per spin (the post-condition of reference _check_ci_strs, fermion.py:1075-1097);

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "sqd_ctx_destroy",
     "sqd_ctx_use_stream",
     "sqd_ctx_set_record_out",
+    "sqd_ctx_set_enqueue_hook",
     "sqd_set_subspace",
     "sqd_set_subspace_rows",
     "sqd_sigma_rows_dev",
@@ -132,6 +133,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_ctx_destroy.argtypes = [_ctxp]
     lib.sqd_ctx_use_stream.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_set_record_out.argtypes = [_ctxp, C.c_void_p, C.c_int64]
+    lib.sqd_ctx_set_enqueue_hook.argtypes = [_ctxp, ENQUEUE_HOOK, C.c_void_p]
     lib.sqd_set_subspace.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64]
     lib.sqd_set_subspace_rows.argtypes = [_ctxp, _u64p, C.c_int64, _u64p, C.c_int64, C.c_int64, C.c_int64]
     lib.sqd_sigma_rows_dev.argtypes = [_ctxp, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
@@ -194,6 +196,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 
 _LIB: C.CDLL | None = None
+
+
+ENQUEUE_HOOK = C.CFUNCTYPE(None, C.c_void_p)  # sqd_enqueue_hook
 
 
 def load_library() -> C.CDLL:
@@ -366,6 +371,36 @@ class Context:
             if rc == -1:
                 raise ValueError(msg)
             raise SQDNativeError(f"libsqd_hip error {rc}: {msg}")
+
+    def set_enqueue_hook(self, fn):
+        """``fn()`` is called once by every following ``solve`` / ``solve_batch`` of this context when its last kernel
+        has been enqueued and before it waits (``sqd_ctx_set_enqueue_hook``): the place to enqueue a collective on the
+        shared stream.  ``None`` removes the hook.  Exceptions raised by ``fn`` are re-raised by ``raise_hook_error``."""
+        if fn is None:
+            self._hook_fn = None
+            self._check(self._lib.sqd_ctx_set_enqueue_hook(self._h, C.cast(None, ENQUEUE_HOOK), None))
+            return
+        if getattr(self, "_hook_c", None) is None:
+            # ONE native-callable thunk per context, made once: a new ctypes closure per call is a libffi allocation
+            # plus cyclic garbage, and the collector's full passes showed up as 30 ms steps in the N > 1 bench
+            self._hook_error = None
+            self._hook_c = ENQUEUE_HOOK(self._hook_trampoline)
+        self._hook_fn = fn
+        self._check(self._lib.sqd_ctx_set_enqueue_hook(self._h, self._hook_c, None))
+
+    def _hook_trampoline(self, _user):
+        fn = self._hook_fn
+        if fn is None:
+            return
+        try:
+            fn()
+        except BaseException as exc:  # (must not propagate through the C frames)
+            self._hook_error = exc
+
+    def raise_hook_error(self):
+        exc, self._hook_error = getattr(self, "_hook_error", None), None
+        if exc is not None:
+            raise exc
 
     def use_stream(self, stream_handle: int):
         """Enqueue all further work of this context on a caller-owned HIP stream (``hipStream_t`` as an integer,

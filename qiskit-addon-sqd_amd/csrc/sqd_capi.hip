@@ -415,6 +415,12 @@ SQD_API int sqd_ctx_set_record_out(sqd_ctx* c, double* d_record, int64_t stride)
   c->record_stride = stride;
   return SQD_OK;
 }
+SQD_API int sqd_ctx_set_enqueue_hook(sqd_ctx* c, sqd_enqueue_hook hook, void* user) {
+  if (!c) return SQD_ERR_INVALID;
+  c->enqueue_hook = hook;
+  c->enqueue_hook_user = user;
+  return SQD_OK;
+}
 SQD_API int sqd_ctx_set_phase_timing(sqd_ctx* c, int on) {
   if (!c) return SQD_ERR_INVALID;
   c->phase_timing = on != 0;
@@ -736,6 +742,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   }
   const bool need_s2 = (s2 != nullptr) || form != 0;
   SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin));
+  if (c->enqueue_hook) c->enqueue_hook(c->enqueue_hook_user);  // (the caller's collective, right behind the last kernel)
   if (by_copy && !staged)
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
   if (by_copy) SQD_STREAM_SYNC(c->copy_stream);
@@ -797,6 +804,7 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
                             const uint64_t* const* strs_b, const int64_t* nb, const sqd_davidson_opts* opts,
                             double* const* amps, double* best_amps, int* best, sqd_davidson_stats* stats, double* e,
                             double* s2, double* occ_a, double* occ_b, int* nelec_a, int* nelec_b) {
+  bool hook_done = false;  // the caller's enqueue hook fires once per call, behind the last launch
   CTX_ENTER(c);
   if (c->parent) {
     set_error("sqd_solve_batch on a sub-context");
@@ -882,6 +890,10 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
       if (amps && amps[p] && !twins[k])
         SQD_HIP_CHECK(hipMemcpyAsync(amps[p], subs[p]->sol.p, (size_t)subs[p]->D * 8, hipMemcpyDeviceToHost, st));
     }
+    if (c->enqueue_hook && sidx.empty()) {  // (every record of the call is on its way: the caller's collective goes here)
+      c->enqueue_hook(c->enqueue_hook_user);
+      hook_done = true;
+    }
     for (sqd_ctx* sub : bs) SQD_TRY(spin_wait_word(sub->h_mail + 3 * 128 + 200, sub->obs_seq, st));
     SQD_TRY(spin_stream_sync(st));
     for (int p : bidx) {
@@ -899,6 +911,7 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
                       occ_b ? occ_b + (size_t)p * c->norb : nullptr));
     if (e) e[p] = e_p;
   }
+  if (c->enqueue_hook && !hook_done) c->enqueue_hook(c->enqueue_hook_user);
   c->batch_n = nbatch;
   c->batch_n_prev_valid = nbatch;
   if (best || best_amps) {

@@ -298,6 +298,9 @@ struct sqd_ctx {
   // occ_a[norb], occ_b[norb], |S2 c|^2} (sqd_ctx_set_record_out): the input of a collective exchange that follows on
   // the same stream, no copy in between.  Batch p of sqd_solve_batch: record_out + p * record_stride.
   double* record_out = nullptr;
+  // called by the solve calls between their last launch and their final wait (sqd_ctx_set_enqueue_hook)
+  void (*enqueue_hook)(void*) = nullptr;
+  void* enqueue_hook_user = nullptr;
   int64_t record_stride = 0;
   sqd_ctx* parent = nullptr;        // set on a sub-context
   std::vector<sqd_ctx*> subs;       // grow-only; subs[i] serves batch i of the latest sqd_solve_batch

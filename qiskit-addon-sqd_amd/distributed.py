@@ -43,6 +43,9 @@ def _dist():
     return dist
 
 
+import os as _os
+
+_HOOK_ON = _os.environ.get("SQD_DIST_HOOK", "1") != "0"  # (probe switch: the exchange enqueued by the solve's hook, or after it)
 _XBUF: dict = {}
 _GROUPS: dict = {}
 last_exchange_ms: float | None = None
@@ -73,6 +76,25 @@ def _group_info(dist, group):
     return hit[0], hit[1], hit[2]
 
 
+class _Exchange:
+    """The path's one collective as a callable the solver's enqueue hook can hold: all-reduce of the record table and
+    the copy of the result to page-locked memory, enqueued on the current stream.  One object per table, reused by every
+    call (a fresh closure per call is cyclic garbage, and what that costs is a full pass of Python's collector over
+    everything ``import torch`` created -- 35 ms -- every thousand calls or so)."""
+
+    __slots__ = ("dev", "host", "group", "done")
+
+    def __init__(self, dev, host, group):
+        self.dev, self.host, self.group, self.done = dev, host, group, False
+
+    def __call__(self):
+        import torch.distributed as dist
+
+        dist.all_reduce(self.dev, op=dist.ReduceOp.SUM, group=self.group)
+        self.host.copy_(self.dev, non_blocking=True)
+        self.done = True
+
+
 def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
     import torch
 
@@ -83,7 +105,7 @@ def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
         if on_gpu:
             host = host.pin_memory()
         dev = torch.zeros((nb, width), dtype=torch.float64, device=tdev) if on_gpu else host
-        hit = _XBUF[key] = (dev, host)
+        hit = _XBUF[key] = (dev, host, _Exchange(dev, host, group))
         while len(_XBUF) > 16:
             _XBUF.pop(next(iter(_XBUF)))
     return hit
@@ -154,7 +176,8 @@ def solve_sci_batch_distributed(
     compute_rdms = kwargs.pop("compute_rdms", "lazy")
     shift = 0.2  # pyscf fix_spin_ default, as solve_sci (reference fermion.py:715)
 
-    dev_table, host_table = _exchange_buffers(group, tdev, nb, width, on_gpu)
+    dev_table, host_table, exchange = _exchange_buffers(group, tdev, nb, width, on_gpu)
+    exchange.done = False
     table = host_table.numpy()
     local: dict[int, SCIResult] = {}
     resident = None  # (context, position of each local batch in its batched solve)
@@ -175,6 +198,10 @@ def solve_sci_batch_distributed(
             from . import fermion as _F
 
             ctx.set_record_out(dev_table.data_ptr() + 8 * rank * width, world * width)
+            if on_gpu and _HOOK_ON:
+                # the exchange is enqueued by the solve itself, right behind its last kernel (before its final host
+                # wait): the stream does not idle while this thread gets back from the native call and into RCCL
+                ctx.set_enqueue_hook(exchange)
             dk = _davidson_kwargs(kwargs)
             dk.pop("verbose", None)
             dk.pop("ci0", None)
@@ -193,6 +220,9 @@ def solve_sci_batch_distributed(
                                           fetch="none", **dk)
             finally:
                 ctx.set_record_out(None)
+                if on_gpu and _HOOK_ON:
+                    ctx.set_enqueue_hook(None)
+            ctx.raise_hook_error()
             resident = (ctx, {i: k for k, i in enumerate(mine)}, len(mine) == 1)
             _F._TLS.stats, _F._TLS.batch_stats = out["stats"][0], out["stats"]
             for k, i in enumerate(mine):
@@ -228,8 +258,8 @@ def solve_sci_batch_distributed(
     # ---- the path's single exchange: all-reduce(sum) of the per-batch records, enqueued behind the solves
     t_x = time.perf_counter()
     if on_gpu:
-        dist.all_reduce(dev_table, op=dist.ReduceOp.SUM, group=group)
-        host_table.copy_(dev_table, non_blocking=True)
+        if not exchange.done:  # (no local batch, a caller-supplied solver, or the hook switched off)
+            exchange()
         _wait_stream(torch.cuda.current_stream(tdev))
     else:
         dist.all_reduce(host_table, op=dist.ReduceOp.SUM, group=group)
