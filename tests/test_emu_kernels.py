@@ -190,3 +190,31 @@ def test_emu_dense_same_spin_mfma(emu_lib, monkeypatch):
     with _capi.Context(h1, eri, lib=emu_lib) as ctx:  # default selection: 20 HF-centred strings of 7 orbitals are dense
         ctx.set_subspace(sa, sb)
         assert ctx.sigma_kernel() == "k_same_spin_mfma+k_sigma"
+
+
+def test_emu_enqueue_hook(emu_lib):
+    """sqd_ctx_set_enqueue_hook: called once per solve call (single and batched), between the last launch and the final
+    wait; removable; an exception raised inside does not cross the C frames and is handed back afterwards."""
+    h1, eri, sa, sb = make_problem(6, (3, 2), 8, 7, 3)
+    _, _, sa2, sb2 = make_problem(6, (3, 2), 6, 9, 4)
+    with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+        calls = []
+        ctx.set_enqueue_hook(lambda: calls.append(1))
+        _amps, _st, (e1, *_rest) = ctx.solve(sa, sb, spin_square=False)
+        assert len(calls) == 1
+        out = ctx.solve_batch([(sa, sb), (sa2, sb2)], spin_square=False, fetch="all")
+        assert len(calls) == 2 and abs(out["energy"][0] - e1) < 1e-12
+        ctx.set_enqueue_hook(None)
+        ctx.solve(sa, sb, spin_square=False)
+        assert len(calls) == 2
+
+        def boom():
+            raise RuntimeError("from the hook")
+
+        ctx.set_enqueue_hook(boom)
+        _amps, _st, (e2, *_rest) = ctx.solve(sa, sb, spin_square=False)  # the solve itself completes
+        assert abs(e2 - e1) < 1e-12
+        ctx.set_enqueue_hook(None)
+        with pytest.raises(RuntimeError, match="from the hook"):
+            ctx.raise_hook_error()
+        ctx.raise_hook_error()  # (raised once)
