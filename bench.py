@@ -288,12 +288,28 @@ def main():
     # show none after their first call) -- the device settling into its power state.  A timed region that starts a
     # few milliseconds after the process touched the GPU catches them at random; 0.3 s of the same solves first.
     # (event sampling of the sigma kernel is switched on BEFORE the warm-up: the first sampled solve creates the events)
+    # Python's cyclic collector runs a FULL pass every thousand calls or so, and a full pass visits everything
+    # `import torch` created: 35 ms -- 170 steps' worth -- landing in the timed region or not by the count of objects
+    # allocated so far (measured: a 100-step N > 1 run read 0.22 or 0.59 ms per step).  gc.freeze() BEFORE the spin-up
+    # (a 40 ms pause right before the timed region would leave the GPU idle and the first timed step slow) moves what
+    # exists -- the imports -- to the permanent generation: collections still run during the timed steps, over what the
+    # steps themselves allocate.  SQD_BENCH_GC=default leaves the collector as it is.
+    if os.environ.get("SQD_BENCH_GC") != "default":
+        import gc
+
+        gc.collect()
+        gc.freeze()
     F.set_profiling(time_sigma_every=args.time_sigma_every)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
         one_step()
     for _ in range(args.warmup):
         e, st = one_step()
+    if os.environ.get("SQD_BENCH_GC") != "default":
+        # (again, over what the spin-up allocated -- a millisecond now: the collector's generation counters start the
+        # timed region at zero, so only young-generation passes fall into a region of 20 steps)
+        gc.collect()
+        gc.freeze()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -301,16 +317,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # Python's cyclic collector runs a FULL pass every thousand calls or so, and a full pass visits everything
-    # `import torch` created: 35 ms -- 170 steps' worth -- landing in the timed region or not by the count of objects
-    # allocated so far (measured: a 100-step N > 1 run read 0.22 or 0.59 ms per step).  gc.freeze() after the warm-up
-    # moves what exists to the permanent generation: collections still run during the timed steps, over what the steps
-    # themselves allocate.  SQD_BENCH_GC=default leaves the collector as it is.
-    if os.environ.get("SQD_BENCH_GC") != "default":
-        import gc
-
-        gc.collect()
-        gc.freeze()
     sync()
     xms.clear()
     t0 = time.perf_counter()
