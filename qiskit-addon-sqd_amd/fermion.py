@@ -493,24 +493,63 @@ def _solve_sci_batched(ci_strings, one_body_tensor, two_body_tensor, nelec, spin
     dk.pop("verbose", None)
     one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
     norb = one_body_tensor.shape[0]
-    ctx = _get_context(one_body_tensor, two_body_tensor, 0, slot="batch")
-    _settle_deferred(ctx)
-    out = ctx.solve_batch(ci_strings, spin_sq=spin_sq, shift=0.2, spin_square=False, fetch="best", **dk)
-    _TLS.stats = out["stats"][out["best"]]
-    _TLS.batch_stats = out["stats"]
     want = tuple(int(x) for x in nelec)
-    results = []
-    for i, (strs_a, strs_b) in enumerate(ci_strings):
-        if out["nelec"][i] != want:
-            raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {out['nelec'][i]} of the CI strings")
-        amps = out["amps"][i]
-        if amps is None:
-            amps = _DeferredAmplitudes(ctx, i, (len(strs_a), len(strs_b)), out["generation"])
-            ctx._deferred.append(weakref.ref(amps))
-        state = SCIState(amplitudes=amps, ci_strs_a=np.asarray(strs_a), ci_strs_b=np.asarray(strs_b), norb=norb, nelec=want)
-        results.append(SCIResult(float(out["energy"][i]), state, orbital_occupancies=(out["occ_a"][i], out["occ_b"][i]),
-                                 _lazy_rdms=(compute_rdms == "lazy")))
+    ngroups = _batch_groups(len(ci_strings))
+
+    def solve_group(g):
+        # batches g, g + ngroups, ... as ONE batched native solve on this group's context (its own stream)
+        ctx = _get_context(one_body_tensor, two_body_tensor, 0, slot="batch" if ngroups == 1 else f"batch{g}")
+        _settle_deferred(ctx)
+        out = ctx.solve_batch(ci_strings[g::ngroups], spin_sq=spin_sq, shift=0.2, spin_square=False, fetch="best", **dk)
+        return ctx, out
+
+    if ngroups == 1:
+        groups = [solve_group(0)]
+    else:
+        groups = list(_group_pool(ngroups).map(solve_group, range(ngroups)))
+    results: list = [None] * len(ci_strings)
+    stats: list = [None] * len(ci_strings)
+    for g, (ctx, out) in enumerate(groups):
+        for k, i in enumerate(range(g, len(ci_strings), ngroups)):
+            strs_a, strs_b = ci_strings[i]
+            if out["nelec"][k] != want:
+                raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {out['nelec'][k]} of the CI strings")
+            amps = out["amps"][k]
+            if amps is None:
+                amps = _DeferredAmplitudes(ctx, k, (len(strs_a), len(strs_b)), out["generation"])
+                ctx._deferred.append(weakref.ref(amps))
+            state = SCIState(amplitudes=amps, ci_strs_a=np.asarray(strs_a), ci_strs_b=np.asarray(strs_b), norb=norb, nelec=want)
+            results[i] = SCIResult(float(out["energy"][k]), state, orbital_occupancies=(out["occ_a"][k], out["occ_b"][k]),
+                                   _lazy_rdms=(compute_rdms == "lazy"))
+            stats[i] = out["stats"][k]
+    best = min(range(len(results)), key=lambda i: results[i].energy)
+    _TLS.stats = stats[best]
+    _TLS.batch_stats = stats
     return results
+
+
+_GROUP_POOLS: dict = {}
+
+
+def _group_pool(n: int):
+    from concurrent.futures import ThreadPoolExecutor
+
+    pool = _GROUP_POOLS.get(n)
+    if pool is None:
+        pool = _GROUP_POOLS[n] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="sqd-batch-group")
+    return pool
+
+
+def _batch_groups(nbatch: int) -> int:
+    """Number of interleaved groups a batched solve is cut into, each a batched native solve of its own on its own stream
+    (experimental switch ``SQD_BATCH_GROUPS``; default 1)."""
+    import os
+
+    try:
+        n = int(os.environ.get("SQD_BATCH_GROUPS", "1"))
+    except ValueError:
+        n = 1
+    return max(1, min(n, nbatch // 2)) if nbatch >= 4 else 1
 
 
 def solve_sci(

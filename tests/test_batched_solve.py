@@ -134,3 +134,20 @@ def test_batched_solve_mixed_classes_on_gpu(hip_lib):
     for _ in range(2):
         check_batched_equals_serial(h1, eri, norb, nelec, batches)
     check_batched_equals_serial(h1, eri, norb, nelec, batches[:3], spin_sq=0.0)
+
+
+@pytest.mark.gpu
+def test_batched_solve_two_groups_on_gpu(hip_lib, monkeypatch):
+    """SQD_BATCH_GROUPS=2 (experimental): the list cut into two interleaved groups, each a batched native solve on its own
+    context and stream, from two host threads -- the same numbers as one by one, bit for bit."""
+    norb, nelec = 30, (8, 8)
+    h1, eri = O.synthetic_integrals(norb)
+    batches = [(O.hf_centred_strings(norb, 8, 150 + 10 * i, 100 + i), O.hf_centred_strings(norb, 8, 140 + 7 * i, 200 + i)) for i in range(7)]
+    serial = [solve_sci(b, h1, eri, norb, nelec) for b in batches]
+    monkeypatch.setenv("SQD_BATCH_GROUPS", "2")
+    for _ in range(2):
+        grouped = solve_sci_batch(batches, h1, eri, norb, nelec)
+        for s, r in zip(serial, grouped):
+            assert r.energy == s.energy
+            assert np.array_equal(r.orbital_occupancies[0], s.orbital_occupancies[0])
+            assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
