@@ -19,7 +19,7 @@ def med(f, n=200):
     return float(np.median(ts))
 print('solve_sci alone            %.1f us' % med(lambda: F.solve_sci((sa, sb), h1, eri, 30, (8, 8), compute_rdms=False)))
 print('solve_sci_batch_distributed %.1f us' % med(lambda: D.solve_sci_batch_distributed(batches, h1, eri, 30, (8, 8), compute_rdms=False)))
-dt, ht = D._exchange_buffers(None, dev, 1, 61, True)
+dt, ht, _xch = D._exchange_buffers(None, dev, 1, 61, True)
 def table():
     dt.copy_(ht, non_blocking=True); dist.all_reduce(dt); ht.copy_(dt, non_blocking=True); D._wait_stream(torch.cuda.current_stream())
 print('table exchange             %.1f us' % med(table))
