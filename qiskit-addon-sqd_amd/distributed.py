@@ -299,9 +299,7 @@ def solve_sci_batch_distributed(
                 bufs[i] = ta
         if ops:
             for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if on_gpu:
-                _wait_stream(torch.cuda.current_stream(tdev))
+                req.wait()  # (RCCL: the CURRENT STREAM waits for the transfer, not this thread -- what follows is ordered)
             if rank == 0:
                 for i, ta in bufs.items():
                     if on_gpu:
