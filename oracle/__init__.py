@@ -16,4 +16,11 @@ image: **parity unpinned** against pyscf itself.  It is anchored instead on an
 independent brute-force second-quantised construction (Jordan-Wigner matrices,
 ``sqd_oracle.jw_*``) that every other oracle function and the HIP path are
 checked against.
+
+Round-4 search for an obtainable pyscf: ``import pyscf``
+fails; ``pip download pyscf`` has no index; no pyscf wheel in ``/opt/wheelhouse``
+(86 wheels), none under ``/opt/conda`` (pkgs / envs), no ``*pyscf*`` path anywhere
+on this image's filesystem outside the reference's own text.  The pin therefore
+stays as described above; ``tests/test_pyscf_opportunistic.py`` runs the pyscf
+cross-check wherever ``import pyscf`` does succeed.
 """

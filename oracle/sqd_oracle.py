@@ -422,6 +422,114 @@ def sigma_string_space(h1, eri, strs_a, strs_b, c, norb: int) -> np.ndarray:
     return out
 
 
+def double_links_chunked(strs, norb: int, rows=None, chunk: int = 512):
+    """``double_links`` without the n x n XOR matrix: targets are taken ``chunk`` at a time (all strings, or only the
+    addresses in ``rows``), so 10^4 strings per spin (BASELINE config 2 read literally) cost 40 MB of scratch instead
+    of 800 MB.  Same arrays, same canonical order (target, then source)."""
+    strs = _u64(strs)
+    tg = np.arange(len(strs), dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
+    keys = ("tgt", "src", "p", "r", "q", "s", "sign")
+    parts = {k: [] for k in keys}
+    for i0 in range(0, len(tg), chunk):
+        t = tg[i0:i0 + chunk]
+        X = strs[t][:, None] ^ strs[None, :]
+        ti, src = np.nonzero(np.bitwise_count(X) == 4)
+        if ti.size == 0:
+            continue
+        tgt = t[ti]
+        I, J = strs[tgt], strs[src]
+        x = I ^ J
+        p, r = _two_bits(x & I)
+        q, s = _two_bits(x & J)
+        sgn = np.ones(len(tgt), dtype=np.int64)
+        state = J.copy()
+        sgn = _apply_sign(state, q, sgn)
+        state = state ^ (np.uint64(1) << q.astype(np.uint64))
+        sgn = _apply_sign(state, s, sgn)
+        state = state ^ (np.uint64(1) << s.astype(np.uint64))
+        sgn = _apply_sign(state, r, sgn)
+        state = state | (np.uint64(1) << r.astype(np.uint64))
+        sgn = _apply_sign(state, p, sgn)
+        for k, v in zip(keys, (tgt, src, p, r, q, s, sgn)):
+            parts[k].append(np.asarray(v, dtype=np.int64))
+    if not parts["tgt"]:
+        return {k: np.zeros(0, dtype=np.int64) for k in keys}
+    return {k: np.concatenate(v) for k, v in parts.items()}
+
+
+def same_spin_hamiltonian_sparse(h1, eri, strs, norb: int, rows=None):
+    """``same_spin_hamiltonian`` as a scipy CSR matrix (all rows, or zero outside ``rows``): Slater-Condon diagonal,
+    singles and doubles of one spin over the string set, for sets too large for the dense n x n form."""
+    strs = _u64(strs)
+    n = len(strs)
+    occ = occupation_matrix(strs, norb)
+    Jm = np.einsum("iijj->ij", eri)
+    Km = np.einsum("ijji->ij", eri)
+    diag = occ @ np.diag(h1) + 0.5 * np.einsum("ni,ij,nj->n", occ, Jm - Km, occ)
+    keep = np.ones(n, dtype=bool)
+    if rows is not None:
+        keep[:] = False
+        keep[np.asarray(rows, dtype=np.int64)] = True
+    I = [np.flatnonzero(keep)]
+    Jc = [np.flatnonzero(keep)]
+    V = [diag[keep]]
+    sl = single_links(strs, norb)
+    if sl["tgt"].size:
+        m = keep[sl["tgt"]]
+        p, q, src = sl["p"][m], sl["q"][m], sl["src"][m]
+        ar = np.arange(norb)
+        coul = eri[p, q][:, ar, ar]
+        exch = eri[p[:, None], ar[None, :], ar[None, :], q[:, None]]
+        val = h1[p, q] + np.einsum("lk,lk->l", coul - exch, occ[src])
+        I.append(sl["tgt"][m])
+        Jc.append(src)
+        V.append(sl["sign"][m] * val)
+    dl = double_links_chunked(strs, norb, rows=rows)
+    if dl["tgt"].size:
+        p, r, q, s = dl["p"], dl["r"], dl["q"], dl["s"]
+        I.append(dl["tgt"])
+        Jc.append(dl["src"])
+        V.append(dl["sign"] * (eri[p, q, r, s] - eri[p, s, r, q]))
+    return sp.csr_matrix((np.concatenate(V), (np.concatenate(I), np.concatenate(Jc))), shape=(n, n))
+
+
+def sigma_rows_string_space(h1, eri, strs_a, strs_b, c, norb: int, rows) -> np.ndarray:
+    """Rows ``rows`` (alpha addresses) of ``sigma_string_space`` -- the same decomposition
+        sigma = Ha C + C Hb^T + sum_{pq,rs} (pq|rs) Ea_pq C Eb_rs^T
+    (E operators with their diagonal; nothing of the kernels' J-table / hdiag split) -- for subspaces where the whole
+    sigma is out of a numpy oracle's reach: D = 10^8 (BASELINE config 2 read literally, 10^4 strings per spin).  The
+    same-spin factors are sparse (``same_spin_hamiltonian_sparse``); the opposite-spin term is evaluated link by link
+    of the requested alpha rows against ALL beta links.  Returns len(rows) x nb.  Checked against
+    ``sigma_string_space`` in tests/test_oracle.py."""
+    na, nb = len(strs_a), len(strs_b)
+    C = np.asarray(c, dtype=float).reshape(na, nb)
+    rows = np.asarray(rows, dtype=np.int64)
+    Ha = same_spin_hamiltonian_sparse(h1, eri, strs_a, norb, rows=rows)
+    Hb = same_spin_hamiltonian_sparse(h1, eri, strs_b, norb)
+    out = (Ha[rows] @ C) + (Hb @ C[rows].T).T
+
+    def all_links(strs, only=None):
+        sl = single_links(strs, norb)
+        occ = occupation_matrix(strs, norb)
+        I, k = np.nonzero(occ)
+        t = np.concatenate((sl["tgt"], I))
+        links = (t, np.concatenate((sl["src"], I)), np.concatenate((sl["p"], k)), np.concatenate((sl["q"], k)),
+                 np.concatenate((sl["sign"], np.ones(len(I), dtype=np.int64))))
+        if only is None:
+            return links
+        m = np.isin(t, only)
+        return tuple(v[m] for v in links)
+
+    ta, sa, pa, qa, ga = all_links(strs_a, only=rows)
+    tb, sb, pb, qb, gb = all_links(strs_b)
+    where = {int(A): i for i, A in enumerate(rows)}
+    for l in range(len(ta)):
+        # <A|Ea_pq|A'> = ga:  sigma[A, B] += ga * sum_{beta links (B <- B', rs, gb)} (pq|rs) gb C[A', B']
+        w = eri[pa[l], qa[l]][pb, qb] * gb * C[sa[l], sb]
+        out[where[int(ta[l])]] += ga[l] * np.bincount(tb, weights=w, minlength=nb)
+    return out
+
+
 class StringSpaceOperator:
     """``sigma_string_space`` with the string-space pieces built once: v -> (P H P) v for the oracle's
     Davidson at BASELINE sizes (flat vectors in, flat vectors out)."""

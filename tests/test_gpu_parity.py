@@ -650,3 +650,60 @@ def test_row_sharded_sigma_on_gpu(hip_lib, monkeypatch):
     assert abs(res.energy - ref.energy) < 1e-8
     assert abs(abs(np.vdot(res.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
     assert np.allclose(res.orbital_occupancies[0], ref.orbital_occupancies[0], atol=5e-6)
+
+
+def test_config2_full_size_1e4_x_1e4(hip_lib):
+    """BASELINE config 2 read literally: N2-sized (16e,30o), 10^4 uniform-random strings per spin, D = 10^8 (800 MB
+    per vector) on one MI355X.  Kernel selection; sigma rows against the row-restricted string-space oracle (O1s,
+    `sigma_rows_string_space`) on a sampled subset of alpha rows -- first and last row, rows with alpha single links,
+    random rows; hermiticity on two vectors; sigma bitwise reproducible; then ONE whole Davidson solve: converged,
+    Ritz value = Rayleigh quotient of the returned state, true residual |Hc - Ec| re-evaluated with a separate sigma
+    call, variational bounds (E0 <= min hdiag; E0 <= the energy of the start vector), observables consistent."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    n = 10000
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, n, 51), S.uniform_strings(30, 8, n, 52)
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((n, n), dtype=np.float32).astype(np.float64)
+    y = rng.standard_normal((n, n), dtype=np.float32).astype(np.float64)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() in ("k_sigma_rows<2>", "k_sigma_lists")
+        assert ctx.sigma_bytes() > 16.0 * n * n
+        sx = ctx.sigma(x)
+        sy = ctx.sigma(y)
+        assert np.array_equal(sx, ctx.sigma(x))  # fixed summation order: the same bits on every run
+        # --- sampled rows against the oracle
+        sl = O.single_links(sa, 30)
+        with_singles = np.unique(sl["tgt"])
+        rows = np.unique(np.concatenate(([0, 1, n - 2, n - 1], with_singles[:6], with_singles[-6:],
+                                         rng.choice(n, 12, replace=False))))
+        ref = O.sigma_rows_string_space(h1, eri, sa, sb, x, 30, rows)
+        hd = ctx.hdiag()
+        hd_max = np.abs(hd).max()
+        assert np.abs(sx[rows] - ref).max() < 1e-11 * hd_max * max(1.0, np.abs(x).max())
+        # the same columns-wise: sigma of the TRANSPOSED problem (alpha <-> beta) on sampled rows = sampled columns here
+        cols = np.unique(np.concatenate(([0, n - 1], rng.choice(n, 6, replace=False))))
+        refT = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), 30, cols)
+        assert np.abs(sx[:, cols].T - refT).max() < 1e-11 * hd_max * max(1.0, np.abs(x).max())
+        # --- hermiticity
+        a, b = np.vdot(y, sx), np.vdot(sy, x)
+        assert abs(a - b) < 1e-9 * abs(a)
+        del sy, y
+        # --- one whole Davidson solve
+        amps, st = ctx.davidson()
+        assert st["converged"] == 1 and st["n_sigma"] >= 2
+        e0 = st["e_davidson"]
+        assert abs(np.vdot(amps, amps) - 1.0) < 1e-12
+        hc = ctx.sigma(amps)
+        assert abs(np.vdot(amps, hc) - e0) < 1e-9  # Ritz value = Rayleigh quotient of the returned vector
+        resid = np.linalg.norm((hc - e0 * amps).ravel())
+        assert resid < 2e-6 and abs(resid - st["residual"]) < 1e-7  # default rule: |r| < sqrt(tol)/32
+        assert e0 <= hd.min() + 1e-12  # variational: below the lowest diagonal element ...
+        x0 = ctx.init_guess()
+        assert e0 <= np.vdot(x0, ctx.sigma(x0)) + 1e-12  # ... and below the start vector's energy
+        e, s2, oa, ob = ctx.observables()
+        assert abs(e - e0) < 1e-9
+        assert abs(oa.sum() - 8.0) < 1e-9 and abs(ob.sum() - 8.0) < 1e-9
+        assert -1e-9 <= s2 <= 8.0 * 9.0 + 1e-9
