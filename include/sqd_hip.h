@@ -286,7 +286,8 @@ int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
 int sqd_sigma_bytes_needed(sqd_ctx* ctx, double* bytes);
 /* Which sigma kernel the current subspace selected (benchmark / test hook, no reference counterpart):
  * kind 0 = work items (k_sigma), 1 = element gather (k_sigma_direct), 2 = whole rows in LDS (k_sigma_rows),
- * 3 = dense same-spin blocks on the f64 matrix cores (k_same_spin_mfma) + work items for the opposite-spin terms;
+ * 3 = dense same-spin blocks on the f64 matrix cores (k_same_spin_mfma) + work items for the opposite-spin terms,
+ * 4 = list passes for large sets with short lists (k_sigma_lists: link lists in registers, rows of C and C^T through LDS);
  * rows_per_workgroup is set for kind 2, else 0. */
 int sqd_sigma_kernel(sqd_ctx* ctx, int* kind, int* rows_per_workgroup);
 

@@ -1,7 +1,10 @@
 """GPU probe (not a test): one sigma at uniform (GEN=hf: HF-centred) N x N under the tuning hooks given in the environment."""
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
-from qiskit_addon_sqd_amd import synthetic as S, fermion as F
+from qiskit_addon_sqd_amd import synthetic as S, fermion as F, _capi
+if os.environ.get('SQD_LIB'):  # another build of the library (tuning probes)
+    from pathlib import Path
+    _capi.LIB_PATH = Path(os.environ['SQD_LIB'])
 n = int(os.environ.get('N', '10000'))
 h1, eri = S.synthetic_integrals(30)
 ctx = F._get_context(h1, eri, 0)

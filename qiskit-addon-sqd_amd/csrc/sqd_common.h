@@ -235,6 +235,10 @@ struct sqd_ctx {
   int sig_rows = 0;              // > 0: k_sigma_rows with this many rows of C per workgroup (implies sig_direct's
                                  // table layout: CSR lists only)
   bool sig_direct = false;       // ultra-sparse coupling: the element-gather kernel k_sigma_direct, no work items
+  // large sets with short, even lists (10^4 x 10^4): k_sigma_lists -- link lists in registers, rows of C / C^T through
+  // LDS, one pass per spin (sqd_lists.hip).  Implies sig_direct's table layout (CSR lists only) and sig_rows == 0.
+  bool sig_lists = false;
+  void* lists = nullptr;         // sqd::ListState (sqd_lists.hip), created on first use, released with the context
   // well-connected string sets (same-spin blocks >= ~8 % dense: what the SQD loop's carry-over produces, 20-22 %
   // measured, profiles/r03/loop_subspaces_probe.txt): the same-spin part H_a C + C H_b runs on the f64 matrix cores
   // (k_same_spin_mfma) from dense, zero-padded copies of the two symmetric blocks; the work items keep the
@@ -323,6 +327,13 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
                  int64_t in_stride = 0, int64_t out_stride = 0);
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride = 0,
             int64_t out_stride = 0);
+// list-pass sigma for large sets with short lists (sqd_lists.hip).  lists_select: phase 2 of set_subspace, CSR pointers
+// on the host, decides sqd_ctx::sig_lists and plans the column blocks; lists_build: device tables, behind launch C
+bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1, const int64_t* tot, const int* nocc);
+int lists_build(sqd_ctx* c);
+int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                       int64_t in_stride, int64_t out_stride);
+void lists_release(sqd_ctx* c);
 // batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class
 struct SigmaBatchPlan {
   struct Launch {

@@ -1,0 +1,1022 @@
+// sigma = P H P c for LARGE string sets with short, even link lists -- uniform-random sets from a few thousand strings
+// per spin up: BASELINE config 2 read literally (10^4 x 10^4 strings, D = 10^8, 800 MB per vector) and the "subspace
+// dimensions of ~10^7" of the reference's README (README.md:78).  Replaces, like the other sigma kernels, pyscf
+// selected_ci.contract_2e + contract_ss behind kernel_fixed_space (reference qiskit_addon_sqd/fermion.py:721-723,
+// :810-818); the formulation is pyscf's own treatment of the same-spin halves -- "beta-beta on C, alpha-alpha on the
+// transpose"  -- with the link lists where the arithmetic is:
+//
+//   * Per spin, the merged same-spin list of a string (singles' one-body value, then doubles: ~11 links at 10^4
+//     strings) lives IN REGISTERS of the lane that owns the string: a workgroup of 1024 lanes owns a block of <= 1024
+//     columns, loads their lists ONCE and then walks a chunk of ~400 rows of the matrix.  Every row is staged in LDS
+//     (80 KB at 10^4 columns; the next row is prefetched into registers while this one is evaluated), so a link costs
+//     one LDS gather and one FMA: no pointer -> record -> operand chain, no record traffic per row at all.  (Round 3's
+//     k_sigma_rows re-read the 1.3 MB of beta records per row PAIR and streamed eleven 80 KB alpha source rows per
+//     target row: 14.8 GB through the memory pipes per sigma, 3.9 ms.)
+//   * The beta side runs on C (rows = alpha strings), the alpha side on C^T (rows = beta strings), which a tiled
+//     transpose pass writes first; the alpha pass hands its result back through 8-row tiles written in C's layout, the
+//     beta pass adds it in place.  Every element of C leaves HBM once per side.
+//   * Columns of a block are sorted by list length (wavefronts then run uniform trip counts without padding); the
+//     result row is un-permuted through LDS so that global loads and stores stay coalesced.  Lists longer than the
+//     register file's share (24 links / 4 single links) keep their tail in a small LDS table.
+//   * The diagonal term is formed in the (natural-order, coalesced) epilogue of the beta pass from hdiag.
+//   * The terms that pair a single link of each spin (2.7 % of the links, but a nested loop per element in the row
+//     kernel) are evaluated on the compact matrix of the strings that HAVE single links (gathered by the transpose
+//     pass; ~2600 x 2600 at 10^4 x 10^4) by a small kernel of their own, and added by the beta pass.
+//   * The ten column-block workgroups that read the same rows are placed on ONE XCD (block b runs on XCD b % 8), so
+//     nine of ten row reads are L2 hits.
+// Fixed order of accumulation everywhere: the same bits on every run.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "sqd_common.h"
+
+namespace sqd {
+
+namespace {
+
+constexpr int LT = 1024;        // column slots of a workgroup
+#ifndef SQD_LISTS_CPL
+#define SQD_LISTS_CPL 2
+#endif
+#ifndef SQD_LISTS_REGCAP
+#define SQD_LISTS_REGCAP 24
+#endif
+constexpr int CPL = SQD_LISTS_CPL;  // columns per lane: the fixed per-lane state (addresses, masks, the next row's share) is paid
+                                // once per CPL columns, which is what lets 24 links per column stay in registers
+constexpr int NT = LT / CPL;    // lanes of a workgroup
+constexpr int REGCAP = SQD_LISTS_REGCAP;  // same-spin links of a column held in registers
+constexpr int SCAP = 4;         // single links of a column held in registers (opposite-spin terms)
+constexpr int OVL_CAP = 512;    // per block: same-spin links beyond REGCAP (LDS)
+constexpr int OVS_CAP = 256;    // per block: single links beyond SCAP (LDS)
+constexpr int NPF2 = 5 * CPL;   // 16-byte pieces of the next row a lane prefetches (rows longer than 2 NPF2 NT: second phase)
+constexpr int TS = 64;          // transpose tile
+constexpr int RPC_MAX = 512;    // rows of a row chunk at most (their per-row scalars sit in LDS)
+
+__device__ inline int l_ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------------------------------------------
+struct ListFillArgs {
+  int nblk;
+  GPtr<const int32_t> col;        // [nblk * LT] string address of the slot, -1 = padding
+  GPtr<const uint32_t> desc;      // [nblk * LT * 2]: {links | singles << 16, overflow starts: links | singles << 16}
+  GPtr<const int64_t> s_ptr, d_ptr;
+  GPtr<const SRec> s_rec;
+  GPtr<const double> s_val;
+  GPtr<const uint32_t> d_src;
+  GPtr<const double> d_val;
+  GPtr<uint32_t> ridx;            // [nblk][REGCAP / 2][LT]: two 16-bit source addresses per word
+  GPtr<double> rval;              // [nblk][REGCAP][LT]
+  GPtr<uint32_t> sing;            // [nblk][SCAP][LT]: src | widx << 16 | sign << 31
+  GPtr<uint32_t> ovl_idx;         // [nblk][OVL_CAP]
+  GPtr<double> ovl_val;           // [nblk][OVL_CAP]
+  GPtr<uint32_t> ovs;             // [nblk][OVS_CAP]
+};
+__device__ inline uint32_t pack_single(const SRec r) {
+  return (r.src & 0xffffu) | (srec_widx(r.meta) << 16) | (r.meta & 0x80000000u);
+}
+__global__ void k_lists_fill(const ListFillArgs g) {
+  const int b = blockIdx.x;
+  const int64_t slot = (int64_t)b * LT + threadIdx.x;
+  const int col = g.col[slot];
+  int64_t s0 = 0, s1 = 0, d0 = 0, d1 = 0;
+  if (col >= 0) {
+    s0 = g.s_ptr[col];
+    s1 = g.s_ptr[col + 1];
+    d0 = g.d_ptr[col];
+    d1 = g.d_ptr[col + 1];
+  }
+  const int ns = (int)(s1 - s0), nl = ns + (int)(d1 - d0);
+  const uint32_t ov = g.desc[2 * slot + 1];
+  const int ovl0 = (int)(ov & 0xffffu), ovs0 = (int)(ov >> 16);
+  uint32_t pend = 0;
+  for (int k = 0; k < (nl > REGCAP ? nl : REGCAP); ++k) {
+    uint32_t src = 0;
+    double val = 0.0;
+    if (k < nl) {
+      if (k < ns) {
+        src = g.s_rec[s0 + k].src;
+        val = g.s_val[s0 + k];
+      } else {
+        src = g.d_src[d0 + (k - ns)];
+        val = g.d_val[d0 + (k - ns)];
+      }
+    }
+    if (k < REGCAP) {
+      g.rval[((int64_t)b * REGCAP + k) * LT + threadIdx.x] = val;
+      if (k & 1) g.ridx[((int64_t)b * (REGCAP / 2) + (k >> 1)) * LT + threadIdx.x] = pend | (src << 16);
+      else pend = src & 0xffffu;
+    } else {
+      g.ovl_idx[(int64_t)b * OVL_CAP + ovl0 + (k - REGCAP)] = src;
+      g.ovl_val[(int64_t)b * OVL_CAP + ovl0 + (k - REGCAP)] = val;
+    }
+  }
+  for (int j = 0; j < (ns > SCAP ? ns : SCAP); ++j) {
+    const uint32_t w = (j < ns) ? pack_single(g.s_rec[s0 + j]) : 0u;
+    if (j < SCAP) g.sing[((int64_t)b * SCAP + j) * LT + threadIdx.x] = w;
+    else g.ovs[(int64_t)b * OVS_CAP + ovs0 + (j - SCAP)] = w;
+  }
+}
+
+// the row-major J table of a spin, J[I][pair] = sum_{k in I} (pair|kk) (jtable_body's order of operations): the alpha
+// pass stages rows of C^T -- beta strings -- and its single links need J_beta[B][.] as a row; the context keeps the beta
+// table transposed for the other kernels
+struct ListAuxArgs {
+  GPtr<const uint64_t> strs;
+  int64_t n;
+  int norb, nnorb;
+  GPtr<const double> jdiag;
+  GPtr<double> jrow;
+};
+__global__ void k_lists_aux(const ListAuxArgs g) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= g.n * g.nnorb) return;
+  const int64_t I = idx / g.nnorb, pair = idx - I * g.nnorb;
+  uint64_t occ = g.strs[I];
+  double v = 0.0;
+  while (occ) {
+    const int k = l_ctz64(occ);
+    occ &= occ - 1;
+    v += g.jdiag[pair * g.norb + k];
+  }
+  g.jrow[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 0: C^T (64 x 64 tiles through LDS) + the compact matrix of the strings with single links
+// ---------------------------------------------------------------------------------------------------------------
+struct ListTransArgs {
+  GPtr<const double> c;
+  GPtr<double> ct;           // [nb][na]; null: compact matrix only
+  int64_t na, nb, c_stride;
+  GPtr<const int32_t> cidx_a, cidx_b;
+  GPtr<double> cs;           // [ma][mb]; null: none
+  int64_t mb;
+  GPtr<const int> stop, vec_index;
+};
+__global__ void __launch_bounds__(256) k_lists_transpose(const ListTransArgs g) {
+  __shared__ double tile[TS * (TS + 1)];
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  const int64_t A0 = (int64_t)blockIdx.y * TS, B0 = (int64_t)blockIdx.x * TS;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t B = B0 + tx;
+  const int cb = (g.cs && B < g.nb) ? g.cidx_b[B] : -1;
+#pragma unroll 4
+  for (int i = ty; i < TS; i += 4) {
+    const int64_t A = A0 + i;
+    if (A < g.na && B < g.nb) {
+      const double v = C[A * g.nb + B];
+      tile[i * (TS + 1) + tx] = v;
+      if (cb >= 0) {
+        const int ca = g.cidx_a[A];
+        if (ca >= 0) g.cs[(int64_t)ca * g.mb + cb] = v;
+      }
+    }
+  }
+  if (!g.ct) return;
+  __syncthreads();
+#pragma unroll 4
+  for (int j = ty; j < TS; j += 4) {
+    const int64_t Bo = B0 + j, Ao = A0 + tx;
+    if (Bo < g.nb && Ao < g.na) g.ct[Bo * g.na + Ao] = tile[tx * (TS + 1) + j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// single x single (and the S^2 exchange term) on the compact matrix:
+//   T[ia][ib] = sum_{alpha singles (A <- A', wa, s)} s sum_{beta singles (B <- B', wb, t)} t W(wa, wb) Cs[A'][B'],
+//   W = (pq|rs)  (+ pen when the beta link undoes the alpha link's orbital move); direct_element's last loop
+// ---------------------------------------------------------------------------------------------------------------
+struct ListT4Args {
+  int64_t ma, mb;
+  GPtr<const uint32_t> clist_a, clist_b;
+  GPtr<const int32_t> cidx_a, cidx_b;
+  GPtr<const int64_t> sa_ptr, sb_ptr;
+  GPtr<const SRec> sa_rec, sb_rec;
+  GPtr<const double> eri_pp;
+  int nnorb, mode, spin;
+  double pen;
+  GPtr<const double> cs;
+  GPtr<double> t4;
+  GPtr<const int> stop;
+};
+__global__ void __launch_bounds__(256) k_lists_t4(const ListT4Args g) {
+  if (g.stop && *g.stop) return;
+  const int64_t n = g.ma * g.mb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ia = i / g.mb, ib = i - ia * g.mb;
+    const int64_t A = g.clist_a[ia], B = g.clist_b[ib];
+    const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1], sb0 = g.sb_ptr[B], sb1 = g.sb_ptr[B + 1];
+    double a = 0.0;
+    for (int64_t la = sa0; la < sa1; ++la) {
+      const SRec ra = g.sa_rec[la];
+      const double* srow = g.cs + (int64_t)g.cidx_a[ra.src] * g.mb;
+      const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
+      const int partner = (int)srec_widx(ra.meta) ^ 1;
+      double t = 0.0;
+      for (int64_t lb = sb0; lb < sb1; ++lb) {
+        const SRec rb = g.sb_rec[lb];
+        double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
+        if (g.spin) wv += ((int)srec_widx(rb.meta) == partner) ? g.pen : 0.0;
+        t += srec_sign(rb.meta) * wv * srow[g.cidx_b[rb.src]];
+      }
+      a += srec_sign(ra.meta) * t;
+    }
+    g.t4[i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the list pass
+// ---------------------------------------------------------------------------------------------------------------
+struct ListsArgs {
+  GPtr<const double> in;      // [n_r][n_c]: the matrix whose rows are staged (C for the beta side, C^T for the alpha side)
+  GPtr<double> out;           // direct: [n_r][n_c]; transposed: [n_c][ldo]
+  int64_t in_stride, out_stride;  // added per selected vector (vec_index); 0 for scratch operands
+  int64_t n_r, n_c, ldo;
+  int transposed_out;         // alpha side: the result goes back in C's layout, G rows (= G consecutive doubles) at a time
+  int addin;                  // beta side: out already holds the alpha side's part of the same element
+  int diag;                   // beta side: diagonal term
+  int lists;                  // same-spin lists and single x occupation terms (mode 0)
+  int mode, spin;
+  double ss, shift, szterm;
+  int nblk, cpb, cpx, rpc, G; // column blocks, columns per block, row chunks per XCD, rows per chunk, tile rows
+  int norb, nnorb;
+  int pitch, o_jr, o_vr, o_ob, o_ovlv, o_ovli, o_ovs, o_tile, o_rs;  // LDS plan, in doubles
+  GPtr<const int32_t> col;
+  GPtr<const uint32_t> desc, ridx, sing, ovl_idx, ovs;
+  GPtr<const double> rval, ovl_val;
+  GPtr<const int32_t> wlen;   // [nblk][16][4]: per wavefront {list trips, list tail, single trips, single tail}
+  GPtr<const uint64_t> strs_c, strs_r;
+  GPtr<const double> hdiag, jrow;
+  GPtr<const int32_t> cidx_c, cidx_r;
+  GPtr<const double> t4;      // compact single x single term [m_r][m_c] (beta side), null: none
+  int64_t t4_ld;
+  GPtr<const int> stop, vec_index;
+  int dbg;  // tuning hook (SQD_LISTS_DBG): bit 0 plain block order instead of the XCD-aware one, 1 no gathers, 2 no staging of the next row
+};
+
+__device__ inline int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// element `i` (a lane's 32-bit index, i * 8 < 2^32) of an array whose base is wave-uniform: written so that the compiler
+// sees base + zext(32-bit BYTE offset) and emits the scalar-base form of global_load / global_store (one VGPR of offset);
+// indexed the usual way the offset is a 64-bit quantity per access -- ISA: a zero high dword kept in a VGPR for each of
+// the twenty loads of the next row's share
+__device__ inline double ldu(const double* base, unsigned i) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (i << 3));
+}
+__device__ inline double2 ldu2(const double* base, unsigned i) {  // 16-byte element i; base must be 16-byte aligned
+  return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (i << 4));
+}
+__device__ inline void stu(double* base, unsigned i, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (i << 3)) = v;
+}
+// The packed source addresses of a lane's links are loop invariants, and left alone the compiler unpacks them ONCE in
+// front of the row loop -- into one VGPR per link instead of one per two links (ISA: 24 v_lshl_add_u32 results kept
+// live), which is what pushed the kernel over its 128 registers.  Passing the word through an empty asm statement
+// makes it opaque, so the two ALU operations of the unpacking stay inside the loop.
+__device__ inline uint32_t opaque(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+  asm volatile("" : "+v"(w));
+#endif
+  return w;
+}
+
+// ---- phase clocks (probe builds only: -DSQD_PHASE_CLOCK; profiles/probes/_lists_clock.py): thread 0 of every workgroup
+// adds the 100 MHz wall-clock deltas of the phases of its row loop into its own row of a device array
+#ifdef SQD_PHASE_CLOCK
+constexpr int LCLK_ROWS = 1024, LCLK_COLS = 8;
+__device__ unsigned long long sqd_clk_lists[4 * LCLK_ROWS * LCLK_COLS];
+#define LCLK_MARK(slot)                                                                  \
+  do {                                                                                   \
+    const unsigned long long t_ = wall_clock64();                                        \
+    if (threadIdx.x == 0) sqd_clk_lists[(VAR * LCLK_ROWS + blockIdx.x % LCLK_ROWS) * LCLK_COLS + (slot)] += t_ - lclk_t; \
+    lclk_t = t_;                                                                         \
+  } while (0)
+#else
+#define LCLK_MARK(slot)
+#endif
+// VAR 0: alpha pass (lists on C^T, result transposed back); 1: beta pass, H; 2: beta pass, H + shift (S^2 - ss);
+// 3: beta pass of the pure S^2 operator (diagonal + compact term only)
+template <int VAR>
+__global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
+  constexpr bool BETA = VAR != 0, SPIN = VAR >= 2, lists = VAR != 3, HMODE = VAR != 3;
+  HIP_DYNAMIC_SHARED(double, smem)
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ M = g.in + vsel * g.in_stride;
+  double* __restrict__ out = g.out + vsel * g.out_stride;
+  // block -> (row chunk, column block): the column blocks of one row chunk share an XCD (block b runs on XCD b % 8)
+  unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+  if (g.dbg & 1) xcd = 0, q = blockIdx.x;
+  const int cb = (int)(q % (unsigned)g.nblk);
+  const int64_t chunk = (int64_t)xcd * g.cpx + q / (unsigned)g.nblk;
+  const int64_t r0 = chunk * g.rpc;
+  const int64_t r1 = (r0 + g.rpc < g.n_r) ? r0 + g.rpc : g.n_r;
+  if (r0 >= r1) return;
+  const int n_c = (int)g.n_c;
+  const int tid = threadIdx.x;
+  double* __restrict__ jr = smem + g.o_jr;
+  double* __restrict__ ob = smem + g.o_ob;
+  double* __restrict__ ovlv = smem + g.o_ovlv;
+  uint32_t* __restrict__ ovli = reinterpret_cast<uint32_t*>(smem + g.o_ovli);
+  uint32_t* __restrict__ ovsl = reinterpret_cast<uint32_t*>(smem + g.o_ovs);
+  double* __restrict__ tile = smem + g.o_tile;
+  // per-row scalars of this workgroup's row chunk (beta pass): the alpha strings, their energies, compact indices
+  uint64_t* __restrict__ rs_str = reinterpret_cast<uint64_t*>(smem + g.o_rs);
+  int* __restrict__ rs_cid = reinterpret_cast<int*>(smem + g.o_rs + g.rpc);
+
+  // ---- this lane's CPL columns and their lists, once.  Slot s = c * NT + tid of the block's LT slots.
+  const int c0 = cb * g.cpb;                          // first column of the block (natural order)
+  const int ncol = (n_c - c0) < g.cpb ? (n_c - c0) : g.cpb;
+  int col[CPL];                                       // (sorted by list length inside the block; -1 = padding)
+  uint32_t d0[CPL], d1[CPL];                          // {links | singles << 16}, overflow starts
+  int trips[CPL], wtail_l[CPL], strips[CPL], wtail_s[CPL];  // wave-uniform trip counts
+  uint32_t ri[CPL][REGCAP / 2];
+  double rv[CPL][REGCAP];
+  uint32_t sg[CPL][SCAP];
+  uint64_t sN[CPL];  // string of the NATURAL-order column c0 + c * NT + tid (epilogue: spin penalty diagonal)
+  int cidN[CPL];     // its compact index (single x single term)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int64_t slot = (int64_t)cb * LT + c * NT + tid;
+    col[c] = g.col[slot];
+    d0[c] = g.desc[2 * slot];
+    d1[c] = g.desc[2 * slot + 1];
+    const int32_t* wl = g.wlen + ((int64_t)cb * (LT / 64) + c * (NT / 64) + (tid >> 6)) * 4;
+    trips[c] = (g.dbg & 2) ? 0 : uniform_int(wl[0]);
+    wtail_l[c] = uniform_int(wl[1]);
+    strips[c] = uniform_int(wl[2]);
+    wtail_s[c] = uniform_int(wl[3]);
+    if (lists) {
+#pragma unroll
+      for (int k = 0; k < REGCAP / 2; ++k) ri[c][k] = g.ridx[((int64_t)cb * (REGCAP / 2) + k) * LT + c * NT + tid];
+#pragma unroll
+      for (int k = 0; k < REGCAP; ++k) rv[c][k] = g.rval[((int64_t)cb * REGCAP + k) * LT + c * NT + tid];
+#pragma unroll
+      for (int j = 0; j < SCAP; ++j) sg[c][j] = g.sing[((int64_t)cb * SCAP + j) * LT + c * NT + tid];
+    } else {
+#pragma unroll
+      for (int k = 0; k < REGCAP / 2; ++k) ri[c][k] = 0;
+#pragma unroll
+      for (int k = 0; k < REGCAP; ++k) rv[c][k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < SCAP; ++j) sg[c][j] = 0;
+    }
+    sN[c] = 0;
+    cidN[c] = -1;
+    if (BETA && c * NT + tid < ncol) {
+      if (SPIN) sN[c] = g.strs_c[c0 + c * NT + tid];
+      if (g.t4) cidN[c] = g.cidx_c[c0 + c * NT + tid];
+    }
+  }
+  if (lists) {
+    for (int i = tid; i < OVL_CAP; i += NT) {
+      ovlv[i] = g.ovl_val[(int64_t)cb * OVL_CAP + i];
+      ovli[i] = g.ovl_idx[(int64_t)cb * OVL_CAP + i];
+    }
+    for (int i = tid; i < OVS_CAP; i += NT) ovsl[i] = g.ovs[(int64_t)cb * OVS_CAP + i];
+  }
+
+  // ---- rows travel as their 16-byte ALIGNED image: a row that starts on an odd double is fetched from the double in
+  // front of it (the previous row's last element, or the neighbouring vector's: always inside the allocation) and
+  // LDS holds that image; row = img + (0 or 1).  16 bytes per lane and request: half the vector-memory instructions
+  // of 8-byte loads for the same bytes.
+  double* __restrict__ img = smem;
+  const double* __restrict__ row;
+  {
+    const double* rp = M + r0 * n_c;
+    const unsigned sh = (unsigned)((reinterpret_cast<uintptr_t>(rp) >> 3) & 1u);
+    const unsigned n2 = ((unsigned)n_c + sh + 1u) >> 1;
+    for (unsigned b = tid; b < n2; b += NT) reinterpret_cast<double2*>(img)[b] = ldu2(rp - sh, b);
+    row = img + sh;
+  }
+  if (lists)
+    for (int i = tid; i < g.nnorb; i += NT) jr[i] = g.jrow[r0 * g.nnorb + i];
+  if (BETA)
+    for (int i = tid; i < (int)(r1 - r0); i += NT) {
+      rs_str[i] = g.strs_r[r0 + i];
+      rs_cid[i] = g.t4 ? g.cidx_r[r0 + i] : -1;
+    }
+  __syncthreads();
+
+#ifdef SQD_PHASE_CLOCK
+  unsigned long long lclk_t = wall_clock64();
+#endif
+  for (int64_t r = r0; r < r1; ++r) {
+    // -- 1. requests: the next row (it moves into LDS behind the barrier) and what the epilogue of THIS row adds.
+    // Nothing here may be USED before the barrier: a use is a wait for every request issued before it.
+    const bool more = r + 1 < r1 && !(g.dbg & 4);
+    double2 pf[NPF2];
+    double pj = 0.0;
+    double addv[CPL], t4v[CPL], hd[CPL], own[CPL];
+    unsigned sh_n = 0, n2_n = 0;
+    const double* __restrict__ nimg = M;
+    if (more) {
+      const double* nrow = M + (r + 1) * n_c;  // (uniform base + 32-bit lane offset: saddr loads)
+      sh_n = (unsigned)((reinterpret_cast<uintptr_t>(nrow) >> 3) & 1u);
+      n2_n = ((unsigned)n_c + sh_n + 1u) >> 1;
+      nimg = nrow - sh_n;
+    }
+    // (the group offset goes into the scalar base: ONE offset register; n2_n = 0 when there is no next row)
+#define SQD_LISTS_REQUEST(u)                                                                   \
+  do {                                                                                         \
+    pf[u] = make_double2(0.0, 0.0);                                                            \
+    if ((unsigned)((u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)((u) * NT))            \
+      pf[u] = ldu2(nimg + 2 * (u) * NT, (unsigned)tid);                                        \
+  } while (0)
+#pragma unroll
+    for (int u = 0; u < NPF2 / 2; ++u) SQD_LISTS_REQUEST(u);
+    if (more) {
+      if (lists && tid < g.nnorb) pj = ldu(g.jrow + (r + 1) * g.nnorb, (unsigned)tid);
+    }
+    const int crow = BETA ? rs_cid[r - r0] : -1;  // (per-row scalars of the chunk come from LDS: a scalar load from
+                                                  // memory here would be a ~1 us wait for the whole workgroup per row)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      addv[c] = 0.0;
+      t4v[c] = 0.0;
+      hd[c] = 0.0;
+      own[c] = 0.0;
+      if (BETA && c * NT + tid < ncol) {
+        // the diagonal term is formed in the epilogue, in natural column order: hdiag is read coalesced (the bit loop
+        // over a table of the row in LDS that round 4's first version used cost eight LDS reads per element -- the
+        // LDS pipe is what this kernel is bound by) and the element itself comes from the staged row
+        if (HMODE) hd[c] = ldu(g.hdiag + r * n_c + c0, (unsigned)(c * NT + tid));
+        own[c] = row[c0 + c * NT + tid];
+      }
+      if (BETA) {
+        if (g.addin && c * NT + tid < ncol) addv[c] = ldu(out + r * n_c + c0, (unsigned)(c * NT + tid));  // the alpha side's part
+        if (cidN[c] >= 0 && crow >= 0) t4v[c] = ldu(g.t4 + (int64_t)crow * g.t4_ld, (unsigned)cidN[c]);  // single x single (compact)
+      }
+    }
+    LCLK_MARK(0);
+    // -- 2. this row from LDS
+    double acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      acc[c] = 0.0;
+    }
+    if (lists) {
+      // the gathers of a lane's CPL columns go out together, four links per column and round: 4 CPL LDS reads in
+      // flight per lane instead of four (two waves per SIMD hide nothing of a dependent LDS round trip)
+#pragma unroll
+      for (int k0 = 0; k0 < REGCAP; k0 += 4) {
+        if (CPL == 2 && k0 < trips[CPL - 1]) {
+          // both columns of the lane (the second one's list is never the longer: plan_side): eight gathers in flight
+          const uint32_t wa = opaque(ri[0][k0 / 2]), wb = opaque(ri[0][k0 / 2 + 1]);
+          const uint32_t wc = opaque(ri[CPL - 1][k0 / 2]), wd = opaque(ri[CPL - 1][k0 / 2 + 1]);
+          const double x0 = row[wa & 0xffffu], x1 = row[wa >> 16], x2 = row[wb & 0xffffu], x3 = row[wb >> 16];
+          const double y0 = row[wc & 0xffffu], y1 = row[wc >> 16], y2 = row[wd & 0xffffu], y3 = row[wd >> 16];
+          acc[0] += rv[0][k0] * x0;
+          acc[CPL - 1] += rv[CPL - 1][k0] * y0;
+          acc[0] += rv[0][k0 + 1] * x1;
+          acc[CPL - 1] += rv[CPL - 1][k0 + 1] * y1;
+          acc[0] += rv[0][k0 + 2] * x2;
+          acc[CPL - 1] += rv[CPL - 1][k0 + 2] * y2;
+          acc[0] += rv[0][k0 + 3] * x3;
+          acc[CPL - 1] += rv[CPL - 1][k0 + 3] * y3;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            if (k0 < trips[c]) {
+              const uint32_t wa = opaque(ri[c][k0 / 2]), wb = opaque(ri[c][k0 / 2 + 1]);
+              const double x0 = row[wa & 0xffffu], x1 = row[wa >> 16], x2 = row[wb & 0xffffu], x3 = row[wb >> 16];
+              acc[c] += rv[c][k0] * x0;
+              acc[c] += rv[c][k0 + 1] * x1;
+              acc[c] += rv[c][k0 + 2] * x2;
+              acc[c] += rv[c][k0 + 3] * x3;
+            }
+          }
+        }
+        if (k0 == 0) {  // the second half of the next row's requests, behind the first round of gathers
+#pragma unroll
+          for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      if (lists) {
+        if (wtail_l[c] > 0) {
+          const int nl = (int)(d0[c] & 0xffffu), ovl0 = (int)(d1[c] & 0xffffu);
+          for (int t = 0; t < wtail_l[c]; ++t) {
+            const bool on = REGCAP + t < nl;
+            const int e = on ? ovl0 + t : 0;
+            const double v = on ? ovlv[e] : 0.0;
+            acc[c] += v * row[ovli[e]];
+          }
+        }
+        const int ns = (int)(d0[c] >> 16);
+#pragma unroll
+        for (int j = 0; j < SCAP; ++j) {
+          if (j < strips[c]) {
+            const uint32_t w = opaque(sg[c][j]);
+            const double sgn = (w >> 31) ? -1.0 : 1.0;
+            const double coef = (j < ns) ? sgn * jr[(w >> 17) & 0xfffu] : 0.0;
+            acc[c] += coef * row[w & 0xffffu];
+          }
+        }
+        if (wtail_s[c] > 0) {
+          const int ovs0 = (int)(d1[c] >> 16);
+          for (int t = 0; t < wtail_s[c]; ++t) {
+            const bool on = SCAP + t < ns;
+            const uint32_t w = ovsl[on ? ovs0 + t : 0];
+            const double sgn = (w >> 31) ? -1.0 : 1.0;
+            const double coef = on ? sgn * jr[(w >> 17) & 0xfffu] : 0.0;
+            acc[c] += coef * row[w & 0xffffu];
+          }
+        }
+      }
+      // -- 3. back to natural column order through LDS
+      if (col[c] >= 0) ob[col[c] - c0] = acc[c];
+    }
+    LCLK_MARK(1);
+    __syncthreads();
+    LCLK_MARK(2);
+    // -- 4. the next row moves in; the finished row moves out (coalesced)
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NPF2; ++u)
+        if ((unsigned)(u * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(u * NT))
+          reinterpret_cast<double2*>(img)[tid + u * NT] = pf[u];
+      for (unsigned b = tid + NPF2 * NT; b < n2_n; b += NT)  // (rows beyond 2 NPF2 NT columns)
+        reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * n_c - sh_n, b);
+      row = img + sh_n;
+      if (lists && tid < g.nnorb) jr[tid] = pj;
+      if (lists)
+        for (int i = tid + NT; i < g.nnorb; i += NT) jr[i] = g.jrow[(r + 1) * g.nnorb + i];  // (nnorb > NT: norb > 31 at CPL 2)
+    }
+    LCLK_MARK(3);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int lc = c * NT + tid;  // natural-order column of the block
+      if (lc < ncol) {
+        double v = ob[lc] + addv[c] + t4v[c];
+        if (BETA) {
+          double d = hd[c];
+          if (SPIN) {
+            const double pop = (double)__popcll(sN[c] & ~rs_str[r - r0]);  // beta occupied, alpha empty
+            d = HMODE ? d + g.shift * (g.szterm + pop - g.ss) : g.szterm + pop;
+          }
+          v += d * own[c];
+        }
+        if (BETA) {
+          stu(out + r * n_c + c0, (unsigned)lc, v);
+        } else {
+          const int gi = (int)((r - r0) % g.G);
+          tile[gi * LT + lc] = v;
+          if (gi == g.G - 1 || !more) {
+            // G (or the last few) consecutive rows of this column = consecutive doubles of the result in C's layout
+            const int cnt = gi + 1;
+            double* __restrict__ dstc = out + (int64_t)(c0 + lc) * g.ldo + (r - gi);
+            if ((reinterpret_cast<uintptr_t>(dstc) & 15) == 0 && (cnt & 1) == 0) {
+              for (int i = 0; i < cnt; i += 2)
+                *reinterpret_cast<double2*>(dstc + i) = make_double2(tile[i * LT + lc], tile[(i + 1) * LT + lc]);
+            } else {
+              for (int i = 0; i < cnt; ++i) dstc[i] = tile[i * LT + lc];
+            }
+          }
+        }
+      }
+    }
+    LCLK_MARK(4);
+    __syncthreads();
+    LCLK_MARK(5);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: plan
+// ---------------------------------------------------------------------------------------------------------------
+struct SidePlan {
+  int nblk = 0, cpb = 0;
+  std::vector<int32_t> col, wlen;
+  std::vector<uint32_t> desc;
+  std::vector<int32_t> cidx;
+  std::vector<uint32_t> clist;
+  bool ok = true;
+};
+
+// columns of each block sorted by list length (longest first), 64 at a time dealt to the wavefronts so that the four
+// SIMDs of a CU carry the same load (a workgroup's wavefronts go to the SIMDs in cyclic order)
+void plan_side(const int64_t* s_ptr, const int64_t* d_ptr, int64_t n, SidePlan& p) {
+  p.nblk = (int)((n + LT - 1) / LT);
+  p.cpb = (int)((n + p.nblk - 1) / p.nblk);
+  p.col.assign((size_t)p.nblk * LT, -1);
+  p.desc.assign((size_t)p.nblk * LT * 2, 0u);
+  p.wlen.assign((size_t)p.nblk * 16 * 4, 0);
+  p.cidx.assign((size_t)n, -1);
+  p.clist.clear();
+  p.ok = true;
+  for (int64_t I = 0; I < n; ++I)
+    if (s_ptr[I + 1] > s_ptr[I]) {
+      p.cidx[(size_t)I] = (int32_t)p.clist.size();
+      p.clist.push_back((uint32_t)I);
+    }
+  std::vector<int> order;
+  for (int b = 0; b < p.nblk; ++b) {
+    const int64_t c0 = (int64_t)b * p.cpb, c1 = std::min<int64_t>(n, c0 + p.cpb);
+    const int m = (int)(c1 - c0);
+    order.resize((size_t)m);
+    std::iota(order.begin(), order.end(), 0);
+    auto len = [&](int i) { return (s_ptr[c0 + i + 1] - s_ptr[c0 + i]) + (d_ptr[c0 + i + 1] - d_ptr[c0 + i]); };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len(x) > len(y); });
+    int ovl = 0, ovs = 0;
+    for (int rank = 0; rank < m; ++rank) {
+      // group j of 64 sorted columns -> (wavefront, column index c of its lanes), slot = c * NT + wave * 64 + lane.
+      // CPL 2: groups j and 15 - j share a wavefront (equal sums); CPL 1: a snake over the four SIMDs of the CU
+      const int j = rank / 64, lane = rank % 64;
+      int wave, cc;
+      if (CPL == 2) {
+        wave = j < 8 ? j : 15 - j;
+        cc = j < 8 ? 0 : 1;
+      } else {
+        const int grp = (j % 8 < 4) ? j % 4 : 3 - (j % 4);
+        wave = grp + 4 * (j / 4);
+        cc = 0;
+      }
+      const int slot = cc * NT + wave * 64 + lane;
+      const int64_t I = c0 + order[(size_t)rank];
+      const int ns = (int)(s_ptr[I + 1] - s_ptr[I]), nl = ns + (int)(d_ptr[I + 1] - d_ptr[I]);
+      if (nl > 60000 || ns > 60000) p.ok = false;
+      const size_t s = (size_t)b * LT + slot;
+      p.col[s] = (int32_t)I;
+      p.desc[2 * s] = (uint32_t)nl | ((uint32_t)ns << 16);
+      p.desc[2 * s + 1] = (uint32_t)ovl | ((uint32_t)ovs << 16);
+      int32_t* wl = &p.wlen[((size_t)b * 16 + slot / 64) * 4];
+      const int trips = std::min(REGCAP, (nl + 3) / 4 * 4);
+      wl[0] = std::max(wl[0], trips);
+      wl[1] = std::max(wl[1], nl > REGCAP ? nl - REGCAP : 0);
+      wl[2] = std::max(wl[2], std::min(SCAP, ns));
+      wl[3] = std::max(wl[3], ns > SCAP ? ns - SCAP : 0);
+      if (nl > REGCAP) ovl += nl - REGCAP;
+      if (ns > SCAP) ovs += ns - SCAP;
+    }
+    if (ovl > OVL_CAP || ovs > OVS_CAP) p.ok = false;
+  }
+}
+
+struct LdsPlan {
+  int pitch, o_jr, o_vr, o_ob, o_ovlv, o_ovli, o_ovs, o_tile, o_rs, G;
+  size_t bytes;
+};
+// LDS of a pass whose staged rows have n_c doubles; want_tile: transposed output (G rows of LT doubles)
+bool lds_plan(int64_t n_c, int nnorb, int lds_bytes, bool want_tile, LdsPlan& L) {
+  int off = (int)((n_c + 3) & ~int64_t(1));  // the aligned image of a row: up to one double in front, one behind
+  L.pitch = off;
+  L.o_jr = off, off += (nnorb + 1) & ~1;
+  L.o_vr = off;
+  L.o_ob = off, off += LT;
+  L.o_ovlv = off, off += OVL_CAP;
+  L.o_ovli = off, off += OVL_CAP / 2;
+  L.o_ovs = off, off += OVS_CAP / 2;
+  L.o_rs = off;
+  if (!want_tile) off += (3 * RPC_MAX + 1) / 2;  // beta pass: per-row scalars of a chunk (8 + 4 bytes a row)
+  L.o_tile = off;
+  L.G = 0;
+  if (want_tile) {
+    for (int G = 8; G >= 1; G >>= 1)
+      if ((size_t)(off + G * LT) * 8 <= (size_t)lds_bytes) {
+        L.G = G;
+        break;
+      }
+    if (!L.G) return false;
+    off += L.G * LT;
+  } else {
+    L.G = 1;
+  }
+  L.bytes = (size_t)off * 8;
+  return L.bytes <= (size_t)lds_bytes;
+}
+
+}  // namespace
+
+// state of the list path, owned by the context (sqd_common.h: sqd_ctx::lists)
+struct ListSideDev {
+  int nblk = 0, cpb = 0;
+  int64_t m = 0;  // strings with single links
+  DevBuf col, desc, wlen, ridx, rval, sing, ovl_idx, ovl_val, ovs, cidx, clist, aux;  // aux: row-major J table (beta)
+};
+struct ListState {
+  ListSideDev side[2];
+  SidePlan plan[2];  // host copies (their uploads are asynchronous)
+  DevBuf ct, cs, t4;
+  LdsPlan lds_a, lds_b;  // alpha pass (rows of C^T: na doubles), beta pass (rows of C: nb doubles)
+};
+
+void lists_release(sqd_ctx* c) {
+  if (!c->lists) return;
+  ListState* s = static_cast<ListState*>(c->lists);
+  for (auto& sd : s->side)
+    for (DevBuf* b : {&sd.col, &sd.desc, &sd.wlen, &sd.ridx, &sd.rval, &sd.sing, &sd.ovl_idx, &sd.ovl_val, &sd.ovs,
+                      &sd.cidx, &sd.clist, &sd.aux})
+      b->release();
+  s->ct.release();
+  s->cs.release();
+  s->t4.release();
+  delete s;
+  c->lists = nullptr;
+}
+
+// Is the list path possible / chosen for the subspace whose CSR pointers are on the host?  (phase 2 of set_subspace)
+bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1, const int64_t* tot, const int* nocc) {
+  c->sig_lists = false;
+  const char* env = std::getenv("SQD_SIGMA_LISTS");
+  const int forced = env ? std::atoi(env) : -1;
+  if (forced == 0) return false;
+  if (row0 != 0 || row1 != na) return false;                  // whole-subspace contexts only
+  if (na > 65535 || nb > 65535) return false;                 // 16-bit source addresses
+  if (nocc[0] < 1 || nocc[1] < 1) return false;
+  if (!c->lists) c->lists = new ListState();
+  ListState* s = static_cast<ListState*>(c->lists);
+  if (!lds_plan(na, c->nnorb, c->lds_bytes, true, s->lds_a) || !lds_plan(nb, c->nnorb, c->lds_bytes, false, s->lds_b))
+    return false;
+  if (forced != 1) {
+    // large sets with short, even lists (the register-resident part must hold nearly all of them)
+    if (na < 3000 || nb < 3000) return false;
+    if (tot[0] + tot[1] > 16 * na || tot[2] + tot[3] > 16 * nb) return false;
+    if (tot[0] > 2 * na || tot[2] > 2 * nb) return false;
+  }
+  plan_side(c->h_sptr, c->h_dptr, na, s->plan[0]);
+  plan_side(c->h_sptr_b, c->h_dptr_b, nb, s->plan[1]);
+  if (!s->plan[0].ok || !s->plan[1].ok) return false;
+  c->sig_lists = true;
+  return true;
+}
+
+template <class T>
+static int upload_vec(sqd_ctx* c, DevBuf& buf, const std::vector<T>& v) {
+  SQD_TRY(buf.reserve(std::max<size_t>(v.size() * sizeof(T), 16)));
+  if (!v.empty()) SQD_HIP_CHECK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return SQD_OK;
+}
+
+// device tables of the list path; enqueued behind launch C of set_subspace (the CSR lists must be filled)
+int lists_build(sqd_ctx* c) {
+  ListState* s = static_cast<ListState*>(c->lists);
+  const int64_t ns[2] = {c->na, c->nb};
+  for (int sp = 0; sp < 2; ++sp) {
+    const SidePlan& p = s->plan[sp];
+    ListSideDev& d = s->side[sp];
+    const SpinTables& t = c->sp[sp];
+    d.nblk = p.nblk;
+    d.cpb = p.cpb;
+    d.m = (int64_t)p.clist.size();
+    SQD_TRY(upload_vec(c, d.col, p.col));
+    SQD_TRY(upload_vec(c, d.desc, p.desc));
+    SQD_TRY(upload_vec(c, d.wlen, p.wlen));
+    SQD_TRY(upload_vec(c, d.cidx, p.cidx));
+    SQD_TRY(upload_vec(c, d.clist, p.clist));
+    SQD_TRY(d.ridx.reserve((size_t)p.nblk * (REGCAP / 2) * LT * 4));
+    SQD_TRY(d.rval.reserve((size_t)p.nblk * REGCAP * LT * 8));
+    SQD_TRY(d.sing.reserve((size_t)p.nblk * SCAP * LT * 4));
+    SQD_TRY(d.ovl_idx.reserve((size_t)p.nblk * OVL_CAP * 4));
+    SQD_TRY(d.ovl_val.reserve((size_t)p.nblk * OVL_CAP * 8));
+    SQD_TRY(d.ovs.reserve((size_t)p.nblk * OVS_CAP * 4));
+    SQD_HIP_CHECK(hipMemsetAsync(d.ovl_idx.p, 0, (size_t)p.nblk * OVL_CAP * 4, c->stream));
+    SQD_HIP_CHECK(hipMemsetAsync(d.ovl_val.p, 0, (size_t)p.nblk * OVL_CAP * 8, c->stream));
+    SQD_HIP_CHECK(hipMemsetAsync(d.ovs.p, 0, (size_t)p.nblk * OVS_CAP * 4, c->stream));
+    ListFillArgs f;
+    f.nblk = p.nblk;
+    f.col = d.col.as<int32_t>();
+    f.desc = d.desc.as<uint32_t>();
+    f.s_ptr = t.s_ptr.as<int64_t>();
+    f.d_ptr = t.d_ptr.as<int64_t>();
+    f.s_rec = t.s_rec.as<SRec>();
+    f.s_val = t.s_val.as<double>();
+    f.d_src = t.d_src.as<uint32_t>();
+    f.d_val = t.d_val.as<double>();
+    f.ridx = d.ridx.as<uint32_t>();
+    f.rval = d.rval.as<double>();
+    f.sing = d.sing.as<uint32_t>();
+    f.ovl_idx = d.ovl_idx.as<uint32_t>();
+    f.ovl_val = d.ovl_val.as<double>();
+    f.ovs = d.ovs.as<uint32_t>();
+    hipLaunchKernelGGL(k_lists_fill, dim3(p.nblk), dim3(LT), 0, c->stream, f);
+    SQD_HIP_CHECK(hipGetLastError());
+    if (sp == 1) {  // row-major J table of the beta strings (the alpha J table of the context is row-major already)
+      ListAuxArgs a;
+      a.strs = t.strs.as<uint64_t>();
+      a.n = ns[sp];
+      a.norb = c->norb;
+      a.nnorb = c->nnorb;
+      a.jdiag = c->jdiag.as<double>();
+      const int64_t cnt = ns[sp] * c->nnorb;
+      SQD_TRY(d.aux.reserve((size_t)cnt * 8));
+      a.jrow = d.aux.as<double>();
+      hipLaunchKernelGGL(k_lists_aux, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, a);
+      SQD_HIP_CHECK(hipGetLastError());
+    }
+  }
+  SQD_TRY(s->ct.reserve((size_t)c->na * c->nb * 8));
+  const int64_t ma = s->side[0].m, mb = s->side[1].m;
+  SQD_TRY(s->cs.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
+  SQD_TRY(s->t4.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
+  return SQD_OK;
+}
+
+static void fill_pass_args(sqd_ctx* c, ListState* s, int side, int mode, bool spin, double ss, double shift,
+                           ListsArgs* gp) {
+  // side 1: beta lists on C (rows = alpha strings); side 0: alpha lists on C^T (rows = beta strings)
+  ListsArgs& g = *gp;
+  std::memset(&g, 0, sizeof(g));
+  const ListSideDev& d = s->side[side];
+  const LdsPlan& L = side ? s->lds_b : s->lds_a;
+  g.n_r = side ? c->na : c->nb;
+  g.n_c = side ? c->nb : c->na;
+  g.mode = mode;
+  g.spin = spin ? 1 : 0;
+  g.ss = ss;
+  g.shift = shift;
+  const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+  g.szterm = sz * (sz + 1.0);
+  g.nblk = d.nblk;
+  g.cpb = d.cpb;
+  // row chunks per XCD: the XCD's 32 CUs over the column blocks, but no chunk shorter than 8 rows
+  g.cpx = (int)std::min<int64_t>(std::max(1, 32 / d.nblk), std::max<int64_t>(1, (g.n_r + 63) / 64));
+  g.cpx = (int)std::max<int64_t>(g.cpx, (g.n_r + 8 * (RPC_MAX - 8) - 1) / (8 * (RPC_MAX - 8)));  // chunks of <= RPC_MAX rows
+  g.G = L.G;
+  const int64_t nchunks = 8 * (int64_t)g.cpx;
+  int64_t rpc = (g.n_r + nchunks - 1) / nchunks;
+  rpc = (rpc + 7) / 8 * 8;  // chunk starts on multiples of 8 rows: whole tiles, 16-byte aligned tile stores
+  g.rpc = (int)rpc;
+  g.norb = c->norb;
+  g.nnorb = c->nnorb;
+  g.pitch = L.pitch;
+  g.o_jr = L.o_jr;
+  g.o_vr = L.o_vr;
+  g.o_ob = L.o_ob;
+  g.o_ovlv = L.o_ovlv;
+  g.o_ovli = L.o_ovli;
+  g.o_ovs = L.o_ovs;
+  g.o_tile = L.o_tile;
+  g.o_rs = L.o_rs;
+  g.col = d.col.as<int32_t>();
+  g.desc = d.desc.as<uint32_t>();
+  g.ridx = d.ridx.as<uint32_t>();
+  g.sing = d.sing.as<uint32_t>();
+  g.ovl_idx = d.ovl_idx.as<uint32_t>();
+  g.ovs = d.ovs.as<uint32_t>();
+  g.rval = d.rval.as<double>();
+  g.ovl_val = d.ovl_val.as<double>();
+  g.wlen = d.wlen.as<int32_t>();
+  g.strs_c = c->sp[side].strs.as<uint64_t>();
+  g.strs_r = c->sp[1 - side].strs.as<uint64_t>();
+  g.hdiag = c->hdiag.as<double>();
+  g.jrow = side ? c->sp[0].jrow.as<double>() : s->side[1].aux.as<double>();        // J of the staged rows' spin
+  g.cidx_c = d.cidx.as<int32_t>();
+  g.cidx_r = s->side[1 - side].cidx.as<int32_t>();
+  g.stop = c->sigma_stop;
+  static const int dbg = [] {
+    const char* env = std::getenv("SQD_LISTS_DBG");
+    return env ? std::atoi(env) : 0;
+  }();
+  g.dbg = dbg;
+}
+
+int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
+                       int64_t in_stride, int64_t out_stride) {
+  ListState* s = static_cast<ListState*>(c->lists);
+  const bool sp = (mode == 1 || spin);
+  const bool indexed = c->sigma_index && (in_stride || out_stride);
+  const int* vec_index = indexed ? c->sigma_index : nullptr;
+  const int64_t na = c->na, nb = c->nb, ma = s->side[0].m, mb = s->side[1].m;
+  const bool cross = ma > 0 && mb > 0;     // single x single term exists
+  const bool alpha_pass = (mode == 0);     // the pure S^2 operator has no same-spin part
+  static const int pass_mask = [] {        // profiling hook: bit 0 transpose, 1 compact term, 2 alpha pass, 3 beta pass
+    const char* env = std::getenv("SQD_LISTS_PASSES");
+    return env ? std::atoi(env) : 15;
+  }();
+  // pass 0: C^T (+ the compact matrix)
+  if ((alpha_pass || cross) && (pass_mask & 1)) {
+    ListTransArgs t;
+    t.c = d_c;
+    t.ct = alpha_pass ? s->ct.as<double>() : nullptr;
+    t.na = na;
+    t.nb = nb;
+    t.c_stride = in_stride;
+    t.cidx_a = s->side[0].cidx.as<int32_t>();
+    t.cidx_b = s->side[1].cidx.as<int32_t>();
+    t.cs = cross ? s->cs.as<double>() : nullptr;
+    t.mb = mb;
+    t.stop = c->sigma_stop;
+    t.vec_index = vec_index;
+    hipLaunchKernelGGL(k_lists_transpose, dim3((unsigned)((nb + TS - 1) / TS), (unsigned)((na + TS - 1) / TS)),
+                       dim3(256), 0, c->stream, t);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (cross && (pass_mask & 2)) {
+    ListT4Args t;
+    t.ma = ma;
+    t.mb = mb;
+    t.clist_a = s->side[0].clist.as<uint32_t>();
+    t.clist_b = s->side[1].clist.as<uint32_t>();
+    t.cidx_a = s->side[0].cidx.as<int32_t>();
+    t.cidx_b = s->side[1].cidx.as<int32_t>();
+    t.sa_ptr = c->sp[0].s_ptr.as<int64_t>();
+    t.sb_ptr = c->sp[1].s_ptr.as<int64_t>();
+    t.sa_rec = c->sp[0].s_rec.as<SRec>();
+    t.sb_rec = c->sp[1].s_rec.as<SRec>();
+    t.eri_pp = c->eri_pp.as<double>();
+    t.nnorb = c->nnorb;
+    t.mode = mode;
+    t.spin = sp ? 1 : 0;
+    t.pen = (mode == 1) ? -1.0 : -shift;
+    t.cs = s->cs.as<double>();
+    t.t4 = s->t4.as<double>();
+    t.stop = c->sigma_stop;
+    int64_t blocks = (ma * mb + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_lists_t4, dim3((unsigned)blocks), dim3(256), 0, c->stream, t);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  auto launch = [&](const ListsArgs& g, size_t shmem, int var) -> int {
+    const unsigned grid = 8u * (unsigned)g.cpx * (unsigned)g.nblk;
+    static std::atomic<size_t> granted[4][64];
+    const int dev = c->device & 63;
+    const void* fn = var == 0   ? reinterpret_cast<const void*>(&k_sigma_lists<0>)
+                     : var == 1 ? reinterpret_cast<const void*>(&k_sigma_lists<1>)
+                     : var == 2 ? reinterpret_cast<const void*>(&k_sigma_lists<2>)
+                                : reinterpret_cast<const void*>(&k_sigma_lists<3>);
+    if (shmem > 64 * 1024 && shmem > granted[var][dev].load(std::memory_order_relaxed)) {
+      SQD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      granted[var][dev].store(shmem, std::memory_order_relaxed);
+    }
+    switch (var) {
+      case 0: hipLaunchKernelGGL((k_sigma_lists<0>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
+      case 1: hipLaunchKernelGGL((k_sigma_lists<1>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
+      case 2: hipLaunchKernelGGL((k_sigma_lists<2>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
+      default: hipLaunchKernelGGL((k_sigma_lists<3>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
+    }
+    SQD_HIP_CHECK(hipGetLastError());
+    return SQD_OK;
+  };
+  // pass 1: alpha lists on C^T; the result lands in sigma (C's layout), 8 rows of C^T = 8 consecutive doubles at a time
+  if (alpha_pass && (pass_mask & 4)) {
+    ListsArgs g;
+    fill_pass_args(c, s, 0, mode, spin, ss, shift, &g);
+    g.in = s->ct.as<double>();
+    g.in_stride = 0;
+    g.out = d_sigma;
+    g.out_stride = out_stride;
+    g.ldo = nb;
+    g.transposed_out = 1;
+    g.lists = 1;
+    g.vec_index = vec_index;
+    SQD_TRY(launch(g, s->lds_a.bytes, 0));
+  }
+  // pass 2: diagonal + beta lists on C + the alpha part (in place) + the compact single x single term
+  if (pass_mask & 8) {
+    ListsArgs g;
+    fill_pass_args(c, s, 1, mode, spin, ss, shift, &g);
+    g.in = d_c;
+    g.in_stride = in_stride;
+    g.out = d_sigma;
+    g.out_stride = out_stride;
+    g.ldo = nb;
+    g.transposed_out = 0;
+    g.addin = alpha_pass ? 1 : 0;
+    g.diag = 1;
+    g.lists = (mode == 0) ? 1 : 0;
+    g.t4 = cross ? s->t4.as<double>() : nullptr;
+    g.t4_ld = mb;
+    g.vec_index = vec_index;
+    SQD_TRY(launch(g, s->lds_b.bytes, mode == 1 ? 3 : (spin ? 2 : 1)));
+  }
+  if (c->ev_after_sigma_kernel) {
+    SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+    c->ev_after_sigma_kernel = nullptr;
+  }
+  return SQD_OK;
+}
+
+}  // namespace sqd
+
+#ifdef SQD_PHASE_CLOCK
+// out[4 * 8]: per kernel variant the column sums over the workgroups' rows {requests, row from LDS, barrier 1, next row into
+// LDS, epilogue, barrier 2} in 10 ns units
+extern "C" __attribute__((visibility("default"))) int sqd_probe_clk_lists(unsigned long long* out, int reset) {
+  static std::vector<unsigned long long> h((size_t)4 * sqd::LCLK_ROWS * sqd::LCLK_COLS);
+  if (out) {
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sqd::sqd_clk_lists), h.size() * 8) != hipSuccess) return -1;
+    for (int k = 0; k < 4 * sqd::LCLK_COLS; ++k) out[k] = 0;
+    for (int v = 0; v < 4; ++v)
+      for (size_t r = 0; r < (size_t)sqd::LCLK_ROWS; ++r)
+        for (int k = 0; k < sqd::LCLK_COLS; ++k) out[v * sqd::LCLK_COLS + k] += h[(v * sqd::LCLK_ROWS + r) * sqd::LCLK_COLS + k];
+  }
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sqd::sqd_clk_lists), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -520,7 +520,7 @@ static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const 
   return SQD_OK;
 }
 static bool obs_s2_inline(const sqd_ctx* c, bool with_s2) {
-  return with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sharded();
+  return with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sig_lists && !c->sharded();
 }
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2, double* host_twin) {
   hipStream_t st = c->stream;

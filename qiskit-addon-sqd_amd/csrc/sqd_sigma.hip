@@ -1261,6 +1261,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
     set_error("no subspace set");
     return SQD_ERR_STATE;
   }
+  if (c->sig_lists) return launch_sigma_lists(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   SigmaArgs g;
   fill_sigma_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);
@@ -1297,7 +1298,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
 // says so, and callers solve anything else one by one.
 bool sigma_batch_supported(const sqd_ctx* c) {
   if (c->sharded()) return false;
-  if (c->sig_rows > 0) return false;
+  if (c->sig_rows > 0 || c->sig_lists) return false;
   if (c->sig_direct) return true;
   return c->sig_lds_rows && !(c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max) && c->sig_R <= 16;
 }

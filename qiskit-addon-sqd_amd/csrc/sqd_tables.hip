@@ -1193,6 +1193,14 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
   c->D = na * nb;
   c->nelec[0] = nocc[0];
   c->nelec[1] = nocc[1];
+  // large sets with short, even lists: the list passes (sqd_lists.hip) take the whole sigma; CSR-only table layout.
+  // Single builds only: the batched solve has no launch class for it (such subspaces are solved one by one there).
+  if (!always_guess && lists_select(c, na, nb, row0, row1, tot, nocc)) {
+    c->sig_direct = true;
+    c->sig_rows = 0;
+  } else {
+    c->sig_lists = false;
+  }
   b.have_ell = b.have_jds = b.have_dense = false;
   b.ups.clear();
   b.blob_bytes = 0;
@@ -1449,6 +1457,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     hipLaunchKernelGGL(k_tables_jds, dim3(b.jds.gx), dim3(256), 0, st, b.jds);
     SQD_HIP_CHECK(hipGetLastError());
   }
+  if (c->sig_lists) SQD_TRY(lists_build(c));
   if (b.have_dense) {
     hipLaunchKernelGGL(k_tables_dense, dim3(b.dense.gx, 2), dim3(256), 0, st, b.dense);
     SQD_HIP_CHECK(hipGetLastError());

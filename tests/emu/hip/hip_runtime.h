@@ -34,6 +34,7 @@ struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
 struct double2 { double x, y; };
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;
@@ -257,6 +258,7 @@ template <class T> inline T __shfl(T v, int src, int width = 64) {
   return emu_exchange(v, (lane / width) * width + (src % width));
 }
 inline int __builtin_amdgcn_readlane(int v, int src) { return emu_exchange(v, src); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return emu_exchange(v, 0); }  // (callers keep every lane alive)
 // v_mov_b32_dpp for the controls the kernels use: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143).
 // A lane whose row is enabled by row_mask and whose source lane exists takes the source's value; every other lane
 // keeps `old` (bound_ctrl = false).  bank_mask must be 0xf.

@@ -218,3 +218,32 @@ def test_emu_enqueue_hook(emu_lib):
         with pytest.raises(RuntimeError, match="from the hook"):
             ctx.raise_hook_error()
         ctx.raise_hook_error()  # (raised once)
+
+
+def test_emu_lists_kernel(emu_lib, monkeypatch):
+    # SQD_SIGMA_LISTS=1 forces the list passes (sqd_lists.hip: link lists in registers, rows of C / C^T through LDS,
+    # transpose + compact single x single kernel) that 10^4 x 10^4 sets take by default.  Small cases reach every
+    # branch: lists longer than the registers' 24 links and more than 4 single links per string (tails in the LDS
+    # overflow tables: 40 of the 70 strings of (4e,8o) have ~30 links, ~9 of them singles), ragged row chunks, odd row
+    # lengths (unaligned tile stores), nalpha != nbeta, all operator forms, a Davidson solve and the observables
+    monkeypatch.setenv("SQD_SIGMA_LISTS", "1")
+
+    def selected(norb, nelec, na, nb, seed, hf):
+        h1, eri, sa, sb = make_problem(norb, nelec, na, nb, seed, hf)
+        with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            return ctx.sigma_kernel() == "k_sigma_lists", ctx.link_counts(0), ctx.link_counts(1)
+
+    cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (6, (3, 2), 13, 9, 5, False),
+             (5, (1, 4), 5, 4, 9, False), (8, (4, 4), 40, 38, 17, False)]
+    for case in cases:
+        ok, la, lb = selected(*case)
+        assert ok, case
+    _, la, lb = selected(*cases[-1])
+    assert la[0] + la[1] > 24 * 40 and la[0] > 4 * 40  # the overflow tables are really in use
+    run_full_parity(emu_lib, *cases[0], variants=False)
+    for case in cases[1:]:
+        run_operator_parity(emu_lib, *case)
+    # a set whose tails exceed the overflow tables (complete beta space: 261 links per string) is refused: another kernel
+    ok, _, _ = selected(12, (2, 6), 3, 300, 19, False)
+    assert not ok
