@@ -39,10 +39,10 @@ namespace {
 
 constexpr int LT = 1024;        // column slots of a workgroup
 #ifndef SQD_LISTS_CPL
-#define SQD_LISTS_CPL 2
+#define SQD_LISTS_CPL 1
 #endif
 #ifndef SQD_LISTS_REGCAP
-#define SQD_LISTS_REGCAP 24
+#define SQD_LISTS_REGCAP 16
 #endif
 constexpr int CPL = SQD_LISTS_CPL;  // columns per lane: the fixed per-lane state (addresses, masks, the next row's share) is paid
                                 // once per CPL columns, which is what lets 24 links per column stay in registers
@@ -55,6 +55,7 @@ constexpr int NPF2 = 5 * CPL;   // 16-byte pieces of the next row a lane prefetc
 constexpr int TS = 64;          // transpose tile
 constexpr int RPC_MAX = 512;    // rows of a row chunk at most (their per-row scalars sit in LDS)
 
+typedef double lists_d2 __attribute__((ext_vector_type(2)));
 __device__ inline int l_ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -151,8 +152,8 @@ __global__ void k_lists_aux(const ListAuxArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 struct ListTransArgs {
   GPtr<const double> c;
-  GPtr<double> ct;           // [nb][na]; null: compact matrix only
-  int64_t na, nb, c_stride;
+  GPtr<double> ct;           // [nb][ld_t]; null: compact matrix only
+  int64_t na, nb, c_stride, ld_t;
   GPtr<const int32_t> cidx_a, cidx_b;
   GPtr<double> cs;           // [ma][mb]; null: none
   int64_t mb;
@@ -164,6 +165,33 @@ __global__ void __launch_bounds__(256) k_lists_transpose(const ListTransArgs g) 
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   const int64_t A0 = (int64_t)blockIdx.y * TS, B0 = (int64_t)blockIdx.x * TS;
+  // 16 bytes per lane both ways when rows of C and of C^T start on 16-byte boundaries (even nb; the scratch pitch is even)
+  const bool wide = ((g.nb & 1) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && A0 + TS <= g.na && B0 + TS <= g.nb;
+  if (wide) {
+    const int tp = threadIdx.x & 31, ty = threadIdx.x >> 5;  // pair index along the contiguous direction, row group
+#pragma unroll
+    for (int i = ty; i < TS; i += 8) {
+      const int64_t A = A0 + i;
+      const double2 v = *reinterpret_cast<const double2*>(C + A * g.nb + B0 + 2 * tp);
+      tile[i * (TS + 1) + 2 * tp] = v.x;
+      tile[i * (TS + 1) + 2 * tp + 1] = v.y;
+      if (g.cs) {
+        const int ca = g.cidx_a[A];
+        if (ca >= 0) {
+          const int cb0 = g.cidx_b[B0 + 2 * tp], cb1 = g.cidx_b[B0 + 2 * tp + 1];
+          if (cb0 >= 0) g.cs[(int64_t)ca * g.mb + cb0] = v.x;
+          if (cb1 >= 0) g.cs[(int64_t)ca * g.mb + cb1] = v.y;
+        }
+      }
+    }
+    if (!g.ct) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < TS; j += 8)
+      *reinterpret_cast<double2*>(g.ct + (B0 + j) * g.ld_t + A0 + 2 * tp) =
+          make_double2(tile[(2 * tp) * (TS + 1) + j], tile[(2 * tp + 1) * (TS + 1) + j]);
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t B = B0 + tx;
   const int cb = (g.cs && B < g.nb) ? g.cidx_b[B] : -1;
@@ -184,7 +212,7 @@ __global__ void __launch_bounds__(256) k_lists_transpose(const ListTransArgs g) 
 #pragma unroll 4
   for (int j = ty; j < TS; j += 4) {
     const int64_t Bo = B0 + j, Ao = A0 + tx;
-    if (Bo < g.nb && Ao < g.na) g.ct[Bo * g.na + Ao] = tile[tx * (TS + 1) + j];
+    if (Bo < g.nb && Ao < g.na) g.ct[Bo * g.ld_t + Ao] = tile[tx * (TS + 1) + j];
   }
 }
 
@@ -239,7 +267,7 @@ struct ListsArgs {
   GPtr<const double> in;      // [n_r][n_c]: the matrix whose rows are staged (C for the beta side, C^T for the alpha side)
   GPtr<double> out;           // direct: [n_r][n_c]; transposed: [n_c][ldo]
   int64_t in_stride, out_stride;  // added per selected vector (vec_index); 0 for scratch operands
-  int64_t n_r, n_c, ldo;
+  int64_t n_r, n_c, ldo, in_ld;   // in_ld: pitch of the input rows (n_c, or the even pitch of the C^T scratch)
   int transposed_out;         // alpha side: the result goes back in C's layout, G rows (= G consecutive doubles) at a time
   int addin;                  // beta side: out already holds the alpha side's part of the same element
   int diag;                   // beta side: diagonal term
@@ -390,7 +418,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
   double* __restrict__ img = smem;
   const double* __restrict__ row;
   {
-    const double* rp = M + r0 * n_c;
+    const double* rp = M + r0 * g.in_ld;
     const unsigned sh = (unsigned)((reinterpret_cast<uintptr_t>(rp) >> 3) & 1u);
     const unsigned n2 = ((unsigned)n_c + sh + 1u) >> 1;
     for (unsigned b = tid; b < n2; b += NT) reinterpret_cast<double2*>(img)[b] = ldu2(rp - sh, b);
@@ -418,7 +446,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     unsigned sh_n = 0, n2_n = 0;
     const double* __restrict__ nimg = M;
     if (more) {
-      const double* nrow = M + (r + 1) * n_c;  // (uniform base + 32-bit lane offset: saddr loads)
+      const double* nrow = M + (r + 1) * g.in_ld;  // (uniform base + 32-bit lane offset: saddr loads)
       sh_n = (unsigned)((reinterpret_cast<uintptr_t>(nrow) >> 3) & 1u);
       n2_n = ((unsigned)n_c + sh_n + 1u) >> 1;
       nimg = nrow - sh_n;
@@ -542,20 +570,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     LCLK_MARK(1);
     __syncthreads();
     LCLK_MARK(2);
-    // -- 4. the next row moves in; the finished row moves out (coalesced)
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < NPF2; ++u)
-        if ((unsigned)(u * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(u * NT))
-          reinterpret_cast<double2*>(img)[tid + u * NT] = pf[u];
-      for (unsigned b = tid + NPF2 * NT; b < n2_n; b += NT)  // (rows beyond 2 NPF2 NT columns)
-        reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * n_c - sh_n, b);
-      row = img + sh_n;
-      if (lists && tid < g.nnorb) jr[tid] = pj;
-      if (lists)
-        for (int i = tid + NT; i < g.nnorb; i += NT) jr[i] = g.jrow[(r + 1) * g.nnorb + i];  // (nnorb > NT: norb > 31 at CPL 2)
-    }
-    LCLK_MARK(3);
+    // -- 4. the finished row moves out (coalesced)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int lc = c * NT + tid;  // natural-order column of the block
@@ -572,21 +587,56 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
         if (BETA) {
           stu(out + r * n_c + c0, (unsigned)lc, v);
         } else {
-          const int gi = (int)((r - r0) % g.G);
-          tile[gi * LT + lc] = v;
-          if (gi == g.G - 1 || !more) {
-            // G (or the last few) consecutive rows of this column = consecutive doubles of the result in C's layout
-            const int cnt = gi + 1;
-            double* __restrict__ dstc = out + (int64_t)(c0 + lc) * g.ldo + (r - gi);
-            if ((reinterpret_cast<uintptr_t>(dstc) & 15) == 0 && (cnt & 1) == 0) {
-              for (int i = 0; i < cnt; i += 2)
-                *reinterpret_cast<double2*>(dstc + i) = make_double2(tile[i * LT + lc], tile[(i + 1) * LT + lc]);
-            } else {
-              for (int i = 0; i < cnt; ++i) dstc[i] = tile[i * LT + lc];
-            }
+          tile[(int)((r - r0) % g.G) * LT + lc] = v;
+        }
+      }
+    }
+    if (!BETA) {
+      const int gi = (int)((r - r0) % g.G);
+      if ((gi == g.G - 1 || !more) && !(g.dbg & 16)) {  // (uniform)
+        // G (or the last few) consecutive rows of a column = consecutive doubles of the result in C's layout.  The
+        // pieces of one column's run go out from ADJACENT lanes (16 bytes each), so that a store instruction touches
+        // 64 / pieces runs instead of 64: lane-per-column stores -- every lane its own run, four instructions each --
+        // were what the whole alpha pass waited for (1.5 ms of it at 10^4 x 10^4 with nothing else left in the loop)
+        const int cnt = gi + 1;
+        const int64_t rbase = r - gi;
+        const bool even = ((g.ldo & 1) == 0) && ((cnt & 1) == 0) &&
+                          ((((reinterpret_cast<uintptr_t>(out) >> 3) + (uint64_t)c0 * (uint64_t)g.ldo + (uint64_t)rbase) & 1) == 0);
+        if (even) {
+          __syncthreads();
+          const int pieces = cnt >> 1;
+          for (int i = tid; i < ncol * pieces; i += NT) {
+            const int lc = i / pieces, pc = i - lc * pieces;
+            lists_d2 v2;
+            v2[0] = tile[(2 * pc) * LT + lc];
+            v2[1] = tile[(2 * pc + 1) * LT + lc];
+            lists_d2* dst = reinterpret_cast<lists_d2*>(out + (int64_t)(c0 + lc) * g.ldo + rbase + 2 * pc);
+            if (g.dbg & 8) *dst = v2;
+            else __builtin_nontemporal_store(v2, dst);  // (half lines that the next flush completes: keep them out of the L2)
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int lc = c * NT + tid;
+            if (lc < ncol)
+              for (int i = 0; i < cnt; ++i) out[(int64_t)(c0 + lc) * g.ldo + rbase + i] = tile[i * LT + lc];
           }
         }
       }
+    }
+    LCLK_MARK(3);
+    // -- 5. the next row moves in -- behind the epilogue: its requests have had the epilogue's time as well to land
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NPF2; ++u)
+        if ((unsigned)(u * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(u * NT))
+          reinterpret_cast<double2*>(img)[tid + u * NT] = pf[u];
+      for (unsigned b = tid + NPF2 * NT; b < n2_n; b += NT)  // (rows beyond 2 NPF2 NT columns)
+        reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * g.in_ld - sh_n, b);
+      row = img + sh_n;
+      if (lists && tid < g.nnorb) jr[tid] = pj;
+      if (lists)
+        for (int i = tid + NT; i < g.nnorb; i += NT) jr[i] = g.jrow[(r + 1) * g.nnorb + i];  // (nnorb > NT: norb > 31 at CPL 2)
     }
     LCLK_MARK(4);
     __syncthreads();
@@ -741,8 +791,12 @@ bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1
   if (!lds_plan(na, c->nnorb, c->lds_bytes, true, s->lds_a) || !lds_plan(nb, c->nnorb, c->lds_bytes, false, s->lds_b))
     return false;
   if (forced != 1) {
-    // large sets with short, even lists (the register-resident part must hold nearly all of them)
-    if (na < 3000 || nb < 3000) return false;
+    // Rows so long that k_sigma_rows keeps only two of them in LDS (8 500 strings per spin and more), lists short and
+    // even enough for the registers to hold nearly all of them.  Measured on the MI355X (profiles/r04, uniform N x N,
+    // ms per sigma, list passes | k_sigma_rows): 10 000: 3.34 | 3.85; 6 000: 0.90 | 0.81; 4 000: 0.35 | 0.29 -- a list
+    // pass costs ~2.5 us per staged row whatever the row's length (one row in flight per CU: the next row's requests
+    // have only this row's evaluation to land in), which R >= 3 rows per workgroup amortise better.
+    if (na < 8500 || nb < 8500) return false;
     if (tot[0] + tot[1] > 16 * na || tot[2] + tot[3] > 16 * nb) return false;
     if (tot[0] > 2 * na || tot[2] > 2 * nb) return false;
   }
@@ -817,7 +871,7 @@ int lists_build(sqd_ctx* c) {
       SQD_HIP_CHECK(hipGetLastError());
     }
   }
-  SQD_TRY(s->ct.reserve((size_t)c->na * c->nb * 8));
+  SQD_TRY(s->ct.reserve((size_t)((c->na + 1) & ~int64_t(1)) * c->nb * 8));  // (even pitch: 16-byte aligned rows)
   const int64_t ma = s->side[0].m, mb = s->side[1].m;
   SQD_TRY(s->cs.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
   SQD_TRY(s->t4.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
@@ -904,6 +958,7 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     t.na = na;
     t.nb = nb;
     t.c_stride = in_stride;
+    t.ld_t = (na + 1) & ~int64_t(1);
     t.cidx_a = s->side[0].cidx.as<int32_t>();
     t.cidx_b = s->side[1].cidx.as<int32_t>();
     t.cs = cross ? s->cs.as<double>() : nullptr;
@@ -966,6 +1021,7 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     fill_pass_args(c, s, 0, mode, spin, ss, shift, &g);
     g.in = s->ct.as<double>();
     g.in_stride = 0;
+    g.in_ld = (na + 1) & ~int64_t(1);
     g.out = d_sigma;
     g.out_stride = out_stride;
     g.ldo = nb;
@@ -980,6 +1036,7 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     fill_pass_args(c, s, 1, mode, spin, ss, shift, &g);
     g.in = d_c;
     g.in_stride = in_stride;
+    g.in_ld = nb;
     g.out = d_sigma;
     g.out_stride = out_stride;
     g.ldo = nb;

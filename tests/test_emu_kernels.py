@@ -223,8 +223,8 @@ def test_emu_enqueue_hook(emu_lib):
 def test_emu_lists_kernel(emu_lib, monkeypatch):
     # SQD_SIGMA_LISTS=1 forces the list passes (sqd_lists.hip: link lists in registers, rows of C / C^T through LDS,
     # transpose + compact single x single kernel) that 10^4 x 10^4 sets take by default.  Small cases reach every
-    # branch: lists longer than the registers' 24 links and more than 4 single links per string (tails in the LDS
-    # overflow tables: 40 of the 70 strings of (4e,8o) have ~30 links, ~9 of them singles), ragged row chunks, odd row
+    # branch: lists longer than the registers' 16 links and more than 4 single links per string (tails in the LDS
+    # overflow tables: 30 of the 70 strings of (4e,8o) have ~22 links, ~7 of them singles), ragged row chunks, odd row
     # lengths (unaligned tile stores), nalpha != nbeta, all operator forms, a Davidson solve and the observables
     monkeypatch.setenv("SQD_SIGMA_LISTS", "1")
 
@@ -235,12 +235,13 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
             return ctx.sigma_kernel() == "k_sigma_lists", ctx.link_counts(0), ctx.link_counts(1)
 
     cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (6, (3, 2), 13, 9, 5, False),
-             (5, (1, 4), 5, 4, 9, False), (8, (4, 4), 40, 38, 17, False)]
+             (5, (1, 4), 5, 4, 9, False), (8, (4, 4), 30, 28, 17, False),
+             (16, (4, 4), 66, 70, 23, False)]  # (the last one: full 64 x 64 tiles in the 16-byte transpose path)
     for case in cases:
         ok, la, lb = selected(*case)
         assert ok, case
     _, la, lb = selected(*cases[-1])
-    assert la[0] + la[1] > 24 * 40 and la[0] > 4 * 40  # the overflow tables are really in use
+    assert la[0] + la[1] > 16 * 30 and la[0] > 4 * 30  # the overflow tables are really in use
     run_full_parity(emu_lib, *cases[0], variants=False)
     for case in cases[1:]:
         run_operator_parity(emu_lib, *case)
