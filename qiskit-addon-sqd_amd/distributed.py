@@ -181,6 +181,7 @@ def solve_sci_batch_distributed(
     table = host_table.numpy()
     local: dict[int, SCIResult] = {}
     resident = None  # (context, position of each local batch in its batched solve)
+    failure = None   # an exception of this rank's solves: raised behind the exchange, so that no rank is left waiting
 
     # ---- independent solves, no communication.  Their records land in the collective's buffer by themselves.
     if local_solver is None and compute_rdms is not True and kwargs.get("ci0") is None:
@@ -192,12 +193,21 @@ def solve_sci_batch_distributed(
                 ctx.use_stream(stream.cuda_stream)  # solver kernels and the collective on ONE stream
                 ctx._on_stream = stream.cuda_stream
         dev_table.zero_()
+        host_formed = False  # (every rank, with or without a batch of its own: the records are the kernels')
+        rec_host = None
         if mine:
             import weakref
 
             from . import fermion as _F
 
-            ctx.set_record_out(dev_table.data_ptr() + 8 * rank * width, world * width)
+            if on_gpu:
+                ctx.set_record_out(dev_table.data_ptr() + 8 * rank * width, world * width)
+            else:
+                # a CPU backend (gloo): the collective's table is pageable host memory, which the observables kernel of a
+                # real GPU must not be handed -- it writes its records into page-locked memory, copied over below
+                rec_host = _capi.pinned_empty((nb, width))
+                rec_host[:] = 0.0
+                ctx.set_record_out(rec_host.ctypes.data + 8 * rank * width, world * width)
             if on_gpu and _HOOK_ON:
                 # the exchange is enqueued by the solve itself, right behind its last kernel (before its final host
                 # wait): the stream does not idle while this thread gets back from the native call and into RCCL
@@ -218,16 +228,34 @@ def solve_sci_batch_distributed(
                 else:
                     out = ctx.solve_batch([ci_strings[i] for i in mine], spin_sq=spin_sq, shift=shift, spin_square=False,
                                           fetch="none", **dk)
+            except Exception as exc:  # noqa: BLE001 -- re-raised behind the exchange
+                failure, out = exc, None
             finally:
                 ctx.set_record_out(None)
                 if on_gpu and _HOOK_ON:
                     ctx.set_enqueue_hook(None)
-            ctx.raise_hook_error()
-            resident = (ctx, {i: k for k, i in enumerate(mine)}, len(mine) == 1)
-            _F._TLS.stats, _F._TLS.batch_stats = out["stats"][0], out["stats"]
-            for k, i in enumerate(mine):
-                if out["nelec"][k] != nelec:
-                    raise ValueError(f"nelec={nelec} does not match the Hamming weights {out['nelec'][k]} of the CI strings")
+            if failure is None:
+                try:
+                    ctx.raise_hook_error()
+                except Exception as exc:  # noqa: BLE001
+                    failure, out = exc, None
+            if failure is None:
+                for k in range(len(mine)):
+                    if out["nelec"][k] != nelec:
+                        failure = ValueError(f"nelec={nelec} does not match the Hamming weights {out['nelec'][k]} of the CI strings")
+                        break
+            if rec_host is not None and failure is None:
+                table[mine, :] = rec_host[mine, :]
+            if failure is not None:
+                # poison this rank's records: every rank sees the NaN behind the all-reduce and raises with this one
+                if on_gpu:
+                    dev_table[mine, 0] = float("nan")
+                else:
+                    table[mine, 0] = np.nan
+            else:
+                resident = (ctx, {i: k for k, i in enumerate(mine)}, len(mine) == 1)
+                _F._TLS.stats, _F._TLS.batch_stats = out["stats"][0], out["stats"]
+            for k, i in enumerate(mine if failure is None else []):
                 sa, sb = ci_strings[i]
                 amps = out["amps"][k]
                 if amps is None:
@@ -236,15 +264,21 @@ def solve_sci_batch_distributed(
                         amps.single = True
                     ctx._deferred.append(weakref.ref(amps))
                 state = SCIState(amps, np.asarray(sa), np.asarray(sb), norb=norb, nelec=nelec)
-                local[i] = SCIResult(float(out["energy"][k]), state, (out["occ_a"][k], out["occ_b"][k]),
-                                     _lazy_rdms=(compute_rdms == "lazy"))
+                local[i] = SCIResult._make(float(out["energy"][k]), state, (out["occ_a"][k], out["occ_b"][k]),
+                                           lazy=(compute_rdms == "lazy"))
     else:
         # a caller-supplied solver (or eager RDMs / a start vector): the records are formed on the host
         solver = local_solver or solve_sci
+        host_formed = True
         table[:] = 0.0
         for i in mine:
-            res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
-                         device=device, compute_rdms=compute_rdms, **kwargs)  # fmt: skip
+            try:
+                res = solver(ci_strings[i], one_body_tensor, two_body_tensor, norb=norb, nelec=nelec, spin_sq=spin_sq,
+                             device=device, compute_rdms=compute_rdms, **kwargs)  # fmt: skip
+            except Exception as exc:  # noqa: BLE001 -- re-raised behind the exchange
+                failure = exc
+                table[i, 0] = np.nan
+                break
             local[i] = res
             # a record that results_from_record maps back to exactly these numbers: c.c = 1, no penalty left to apply
             table[i, 0] = res.energy
@@ -253,7 +287,6 @@ def solve_sci_batch_distributed(
             table[i, 4 + norb : 4 + 2 * norb] = res.orbital_occupancies[1]
         if on_gpu:
             dev_table.copy_(host_table, non_blocking=True)
-    host_formed = resident is None
 
     # ---- the path's single exchange: all-reduce(sum) of the per-batch records, enqueued behind the solves
     t_x = time.perf_counter()
@@ -264,6 +297,12 @@ def solve_sci_batch_distributed(
     else:
         dist.all_reduce(host_table, op=dist.ReduceOp.SUM, group=group)
     table = table.copy()
+    if failure is not None:
+        raise failure
+    if np.isnan(table[:, 0]).any():
+        bad = [int(i) for i in np.flatnonzero(np.isnan(table[:, 0]))]
+        raise RuntimeError(f"solve_sci_batch_distributed: the solves of batches {bad} failed on ranks "
+                           f"{sorted({i % world for i in bad})} (their own exceptions are raised there)")
     energies = np.empty(nb)
     occs = []
     for i in range(nb):
@@ -320,12 +359,12 @@ def solve_sci_batch_distributed(
         sa, sb = ci_strings[i]
         if i in local:
             r = local[i]
-            raw = lambda name: object.__getattribute__(r, name)  # noqa: E731  (do not trigger lazy RDMs)
-            out_list.append(SCIResult(float(energies[i]), r.sci_state, occ, rdm1=raw("rdm1"), rdm2=raw("rdm2"),
-                                      _lazy_rdms=raw("_lazy_rdms")))
+            raw = r.__dict__.get  # (do not trigger lazy RDMs)
+            out_list.append(SCIResult._make(float(energies[i]), r.sci_state, occ, rdm1=raw("rdm1"), rdm2=raw("rdm2"),
+                                            lazy=r._is_lazy()))
         elif i in shipped:
             state = SCIState(shipped[i], np.asarray(sa), np.asarray(sb), norb=norb, nelec=nelec)
-            out_list.append(SCIResult(float(energies[i]), state, occ, _lazy_rdms=True))
+            out_list.append(SCIResult._make(float(energies[i]), state, occ, lazy=True))
         else:
             state = SCIState(_RemoteAmplitudes(i, (len(sa), len(sb)), i % world), np.asarray(sa), np.asarray(sb),
                              norb=norb, nelec=nelec)

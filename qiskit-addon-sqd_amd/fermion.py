@@ -198,12 +198,17 @@ class SCIState:
     """The numbers of alpha and beta electrons."""
 
     def __post_init__(self):
-        amps = object.__getattribute__(self, "amplitudes")
+        d = self.__dict__
+        amps = d["amplitudes"]
         if isinstance(amps, _DeferredAmplitudes):
+            # a state still on the device: the attribute stays UNSET until it is first read -- ``__getattr__`` below is
+            # only consulted for attributes that are missing, so no other attribute access pays a Python-level hook
             shape = amps.shape
+            del d["amplitudes"]
+            d["_deferred_amplitudes"] = amps
         else:
             amps = np.asarray(amps)
-            object.__setattr__(self, "amplitudes", amps)
+            d["amplitudes"] = amps  # (frozen dataclass: through the instance dictionary)
             shape = amps.shape
         if shape != (len(self.ci_strs_a), len(self.ci_strs_b)):
             raise ValueError(
@@ -211,12 +216,19 @@ class SCIState:
                 f"but got {shape}"
             )
 
-    def __getattribute__(self, name):
-        value = object.__getattribute__(self, name)
-        if name == "amplitudes" and isinstance(value, _DeferredAmplitudes):
-            value = value.fetch()
-            object.__setattr__(self, "amplitudes", value)  # frozen dataclass: cache through object
-        return value
+    def __getattr__(self, name):  # reached only when ``name`` is not set on the instance
+        if name == "amplitudes":
+            pending = self.__dict__.get("_deferred_amplitudes")
+            if pending is not None:
+                value = pending.fetch() if isinstance(pending, _DeferredAmplitudes) else np.asarray(pending)
+                self.__dict__["amplitudes"] = value
+                self.__dict__.pop("_deferred_amplitudes", None)
+                return value
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
+    def _pending_amplitudes(self):
+        """The not-yet-fetched device-resident amplitudes of this state, or None (never triggers a fetch)."""
+        return self.__dict__.get("_deferred_amplitudes")
 
     def save(self, filename):
         """Save the SCIState object to an .npz file (same keys as the reference, ``fermion.py:90-99``)."""
@@ -291,18 +303,36 @@ class SCIResult:
     rdm2: np.ndarray | None = None
     """Spin-summed 2-particle reduced density matrix."""
 
-    _lazy_rdms: bool = field(default=False, repr=False, compare=False)
-    """True: ``rdm1`` / ``rdm2`` are computed from ``sci_state`` on first access.  The SQD loop never reads
-    them (reference ``fermion.py:577-622`` uses energy, occupancies and the state), and the norb^4 ``rdm2``
-    costs more than the whole solve at the sizes of one subsample batch."""
+    # The five fields above are the reference's (``dataclasses.fields`` / ``astuple`` / ``replace`` agree with it).  A
+    # result made by ``_make(..., lazy=True)`` leaves ``rdm1`` / ``rdm2`` UNSET and computes them from ``sci_state`` when
+    # first read (``__getattr__`` is only consulted for missing attributes): the SQD loop never reads them (reference
+    # ``fermion.py:577-622`` uses energy, occupancies and the state), and the norb^4 ``rdm2`` costs more than the whole
+    # solve at the sizes of one subsample batch.
+    @classmethod
+    def _make(cls, energy, sci_state, orbital_occupancies, rdm1=None, rdm2=None, lazy: bool = False) -> "SCIResult":
+        res = cls(energy, sci_state, orbital_occupancies, rdm1, rdm2)
+        if lazy:
+            d = res.__dict__
+            for name in ("rdm1", "rdm2"):
+                if d.get(name) is None:
+                    d.pop(name, None)
+            d["_lazy_rdms"] = True
+        return res
 
-    def __getattribute__(self, name):
-        value = object.__getattribute__(self, name)
-        if value is None and name in ("rdm1", "rdm2") and object.__getattribute__(self, "_lazy_rdms"):
-            state = object.__getattribute__(self, "sci_state")
-            value = state.rdm(1 if name == "rdm1" else 2, spin_summed=True)
-            object.__setattr__(self, name, value)  # frozen dataclass: cache through object
-        return value
+    def _is_lazy(self) -> bool:
+        return bool(self.__dict__.get("_lazy_rdms", False))
+
+    def __getattr__(self, name):  # reached only when ``name`` is not set on the instance
+        if name in ("rdm1", "rdm2") and self.__dict__.get("_lazy_rdms"):
+            value = self.sci_state.rdm(1 if name == "rdm1" else 2, spin_summed=True)
+            self.__dict__[name] = value
+            return value
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
+
+# (the dataclass leaves its defaults behind as CLASS attributes; with them in place a missing instance attribute would be
+# found there -- None -- and ``__getattr__`` never asked.  The generated ``__init__`` keeps its own copy of the defaults.)
+del SCIResult.rdm1, SCIResult.rdm2
 
 
 # --------------------------------------------------------------------------- string formatting
@@ -364,7 +394,11 @@ def _davidson_kwargs(kwargs: dict) -> dict:
         raise TypeError(f"unexpected keyword argument(s) for kernel_fixed_space: {sorted(unknown)}")
     nroots = kwargs.get("nroots")
     if nroots not in (None, 1):
-        raise NotImplementedError("only nroots=1 is supported")
+        # the reference forwards nroots to pyscf (fermion.py:722) but everything downstream of that call reads ONE
+        # state (amplitudes -> SCIState, RDMs, energy: :724-742): the lowest root is what a caller gets here too
+        import warnings
+
+        warnings.warn(f"nroots={nroots}: only the lowest root is computed and returned", stacklevel=3)
     out = {}
     for k in ("tol", "tol_residual", "lindep", "max_cycle", "max_space"):
         if kwargs.get(k) is not None:
@@ -519,8 +553,8 @@ def _solve_sci_batched(ci_strings, one_body_tensor, two_body_tensor, nelec, spin
                 amps = _DeferredAmplitudes(ctx, k, (len(strs_a), len(strs_b)), out["generation"])
                 ctx._deferred.append(weakref.ref(amps))
             state = SCIState(amplitudes=amps, ci_strs_a=np.asarray(strs_a), ci_strs_b=np.asarray(strs_b), norb=norb, nelec=want)
-            results[i] = SCIResult(float(out["energy"][k]), state, orbital_occupancies=(out["occ_a"][k], out["occ_b"][k]),
-                                   _lazy_rdms=(compute_rdms == "lazy"))
+            results[i] = SCIResult._make(float(out["energy"][k]), state, (out["occ_a"][k], out["occ_b"][k]),
+                                         lazy=(compute_rdms == "lazy"))
             stats[i] = out["stats"][k]
     best = min(range(len(results)), key=lambda i: results[i].energy)
     _TLS.stats = stats[best]
@@ -600,8 +634,7 @@ def solve_sci(
         norb=norb,
         nelec=tuple(int(x) for x in nelec),
     )
-    return SCIResult(energy, sci_state, orbital_occupancies=occupancies, rdm1=dm1, rdm2=dm2,
-                     _lazy_rdms=(compute_rdms == "lazy"))
+    return SCIResult._make(energy, sci_state, occupancies, rdm1=dm1, rdm2=dm2, lazy=(compute_rdms == "lazy"))
 
 
 def solve_fermion(

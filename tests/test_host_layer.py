@@ -102,9 +102,16 @@ def test_python_api_through_emulator(emu_backend):
     assert abs(np.trace(res.rdm1) - 5) < 1e-9 and res.rdm2.shape == (6,) * 4
     # default: RDMs are built on first access; compute_rdms=True builds them in the call and contracts
     # the energy from them exactly as the reference does -- same numbers either way
-    assert object.__getattribute__(solve_sci((sa, sb), h1, eri, norb, nelec), "rdm2") is None
+    lazy = solve_sci((sa, sb), h1, eri, norb, nelec)
+    assert lazy._is_lazy() and "rdm2" not in lazy.__dict__
     eager = solve_sci((sa, sb), h1, eri, norb, nelec, compute_rdms=True)
-    assert object.__getattribute__(eager, "rdm2") is not None
+    assert eager.__dict__.get("rdm2") is not None
+    # the dataclass is the reference's: five fields (fermion.py:142-159), whatever the laziness
+    import dataclasses
+    assert [f.name for f in dataclasses.fields(SCIResult)] == ["energy", "sci_state", "orbital_occupancies", "rdm1", "rdm2"]
+    assert len(dataclasses.astuple(lazy)) == 5 and dataclasses.replace(eager, energy=0.0).energy == 0.0
+    with pytest.warns(UserWarning, match="lowest root"):
+        assert abs(solve_sci((sa, sb), h1, eri, norb, nelec, nroots=2).energy - res.energy) < 1e-10
     assert abs(eager.energy - res.energy) < 1e-10
     assert np.allclose(eager.rdm1, res.rdm1, atol=1e-12) and np.allclose(eager.rdm2, res.rdm2, atol=1e-12)
     assert np.allclose(res.sci_state.orbital_occupancies()[0], res.orbital_occupancies[0], atol=1e-12)
