@@ -98,15 +98,114 @@ def freeze_integrals(hcore, eri) -> tuple[np.ndarray, np.ndarray]:
     return out[0], out[1]
 
 
-def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int):
-    return (device, int(np.asarray(hcore).shape[0]), int(np.asarray(eri).size), _full_hash(hcore), _full_hash(eri))
+def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int, digests=None):
+    if digests is None:
+        digests = (_full_hash(hcore), _full_hash(eri))
+    return (device, int(np.asarray(hcore).shape[0]), int(np.asarray(eri).size), digests[0], digests[1])
 
 
-def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int = 0) -> _capi.Context:
+# ---- writeable integral tensors (what a reference user passes: plain numpy arrays).  They may have been edited in place
+# since the last call, so their context can only be trusted once every byte has been hashed again -- a full xxh3 pass over
+# the 6.5 MB of norb = 30 per call, most of the time of a 0.2 ms solve.  Instead of waiting for it, the call SPECULATES:
+# tensors with the identity (object, address, size) of the previous call get the previous call's context at once, the
+# solve is launched, and a worker thread hashes the bytes meanwhile (the native call runs without the GIL).  When the
+# solve returns the digests are compared; a mismatch -- the caller did edit the tensors -- discards the result and solves
+# again on the right context.  Never a wrong answer, and no hashing on the critical path when nothing changed.
+_SPEC_LOCK = threading.Lock()
+_SPEC: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of (hcore, eri, device, slot) -> (context key, hcore, eri)
+_SPEC_MAX = 4
+_HASH_QUEUE = None
+
+
+class _HashJob:
+    """Digests of two arrays, computed on the worker thread."""
+
+    __slots__ = ("arrays", "digests", "done")
+
+    def __init__(self, arrays):
+        self.arrays, self.digests, self.done = arrays, None, threading.Event()
+
+    def result(self):
+        self.done.wait()
+        return self.digests
+
+
+def _hash_worker(q):
+    while True:
+        job = q.get()
+        try:
+            job.digests = tuple(_full_hash(a) for a in job.arrays)
+        except BaseException:  # noqa: BLE001 -- the caller falls back to the verified path
+            job.digests = None
+        job.done.set()
+
+
+def _submit_hash(arrays) -> _HashJob:
+    global _HASH_QUEUE
+    if _HASH_QUEUE is None:
+        import queue
+
+        with _SPEC_LOCK:
+            if _HASH_QUEUE is None:
+                q = queue.SimpleQueue()
+                threading.Thread(target=_hash_worker, args=(q,), daemon=True, name="sqd-hash").start()
+                _HASH_QUEUE = q
+    job = _HashJob(arrays)
+    _HASH_QUEUE.put(job)
+    return job
+
+
+def _identity(hcore, eri, device, slot):
+    h, e = np.asarray(hcore), np.asarray(eri)
+    return (id(hcore), h.__array_interface__["data"][0], h.size, id(eri), e.__array_interface__["data"][0], e.size,
+            device, slot)
+
+
+def _run_on_context(hcore, eri, device, slot, fn):
+    """``fn(ctx)`` on the solver context of this Hamiltonian; returns (result, ctx).  Immutable tensors are recognised by
+    identity (``_full_hash``'s memo); writeable ones take the speculative path described above."""
+    e_arr = np.asarray(eri)
+    if e_arr.size <= _HASH_SMALL or (e_arr.flags.c_contiguous and e_arr.dtype == np.float64 and _immutable(e_arr)):
+        ctx = _get_context(hcore, eri, device, slot)  # a full hash costs microseconds, or nothing
+        return fn(ctx), ctx
+    ident = _identity(hcore, eri, device, slot)
+    with _SPEC_LOCK:
+        hit = _SPEC.get(ident)
+        ctx = None
+        if hit is not None and hit[1] is hcore and hit[2] is eri:
+            with _CTX_LOCK:
+                ctx = _CTX_CACHE.get(hit[0])
+    digests = None
+    if ctx is not None:
+        job = _submit_hash((hcore, eri))
+        try:
+            out = fn(ctx)
+        except Exception:  # noqa: BLE001 -- a failure on a context that may be the wrong one: decide below
+            out = _FAILED
+        digests = job.result()
+        if digests is not None and _ham_key(hcore, eri, device, digests) + (slot,) == hit[0] and out is not _FAILED:
+            return out, ctx
+        if digests is not None and _ham_key(hcore, eri, device, digests) + (slot,) == hit[0]:
+            return fn(ctx), ctx  # (the right context after all: let the exception surface from a clean call)
+    if digests is None:
+        digests = (_full_hash(hcore), _full_hash(eri))
+    ctx = _get_context(hcore, eri, device, slot, digests=digests)
+    with _SPEC_LOCK:
+        _SPEC[ident] = (_ham_key(hcore, eri, device, digests) + (slot,), hcore, eri)
+        _SPEC.move_to_end(ident)
+        while len(_SPEC) > _SPEC_MAX:
+            _SPEC.popitem(last=False)
+    return fn(ctx), ctx
+
+
+_FAILED = object()
+
+
+def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int = 0, digests=None) -> _capi.Context:
     """Context (device-resident integral tables + arenas) for this Hamiltonian, cached so that the
     SQD loop's repeated calls with the same integrals do not re-upload or re-pack them.  ``slot``
     distinguishes the contexts of concurrent host threads on one device (a context is not re-entrant)."""
-    key = _ham_key(hcore, eri, device) + (slot,)
+    key = _ham_key(hcore, eri, device, digests) + (slot,)
     with _CTX_LOCK:
         ctx = _CTX_CACHE.pop(key, None)
         if ctx is None:
@@ -120,6 +219,8 @@ def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int 
 
 
 def clear_context_cache() -> None:
+    with _SPEC_LOCK:
+        _SPEC.clear()
     with _CTX_LOCK:
         while _CTX_CACHE:
             _, old = _CTX_CACHE.popitem()
@@ -610,10 +711,11 @@ def solve_sci(
     """
     one_body_tensor = np.asarray(one_body_tensor, dtype=np.float64)
     norb, _ = one_body_tensor.shape
-    ctx = _get_context(one_body_tensor, two_body_tensor, device, _slot)
     strs_a, strs_b = ci_strings
     eager = compute_rdms is True
-    amps, _stats, obs = _solve(ctx, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not eager, spin_square=False)
+    (amps, _stats, obs), ctx = _run_on_context(
+        one_body_tensor, two_body_tensor, device, _slot,
+        lambda c: _solve(c, (strs_a, strs_b), spin_sq, 0.2, kwargs, observables=not eager, spin_square=False))
     if tuple(int(x) for x in nelec) != ctx.nelec:
         raise ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {ctx.nelec} of the CI strings")
     if eager:
@@ -662,10 +764,10 @@ def solve_fermion(
 
     hcore = np.asarray(hcore, dtype=np.float64)
     norb = hcore.shape[0]
-    ctx = _get_context(hcore, eri, device)
     # one native call (sqd_solve): Davidson, then <c|H|c> (the quantity the reference rebuilds from
     # rdm1/rdm2, :825-827), <S^2> (:830) and the rdm1s diagonals (:821-822) while the amplitudes travel
-    amps, _stats, (e_sci, spin_squared, occ_a, occ_b) = _solve(ctx, ci_strs, spin_sq, shift, kwargs)
+    (amps, _stats, (e_sci, spin_squared, occ_a, occ_b)), ctx = _run_on_context(
+        hcore, eri, device, 0, lambda c: _solve(c, ci_strs, spin_sq, shift, kwargs))
     num_up, num_dn = ctx.nelec
     avg_occupancy = (occ_a, occ_b)
     sci_state = SCIState(

@@ -156,3 +156,34 @@ def test_recover_configurations_deprecated_flat_occupancies():
     with pytest.warns(DeprecationWarning):
         m, p = recover_configurations(mat, probs, flat, 2, 2, rand_seed=11)
     assert np.array_equal(m, ref_m) and np.array_equal(p, ref_p)
+
+
+def test_writeable_integrals_speculation_is_safe(emu_backend):
+    """Plain (writeable) numpy integrals -- the reference user's call: the second call with the same array objects takes
+    the previous call's solver context at once and hashes the bytes on a worker thread while the solve runs; an
+    IN-PLACE edit of either tensor between calls must still be seen (the speculative result is discarded and the solve
+    repeated on a fresh context), and going back to the old values finds the old context again."""
+    from qiskit_addon_sqd_amd import fermion as F
+
+    norb, nelec = 14, (3, 3)  # 14^4 elements: above the size below which every call hashes in full anyway
+    h1, eri = O.synthetic_integrals(norb, seed=4)
+    h1, eri = np.array(h1), np.array(eri)
+    assert eri.flags.writeable and eri.size > F._HASH_SMALL
+    sa, sb = O.hf_centred_strings(norb, 3, 12, 1), O.hf_centred_strings(norb, 3, 10, 2)
+
+    def truth(h, e):  # frozen copies: identity-memoised contexts, no speculation
+        return solve_fermion((sa, sb), *F.freeze_integrals(h.copy(), e.copy()))[0]
+
+    e1 = solve_fermion((sa, sb), h1, eri)[0]
+    assert e1 == truth(h1, eri)
+    assert len(F._SPEC) == 1
+    assert solve_fermion((sa, sb), h1, eri)[0] == e1  # speculative hit, digests agree
+    eri *= 1.25  # in place: same object, same address
+    e2 = solve_fermion((sa, sb), h1, eri)[0]
+    assert e2 == truth(h1, eri) and abs(e2 - e1) > 1e-6
+    h1[0, 0] -= 0.5
+    e3 = solve_sci((sa, sb), h1, eri, norb, nelec).energy
+    assert abs(e3 - truth(h1, eri)) < 1e-12 and abs(e3 - e2) > 1e-6
+    h1[0, 0] += 0.5
+    eri /= 1.25
+    assert abs(solve_fermion((sa, sb), h1, eri)[0] - e1) < 1e-10
