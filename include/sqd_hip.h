@@ -105,6 +105,15 @@ int sqd_solution_device_ptr(sqd_ctx* ctx, const double** d_ptr);
 /* Copy the resident solution of the latest sqd_davidson / sqd_solve (called with amps == NULL) to `amps`
  * (na*nb doubles): the state on demand, for callers that leave it on the device by default. */
 int sqd_solution_copy(sqd_ctx* ctx, double* amps);
+/* on != 0: sqd_solve / sqd_solve_strings return as soon as the RESULTS (energy, <S^2>, occupancies, statistics) are on the
+ * host; the amplitudes follow into `amps` -- which must then come from sqd_host_alloc and be at most 64 MB, else the call
+ * behaves as before -- written by a second stage of the observables kernel behind the results (0.8 MB at the headline size
+ * are 24 us of posted PCIe writes: longer than every other kernel of the solve).  stats->state_ticket > 0 says so;
+ * sqd_ctx_state_wait(ctx, ticket) returns when the buffer is complete (a later ticket of the same context implies every
+ * earlier one).  The reference returns the numpy array with the call (fermion.py:724, :820); the Python layer wraps the
+ * pending buffer so that the first READ of SCIState.amplitudes waits.  Default: off. */
+int sqd_ctx_set_async_state(sqd_ctx* ctx, int on);
+int sqd_ctx_state_wait(sqd_ctx* ctx, long long ticket);
 /* on != 0: bracket every following sqd_set_subspace and Davidson run of this context with HIP events, so that
  * sqd_davidson_stats::ms_setup / ms_total are filled.  Off by default: each event record is a bubble in a stream of
  * ~5 us kernels (four records cost ~40 us of a 0.2 ms solve).  The sigma-launch sampling of time_sigma_every is
@@ -179,6 +188,8 @@ typedef struct sqd_davidson_stats {
                                two event records cost by themselves; ms_sigma_kernel minus this is the kernel time */
   int n_eig_solves;    /* device-side projected eigenproblem: shifted solves of the warm-started Rayleigh-quotient iteration */
   int n_eig_fallbacks; /* ... and how many projected problems fell back to the Jacobi solver */
+  long long state_ticket; /* sqd_solve / sqd_solve_strings on a context with sqd_ctx_set_async_state(ctx, 1): > 0 when the
+                             amplitudes were still on their way to `amps` at return -- sqd_ctx_state_wait(ctx, ticket) */
 } sqd_davidson_stats;
 
 void sqd_davidson_default_opts(sqd_davidson_opts* o);

@@ -46,6 +46,8 @@ EXPORTED_SYMBOLS = (
     "sqd_solution_device_ptr",
     "sqd_solution_copy",
     "sqd_ctx_set_phase_timing",
+    "sqd_ctx_set_async_state",
+    "sqd_ctx_state_wait",
     "sqd_get_dims",
     "sqd_link_counts",
     "sqd_single_links",
@@ -112,6 +114,7 @@ class DavidsonStats(C.Structure):
         ("ms_event_overhead", C.c_double),
         ("n_eig_solves", C.c_int),
         ("n_eig_fallbacks", C.c_int),
+        ("state_ticket", C.c_longlong),
     ]
 
 
@@ -151,6 +154,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_solution_device_ptr.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
     lib.sqd_solution_copy.argtypes = [_ctxp, C.c_void_p]
     lib.sqd_ctx_set_phase_timing.argtypes = [_ctxp, C.c_int]
+    lib.sqd_ctx_set_async_state.argtypes = [_ctxp, C.c_int]
+    lib.sqd_ctx_state_wait.argtypes = [_ctxp, C.c_longlong]
     lib.sqd_get_dims.argtypes = [_ctxp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.sqd_link_counts.argtypes = [_ctxp, C.c_int, _i64p, _i64p]
     lib.sqd_single_links.argtypes = [_ctxp, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _dp]
@@ -571,6 +576,17 @@ class Context:
         out = C.c_void_p()
         self._check(self._lib.sqd_solution_device_ptr(self._h, C.byref(out)))
         return int(out.value)
+
+    def set_async_state(self, on: bool):
+        """``solve`` returns when the results are on the host; the amplitudes follow into the (page-locked) result
+        buffer -- ``stats["state_ticket"]`` > 0 then, and ``state_wait(ticket)`` says when they are complete."""
+        if getattr(self, "_async_state", False) != bool(on):
+            self._check(self._lib.sqd_ctx_set_async_state(self._h, 1 if on else 0))
+            self._async_state = bool(on)
+
+    def state_wait(self, ticket: int):
+        if getattr(self, "_h", None) is not None and self._h.value:  # (a closed context has drained its stream)
+            self._check(self._lib.sqd_ctx_state_wait(self._h, int(ticket)))
 
     def set_phase_timing(self, on: bool):
         """Fill ``ms_setup`` / ``ms_total`` of the Davidson statistics (HIP events around the table build and the

@@ -422,6 +422,17 @@ SQD_API int sqd_ctx_set_enqueue_hook(sqd_ctx* c, sqd_enqueue_hook hook, void* us
   c->enqueue_hook_user = user;
   return SQD_OK;
 }
+SQD_API int sqd_ctx_set_async_state(sqd_ctx* c, int on) {
+  CTX_ENTER(c);
+  c->async_state = on != 0;
+  return SQD_OK;
+}
+SQD_API int sqd_ctx_state_wait(sqd_ctx* c, long long ticket) {
+  CTX_ENTER(c);
+  if (ticket <= 0) return SQD_OK;
+  return state_copy_wait(c, ticket);
+}
+
 SQD_API int sqd_ctx_set_phase_timing(sqd_ctx* c, int on) {
   if (!c) return SQD_ERR_INVALID;
   c->phase_timing = on != 0;
@@ -742,15 +753,20 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     form = (o.ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
   }
   const bool need_s2 = (s2 != nullptr) || form != 0;
-  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin));
+  // sqd_ctx_set_async_state: the state follows the results (second stage of the observables kernel); the call returns
+  // with the results and a ticket, sqd_ctx_state_wait(ticket) says when the caller's buffer is complete
+  const bool late = c->async_state && twin != nullptr;
+  SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin, late));
   if (c->enqueue_hook) c->enqueue_hook(c->enqueue_hook_user);  // (the caller's collective, right behind the last kernel)
   if (by_copy && !staged)
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
   if (by_copy) SQD_STREAM_SYNC(c->copy_stream);
   if (staged) std::memcpy(amps, c->h_amps, bytes);
-  SQD_TRY(dev_observables_wait(c));
-  c->stage_pending = false;
-  return solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
+  SQD_TRY(dev_observables_wait(c, /*whole_kernel=*/!late));
+  c->stage_pending = false;  // (the results are there: every upload in front of them in the stream has been consumed)
+  const int rc = solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
+  if (stats) stats->state_ticket = late ? (long long)c->state_seq : 0;
+  return rc;
 }
 
 // sqd_set_subspace + sqd_solve in ONE crossing of the boundary: the body of reference solve_fermion / solve_sci from

@@ -272,6 +272,10 @@ struct sqd_ctx {
   double* d_mail = nullptr;    // the same memory as seen from the device
   int64_t mail_seq = 0;
   int64_t obs_seq = 0;  // sequence number the latest k_observables posts behind its results
+  // sqd_ctx_set_async_state: sqd_solve returns when the RESULTS are on the host; the state follows (written by the
+  // second stage of the observables kernel) and has landed when the mailbox's state word reaches state_seq
+  bool async_state = false;
+  int64_t state_seq = 0;
   int64_t sigma_launches = 0;  // sigma launches of Davidson runs on this context (event sampling)
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
@@ -387,6 +391,7 @@ int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const
 // themselves after every use; a Davidson run also zeroes them, so a kernel aborted mid-way cannot poison later ones.
 int reserve_counters(sqd_ctx* c);
 unsigned* counter_ptr(sqd_ctx* c);
+unsigned* counter2_ptr(sqd_ctx* c);  // a second, independent set (same self-resetting protocol)
 void* dav_state_ptr(sqd_ctx* c);  // DavState* (sqd_davstate.h)
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);
@@ -396,9 +401,12 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host);
 // kernels only, no synchronisation.  with_h: <c|H|c> by a sigma build (else out[0] = 0); with_s2: S^2 c is built and
 // <c|S^2|c>, |S^2 c|^2 reduced (else 0).  Results land in host-visible memory, read by dev_observables_collect:
 // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}
+// late_state: the copy of the state into host_twin is a SECOND stage of the kernel, behind the results and their sequence
+// word (sqd_ctx::state_seq is posted when it has landed): dev_observables_wait(c, false) returns with the results alone
 int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, bool with_s2 = true,
-                            double* host_twin = nullptr);
-int dev_observables_wait(sqd_ctx* c);
+                            double* host_twin = nullptr, bool late_state = false);
+int dev_observables_wait(sqd_ctx* c, bool whole_kernel = true);
+int state_copy_wait(sqd_ctx* c, long long ticket);
 // batched (sqd_solve_batch)
 struct ObsBatchPlan {
   const char* args = nullptr;  // device array of ObsArgs

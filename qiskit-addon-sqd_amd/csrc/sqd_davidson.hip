@@ -1133,7 +1133,8 @@ static int reserve_reduction_buffers(sqd_ctx* c) {
   SQD_TRY(c->partial.reserve((size_t)2 * RED_BLOCKS * (SQD_MAX_SPACE + 4) * 8));
   // scal: [0..128) scalars of stand-alone reductions | arrival counters | DavState
   const void* before = c->scal.p;
-  const size_t bytes = (size_t)128 * 8 + COUNT_WORDS * sizeof(unsigned) + sizeof(DavState) + 256;
+  // scal: ... | DavState | a second set of arrival counters (kernels with two "last workgroup" stages: k_observables)
+  const size_t bytes = (size_t)128 * 8 + 2 * COUNT_WORDS * sizeof(unsigned) + ((sizeof(DavState) + 255) & ~size_t(255)) + 256;
   SQD_TRY(c->scal.reserve(bytes));
   if (c->scal.p != before)  // fresh allocation: the self-resetting arrival counters start from zero
     SQD_HIP_CHECK(hipMemsetAsync(c->scal.p, 0, bytes, c->stream));
@@ -1145,6 +1146,9 @@ static DavState* state_ptr_dev(sqd_ctx* c) {
   return reinterpret_cast<DavState*>(reinterpret_cast<char*>(counter_ptr(c)) + COUNT_WORDS * sizeof(unsigned));
 }
 void* dav_state_ptr(sqd_ctx* c) { return state_ptr_dev(c); }
+unsigned* counter2_ptr(sqd_ctx* c) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(state_ptr_dev(c)) + ((sizeof(DavState) + 255) & ~size_t(255)));
+}
 
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
   SQD_TRY(reserve_reduction_buffers(c));

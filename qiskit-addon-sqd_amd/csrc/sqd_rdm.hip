@@ -282,6 +282,12 @@ struct ObsArgs {
   GPtr<double> host_c;
   GPtr<long long> seq_word;
   long long seq;
+  // late copy of the state (sqd_ctx::async_state): written to host_late by a second stage, BEHIND the results' sequence
+  // word; state_word <- state_seq when every workgroup's part has been issued and fenced
+  GPtr<double> host_late;
+  GPtr<unsigned> counter2;
+  GPtr<long long> state_word;
+  long long state_seq;
   int s2_inline;
   DirectArgs dg;
   // optional device-side copy of the results, led by the Davidson eigenvalue (sqd_ctx::record_out): what a collective
@@ -289,6 +295,7 @@ struct ObsArgs {
   GPtr<double> record;
   GPtr<const DavState> st;
 };
+__device__ inline void observables_finish(const ObsArgs& g, unsigned nbx, double* red);
 __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned nbx) {
   __shared__ double red[1024];
   __shared__ double wrow[64];
@@ -394,7 +401,44 @@ __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned 
       coherent_store(&rec[4 + p], t);
     }
   }
-  if (!arrive_last(g.counter, bx, nbx)) return;
+  if (arrive_last(g.counter, bx, nbx)) observables_finish(g, nbx, red);
+  if (!g.host_late) return;
+  // ---- second stage: the state to the caller's page-locked buffer (posted full-line PCIe writes, 33 GB/s: 24 us for the
+  // 0.8 MB of a headline solve).  The host has its results by now and is already on its way back to the caller; the
+  // rows come from the L2 this time.
+  if (bx < nrb) {
+    double* __restrict__ dst = g.host_late;
+    const int64_t A = (int64_t)bx * OBS_ROWS + wv;
+    if (A < na)
+      for (int64_t b0 = lane; b0 < nb; b0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t b = b0 + 64 * u;
+          v[u] = C[A * nb + (b < nb ? b : b0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (b0 + 64 * u < nb) __builtin_nontemporal_store(v[u], &dst[A * nb + b0 + 64 * u]);
+      }
+  }
+  // (one system-scope release per workgroup, behind everybody's stores: sqd_device.h, mailbox protocol)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __threadfence_system();
+  if (!arrive_last(g.counter2, bx, nbx)) return;
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *static_cast<volatile long long*>(static_cast<long long*>(g.state_word)) = g.state_seq;
+  }
+}
+
+// the last workgroup's part of k_observables: fold the partial records, post the results and their sequence word
+__device__ inline void observables_finish(const ObsArgs& g, unsigned nbx, double* red) {
+  const int norb = g.norb;
+  const unsigned nrb = g.nrb;
+  double* partial = g.partial;
+  double* out = g.out;
   // out = {c.Hc, c.S2c, c.c, occ_a[norb], occ_b[norb], |S2 c|^2}.  J threads share one result: thread (r, j) adds the
   // partial records b0 + j, b0 + j + J, ... (eight write-through loads in flight per round -- one thread per result
   // walked the records in ~2 us rounds, 10 us for 45 workgroups), the J sub-sums are added in order j = 0..J-1.
@@ -466,6 +510,7 @@ __global__ void k_observables_b(const ObsArgs* __restrict__ gs) {
 
 constexpr int OBS_MAIL = 3 * 128;  // doubles into the host-visible mailbox (slots 0..2 belong to the Davidson)
 constexpr int OBS_SEQ = OBS_MAIL + 200;  // its sequence word (results: at most 3 + 2 * 64 + 1 doubles)
+constexpr int OBS_STATE_SEQ = OBS_MAIL + 272;  // "the late copy of the state has landed" (its own 128-byte line)
 
 int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
   SQD_TRY(dev_observables_enqueue(c, d_c));
@@ -476,9 +521,14 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
 // wait for the latest k_observables: its sequence word first (a memory read per poll), then the stream itself, which is
 // done or about to be (the kernel's other effects -- the state written to the caller's buffer -- count as complete
 // only with the kernel)
-int dev_observables_wait(sqd_ctx* c) {
+int dev_observables_wait(sqd_ctx* c, bool whole_kernel) {
   SQD_TRY(spin_wait_word(c->h_mail + OBS_SEQ, c->obs_seq, c->stream));
-  return spin_stream_sync(c->stream);
+  return whole_kernel ? spin_stream_sync(c->stream) : SQD_OK;
+}
+// the late copy of the state with this ticket (or a later one: tickets grow with every solve of the context, and the
+// stream runs them in order) has landed in the caller's buffer
+int state_copy_wait(sqd_ctx* c, long long ticket) {
+  return spin_wait_word(c->h_mail + OBS_STATE_SEQ, ticket, c->stream);
 }
 void dev_observables_collect(sqd_ctx* c, double* out_host) {
   const int nres = 3 + 2 * c->norb + 1;
@@ -486,7 +536,7 @@ void dev_observables_collect(sqd_ctx* c, double* out_host) {
 }
 // arguments of k_observables for the state d_c of this subspace; t1 / t2: H c and S^2 c already built, or nullptr
 static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const double* t2, bool s2_inline,
-                         double* host_twin, ObsArgs* gp) {
+                         double* host_twin, ObsArgs* gp, bool late_state = false) {
   ObsArgs& g = *gp;
   std::memset(&g.dg, 0, sizeof(g.dg));
   if (s2_inline) {
@@ -511,7 +561,15 @@ static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const 
   g.partial = c->scratch.as<double>();
   g.counter = counter_ptr(c);
   g.out = c->d_mail + OBS_MAIL;
-  g.host_c = host_twin;
+  g.host_c = late_state ? nullptr : host_twin;
+  g.host_late = late_state ? host_twin : nullptr;
+  g.counter2 = counter2_ptr(c);
+  g.state_word = reinterpret_cast<long long*>(c->d_mail + OBS_STATE_SEQ);
+  g.state_seq = 0;
+  if (late_state && host_twin) {
+    c->state_seq = c->obs_seq;  // (one monotonic sequence per context: mail_seq)
+    g.state_seq = (long long)c->state_seq;
+  }
   g.seq_word = reinterpret_cast<long long*>(c->d_mail + OBS_SEQ);
   g.seq = (long long)c->obs_seq;
   g.s2_inline = s2_inline ? 1 : 0;
@@ -522,7 +580,7 @@ static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const 
 static bool obs_s2_inline(const sqd_ctx* c, bool with_s2) {
   return with_s2 && c->sig_direct && c->sig_rows == 0 && !c->sig_lists && !c->sharded();
 }
-int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2, double* host_twin) {
+int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool with_s2, double* host_twin, bool late_state) {
   hipStream_t st = c->stream;
   const int64_t D = c->D;
   const double *t1 = nullptr, *t2 = nullptr;
@@ -538,7 +596,7 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h, bool wit
     t2 = c->tmp2.as<double>();
   }
   ObsArgs g;
-  SQD_TRY(fill_obs_args(c, d_c, t1, t2, s2_inline, host_twin, &g));
+  SQD_TRY(fill_obs_args(c, d_c, t1, t2, s2_inline, host_twin, &g, late_state));
   hipLaunchKernelGGL(k_observables, dim3(g.gx), dim3(512), 0, st, g);
   SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;

@@ -11,6 +11,7 @@ CPU fallback.
 
 from __future__ import annotations
 
+import os
 import threading
 import zlib
 from collections import OrderedDict
@@ -258,6 +259,35 @@ class _DeferredAmplitudes:
             self.value = ctx.fetch_solution() if self.single else ctx.batch_state(self.index, self.generation)
             self.ctx = None
         return self.value
+
+
+class _PendingAmplitudes(_DeferredAmplitudes):
+    """Amplitudes of a single solve that were still on their way to the host (into ``array``, page-locked) when the
+    native call returned (``sqd_ctx_set_async_state``): the results -- energy, occupancies, <S^2> -- come back first,
+    the 0.8 MB of a headline-size state follow as 24 us of posted PCIe writes.  ``SCIState.amplitudes`` waits for the
+    ticket on first read."""
+
+    __slots__ = ("array", "ticket")
+
+    def __init__(self, ctx, array, ticket):
+        super().__init__(ctx, 0, array.shape)
+        self.array, self.ticket = array, int(ticket)
+
+    def fetch(self) -> np.ndarray:
+        if self.value is None:
+            ctx = self.ctx
+            if ctx is not None:
+                ctx.state_wait(self.ticket)
+            self.value, self.ctx = self.array, None
+        return self.value
+
+    def __del__(self):
+        # never read: the page-locked block goes back to the result pool only when nothing writes into it any more
+        try:
+            if self.value is None and self.ctx is not None:
+                self.ctx.state_wait(self.ticket)
+        except Exception:  # noqa: BLE001  (interpreter shutdown, closed context)
+            pass
 
 
 def _settle_deferred(ctx, final: bool = False) -> None:
@@ -516,6 +546,9 @@ def _davidson_kwargs(kwargs: dict) -> dict:
 
 _TLS = threading.local()
 _PROFILE = {"time_sigma_every": 0}
+# solve_fermion / solve_sci return as soon as energy, occupancies and <S^2> are on the host; the amplitudes follow into
+# the SCIState's (page-locked) array and its first read waits for them.  SQD_ASYNC_STATE=0: the state arrives with the call.
+_ASYNC_STATE = os.environ.get("SQD_ASYNC_STATE", "1") != "0"
 
 
 def set_profiling(time_sigma_every: int = 0) -> None:
@@ -538,8 +571,12 @@ def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True
     if _PROFILE["time_sigma_every"]:
         dk["time_sigma_every"] = _PROFILE["time_sigma_every"]
     if observables:  # tables + Davidson + observables: one native call
+        ctx.set_async_state(_ASYNC_STATE)
         out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square, **dk)
         _TLS.stats = out[1]
+        ticket = out[1].get("state_ticket", 0)
+        if ticket:  # the state is still landing in out[0]: wrapped, the first read of SCIState.amplitudes waits
+            return (_PendingAmplitudes(ctx, out[0], ticket),) + tuple(out[1:])
         return out
     ctx.set_subspace(ci_strs[0], ci_strs[1])
     amps, stats = ctx.davidson(ci0, spin_sq=spin_sq, shift=shift, **dk)

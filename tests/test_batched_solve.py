@@ -92,7 +92,7 @@ def test_batched_solve_falls_back(emu_backend, monkeypatch):
     out = solve_sci_batch(batches, h1, eri, norb, nelec, compute_rdms=True)
     assert out[0].__dict__.get("rdm2") is not None
     one = solve_sci_batch(batches[:1], h1, eri, norb, nelec)
-    assert isinstance(one[0].sci_state.__dict__.get("amplitudes"), np.ndarray)
+    assert isinstance(one[0].sci_state.amplitudes, np.ndarray)
     # the squared penalty form is solved one by one INSIDE the native batched call
     nel = (3, 3)
     b3 = _batches(norb, nel, [(8, 8), (6, 6)], hf=True)
