@@ -107,8 +107,9 @@ int sqd_solution_device_ptr(sqd_ctx* ctx, const double** d_ptr);
 int sqd_solution_copy(sqd_ctx* ctx, double* amps);
 /* on != 0: sqd_solve / sqd_solve_strings return as soon as the RESULTS (energy, <S^2>, occupancies, statistics) are on the
  * host; the amplitudes follow into `amps` -- which must then come from sqd_host_alloc and be at most 64 MB, else the call
- * behaves as before -- written by a second stage of the observables kernel behind the results (0.8 MB at the headline size
- * are 24 us of posted PCIe writes: longer than every other kernel of the solve).  stats->state_ticket > 0 says so;
+ * behaves as before -- written by a kernel of their own on the context's copy stream, started behind the solution (0.8 MB
+ * at the headline size are 24 us of posted PCIe writes: longer than every other kernel of the solve, and now beside the
+ * next solve's table build instead of in front of it).  stats->state_ticket > 0 says so;
  * sqd_ctx_state_wait(ctx, ticket) returns when the buffer is complete (a later ticket of the same context implies every
  * earlier one).  The reference returns the numpy array with the call (fermion.py:724, :820); the Python layer wraps the
  * pending buffer so that the first READ of SCIState.amplitudes waits.  Default: off. */

@@ -246,13 +246,14 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   hipError_t e = hipSetDevice(c->device);
   (void)e;
   if (c->stream) e = hipStreamSynchronize(c->stream);
+  if (c->copy_stream) e = hipStreamSynchronize(c->copy_stream);  // (a state may still be leaving: k_state_copy)
   for (sqd_ctx* sub : c->subs) sqd_ctx_destroy(sub);  // (their integral tables are views of this context's)
   c->subs.clear();
   for (auto& bs : c->bstage) bs.release();
   DevBuf* bufs[] = {&c->h1, &c->eri4, &c->eri_pp, &c->jm, &c->km, &c->hdiag, &c->X, &c->AX,
                     &c->sol, &c->tmp1, &c->tmp2, &c->partial, &c->scal, &c->scratch, &c->io_in, &c->io_out,
                     &c->items, &c->multi, &c->sig_partial, &c->ptrs, &c->d_blob, &c->strs2, &c->guess_min, &c->jdiag, &c->rowinfo,
-                    &c->hdense_a, &c->hdense_b, &c->gdense, &c->sol_prev, &c->shard_tot};
+                    &c->hdense_a, &c->hdense_b, &c->gdense, &c->sol_prev, &c->shard_tot, &c->sol_alt};
   for (DevBuf* b : bufs) b->release();
   lists_release(c);
   c->sp[0].release();
@@ -721,16 +722,25 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     return SQD_ERR_INVALID;
   }
   c->want_timing = c->phase_timing || o.verbose;
-  SQD_TRY(run_davidson(c, &o, ci0, nullptr, /*defer_sync=*/true));
   const size_t bytes = (size_t)c->D * 8;
+  double* twin = nullptr;
+  if (amps && bytes <= (size_t(64) << 20)) twin = static_cast<double*>(pinned_device_ptr(amps, bytes));
+  const bool late = c->async_state && twin != nullptr && !c->parent;
+  if (late) {
+    // the previous solve's state may still be leaving `sol` (k_state_copy on the copy stream): this solve forms its
+    // solution in the other buffer.  What last left THAT one -- two solves ago -- has landed long since; checked, not assumed.
+    if (c->sol_alt_ticket > 0 && !state_copy_landed(c, c->sol_alt_ticket)) SQD_TRY(state_copy_wait(c, c->sol_alt_ticket));
+    std::swap(c->sol, c->sol_alt);
+    std::swap(c->sol_ticket, c->sol_alt_ticket);
+    c->have_solution = false;
+  }
+  SQD_TRY(run_davidson(c, &o, ci0, nullptr, /*defer_sync=*/true));
   // Three ways for the state to reach the caller:
   //  * the caller's buffer is page-locked (sqd_host_alloc) and the state is small: the observables' kernel, which
   //    reads every element anyway, also WRITES it there (posted PCIe writes) -- no second stream, no event, no DMA
   //    set-up, one wait.  (Beyond 64 MB the DMA engine on the copy stream wins: it overlaps the S^2 sigma build.)
   //  * small and pageable: through the context's pinned staging buffer on the copy stream (a truly asynchronous copy)
   //  * large: DMA straight to the caller's memory on the copy stream
-  double* twin = nullptr;
-  if (amps && bytes <= (size_t(64) << 20)) twin = static_cast<double*>(pinned_device_ptr(amps, bytes));
   const bool by_copy = amps && !twin;
   const bool staged = by_copy && bytes <= (size_t(64) << 20);
   if (by_copy) {
@@ -753,10 +763,14 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     form = (o.ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
   }
   const bool need_s2 = (s2 != nullptr) || form != 0;
-  // sqd_ctx_set_async_state: the state follows the results (second stage of the observables kernel); the call returns
-  // with the results and a ticket, sqd_ctx_state_wait(ticket) says when the caller's buffer is complete
-  const bool late = c->async_state && twin != nullptr;
+  // sqd_ctx_set_async_state: the state follows the results (k_state_copy on the copy stream); the call returns with the
+  // results and a ticket, sqd_ctx_state_wait(ticket) says when the caller's buffer is complete
   SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin, late));
+  long long ticket = 0;
+  if (late) {
+    SQD_TRY(state_copy_enqueue(c, twin, &ticket));
+    c->sol_ticket = ticket;
+  }
   if (c->enqueue_hook) c->enqueue_hook(c->enqueue_hook_user);  // (the caller's collective, right behind the last kernel)
   if (by_copy && !staged)
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
@@ -765,7 +779,7 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   SQD_TRY(dev_observables_wait(c, /*whole_kernel=*/!late));
   c->stage_pending = false;  // (the results are there: every upload in front of them in the stream has been consumed)
   const int rc = solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
-  if (stats) stats->state_ticket = late ? (long long)c->state_seq : 0;
+  if (stats) stats->state_ticket = ticket;
   return rc;
 }
 

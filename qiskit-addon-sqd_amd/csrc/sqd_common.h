@@ -276,6 +276,10 @@ struct sqd_ctx {
   // second stage of the observables kernel) and has landed when the mailbox's state word reaches state_seq
   bool async_state = false;
   int64_t state_seq = 0;
+  // ... read by k_state_copy from `sol` while the NEXT solve already runs: that one forms its solution in sol_alt (the
+  // two swap at the start of every asynchronous solve; sol_alt_ticket = the copy that may still be reading sol_alt)
+  sqd::DevBuf sol_alt;
+  int64_t sol_alt_ticket = 0, sol_ticket = 0;
   int64_t sigma_launches = 0;  // sigma launches of Davidson runs on this context (event sampling)
   double ms_setup = 0.0;
   std::vector<double> host_tmp;
@@ -407,6 +411,8 @@ int dev_observables_enqueue(sqd_ctx* c, const double* d_c, bool with_h = true, b
                             double* host_twin = nullptr, bool late_state = false);
 int dev_observables_wait(sqd_ctx* c, bool whole_kernel = true);
 int state_copy_wait(sqd_ctx* c, long long ticket);
+int state_copy_enqueue(sqd_ctx* c, double* host_twin, long long* ticket);  // k_state_copy on the copy stream
+bool state_copy_landed(const sqd_ctx* c, long long ticket);
 // batched (sqd_solve_batch)
 struct ObsBatchPlan {
   const char* args = nullptr;  // device array of ObsArgs

@@ -282,12 +282,7 @@ struct ObsArgs {
   GPtr<double> host_c;
   GPtr<long long> seq_word;
   long long seq;
-  // late copy of the state (sqd_ctx::async_state): written to host_late by a second stage, BEHIND the results' sequence
-  // word; state_word <- state_seq when every workgroup's part has been issued and fenced
-  GPtr<double> host_late;
-  GPtr<unsigned> counter2;
-  GPtr<long long> state_word;
-  long long state_seq;
+
   int s2_inline;
   DirectArgs dg;
   // optional device-side copy of the results, led by the Davidson eigenvalue (sqd_ctx::record_out): what a collective
@@ -402,35 +397,6 @@ __device__ inline void observables_body(const ObsArgs& g, unsigned bx, unsigned 
     }
   }
   if (arrive_last(g.counter, bx, nbx)) observables_finish(g, nbx, red);
-  if (!g.host_late) return;
-  // ---- second stage: the state to the caller's page-locked buffer (posted full-line PCIe writes, 33 GB/s: 24 us for the
-  // 0.8 MB of a headline solve).  The host has its results by now and is already on its way back to the caller; the
-  // rows come from the L2 this time.
-  if (bx < nrb) {
-    double* __restrict__ dst = g.host_late;
-    const int64_t A = (int64_t)bx * OBS_ROWS + wv;
-    if (A < na)
-      for (int64_t b0 = lane; b0 < nb; b0 += 64 * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int64_t b = b0 + 64 * u;
-          v[u] = C[A * nb + (b < nb ? b : b0)];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (b0 + 64 * u < nb) __builtin_nontemporal_store(v[u], &dst[A * nb + b0 + 64 * u]);
-      }
-  }
-  // (one system-scope release per workgroup, behind everybody's stores: sqd_device.h, mailbox protocol)
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) __threadfence_system();
-  if (!arrive_last(g.counter2, bx, nbx)) return;
-  if (threadIdx.x == 0) {
-    __threadfence_system();
-    *static_cast<volatile long long*>(static_cast<long long*>(g.state_word)) = g.state_seq;
-  }
 }
 
 // the last workgroup's part of k_observables: fold the partial records, post the results and their sequence word
@@ -521,6 +487,50 @@ int dev_observables(sqd_ctx* c, const double* d_c, double* out_host) {
 // wait for the latest k_observables: its sequence word first (a memory read per poll), then the stream itself, which is
 // done or about to be (the kernel's other effects -- the state written to the caller's buffer -- count as complete
 // only with the kernel)
+// ---- the state to the caller's page-locked buffer, asynchronously (sqd_ctx_set_async_state): a kernel of its own on the
+// context's COPY stream, started by an event behind the solution.  Posted full-line PCIe writes, 33 GB/s: 24 us for the
+// 0.8 MB of a headline solve -- longer than any other kernel of that solve, and on the solver's stream it would sit in
+// front of the next solve's table build.  The last workgroup posts the ticket behind everybody's stores.
+__global__ void __launch_bounds__(256) k_state_copy(const double* __restrict__ C, double* __restrict__ host, int64_t n,
+                                                     unsigned* counter, long long* state_word, long long seq) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = C[i0 + u * stride < n ? i0 + u * stride : i0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * stride < n) __builtin_nontemporal_store(v[u], &host[i0 + u * stride]);
+  }
+  // (one system-scope release per workgroup, behind everybody's stores: sqd_device.h, mailbox protocol)
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) __threadfence_system();
+  if (!arrive_last(counter, blockIdx.x, gridDim.x)) return;
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    *static_cast<volatile long long*>(state_word) = seq;
+  }
+}
+// enqueue it for the resident solution; *ticket = what state_copy_wait takes
+int state_copy_enqueue(sqd_ctx* c, double* host_twin, long long* ticket) {
+  SQD_TRY(reserve_counters(c));
+  c->state_seq = ++c->mail_seq;
+  SQD_HIP_CHECK(hipEventRecord(c->ev_sol, c->stream));
+  SQD_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_sol, 0));
+  const int64_t n = c->D;
+  unsigned blocks = (unsigned)((n + 1023) / 1024);
+  if (blocks > 128) blocks = 128;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_state_copy, dim3(blocks), dim3(256), 0, c->copy_stream, c->sol.as<double>(), host_twin, n,
+                     counter2_ptr(c), reinterpret_cast<long long*>(c->d_mail + OBS_STATE_SEQ), (long long)c->state_seq);
+  SQD_HIP_CHECK(hipGetLastError());
+  *ticket = (long long)c->state_seq;
+  return SQD_OK;
+}
+bool state_copy_landed(const sqd_ctx* c, long long ticket) {
+  return *reinterpret_cast<const volatile long long*>(c->h_mail + OBS_STATE_SEQ) >= ticket;
+}
 int dev_observables_wait(sqd_ctx* c, bool whole_kernel) {
   SQD_TRY(spin_wait_word(c->h_mail + OBS_SEQ, c->obs_seq, c->stream));
   return whole_kernel ? spin_stream_sync(c->stream) : SQD_OK;
@@ -528,7 +538,7 @@ int dev_observables_wait(sqd_ctx* c, bool whole_kernel) {
 // the late copy of the state with this ticket (or a later one: tickets grow with every solve of the context, and the
 // stream runs them in order) has landed in the caller's buffer
 int state_copy_wait(sqd_ctx* c, long long ticket) {
-  return spin_wait_word(c->h_mail + OBS_STATE_SEQ, ticket, c->stream);
+  return spin_wait_word(c->h_mail + OBS_STATE_SEQ, ticket, c->copy_stream);
 }
 void dev_observables_collect(sqd_ctx* c, double* out_host) {
   const int nres = 3 + 2 * c->norb + 1;
@@ -562,14 +572,6 @@ static int fill_obs_args(sqd_ctx* c, const double* d_c, const double* t1, const 
   g.counter = counter_ptr(c);
   g.out = c->d_mail + OBS_MAIL;
   g.host_c = late_state ? nullptr : host_twin;
-  g.host_late = late_state ? host_twin : nullptr;
-  g.counter2 = counter2_ptr(c);
-  g.state_word = reinterpret_cast<long long*>(c->d_mail + OBS_STATE_SEQ);
-  g.state_seq = 0;
-  if (late_state && host_twin) {
-    c->state_seq = c->obs_seq;  // (one monotonic sequence per context: mail_seq)
-    g.state_seq = (long long)c->state_seq;
-  }
   g.seq_word = reinterpret_cast<long long*>(c->d_mail + OBS_SEQ);
   g.seq = (long long)c->obs_seq;
   g.s2_inline = s2_inline ? 1 : 0;
