@@ -395,7 +395,8 @@ int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const
 // themselves after every use; a Davidson run also zeroes them, so a kernel aborted mid-way cannot poison later ones.
 int reserve_counters(sqd_ctx* c);
 unsigned* counter_ptr(sqd_ctx* c);
-unsigned* counter2_ptr(sqd_ctx* c);  // a second, independent set (same self-resetting protocol)
+unsigned* counter2_ptr(sqd_ctx* c);  // a second, independent set (same self-resetting protocol): k_state_copy
+unsigned* counter3_ptr(sqd_ctx* c);  // a third: k_tables_diag_fill
 void* dav_state_ptr(sqd_ctx* c);  // DavState* (sqd_davstate.h)
 // observables (sqd_rdm.hip)
 int dev_rdm1s(sqd_ctx* c, const double* d_c, double* dm1a, double* dm1b);

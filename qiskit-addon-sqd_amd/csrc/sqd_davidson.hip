@@ -1134,7 +1134,7 @@ static int reserve_reduction_buffers(sqd_ctx* c) {
   // scal: [0..128) scalars of stand-alone reductions | arrival counters | DavState
   const void* before = c->scal.p;
   // scal: ... | DavState | a second set of arrival counters (kernels with two "last workgroup" stages: k_observables)
-  const size_t bytes = (size_t)128 * 8 + 2 * COUNT_WORDS * sizeof(unsigned) + ((sizeof(DavState) + 255) & ~size_t(255)) + 256;
+  const size_t bytes = (size_t)128 * 8 + 3 * COUNT_WORDS * sizeof(unsigned) + ((sizeof(DavState) + 255) & ~size_t(255)) + 256;
   SQD_TRY(c->scal.reserve(bytes));
   if (c->scal.p != before)  // fresh allocation: the self-resetting arrival counters start from zero
     SQD_HIP_CHECK(hipMemsetAsync(c->scal.p, 0, bytes, c->stream));
@@ -1149,6 +1149,7 @@ void* dav_state_ptr(sqd_ctx* c) { return state_ptr_dev(c); }
 unsigned* counter2_ptr(sqd_ctx* c) {
   return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(state_ptr_dev(c)) + ((sizeof(DavState) + 255) & ~size_t(255)));
 }
+unsigned* counter3_ptr(sqd_ctx* c) { return counter2_ptr(c) + COUNT_WORDS; }
 
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out) {
   SQD_TRY(reserve_reduction_buffers(c));

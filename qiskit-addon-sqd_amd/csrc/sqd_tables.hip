@@ -340,6 +340,7 @@ struct DiagArgs {
   GPtr<double> hdiag, pmin;
   GPtr<int64_t> pidx;
   unsigned gx;
+  int coherent_min;  // the row minima are read by another workgroup of the SAME launch (k_tables_diag_fill)
 };
 __device__ inline void tables_diag_body(const DiagArgs& g, unsigned bx, unsigned by, unsigned nbx) {
   __shared__ double v[SQD_MAX_NORB];
@@ -384,8 +385,13 @@ __device__ inline void tables_diag_body(const DiagArgs& g, unsigned bx, unsigned
     }
     block_argmin(best, bi);
     if (threadIdx.x == 0) {
-      g.pmin[A - row0] = best;
-      g.pidx[A - row0] = bi;
+      if (g.coherent_min) {
+        coherent_store(&g.pmin[A - row0], best);
+        coherent_store_i64(&g.pidx[A - row0], bi);
+      } else {
+        g.pmin[A - row0] = best;
+        g.pidx[A - row0] = bi;
+      }
     }
   }
 }
@@ -434,6 +440,62 @@ __global__ void k_tables_fill_b(const FillArgs* __restrict__ gs) {
   if (blockIdx.x >= g.gx) return;
   tables_fill_body(g, blockIdx.x, blockIdx.y, g.gx);
 }
+// B + C in ONE launch (single solves of batch size: both string lists <= 1024, link arrays reserved at their upper
+// bound, so the launch needs nothing from the host's look at the CSR pointers and goes out right behind launch A; the
+// headline solve's table build is then count -> [diag | fill] with no host wait in between: 12.3 + 8.6 + 3.9 (gap) +
+// 8.7 us -> 12.3 + ~9).  by = 0, 1: J tables; 2: diagonal + row minima; 3, 4: link fill of spin by - 3.
+// The Davidson start vector needs the row minima of THIS launch: the fill workgroups zero X[0] with write-through
+// stores (a plain store would sit dirty in its XCD's L2 and could be written back over the value below), every diag and
+// fill workgroup arrives on a counter, and the last one finishes the argmin and writes the (at most three) non-zero
+// elements -- init_guess_write's values, bit for bit.
+struct DiagFillArgs {
+  DiagArgs d;
+  FillArgs f;
+  GPtr<unsigned> counter;  // an arrival-counter set of its own (dav_state_init resets the Davidson's)
+};
+__global__ void __launch_bounds__(256) k_tables_diag_fill(const DiagFillArgs g) {
+  const unsigned by = blockIdx.y, bx = blockIdx.x;
+  const GuessJob& job = g.f.job;
+  unsigned me;
+  if (by < 3) {
+    if (bx >= g.d.gx) return;
+    tables_diag_body(g.d, bx, by, g.d.gx);
+    if (by < 2) return;
+    me = bx;
+  } else {
+    if (bx >= g.f.gx) return;
+    tables_fill_wave(g.f.p.a[by - 3], g.f.h1, g.f.eri4, g.f.norb, bx);
+    if (bx == 0 && by == 3) dav_state_init(job.st, job.counter);
+    const int64_t blk = (int64_t)(by - 3) * g.f.gx + bx;
+    for (int64_t i = blk * blockDim.x + threadIdx.x; i < job.n; i += (int64_t)g.f.gx * 2 * blockDim.x)
+      coherent_store(&job.x[i], 0.0);
+    me = g.d.gx + (by - 3) * g.f.gx + bx;
+  }
+  if (!arrive_last(g.counter, me, g.d.gx + 2 * g.f.gx)) return;
+  double best = 1e300;
+  int64_t bi = -1;
+  for (int b = threadIdx.x; b < job.nrows; b += blockDim.x) {
+    const double v = coherent_load(&job.pmin[b]);
+    const int64_t i = coherent_load_i64(&job.pidx[b]);
+    if (i >= 0 && (v < best || (v == best && i < bi) || bi < 0)) {
+      best = v;
+      bi = i;
+    }
+  }
+  block_argmin(best, bi);
+  if (threadIdx.x == 0) {
+    const int64_t n = job.n, addr = bi < 0 ? 0 : bi;
+    auto f = [=](int64_t i) { return ((i == addr) ? 1.0 : 0.0) + ((i == 0) ? 1e-5 : 0.0) - ((i == n - 1) ? 1e-5 : 0.0); };
+    double nn = f(0) * f(0);
+    if (n - 1 != 0) nn += f(n - 1) * f(n - 1);
+    if (addr != 0 && addr != n - 1) nn += f(addr) * f(addr);
+    const double inv = 1.0 / sqrt(nn);
+    coherent_store(&job.x[0], f(0) * inv);
+    coherent_store(&job.x[n - 1], f(n - 1) * inv);
+    coherent_store(&job.x[addr], f(addr) * inv);
+  }
+}
+
 __device__ inline void tables_fill_wave(const SpinLinkArgs& a, const double* __restrict__ h1,
                                         const double* __restrict__ eri4, int norb, unsigned bx) {
   const uint64_t* __restrict__ strs = a.strs;
@@ -937,6 +999,7 @@ struct SubspaceBuild {
   JdsArgs jds;
   DenseFillArgs dense;
   bool have_fill = false, have_ell = false, have_jds = false, have_dense = false;
+  bool fill_launched = false;  // launch C went out together with launch B, before the host saw the link counts
   std::vector<int64_t> zero_ptr;  // dense same-spin blocks: the beta doubles leave the work items (empty lists)
   unsigned ell_gx = 0;
   struct Up {
@@ -1074,6 +1137,7 @@ static int subspace_phase1(sqd_ctx* c, SubspaceBuild& b, const uint64_t* sa, int
   da.pmin = pmin;
   da.pidx = reinterpret_cast<int64_t*>(pmin + b.nrows);
   da.gx = (unsigned)(gx_j > gx_h ? gx_j : gx_h);
+  da.coherent_min = 0;
   return SQD_OK;
 }
 
@@ -1089,6 +1153,65 @@ static int subspace_wait_pointers(sqd_ctx* c, SubspaceBuild& b) {
   b.tot[1] = c->h_dptr[na];
   b.tot[2] = c->h_sptr_b[nb];
   b.tot[3] = c->h_dptr_b[nb];
+  return SQD_OK;
+}
+
+// arguments of launch C (fill + decorate + the start of the Davidson run), link arrays reserved for cap[2 s] single and
+// cap[2 s + 1] double links of spin s: the counted totals -- or, for the launch that goes out BEFORE the host has seen
+// them, their upper bound
+static int subspace_fill_setup(sqd_ctx* c, SubspaceBuild& b, const int64_t* cap, bool want_fill) {
+  const int64_t na = b.na, nb = b.nb, row0 = b.row0, row1 = b.row1, nrows = b.nrows;
+  SpinLinkArgs2 la = b.count.p;
+  for (int s = 0; s < 2; ++s) {
+    SpinTables& t = c->sp[s];
+    SQD_TRY(t.s_rec.reserve((size_t)cap[2 * s] * sizeof(SRec)));
+    SQD_TRY(t.s_row.reserve((size_t)cap[2 * s] * 4));
+    SQD_TRY(t.s_val.reserve((size_t)cap[2 * s] * 8));
+    SQD_TRY(t.d_src.reserve((size_t)cap[2 * s + 1] * 4));
+    SQD_TRY(t.d_row.reserve((size_t)cap[2 * s + 1] * 4));
+    SQD_TRY(t.d_orb.reserve((size_t)cap[2 * s + 1] * 4));
+    SQD_TRY(t.d_val.reserve((size_t)cap[2 * s + 1] * 8));
+    la.a[s].jtab = b.diag.p.a[s].jtab;
+    la.a[s].transposed = s;
+    la.a[s].n_s = cap[2 * s];
+    la.a[s].n_d = cap[2 * s + 1];
+    la.a[s].s_rec = t.s_rec.as<SRec>();
+    la.a[s].s_row = t.s_row.as<uint32_t>();
+    la.a[s].s_val = t.s_val.as<double>();
+    la.a[s].d_src = t.d_src.as<uint32_t>();
+    la.a[s].d_row = t.d_row.as<uint32_t>();
+    la.a[s].d_orb = t.d_orb.as<uint32_t>();
+    la.a[s].d_val = t.d_val.as<double>();
+  }
+  b.have_fill = false;
+  if (want_fill) {
+    GuessJob job;
+    std::memset(&job, 0, sizeof(job));
+    c->guess_x = nullptr;
+    if (row0 == 0 && row1 == na && (size_t)c->dav_nvecs_hint * na * nb * 8 <= (size_t(1) << 30)) {
+      // (small problems only: there a launch matters, and the workspace costs nothing to have early)
+      // the Davidson workspace at the size the last run used (default max_space + 1 vectors): if the run that
+      // follows needs more, its reserve moves the buffer and it falls back to its own k_init_guess launch
+      SQD_TRY(c->X.reserve((size_t)c->dav_nvecs_hint * na * nb * 8));
+      SQD_TRY(reserve_counters(c));
+      job.x = c->X.as<double>();
+      job.pmin = c->guess_min.as<double>();
+      job.pidx = reinterpret_cast<const int64_t*>(job.pmin + nrows);
+      job.nrows = (int)nrows;
+      job.n = na * nb;
+      job.st = static_cast<DavState*>(dav_state_ptr(c));
+      job.counter = counter_ptr(c);
+      c->guess_x = job.x;
+    }
+    FillArgs& fa = b.fill;
+    fa.p = la;
+    fa.h1 = c->h1.as<double>();
+    fa.eri4 = c->eri4.as<double>();
+    fa.norb = c->norb;
+    fa.job = job;
+    fa.gx = nblk(b.maxn, 4);
+    b.have_fill = true;
+  }
   return SQD_OK;
 }
 
@@ -1128,63 +1251,15 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
     c->sig_rows = rows > 0 ? rows : 0;
     c->sig_direct = direct || c->sig_rows > 0;
   }
-  // launch C: fill + decorate
-  SpinLinkArgs2 la = b.count.p;
+  // launch C: fill + decorate (unless it went out already, behind launch A: build_subspace)
   for (int s = 0; s < 2; ++s) {
-    SpinTables& t = c->sp[s];
-    t.n_s = tot[2 * s];
-    t.n_d = tot[2 * s + 1];
-    SQD_TRY(t.s_rec.reserve((size_t)t.n_s * sizeof(SRec)));
-    SQD_TRY(t.s_row.reserve((size_t)t.n_s * 4));
-    SQD_TRY(t.s_val.reserve((size_t)t.n_s * 8));
-    SQD_TRY(t.d_src.reserve((size_t)t.n_d * 4));
-    SQD_TRY(t.d_row.reserve((size_t)t.n_d * 4));
-    SQD_TRY(t.d_orb.reserve((size_t)t.n_d * 4));
-    SQD_TRY(t.d_val.reserve((size_t)t.n_d * 8));
-    la.a[s].jtab = b.diag.p.a[s].jtab;
-    la.a[s].transposed = s;
-    la.a[s].n_s = t.n_s;
-    la.a[s].n_d = t.n_d;
-    la.a[s].s_rec = t.s_rec.as<SRec>();
-    la.a[s].s_row = t.s_row.as<uint32_t>();
-    la.a[s].s_val = t.s_val.as<double>();
-    la.a[s].d_src = t.d_src.as<uint32_t>();
-    la.a[s].d_row = t.d_row.as<uint32_t>();
-    la.a[s].d_orb = t.d_orb.as<uint32_t>();
-    la.a[s].d_val = t.d_val.as<double>();
+    c->sp[s].n_s = tot[2 * s];
+    c->sp[s].n_d = tot[2 * s + 1];
   }
-  b.have_fill = false;
-  {
+  if (!b.fill_launched) {
     int64_t maxl = 0;
     for (int k = 0; k < 4; ++k) maxl = tot[k] > maxl ? tot[k] : maxl;
-    if (maxl > 0 || always_guess) {
-      GuessJob job;
-      std::memset(&job, 0, sizeof(job));
-      c->guess_x = nullptr;
-      if (row0 == 0 && row1 == na && (size_t)c->dav_nvecs_hint * na * nb * 8 <= (size_t(1) << 30)) {
-        // (small problems only: there a launch matters, and the workspace costs nothing to have early)
-        // the Davidson workspace at the size the last run used (default max_space + 1 vectors): if the run that
-        // follows needs more, its reserve moves the buffer and it falls back to its own k_init_guess launch
-        SQD_TRY(c->X.reserve((size_t)c->dav_nvecs_hint * na * nb * 8));
-        SQD_TRY(reserve_counters(c));
-        job.x = c->X.as<double>();
-        job.pmin = c->guess_min.as<double>();
-        job.pidx = reinterpret_cast<const int64_t*>(job.pmin + nrows);
-        job.nrows = (int)nrows;
-        job.n = na * nb;
-        job.st = static_cast<DavState*>(dav_state_ptr(c));
-        job.counter = counter_ptr(c);
-        c->guess_x = job.x;
-      }
-      FillArgs& fa = b.fill;
-      fa.p = la;
-      fa.h1 = c->h1.as<double>();
-      fa.eri4 = c->eri4.as<double>();
-      fa.norb = c->norb;
-      fa.job = job;
-      fa.gx = nblk(b.maxn, 4);
-      b.have_fill = true;
-    }
+    SQD_TRY(subspace_fill_setup(c, b, tot, maxl > 0 || always_guess));
   }
   c->na = na;
   c->nb = nb;
@@ -1444,12 +1519,35 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   hipLaunchKernelGGL(k_tables_count, dim3(b.count.gx, 4), dim3(256), 0, st, b.count);
   SQD_HIP_CHECK(hipGetLastError());
-  // launch B is queued behind A and runs while the host waits for the pointers and cuts the work lists
-  hipLaunchKernelGGL(k_tables_diag, dim3(b.diag.gx, 3), dim3(256), 0, st, b.diag);
-  SQD_HIP_CHECK(hipGetLastError());
+  // Single solves of batch size (both lists <= 1024 strings, all rows): the link arrays are reserved at their upper
+  // bound -- every ordered pair of strings is at most one link: n (n - 1) records, 42 MB per spin at 1024 -- so launch C
+  // needs nothing from the host and shares ONE launch with B, right behind A (k_tables_diag_fill)
+  static const bool fused_env = [] {
+    const char* env = std::getenv("SQD_TABLES_FUSED");
+    return !env || std::atoi(env) != 0;
+  }();
+  const bool fused = fused_env && row0 == 0 && (row1 < 0 || row1 == na) && na <= 1024 && nb <= 1024 &&
+                     (size_t)c->dav_nvecs_hint * na * nb * 8 <= (size_t(1) << 30);
+  if (fused) {
+    const int64_t cap[4] = {na * (na - 1) + 1, na * (na - 1) + 1, nb * (nb - 1) + 1, nb * (nb - 1) + 1};
+    SQD_TRY(subspace_fill_setup(c, b, cap, true));
+    DiagFillArgs df;
+    df.d = b.diag;
+    df.d.coherent_min = 1;
+    df.f = b.fill;
+    df.counter = counter3_ptr(c);
+    const unsigned gx = df.d.gx > df.f.gx ? df.d.gx : df.f.gx;
+    hipLaunchKernelGGL(k_tables_diag_fill, dim3(gx, 5), dim3(256), 0, st, df);
+    SQD_HIP_CHECK(hipGetLastError());
+    b.fill_launched = true;
+  } else {
+    // launch B is queued behind A and runs while the host waits for the pointers and cuts the work lists
+    hipLaunchKernelGGL(k_tables_diag, dim3(b.diag.gx, 3), dim3(256), 0, st, b.diag);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
   SQD_TRY(subspace_wait_pointers(c, b));
   SQD_TRY(subspace_phase2_plan(c, b, /*always_guess=*/false));
-  if (b.have_fill) {
+  if (b.have_fill && !b.fill_launched) {
     hipLaunchKernelGGL(k_tables_fill, dim3(b.fill.gx, 2), dim3(256), 0, st, b.fill);
     SQD_HIP_CHECK(hipGetLastError());
   }
