@@ -979,8 +979,11 @@ __device__ inline void solution_body(int64_t n, const double* __restrict__ X, in
     out[i] = s;
   }
 }
+// only_if_stopped: a launch queued speculatively behind a round of the first few (run_davidson): it forms the solution
+// if that round stopped the solve and is an early exit otherwise
 __global__ void k_solution(int64_t n, const double* __restrict__ X, int64_t stride, const DavState* __restrict__ st,
-                           double* __restrict__ out, double* res) {
+                           double* __restrict__ out, double* res, int only_if_stopped) {
+  if (only_if_stopped && !st->stop) return;
   solution_body(n, X, stride, st, out, res, blockIdx.x, gridDim.x);
 }
 
@@ -1285,6 +1288,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   const int full_from = 3;
   long long seq_of[4] = {0, 0, 0, 0};  // sequence numbers of the latest rounds enqueued (ring)
   bool stopped = false;
+  int spec_round = -1;  // the latest round with a conditional solution launch queued behind it
   auto settle = [&](int j) -> int {  // wait for round j's progress record
     SQD_TRY(wait_mail(c, 1, seq_of[j & 3]));
     if (h_prog[MAIL_PAYLOAD + 1] != 0.0) stopped = true;
@@ -1332,8 +1336,19 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
                          (int)gb, width, mail_prog, seq);
     }
     SQD_HIP_CHECK(hipGetLastError());
+    // In the first rounds -- where the solves of uniform-random sets stop -- the solution kernel is queued right behind
+    // the round, conditional on the stop flag: a solve that stops there has its solution formed without waiting for
+    // the host to see the record and come back with the launch (13 us of idle stream at the headline); a round that
+    // does not stop pays one early-exit dispatch.
+    if (!lockstep && round < full_from) {
+      hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
+                         c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 1);
+      SQD_HIP_CHECK(hipGetLastError());
+      spec_round = round;
+    }
     return SQD_OK;
   };
+  int last_settled = -1;
   {
     const int max_rounds = o->max_cycle;
     int n_a = 0, n_b = 0;  // rounds whose part A / part B have been enqueued
@@ -1345,6 +1360,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
         if (n_a == r + 2 && n_b == r + 1 && r + 1 >= full_from) SQD_TRY(part_b(n_b++));
       }
       SQD_TRY(settle(r));
+      last_settled = r;
       if (stopped) break;
       ++r;
       // round r has to be complete in the queue before its record can be waited for
@@ -1353,10 +1369,17 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
       if (n_b == r) break;  // the cycle limit: nothing more to run
     }
   }
-  // solution = Ritz vector of the last projected problem, normalised; the run's outcome to mailbox slot 2
-  hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
-                     c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
-  SQD_HIP_CHECK(hipGetLastError());
+  // solution = Ritz vector of the last projected problem, normalised; the run's outcome to mailbox slot 2 -- unless the
+  // conditional launch behind the stopping round has formed it already
+  // (WHICH round stopped the solve is read from the record itself -- its iteration counter freezes at the stop --: with
+  // rounds queued ahead, the record the host finds may already be a later round's)
+  const int stop_round = stopped ? (int)h_prog[MAIL_PAYLOAD + 0] - 1 : -1;
+  (void)last_settled;
+  if (!(stopped && stop_round >= 0 && stop_round <= spec_round)) {
+    hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
+                       c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 0);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
   if (timing) SQD_HIP_CHECK(hipEventRecord(c->ev[3], s));
   c->dav_timed = timing;
   c->have_solution = true;
@@ -1727,7 +1750,7 @@ int shard_dav_end(sqd_ctx* c, double** d_solution_rows, sqd_davidson_stats* st) 
   SQD_TRY(shard_check(c));
   const int64_t Dl = c->shard_Dl;
   hipLaunchKernelGGL(k_solution, dim3(red_blocks(Dl)), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(), Dl,
-                     (const DavState*)state_ptr_dev(c), c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
+                     (const DavState*)state_ptr_dev(c), c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 0);
   SQD_HIP_CHECK(hipGetLastError());
   SQD_STREAM_SYNC(c->stream);
   c->shard_active = false;
