@@ -37,6 +37,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+F64_MFMA_PEAK_TFLOPS = 78.6  # dense f64 matrix peak of the MI355X (public spec)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PROFILE_ROUND = "r03"
 
@@ -524,6 +525,24 @@ def secondary_entries(args, h1, eri, device):
         "us_per_davidson_iteration": 1e3 * ms_dav / max(nsig / steps, 1), "energy": float(e),
         "roofline": roofline_entry(ctx, ms_k / max(nt, 1), ms_a / max(nt, 1), nt, t_empty_ms=ms_e / max(nt, 1)),
     }
+    # --- MFMA roofline of the dense same-spin product of that subspace (north_star: "MFMA utilisation against the chip's
+    # roofline"): the kernel alone, HIP events around 20 launches, as one problem per launch (what a single solve
+    # launches: 25 tiles x 8 k-ranges, latency-bound) and as 16 per launch (a batched solve's full chip)
+    try:
+        ctx.set_subspace(sa, sb)
+        if ctx.sigma_kernel().startswith("k_same_spin_mfma"):
+            for copies, key in ((1, "roofline_mfma"), (16, "roofline_mfma_16_per_launch")):
+                ms1, fl1 = ctx.time_dense(20, copies)
+                res["hf_centred_317x317"][key] = {
+                    "bound": "mfma", "kernel": "sqd::k_same_spin_mfma_b", "dtype": "f64", "problems_per_launch": copies,
+                    "flops_per_launch": fl1, "avg_launch_ms": ms1, "achieved": fl1 / (ms1 * 1e-3) / 1e12,
+                    "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl1 / (ms1 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                    "note": "G = H_a C + C H_b on the zero-padded orders (320): 2 pa^2 pb + 2 pa pb^2 flops per problem; "
+                            "v_mfma_f64_16x16x4_f64; peak = dense f64 matrix rate (public spec, SURVEY 8d); counters: "
+                            "profiles/r04/pmc/final_mfma_batch_hf16_summary.json",
+                }
+    except Exception as exc:
+        res["hf_centred_317x317"]["roofline_mfma"] = {"error": repr(exc)}
     # --- the same HF-centred solve with pyscf's residual rule (|r| < sqrt(tol) instead of this library's default
     # sqrt(tol)/32): the wall clock to an energy within 1e-6 Ha the way the reference converges
     try:

@@ -290,6 +290,11 @@ int sqd_rdm2s(sqd_ctx* ctx, const double* amps, double* dm2aa, double* dm2ab, do
 /* Benchmark hooks: run `reps` sigma builds on the resident solution buffer and report the
  * average device time per launch of the dominant sigma kernel (HIP events on the context stream). */
 int sqd_time_sigma(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift, double* ms_per_sigma);
+/* ... and of the matrix-core same-spin product alone (subspaces in dense mode, sqd_sigma_kernel kind 3): `copies` identical
+ * problems per launch (1 = what a single solve launches, 16 = a batched solve's full chip), average device time per
+ * launch and the flops of one launch on the padded orders (2 pa^2 pb + 2 pa pb^2 per copy) -- the MFMA roofline entry of
+ * bench.py. */
+int sqd_time_dense(sqd_ctx* ctx, int reps, int copies, double* ms_per_launch, double* flops_per_launch);
 /* Populated-link count and algorithmic bytes of one sigma (SURVEY 8d formula) for the current subspace. */
 int sqd_sigma_bytes(sqd_ctx* ctx, double* bytes);
 /* Bytes this build's formulation has to move once per sigma (vectors + hdiag + the link records at their stored

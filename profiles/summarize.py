@@ -77,9 +77,24 @@ for sub in ("pmc_mfma_batch_hf16", "pmc_mfma2_batch_hf16"):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if acc:
         out = {k: {c: {"dispatches": len(v), "avg": sum(v) / len(v)} for c, v in d.items()} for k, d in acc.items()}
+        # kernel durations of the same command (kernel trace of the batched HF-centred run), for the normalisation below
+        dur_ns = {}
+        for f in glob.glob(os.path.join(src, "prof_batch_hf16", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                dur_ns[short(r["Name"])] = float(r["AverageNs"])
         for k, d in out.items():
             if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]["avg"] > 0:
                 d["mfma_busy_over_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / d["SQ_BUSY_CYCLES"]["avg"]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d and k in dur_ns:
+                # fraction of the launch during which a SIMD's matrix pipe is busy: the counter is summed over the
+                # chip's 1024 SIMDs (256 CUs x 4), in shader-clock cycles (2.4 GHz under load)
+                cyc = dur_ns[k] * 1e-9 * 2.4e9
+                d["avg_launch_ns_kernel_trace"] = dur_ns[k]
+                d["mfma_pipe_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (1024.0 * cyc)
+                d["mfma_pipe_busy_frac_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x avg launch ns x 2.4 GHz)"
+            if "SQ_INSTS_VALU_MFMA_MOPS_F64" in d and k in dur_ns:
+                # MOPS_F64 counts 512 flops each (MI355X_MICROARCH / rocprof counter definition): achieved TFLOP/s
+                d["tflops_from_mops_counter"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"]["avg"] * 512.0 / (dur_ns[k] * 1e-9) / 1e12
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{sub[4:]}_summary.json"), "w"), indent=1)
         print(sub, {k: {c: (round(v["avg"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in d.items()} for k, d in out.items() if "mfma" in k or "sigma" in k})
 print("written to", dst)

@@ -70,6 +70,7 @@ EXPORTED_SYMBOLS = (
     "sqd_rdm2",
     "sqd_rdm2s",
     "sqd_time_sigma",
+    "sqd_time_dense",
     "sqd_sigma_bytes",
     "sqd_sigma_bytes_needed",
     "sqd_sigma_kernel",
@@ -184,6 +185,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_rdm2.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm2s.argtypes = [_ctxp, _dp, _dp, _dp, _dp]
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+    lib.sqd_time_dense.argtypes = [_ctxp, C.c_int, C.c_int, _dp, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
     lib.sqd_sigma_bytes_needed.argtypes = [_ctxp, _dp]
     lib.sqd_sigma_kernel.argtypes = [_ctxp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -880,6 +882,12 @@ class Context:
         out = C.c_double()
         self._check(self._lib.sqd_time_sigma(self._h, reps, use_spin, ss, shift, C.byref(out)))
         return float(out.value)
+
+    def time_dense(self, reps: int = 10, copies: int = 1):
+        """(ms per launch, flops per launch) of the matrix-core same-spin product alone, ``copies`` problems per launch."""
+        ms, fl = C.c_double(), C.c_double()
+        self._check(self._lib.sqd_time_dense(self._h, reps, copies, C.byref(ms), C.byref(fl)))
+        return float(ms.value), float(fl.value)
 
     def sigma_bytes(self) -> float:
         out = C.c_double()

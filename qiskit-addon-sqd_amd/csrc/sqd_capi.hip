@@ -1063,6 +1063,18 @@ SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double
   return SQD_OK;
 }
 
+SQD_API int sqd_time_dense(sqd_ctx* c, int reps, int copies, double* ms_per_launch, double* flops_per_launch) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
+  if (reps < 1 || !ms_per_launch || !flops_per_launch) return SQD_ERR_INVALID;
+  if (!c->have_solution) {
+    SQD_TRY(c->sol.reserve((size_t)c->D * 8));
+    SQD_HIP_CHECK(hipMemsetAsync(c->sol.p, 0, c->D * 8, c->stream));
+  }
+  return time_dense_product(c, c->sol.as<double>(), reps, copies, ms_per_launch, flops_per_launch);
+}
+
 SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);

@@ -335,6 +335,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
                  int64_t in_stride = 0, int64_t out_stride = 0);
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride = 0,
             int64_t out_stride = 0);
+int time_dense_product(sqd_ctx* c, const double* d_c, int reps, int copies, double* ms, double* flops);
 // list-pass sigma for large sets with short lists (sqd_lists.hip).  lists_select: phase 2 of set_subspace, CSR pointers
 // on the host, decides sqd_ctx::sig_lists and plans the column blocks; lists_build: device tables, behind launch C
 bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1, const int64_t* tot, const int* nocc);

@@ -1482,6 +1482,44 @@ int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan) {
   return SQD_OK;
 }
 
+// benchmark hook (sqd_time_dense): `reps` launches of the matrix-core same-spin product of the current subspace on
+// `copies` identical argument records at once -- copies = 1 is the launch of a single solve (25 tiles x DENSE_SPLIT
+// workgroups at 317 x 317: latency, not throughput), copies = 16 fills the chip the way a batched solve of 16 subspaces
+// does (every copy reads the same operands and writes the same partial products: timing only)
+int time_dense_product(sqd_ctx* c, const double* d_c, int reps, int copies, double* ms, double* flops) {
+  if (!c->sig_dense) {
+    set_error("the current subspace does not use the dense same-spin product");
+    return SQD_ERR_STATE;
+  }
+  if (copies < 1) copies = 1;
+  if (copies > 64) copies = 64;
+  DenseArgs d;
+  fill_dense_args(c, d_c, 0, &d);
+  d.stop = nullptr;
+  d.vec_index = nullptr;
+  std::vector<DenseArgs> h((size_t)copies, d);
+  SQD_TRY(c->io_out.reserve((size_t)copies * sizeof(DenseArgs)));
+  SQD_HIP_CHECK(hipMemcpyAsync(c->io_out.p, h.data(), (size_t)copies * sizeof(DenseArgs), hipMemcpyHostToDevice, c->stream));
+  SQD_STREAM_SYNC(c->stream);
+  auto launch = [&]() {
+    hipLaunchKernelGGL(k_same_spin_mfma_b, dim3(d.gx, DENSE_SPLIT, (unsigned)copies), dim3(256), 0, c->stream,
+                       static_cast<const DenseArgs*>(c->io_out.p));
+  };
+  launch();
+  SQD_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+  for (int i = 0; i < reps; ++i) launch();
+  SQD_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+  SQD_HIP_CHECK(hipGetLastError());
+  SQD_STREAM_SYNC(c->stream);
+  float t = 0.f;
+  SQD_HIP_CHECK(hipEventElapsedTime(&t, c->ev[2], c->ev[3]));
+  *ms = (double)t / reps;
+  // G = H_a C + C H_b on the padded orders: 2 pa^2 pb + 2 pa pb^2 flops per copy
+  const double pa = c->dense_pa, pb = c->dense_pb;
+  *flops = (double)copies * (2.0 * pa * pa * pb + 2.0 * pa * pb * pb);
+  return SQD_OK;
+}
+
 int apply_h(sqd_ctx* c, const double* d_c, double* d_sigma, int use_spin, double ss, double shift, int64_t in_stride,
             int64_t out_stride) {
   if (use_spin == 3) {
