@@ -78,6 +78,9 @@ EXPORTED_SYMBOLS = (
     "sqd_pauli_fill",
     "sqd_pauli_free",
     "sqd_recover_rows",
+    "sqd_hamming_excess",
+    "sqd_merge_rows",
+    "sqd_choice_replay",
 )
 
 
@@ -195,6 +198,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_pauli_free.argtypes = [_ctxp]
     lib.sqd_recover_rows.argtypes = [C.POINTER(C.c_uint8), C.c_int64, C.c_int, _i64p, C.c_int64, _dp, _dp, _dp, _dp,
                                      C.c_int, C.c_int, _dp, C.c_int64, _i64p]
+    lib.sqd_hamming_excess.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p]
+    lib.sqd_merge_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _i64p]
+    lib.sqd_choice_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, _i64p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("sqd_last_error", "sqd_davidson_default_opts"):

@@ -16,6 +16,9 @@
 // to the reference's; tests/test_sqd_loop.py replays a recorded run of the reference against it.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "sqd_common.h"
 
@@ -52,22 +55,21 @@ struct UniformStream {
 static int repair_half(uint8_t* b, int n, const double* w_up, const double* w_down, int target, UniformStream& us) {
   double w[SQD_MAX_NORB], sub[SQD_MAX_NORB], p[SQD_MAX_NORB], cdf[SQD_MAX_NORB];
   int cand[SQD_MAX_NORB], found[SQD_MAX_NORB], fresh[SQD_MAX_NORB];
-  bool any = false;
+  // (nothing to repair in this half: no weights are formed and no random number is drawn -- the reference returns from
+  // the same two conditions, in the other order)
   int cnt = 0;
+  for (int i = 0; i < n; ++i) cnt += b[i] ? 1 : 0;
+  const int excess = cnt - target;
+  if (excess == 0) return 0;
+  bool any = false;
   for (int i = 0; i < n; ++i) {
-    double x = b[i] ? w_down[i] : w_up[i];
-    x = std::fmax(0.0, x);  // np.maximum / np.minimum propagate NaN; fmax does not: checked below
-    x = std::fmin(1.0, x);
-    if (std::isnan(w_down[i]) || std::isnan(w_up[i])) return 2;
+    const double x = b[i] ? w_down[i] : w_up[i];  // (clipped to [0, 1] and checked for NaN once per call)
     w[i] = x;
     any = any || (x != 0.0);
-    cnt += b[i] ? 1 : 0;
   }
   if (!any) return 0;
   const double s = np_pairwise_sum(w, n);
   for (int i = 0; i < n; ++i) w[i] /= s;
-  const int excess = cnt - target;
-  if (excess == 0) return 0;
   const uint8_t want = excess > 0 ? 1 : 0;  // flip occupied bits down, or empty bits up
   const int size = excess > 0 ? excess : -excess;
   int m = 0;
@@ -129,13 +131,25 @@ extern "C" __attribute__((visibility("default"))) int sqd_recover_rows(
     uint8_t* bits, int64_t n_total, int norb, const int64_t* rows, int64_t nrows, const double* up_left,
     const double* down_left, const double* up_right, const double* down_right, int target_left, int target_right,
     const double* uniforms, int64_t n_uniforms, int64_t* n_used) {
-  if (!bits || !rows || !uniforms || !n_used || norb < 1 || norb > SQD_MAX_NORB) {
+  if (!bits || !uniforms || !n_used || norb < 1 || norb > SQD_MAX_NORB) {  // (rows == NULL: every row, in order)
     set_error("sqd_recover_rows: bad argument");
     return SQD_ERR_INVALID;
   }
   UniformStream us{uniforms, n_uniforms, 0};
+  // np.minimum(1, np.maximum(0, weights)) once per call instead of once per half-row; NaN weights: Python's job
+  double cl[4][SQD_MAX_NORB];
+  const double* src[4] = {up_left, down_left, up_right, down_right};
+  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < norb; ++i) {
+      if (std::isnan(src[t][i])) {
+        set_error("sqd_recover_rows: NaN weight");
+        return SQD_ERR_STATE;
+      }
+      cl[t][i] = std::fmin(1.0, std::fmax(0.0, src[t][i]));
+    }
+  up_left = cl[0], down_left = cl[1], up_right = cl[2], down_right = cl[3];
   for (int64_t r = 0; r < nrows; ++r) {
-    const int64_t i = rows[r];
+    const int64_t i = rows ? rows[r] : r;
     if (i < 0 || i >= n_total) {
       set_error("sqd_recover_rows: row index out of range");
       return SQD_ERR_INVALID;
@@ -154,5 +168,164 @@ extern "C" __attribute__((visibility("default"))) int sqd_recover_rows(
     }
   }
   *n_used = us.pos;
+  return SQD_OK;
+}
+
+// ---- the rest of the host side of an SQD iteration's sample processing, natively: at 1e5 samples the numpy
+// passes around the repair -- Hamming weights of every row, the duplicate merge, the subsampling draws -- cost more than
+// the repair itself and, together, several times the batched solve they feed.
+//
+// sqd_hamming_excess: per row the distance of both halves from their target weights; *bound = an upper bound on the
+// uniform doubles sqd_recover_rows can consume (a draw of k bits takes k, then at most k - 1, ... doubles), *nbad = rows
+// off target.  bits: [n][2 norb] bytes (0 / 1).
+extern "C" __attribute__((visibility("default"))) int sqd_hamming_excess(const uint8_t* bits, int64_t n, int norb,
+                                                                          int target_left, int target_right,
+                                                                          int64_t* bound, int64_t* nbad) {
+  if (!bits || !bound || !nbad || norb < 1) return SQD_ERR_INVALID;
+  int64_t bd = 0, bad = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const uint8_t* row = bits + r * 2 * (int64_t)norb;
+    int cl = 0, cr = 0;
+    for (int i = 0; i < norb; ++i) cl += row[i], cr += row[norb + i];
+    const int64_t el = std::abs(cl - target_left), er = std::abs(cr - target_right);
+    bd += el * (el + 1) / 2 + er * (er + 1) / 2;
+    bad += (el || er) ? 1 : 0;
+  }
+  *bound = bd;
+  *nbad = bad;
+  return SQD_OK;
+}
+
+// sqd_merge_rows: duplicates of a bool matrix merged in FIRST-OCCURRENCE order, their probabilities added one by one in
+// row order (what the reference's running dictionary does, configuration_recovery.py:112-126).  first[k] = row index of
+// the k-th distinct row, freq[k] = its summed probability (not normalised); *n_unique.  nbits <= 128.
+extern "C" __attribute__((visibility("default"))) int sqd_merge_rows(const uint8_t* bits, int64_t n, int nbits,
+                                                                      const double* probs, int64_t* first, double* freq,
+                                                                      int64_t* n_unique) {
+  if (!bits || !probs || !first || !freq || !n_unique || nbits < 1 || nbits > 128) return SQD_ERR_INVALID;
+  size_t cap = 16;
+  while (cap < (size_t)n * 2 + 16) cap <<= 1;
+  std::vector<int64_t> slot(cap, -1);  // -> index into first / freq
+  std::vector<uint64_t> keys((size_t)n * 2);
+  int64_t nu = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const uint8_t* row = bits + r * (int64_t)nbits;
+    // eight 0 / 1 bytes -> eight bits with one multiplication (byte j lands on bit 56 + j of the product)
+    uint64_t k0 = 0, k1 = 0;
+    int i = 0;
+    for (; i + 8 <= nbits; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, row + i, 8);
+      const uint64_t b8 = ((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56;
+      if (i < 64) k0 |= b8 << i;
+      else k1 |= b8 << (i - 64);
+    }
+    for (; i < nbits; ++i) {
+      if (i < 64) k0 |= (uint64_t)(row[i] & 1) << i;
+      else k1 |= (uint64_t)(row[i] & 1) << (i - 64);
+    }
+    uint64_t h = (k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32;
+    size_t pos = (size_t)h & (cap - 1);
+    for (;;) {
+      const int64_t e = slot[pos];
+      if (e < 0) {
+        slot[pos] = nu;
+        keys[2 * (size_t)nu] = k0;
+        keys[2 * (size_t)nu + 1] = k1;
+        first[nu] = r;
+        freq[nu] = probs[r];
+        ++nu;
+        break;
+      }
+      if (keys[2 * (size_t)e] == k0 && keys[2 * (size_t)e + 1] == k1) {
+        freq[e] += probs[r];
+        break;
+      }
+      pos = (pos + 1) & (cap - 1);
+    }
+  }
+  *n_unique = nu;
+  return SQD_OK;
+}
+
+// sqd_choice_replay: numpy's Generator.choice(n, size, replace=False, p=p) (subsampling.py:200-207: one call per batch)
+// replayed on a block of uniforms, as sqd_recover_rows does for the repair draws: out[size] indices, *n_used doubles
+// consumed (size at least; more only when two draws of a round land on the same element).  Returns SQD_ERR_STATE for
+// inputs numpy raises on (the caller then makes the numpy call, which raises), SQD_ERR_LIMIT for a short stream.
+extern "C" __attribute__((visibility("default"))) int sqd_choice_replay(const double* p_in, int64_t n, int64_t size,
+                                                                         int64_t nbatches, const double* uniforms,
+                                                                         int64_t n_uniforms, int64_t* out, int64_t* n_used) {
+  if (!p_in || !uniforms || !out || !n_used || n < 1 || size < 1 || nbatches < 1) return SQD_ERR_INVALID;
+  int64_t nonzero = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!(p_in[i] >= 0.0) || !std::isfinite(p_in[i])) return SQD_ERR_STATE;
+    nonzero += p_in[i] > 0.0 ? 1 : 0;
+  }
+  if (size > n || nonzero < size) return SQD_ERR_STATE;
+  {  // numpy's check that p sums to one (Kahan summation, tolerance sqrt(eps)): its ValueError is Python's to raise
+    double sum = p_in[0], c = 0.0;
+    for (int64_t i = 1; i < n; ++i) {
+      const double y = p_in[i] - c, t = sum + y;
+      c = (t - sum) - y;
+      sum = t;
+    }
+    if (std::fabs(sum - 1.0) > 1.4901161193847656e-08) return SQD_ERR_STATE;
+  }
+  // the first round of every batch works on the untouched p: one cumulative sum serves them all
+  std::vector<double> cdf0((size_t)n), p, cdf;
+  {
+    double run = 0.0;
+    for (int64_t i = 0; i < n; ++i) {  // np.cumsum: a plain running sum
+      run += p_in[i];
+      cdf0[i] = run;
+    }
+    const double last = cdf0[n - 1];
+    for (int64_t i = 0; i < n; ++i) cdf0[i] /= last;
+  }
+  std::vector<char> taken((size_t)n, 0);
+  std::vector<int64_t> fresh;
+  int64_t pos = 0;
+  for (int64_t bt = 0; bt < nbatches; ++bt) {
+    int64_t* found = out + bt * size;
+    int64_t nf = 0;
+    const double* cur = cdf0.data();
+    while (nf < size) {
+      const int64_t k = size - nf;
+      if (pos + k > n_uniforms) return SQD_ERR_LIMIT;
+      const double* x = uniforms + pos;
+      pos += k;
+      if (nf > 0) {  // a later round: the elements found so far drop out of p
+        if (p.empty()) p.assign(p_in, p_in + n), cdf.resize((size_t)n);
+        else if (cur == cdf0.data()) std::copy(p_in, p_in + n, p.begin());
+        for (int64_t f = 0; f < nf; ++f) p[found[f]] = 0.0;
+        double run = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+          run += p[i];
+          cdf[i] = run;
+        }
+        const double last = cdf[n - 1];
+        for (int64_t i = 0; i < n; ++i) cdf[i] /= last;
+        cur = cdf.data();
+      }
+      fresh.clear();
+      for (int64_t j = 0; j < k; ++j) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {  // searchsorted(side='right')
+          const int64_t mid = (lo + hi) >> 1;
+          if (cur[mid] <= x[j]) lo = mid + 1;
+          else hi = mid;
+        }
+        if (lo >= n) return SQD_ERR_STATE;
+        if (!taken[lo]) {  // first occurrence of every index, in draw order
+          taken[lo] = 1;
+          fresh.push_back(lo);
+        }
+      }
+      for (int64_t q : fresh) found[nf++] = q;
+    }
+    for (int64_t f = 0; f < size; ++f) taken[found[f]] = 0;  // (the next batch draws from the whole set again)
+  }
+  *n_used = pos;
   return SQD_OK;
 }

@@ -125,9 +125,52 @@ def subsample(
     if samples_per_batch >= n:
         return [bitstring_matrix[np.arange(n)] for _ in range(num_batches)]
     pool = np.arange(n).astype("int")
+    idx_all = _choice_native(rng, probabilities, samples_per_batch, num_batches)
+    if idx_all is not None:
+        return [bitstring_matrix[idx] for idx in idx_all]
     return [
         bitstring_matrix[rng.choice(pool, samples_per_batch, replace=False, p=probabilities)] for _ in range(num_batches)
     ]
+
+
+def _native_lib():
+    """The native library when it can be loaded (the host-side helpers need no GPU), else None: numpy then."""
+    try:
+        from . import _capi
+
+        return _capi.load_library(), _capi
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def _choice_native(rng, probabilities, size: int, nbatches: int):
+    """``nbatches`` calls ``rng.choice(n, size, replace=False, p=probabilities)`` replayed natively (``sqd_choice_replay``) on
+    uniforms drawn from the same generator, which is rewound by what was not consumed: the indices and the stream position
+    are numpy's (7 ms per batch at 1e5 samples in numpy -- validation passes and temporaries around a cumsum and ``size``
+    binary searches; the batches of an iteration share the first round's cumulative sum here).  Returns [nbatches][size]
+    indices, or None: not applicable (another bit generator, inputs numpy raises on) -- numpy then decides."""
+    bitgen = rng.bit_generator
+    if not isinstance(bitgen, np.random.PCG64):
+        return None
+    lib, capi = _native_lib()
+    if lib is None:
+        return None
+    p = np.ascontiguousarray(probabilities, dtype=np.float64)
+    if p.ndim != 1 or size > p.size:
+        return None
+    # (a batch takes `size` doubles plus a few per round with two draws on one element; beyond this bound: numpy's turn)
+    bound = int(nbatches) * (int(size) * (int(size) + 1) // 2 if size < 64 else 4 * int(size) + 64)
+    state = bitgen.state
+    uniforms = rng.random(bound)
+    out = np.empty((int(nbatches), int(size)), dtype=np.int64)
+    used = capi.C.c_int64(0)
+    rc = lib.sqd_choice_replay(p.ctypes.data, p.size, int(size), int(nbatches), uniforms.ctypes.data, uniforms.size,
+                               out.ctypes.data, capi.C.byref(used))
+    if rc != 0:  # numpy raises on these inputs, or the block was too short (many collisions): numpy does the draw
+        bitgen.state = state
+        return None
+    bitgen.advance(-(bound - used.value))
+    return out
 
 
 # ----------------------------------------------------------------------------- configuration recovery
@@ -200,6 +243,11 @@ def recover_configurations(
     up_r, dn_r = _flip_weight_up(num_elec_a / norb, occ_right), _flip_weight_down(num_elec_a / norb, occ_right)
 
     out = np.ascontiguousarray(bitstring_matrix).copy()
+    probabilities = np.asarray(probabilities, dtype=float)
+    fast = _recover_all_native(out, probabilities, norb, up_l, dn_l, up_r, dn_r, num_elec_b, num_elec_a, rng)
+    if fast is not None:
+        return fast
+    out = np.ascontiguousarray(bitstring_matrix).copy()  # (a failed native pass may have touched some rows)
     sum_l, sum_r = out[:, :norb].sum(axis=1), out[:, norb:].sum(axis=1)
     rows = np.nonzero((sum_l != num_elec_b) | (sum_r != num_elec_a))[0]
     if rows.size and not _recover_rows_native(out, rows, sum_l, sum_r, norb, up_l, dn_l, up_r, dn_r,
@@ -210,7 +258,6 @@ def recover_configurations(
             _repair_half(out[i, norb:], up_r, dn_r, num_elec_a, rng)
 
     # merge duplicates in first-occurrence order, adding their probabilities in row order
-    probabilities = np.asarray(probabilities, dtype=float)
     _, first_idx, inverse = np.unique(_row_keys(out), return_index=True, return_inverse=True)
     order = np.argsort(first_idx, kind="stable")  # groups in order of first appearance
     rank = np.empty_like(order)
@@ -219,6 +266,51 @@ def recover_configurations(
     freqs = np.bincount(rank[inverse.ravel()], weights=probabilities, minlength=order.size)
     freqs = np.abs(freqs) / np.sum(np.abs(freqs))
     return out[first_idx[order]], freqs
+
+
+def _recover_all_native(out, probabilities, norb, up_l, dn_l, up_r, dn_r, target_l, target_r, rng):
+    """The whole of ``recover_configurations`` behind the flip weights in three native passes over the byte matrix --
+    Hamming excess of every row (``sqd_hamming_excess``: the bound on the uniforms to draw), repair of the rows off target
+    in row order (``sqd_recover_rows`` with rows = NULL), duplicate merge in first-occurrence order with the
+    probabilities added in row order (``sqd_merge_rows``) -- instead of numpy's column sums, ``np.unique`` with inverse,
+    ``argsort`` and ``bincount`` over 1e5 rows.  Returns (bitstrings, frequencies), or None when the fast path does not
+    apply (another bit generator, > 64 orbitals, weights numpy would raise on): the stream is then untouched."""
+    bitgen = rng.bit_generator
+    if not isinstance(bitgen, np.random.PCG64) or norb > 64 or 2 * norb > 128 or out.shape[0] == 0:
+        return None
+    if probabilities.ndim != 1 or probabilities.size != out.shape[0]:
+        return None
+    lib, capi = _native_lib()
+    if lib is None:
+        return None
+    C = capi.C
+    work = out.view(np.uint8)
+    n = out.shape[0]
+    bound, nbad = C.c_int64(0), C.c_int64(0)
+    if lib.sqd_hamming_excess(work.ctypes.data, n, int(norb), int(target_l), int(target_r), C.byref(bound), C.byref(nbad)) != 0:
+        return None
+    if nbad.value:
+        state = bitgen.state
+        uniforms = rng.random(bound.value)
+        used = C.c_int64(0)
+        args = [np.ascontiguousarray(a, dtype=np.float64) for a in (up_l, dn_l, up_r, dn_r)]
+        dp, u8p = capi._dp, C.POINTER(C.c_uint8)
+        rc = lib.sqd_recover_rows(work.ctypes.data_as(u8p), n, int(norb), None, n, *(a.ctypes.data_as(dp) for a in args),
+                                  int(target_l), int(target_r), uniforms.ctypes.data_as(dp), uniforms.size, C.byref(used))
+        if rc != 0:
+            bitgen.state = state
+            return None
+        bitgen.advance(-(bound.value - used.value))
+    probs = np.ascontiguousarray(probabilities, dtype=np.float64)
+    first = np.empty(n, dtype=np.int64)
+    freq = np.empty(n, dtype=np.float64)
+    nu = C.c_int64(0)
+    if lib.sqd_merge_rows(work.ctypes.data, n, int(2 * norb), probs.ctypes.data, first.ctypes.data, freq.ctypes.data,
+                          C.byref(nu)) != 0:
+        raise RuntimeError("sqd_merge_rows failed")  # (cannot happen behind the checks above; the stream has moved)
+    first, freq = first[: nu.value], freq[: nu.value]
+    freq = np.abs(freq) / np.sum(np.abs(freq))
+    return out[first], freq
 
 
 def _recover_rows_native(out, rows, sum_l, sum_r, norb, up_l, dn_l, up_r, dn_r, target_l, target_r, rng) -> bool:

@@ -178,3 +178,46 @@ def test_unique_rows_matches_numpy_axis0():
         r0, c0 = np.unique(b, axis=0, return_counts=True)
         r1, c1 = _unique_rows(b)
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1), nbits
+
+
+def test_native_sample_processing_matches_numpy():
+    """The native helpers of the loop's host side (libsqd_hip.so, no GPU needed: `sqd_choice_replay`, `sqd_hamming_excess`
+    + `sqd_recover_rows` on all rows + `sqd_merge_rows`) against the numpy code paths they replace: same indices, same
+    rows, same probabilities bit for bit, and the SAME position of the random stream afterwards."""
+    from qiskit_addon_sqd_amd import sampling as SP
+
+    rng0 = np.random.default_rng(5)
+    # --- subsampling draws: many collisions (size close to n) and few (size << n)
+    for n, size, nb in ((12, 9, 5), (400, 37, 8), (5000, 250, 3)):
+        p = rng0.random(n)
+        p[rng0.random(n) < 0.2] = 0.0
+        if np.count_nonzero(p) < size:
+            p[:size] = 0.5
+        p /= p.sum()
+        a, b = np.random.default_rng(99), np.random.default_rng(99)
+        got = SP._choice_native(a, p, size, nb)
+        assert got is not None
+        ref = [b.choice(np.arange(n), size, replace=False, p=p) for _ in range(nb)]
+        assert all(np.array_equal(g, r) for g, r in zip(got, ref))
+        assert a.bit_generator.state == b.bit_generator.state
+    # --- inputs numpy raises on are left to numpy (and the stream is not moved)
+    a = np.random.default_rng(1)
+    s0 = a.bit_generator.state
+    assert SP._choice_native(a, np.array([0.5, 0.5, 0.0]), 3, 1) is None and a.bit_generator.state == s0
+    # --- whole recover_configurations: native three-pass path against the numpy path on the same input and stream
+    norb, n = 9, 3000
+    bits = rng0.random((n, 2 * norb)) < 0.4
+    bits = np.concatenate([bits, bits[:200]])  # duplicates
+    probs = rng0.random(len(bits))
+    probs /= probs.sum()
+    occ = (rng0.random(norb), rng0.random(norb))
+    a, b = np.random.default_rng(7), np.random.default_rng(7)
+    m1, f1 = SP.recover_configurations(bits, probs, occ, 4, 3, rand_seed=a)
+    real = SP._recover_all_native
+    SP._recover_all_native = lambda *args, **kw: None  # force the numpy path
+    try:
+        m2, f2 = SP.recover_configurations(bits, probs, occ, 4, 3, rand_seed=b)
+    finally:
+        SP._recover_all_native = real
+    assert np.array_equal(m1, m2) and np.array_equal(f1, f2)
+    assert a.bit_generator.state == b.bit_generator.state
