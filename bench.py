@@ -39,7 +39,7 @@ sys.path.insert(0, str(ROOT))
 
 F64_MFMA_PEAK_TFLOPS = 78.6  # dense f64 matrix peak of the MI355X (public spec)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse_args():
@@ -92,7 +92,7 @@ def pmc_traffic(args):
     bench.py cannot collect counters itself.  (None, source) when no matching profile is committed."""
     if (args.norb, args.nelec, args.na, args.nb) != (30, 8, 317, 317):
         return None, None
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r01"):
         f = ROOT / "profiles" / rnd / "pmc" / f"final_{args.strings}317_pmc_summary.json"
         try:
             d = json.loads(f.read_text())["HBM_BYTES"]
@@ -448,9 +448,12 @@ def main():
             for _ in range(3):
                 F.solve_fermion((sa, sb), h1_rw, eri_rw, spin_sq=args.spin_sq, device=local_rank)
             t_rw = time.perf_counter()
-            for _ in range(10):
+            for _ in range(40):
                 F.solve_fermion((sa, sb), h1_rw, eri_rw, spin_sq=args.spin_sq, device=local_rank)
-            out["ms_per_step_writeable_integrals"] = 1e2 * (time.perf_counter() - t_rw)
+            out["ms_per_step_writeable_integrals"] = 1e3 * (time.perf_counter() - t_rw) / 40
+            out["writeable_integrals_note"] = ("plain (writeable) numpy tensors, the reference user's call: the previous call's "
+                                               "solver context is taken at once and a worker thread re-hashes the tensors "
+                                               "while the solve runs; a mismatch repeats the solve (fermion._run_on_context)")
             if args.spin_sq is not None:
                 # the oracle's Davidson here runs the bare operator; the penalised solve is compared with the
                 # reference flow in tests/test_gpu_parity.py (spin-penalty cases), not in the bench
@@ -597,6 +600,12 @@ def secondary_entries(args, h1, eri, device):
         t_sig = ctx.time_sigma(5)
         res["sigma_uniform_1e4x1e4"] = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
                                         "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
+        if ctx.sigma_kernel() == "k_sigma_lists":
+            res["sigma_uniform_1e4x1e4"]["roofline"]["launches_per_sigma"] = 4
+            res["sigma_uniform_1e4x1e4"]["roofline"]["note_kernels"] = (
+                "one sigma = k_lists_transpose + k_lists_t4 + k_sigma_lists<0> (alpha lists on C^T) + k_sigma_lists<1> (beta "
+                "lists on C); avg_launch_ms is the whole application (HIP events around 5 of them); per-kernel times and "
+                "counters: profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
         ctx.set_subspace(sa[:16], sb[:16])  # release nothing, but leave a small subspace behind
     except Exception as exc:
         res["sigma_uniform_1e4x1e4"] = {"error": repr(exc)}

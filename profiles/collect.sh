@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the measurements that DESIGN.md section 8 and profiles/rNN/ quote.  Run on the GPU box:
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r04'
 # Everything lands under gpurun_out/<round>/; profiles/summarize.py then writes the tracked summaries.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -27,6 +27,9 @@ python profiles/probes/_sharded_probe.py 2>&1 | eval $F > $OUT/sharded_probe.txt
 python profiles/probes/_phase_probe2.py 2>&1 | eval $F > $OUT/phase_probe.txt
 python profiles/probes/_jitter_probe.py 2>&1 | eval $F > $OUT/jitter_probe.txt
 python profiles/probes/_big_sigma_probe.py 2>&1 | eval $F > $OUT/big_sigma_probe.txt
+SQD_SIGMA_LISTS=0 python profiles/probes/_big_sigma_probe.py 2>&1 | eval $F >> $OUT/big_sigma_probe.txt
+SIZES="10000 6000 4000" bash profiles/probes/_lists_passes.sh 2>&1 | eval $F > $OUT/lists_passes_probe.txt
+[ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_lists_clock.py 2>&1 | eval $F > $OUT/lists_clock_probe.txt
 # phase clocks of the Davidson BLAS-1 kernels (probe build of the library: hipcc ... -DSQD_PHASE_CLOCK, see the probe's header)
 [ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_phase_clock.py 2>&1 | eval $F > $OUT/phase_clock_probe.txt
 [ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_sigma_clock.py 2>&1 | eval $F > $OUT/sigma_clock_probe.txt
@@ -57,6 +60,7 @@ CASE=hf16 REPS=3 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA --out
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 # keep only what travels back comfortably (the merge limit is 64 MiB)
+TAG=$R/pmc_lists bash profiles/probes/_pmc_lists.sh > $OUT/pmc_lists_probe.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +12M -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT

@@ -22,7 +22,7 @@ def main():
     total = sum(v[1] for v in stats.values())
     lines = ["name,calls,total_us,avg_us,min_us,max_us,pct"]
     for name, (n, t, lo, hi) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-        short = name.split("(")[0][:70]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][:70]
         lines.append(f"\"{short}\",{n},{t / 1e3:.1f},{t / n / 1e3:.2f},{lo / 1e3:.2f},{hi / 1e3:.2f},{100.0 * t / total:.1f}")
     out = "\n".join(lines)
     if "--csv" in sys.argv:

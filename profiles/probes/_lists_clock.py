@@ -25,7 +25,7 @@ ms = ctx.time_sigma(reps - 1)  # (time_sigma runs one warm-up application: reps 
 lib.sqd_probe_clk_lists(buf, 0)
 c = np.array(buf[:], dtype=np.float64).reshape(4, 8)
 names = ['requests', 'row from LDS', 'barrier 1', 'next row -> LDS', 'epilogue', 'barrier 2']
-nwg = 240.0
+nwg = 240.0  # (8 XCDs x 3 row chunks x 10 column blocks at 10^4 x 10^4)
 for v, tag in ((0, 'alpha pass'), (1, 'beta pass')):
     tot = c[v, :6].sum()
     print(f'{tag}: per workgroup and launch {tot / nwg / reps / 100.0:.1f} us  |  ' +

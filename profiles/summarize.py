@@ -5,7 +5,7 @@ profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traf
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
@@ -19,6 +19,8 @@ for d in glob.glob(os.path.join(src, "prof_*")):
 
 
 def short(name):
+    # (kernels of an anonymous namespace -- sqd_lists.hip -- carry "(anonymous namespace)::" in front of their name)
+    name = name.replace("(anonymous namespace)::", "")
     return name.split("(")[0].replace("void ", "").strip()
 
 
@@ -30,7 +32,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
         real, early, alld = defaultdict(list), defaultdict(int), defaultdict(list)
         for r in csv.DictReader(open(f)):
             name = short(r["Kernel_Name"])
-            if "k_sigma" not in name and "k_same_spin" not in name:
+            if "k_sigma" not in name and "k_same_spin" not in name and "k_lists" not in name:
                 continue
             alld[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for name, ds in alld.items():
@@ -97,4 +99,7 @@ for sub in ("pmc_mfma_batch_hf16", "pmc_mfma2_batch_hf16"):
                 d["tflops_from_mops_counter"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"]["avg"] * 512.0 / (dur_ns[k] * 1e-9) / 1e12
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{sub[4:]}_summary.json"), "w"), indent=1)
         print(sub, {k: {c: (round(v["avg"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in d.items()} for k, d in out.items() if "mfma" in k or "sigma" in k})
+f = os.path.join(src, "pmc_lists", "summary.txt")
+if os.path.exists(f):  # per-kernel counters of the list-pass sigma at 10^4 x 10^4 (profiles/probes/_pmc_lists.sh)
+    shutil.copy(f, os.path.join(dst, "pmc", "final_lists_uniform10000_counters.txt"))
 print("written to", dst)
