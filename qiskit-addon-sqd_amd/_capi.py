@@ -790,7 +790,8 @@ class Context:
             best_buf = pinned_empty(max(a_arr[i].size * b_arr[i].size for i in range(n)))
         elif fetch != "none":
             raise ValueError("fetch must be 'best', 'all' or 'none'")
-        self._batch_gen = getattr(self, "_batch_gen", 0) + 1
+        # (the generation moves only with a call that succeeds: a failing call leaves the resident solutions of the
+        # previous calls where they were -- sqd_solve_batch rotates them back)
         self._check(
             self._lib.sqd_solve_batch(self._h, n, C.addressof(pa), C.addressof(na), C.addressof(pb), C.addressof(nb),
                                       C.byref(opts), C.addressof(pamps) if pamps is not None else None,
@@ -798,6 +799,7 @@ class Context:
                                       C.addressof(stats), _addr(e), _addr(s2) if s2 is not None else None, _addr(occ[0]),
                                       _addr(occ[1]), C.addressof(ea), C.addressof(eb))
         )
+        self._batch_gen = getattr(self, "_batch_gen", 0) + 1
         self._batch_shapes_prev = getattr(self, "_batch_shapes", [])
         self._batch_shapes = [(a_arr[i].size, b_arr[i].size) for i in range(n)]
         if best_buf is not None:

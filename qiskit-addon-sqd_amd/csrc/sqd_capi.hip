@@ -857,15 +857,39 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
   }
   o.verbose = 0;
   o.time_sigma_every = 0;
-  c->batch_n = 0;
   while ((int)c->subs.size() < nbatch) {
     sqd_ctx* sub = nullptr;
     SQD_TRY(sub_ctx_create(c, &sub));
     c->subs.push_back(sub);
   }
   std::vector<sqd_ctx*> subs(c->subs.begin(), c->subs.begin() + nbatch);
-  for (size_t p = 0; p < c->subs.size(); ++p) {  // the latest solutions become the previous ones
+  // The latest solutions become the previous ones.  A call that FAILS further down (a bad string list, a zero-norm
+  // state, a HIP error) rotates them back: the caller's bookkeeping of which call's states are resident (generation
+  // counter of the Python layer) moves only with calls that succeed.
+  struct Rotation {
+    sqd_ctx* c;
+    int batch_n;
+    std::vector<int64_t> d_prev, d_now;
+    std::vector<char> had_solution;
+    bool keep = false;
+    ~Rotation() {
+      if (keep) return;
+      for (size_t p = 0; p < c->subs.size() && p < d_prev.size(); ++p) {
+        sqd_ctx* sub = c->subs[p];
+        std::swap(sub->sol, sub->sol_prev);
+        sub->D_prev = d_prev[p];
+        sub->D = d_now[p];  // (the size of the solution that is resident again; the tables may be the failed call's)
+        sub->have_solution = had_solution[p] != 0;
+      }
+      c->batch_n = batch_n;
+    }
+  } rotation{c, c->batch_n, {}, {}, {}};
+  c->batch_n = 0;
+  for (size_t p = 0; p < c->subs.size(); ++p) {
     sqd_ctx* sub = c->subs[p];
+    rotation.d_prev.push_back(sub->D_prev);
+    rotation.d_now.push_back(sub->D);
+    rotation.had_solution.push_back(sub->have_solution ? 1 : 0);
     const bool had = (int)p < c->batch_n_prev_valid && sub->have_solution;
     std::swap(sub->sol, sub->sol_prev);
     sub->D_prev = had ? sub->D : 0;
@@ -945,6 +969,7 @@ SQD_API int sqd_solve_batch(sqd_ctx* c, int nbatch, const uint64_t* const* strs_
   if (c->enqueue_hook && !hook_done) c->enqueue_hook(c->enqueue_hook_user);
   c->batch_n = nbatch;
   c->batch_n_prev_valid = nbatch;
+  rotation.keep = true;
   if (best || best_amps) {
     int w = 0;
     for (int p = 1; p < nbatch; ++p)

@@ -150,3 +150,22 @@ def test_batched_solve_two_groups_on_gpu(hip_lib, monkeypatch):
             assert r.energy == s.energy
             assert np.array_equal(r.orbital_occupancies[0], s.orbital_occupancies[0])
             assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
+
+
+def test_failed_batched_call_leaves_resident_states_readable(emu_backend):
+    """A batched call that fails (here: a string list with mixed Hamming weights) must not move the bookkeeping of which
+    call's states are resident: the deferred states of the call before it still resolve to the right amplitudes
+    (the native slots rotated while the Python generation counter did not)."""
+    norb, nelec = 6, (3, 2)
+    h1, eri = O.synthetic_integrals(norb, seed=3)
+    b1 = _batches(norb, nelec, [(10, 8), (7, 9), (5, 4)], hf=True)
+    ref = [solve_sci(b, h1, eri, norb, nelec) for b in b1]
+    first = solve_sci_batch(b1, h1, eri, norb, nelec)
+    bad = [b1[0], (np.array([1, 3, 7]), b1[1][1]), b1[2]]  # popcounts 1, 2, 3
+    with pytest.raises(ValueError):
+        solve_sci_batch(bad, h1, eri, norb, nelec)
+    for r, s in zip(first, ref):
+        assert np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
+    again = solve_sci_batch(b1, h1, eri, norb, nelec)
+    for r, s in zip(again, ref):
+        assert r.energy == s.energy and np.array_equal(r.sci_state.amplitudes, s.sci_state.amplitudes)
