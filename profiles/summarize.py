@@ -98,7 +98,7 @@ for sub in ("pmc_mfma_batch_hf16", "pmc_mfma2_batch_hf16"):
                 # MOPS_F64 counts 512 flops each (MI355X_MICROARCH / rocprof counter definition): achieved TFLOP/s
                 d["tflops_from_mops_counter"] = d["SQ_INSTS_VALU_MFMA_MOPS_F64"]["avg"] * 512.0 / (dur_ns[k] * 1e-9) / 1e12
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{sub[4:]}_summary.json"), "w"), indent=1)
-        print(sub, {k: {c: (round(v["avg"], 1) if isinstance(v, dict) else round(v, 4)) for c, v in d.items()} for k, d in out.items() if "mfma" in k or "sigma" in k})
+        print(sub, {k: {c: (round(v["avg"], 1) if isinstance(v, dict) else (round(v, 4) if isinstance(v, float) else v)) for c, v in d.items()} for k, d in out.items() if "mfma" in k})
 f = os.path.join(src, "pmc_lists", "summary.txt")
 if os.path.exists(f):  # per-kernel counters of the list-pass sigma at 10^4 x 10^4 (profiles/probes/_pmc_lists.sh)
     shutil.copy(f, os.path.join(dst, "pmc", "final_lists_uniform10000_counters.txt"))

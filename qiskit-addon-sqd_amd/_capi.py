@@ -740,6 +740,9 @@ class Context:
         occ = np.empty((2, self.norb))
         occ_a, occ_b = occ[0], occ[1]
         base = _addr(occ)
+        hook = getattr(self, "_before_native", None)
+        if hook is not None:  # (fermion._run_on_context: "the GIL is about to be released" -- the hash worker's cue)
+            hook()
         self._check(
             self._lib.sqd_solve_strings(self._h, _addr(a), a.size, _addr(b), b.size, C.byref(opts), ci0p,
                                         _addr(amps) if amps is not None else None, C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,

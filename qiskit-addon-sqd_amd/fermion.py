@@ -121,10 +121,10 @@ _HASH_QUEUE = None
 class _HashJob:
     """Digests of two arrays, computed on the worker thread."""
 
-    __slots__ = ("arrays", "digests", "done")
+    __slots__ = ("arrays", "digests", "done", "go")
 
     def __init__(self, arrays):
-        self.arrays, self.digests, self.done = arrays, None, threading.Event()
+        self.arrays, self.digests, self.done, self.go = arrays, None, threading.Event(), threading.Event()
 
     def result(self):
         self.done.wait()
@@ -134,6 +134,9 @@ class _HashJob:
 def _hash_worker(q):
     while True:
         job = q.get()
+        # xxhash keeps the GIL for the whole pass: started at once it would hold up the calling thread's last Python steps
+        # in front of its native call.  The cue comes from the binding, right before that call releases the GIL.
+        job.go.wait(0.002)
         try:
             job.digests = tuple(_full_hash(a) for a in job.arrays)
         except BaseException:  # noqa: BLE001 -- the caller falls back to the verified path
@@ -179,10 +182,14 @@ def _run_on_context(hcore, eri, device, slot, fn):
     digests = None
     if ctx is not None:
         job = _submit_hash((hcore, eri))
+        ctx._before_native = job.go.set
         try:
             out = fn(ctx)
         except Exception:  # noqa: BLE001 -- a failure on a context that may be the wrong one: decide below
             out = _FAILED
+        finally:
+            ctx._before_native = None
+            job.go.set()
         digests = job.result()
         if digests is not None and _ham_key(hcore, eri, device, digests) + (slot,) == hit[0] and out is not _FAILED:
             return out, ctx

@@ -707,3 +707,40 @@ def test_config2_full_size_1e4_x_1e4(hip_lib):
         assert abs(e - e0) < 1e-9
         assert abs(oa.sum() - 8.0) < 1e-9 and abs(ob.sum() - 8.0) < 1e-9
         assert -1e-9 <= s2 <= 8.0 * 9.0 + 1e-9
+
+
+@pytest.mark.parametrize("na,nb", [(1500, 1111), (1111, 2050), (700, 4097)])
+def test_list_passes_forced_against_work_items(hip_lib, monkeypatch, na, nb):
+    """The list passes (sqd_lists.hip; the default from 8 500 strings per spin) forced at sizes where the work-item kernel
+    can be forced on the same inputs: ragged shapes (last column block and last row chunk partial, odd row lengths: the
+    16-byte aligned image of a row starts one double early on every other row, unaligned tile stores), nalpha != nbeta,
+    every operator form -- H, S^2 alone (kernel variant 3), the linear penalty (variant 2), the squared penalty -- and a
+    Davidson solve with the spin penalty."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, na, 31), S.uniform_strings(30, 7, nb, 32)
+    x = np.random.default_rng(8).standard_normal((na, nb))
+    out = {}
+    for forced in ("lists", "items"):
+        if forced == "lists":
+            monkeypatch.setenv("SQD_SIGMA_LISTS", "1")
+            monkeypatch.delenv("SQD_SIGMA_ROWS", raising=False)
+            monkeypatch.delenv("SQD_SIGMA_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("SQD_SIGMA_LISTS", "0")
+            monkeypatch.setenv("SQD_SIGMA_ROWS", "0")
+            monkeypatch.setenv("SQD_SIGMA_DIRECT", "0")
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == ("k_sigma_lists" if forced == "lists" else "k_sigma")
+            ops = (ctx.sigma(x), ctx.contract_ss(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.sigma(x, 2, 0.75, 0.3))
+            assert np.array_equal(ops[0], ctx.sigma(x))  # fixed summation order
+            _, st = ctx.davidson(spin_sq=0.75, shift=0.3)
+            out[forced] = ops + (st["e_davidson"], st["converged"], ctx.observables())
+    a, b = out["lists"], out["items"]
+    for u, v in zip(a[:4], b[:4]):
+        assert np.abs(u - v).max() < 1e-12 * max(1.0, np.abs(v).max())
+    assert a[5] == 1 and b[5] == 1 and abs(a[4] - b[4]) < 1e-9
+    assert abs(a[6][0] - b[6][0]) < 1e-9 and abs(a[6][1] - b[6][1]) < 1e-8
+    assert np.abs(a[6][2] - b[6][2]).max() < 1e-8 and np.abs(a[6][3] - b[6][3]).max() < 1e-8
