@@ -44,6 +44,12 @@ constexpr int LT = 1024;        // column slots of a workgroup
 #ifndef SQD_LISTS_REGCAP
 #define SQD_LISTS_REGCAP 16
 #endif
+#ifndef SQD_LISTS_ROT
+#define SQD_LISTS_ROT 0
+#endif
+#ifndef SQD_LISTS_L2PF
+#define SQD_LISTS_L2PF 0
+#endif
 constexpr int CPL = SQD_LISTS_CPL;  // columns per lane: the fixed per-lane state (addresses, masks, the next row's share) is paid
                                 // once per CPL columns, which is what lets 24 links per column stay in registers
 constexpr int NT = LT / CPL;    // lanes of a workgroup
@@ -57,6 +63,20 @@ constexpr int RPC_MAX = 512;    // rows of a row chunk at most (their per-row sc
 
 typedef double lists_d2 __attribute__((ext_vector_type(2)));
 __device__ inline int l_ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
+__device__ inline int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// element `i` (a lane's 32-bit index, i * 8 < 2^32) of an array whose base is wave-uniform: written so that the compiler
+// sees base + zext(32-bit BYTE offset) and emits the scalar-base form of global_load / global_store (one VGPR of offset);
+// indexed the usual way the offset is a 64-bit quantity per access -- ISA: a zero high dword kept in a VGPR for each of
+// the twenty loads of the next row's share
+__device__ inline double ldu(const double* base, unsigned i) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (i << 3));
+}
+__device__ inline double2 ldu2(const double* base, unsigned i) {  // 16-byte element i; base must be 16-byte aligned
+  return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (i << 4));
+}
+__device__ inline void stu(double* base, unsigned i, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (i << 3)) = v;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // tables
@@ -261,6 +281,158 @@ __global__ void __launch_bounds__(256) k_lists_t4(const ListT4Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// the compact matrix alone (alpha side by rows: no transposition pass to ride on): Cs[ia][ib] = C[clist_a[ia]][clist_b[ib]]
+// ---------------------------------------------------------------------------------------------------------------
+struct ListCompactArgs {
+  GPtr<const double> c;
+  int64_t nb, c_stride, ma, mb;
+  GPtr<const uint32_t> clist_a, clist_b;
+  GPtr<double> cs;
+  GPtr<const int> stop, vec_index;
+};
+__global__ void __launch_bounds__(256) k_lists_compact(const ListCompactArgs g) {
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const int64_t ia = blockIdx.x;
+  const double* __restrict__ row = g.c + vsel * g.c_stride + (int64_t)g.clist_a[ia] * g.nb;
+  double* __restrict__ dst = g.cs + ia * g.mb;
+  for (int64_t ib = threadIdx.x; ib < g.mb; ib += 256) dst[ib] = row[g.clist_b[ib]];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the alpha side by rows, on C itself (round 4, second half): sigma_a[A][.] = sum over the merged same-spin list of
+// A of value x C[A'][.]  (+ sign J_beta[.][pair] C[A'][.] for the single links) -- rows of 80 KB streamed with 16 bytes
+// per lane, no LDS, no transposition either way.  Every element is read once per link of its row (~11 x 800 MB at
+// 10^4 x 10^4), which is what round 3's k_sigma_rows did beside everything else; here it is a pass of its own and the
+// tasks are ordered PANEL-major: all rows of a panel of columns (sized for the 256 MB Infinity Cache) before the next
+// panel, so that the eleven reads of a row segment find it on the die and HBM sees every element once.
+// A wavefront owns (row, panel): its lists sit one link per lane and are broadcast with readlane (scalar base address +
+// 32-bit lane offset per request), eight requests in flight per lane.  Fixed order: the same bits on every run.
+// ---------------------------------------------------------------------------------------------------------------
+struct AlphaRowsArgs {
+  GPtr<const double> in;
+  GPtr<double> out;
+  int64_t in_stride, out_stride, na, nb;
+  int pw, npanel;                 // panel width in columns (a multiple of 128), panels
+  int chunk;                      // links of a list held by the lanes at a time: 64 (test hook SQD_ALPHA_CHUNK: fewer)
+  GPtr<const int64_t> s_ptr, d_ptr;
+  GPtr<const SRec> s_rec;
+  GPtr<const double> s_val;
+  GPtr<const uint32_t> d_src;
+  GPtr<const double> d_val;
+  GPtr<const double> jT;          // [nnorb][nb]
+  GPtr<const int> stop, vec_index;
+};
+constexpr int AR_K = 8;           // requests in flight per lane
+template <bool WIDE>
+struct ArPair {
+  // the two columns of a lane inside a 128-column segment: WIDE (16-byte requests) 2 lane, 2 lane + 1; else lane, lane + 64
+  static __device__ inline double2 ld(const double* seg, unsigned lane, int left) {
+    if (WIDE) return (int)(2 * lane) < left ? ldu2(seg, lane) : make_double2(0.0, 0.0);
+    double2 v = make_double2(0.0, 0.0);
+    if ((int)lane < left) v.x = ldu(seg, lane);
+    if ((int)lane + 64 < left) v.y = ldu(seg, lane + 64);
+    return v;
+  }
+  static __device__ inline void st(double* seg, unsigned lane, int left, double2 v) {
+    if (WIDE) {
+      if ((int)(2 * lane) < left) *reinterpret_cast<double2*>(reinterpret_cast<char*>(seg) + (lane << 4)) = v;
+    } else {
+      if ((int)lane < left) stu(seg, lane, v.x);
+      if ((int)lane + 64 < left) stu(seg, lane + 64, v.y);
+    }
+  }
+};
+__device__ inline double readlane_f64(double v, int l) {
+  uint32_t w[2];
+  __builtin_memcpy(w, &v, 8);
+  w[0] = (uint32_t)__builtin_amdgcn_readlane((int)w[0], l);
+  w[1] = (uint32_t)__builtin_amdgcn_readlane((int)w[1], l);
+  double r;
+  __builtin_memcpy(&r, w, 8);
+  return r;
+}
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
+  if (g.stop && *g.stop) return;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.in + vsel * g.in_stride;
+  double* __restrict__ out = g.out + vsel * g.out_stride;
+  const unsigned lane = threadIdx.x & 63u;
+  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p = uniform_int((int)(task / g.na));
+  if (p >= g.npanel) return;
+  const int64_t A = (int64_t)uniform_int((int)(task - (int64_t)p * g.na));
+  const int64_t nb = g.nb;
+  const int64_t s0 = g.s_ptr[A], d0 = g.d_ptr[A];
+  const int ns = uniform_int((int)(g.s_ptr[A + 1] - s0)), nd = uniform_int((int)(g.d_ptr[A + 1] - d0));
+  const int c_lo = p * g.pw, c_hi = (int)((int64_t)c_lo + g.pw < nb ? (int64_t)c_lo + g.pw : nb);
+  // the lists, one link per lane (lists longer than 64: reloaded per segment, 64 at a time)
+  const int CH = g.chunk;
+  uint32_t v_ssrc = 0, v_smeta = 0, v_dsrc = 0;
+  double v_sval = 0.0, v_dval = 0.0;
+  auto load_s = [&](int base) {
+    if ((int)lane < CH && base + (int)lane < ns) {
+      const SRec r = g.s_rec[s0 + base + lane];
+      v_ssrc = r.src;
+      v_smeta = r.meta;
+      v_sval = g.s_val[s0 + base + lane];
+    }
+  };
+  auto load_d = [&](int base) {
+    if ((int)lane < CH && base + (int)lane < nd) {
+      v_dsrc = g.d_src[d0 + base + lane];
+      v_dval = g.d_val[d0 + base + lane];
+    }
+  };
+  if (ns > 0 && ns <= CH) load_s(0);
+  if (nd > 0 && nd <= CH) load_d(0);
+  for (int cs = c_lo; cs < c_hi; cs += 128) {
+    const int left = c_hi - cs;  // columns of this segment (and beyond) that exist
+    double2 acc = make_double2(0.0, 0.0);
+    // single links: one-body value + sign x J_beta[column][pair]
+    for (int base = 0; base < ns; base += CH) {
+      if (ns > CH) load_s(base);
+      const int m = ns - base < CH ? ns - base : CH;
+      for (int l = 0; l < m; ++l) {
+        const uint32_t src = __builtin_amdgcn_readlane((int)v_ssrc, l), meta = __builtin_amdgcn_readlane((int)v_smeta, l);
+        const double val = readlane_f64(v_sval, l);
+        const double2 x = ArPair<WIDE>::ld(C + (int64_t)src * nb + cs, lane, left);
+        const double2 j = ArPair<WIDE>::ld(g.jT + (int64_t)(srec_widx(meta) >> 1) * nb + cs, lane, left);
+        const double sgn = (meta >> 31) ? -1.0 : 1.0;
+        acc.x += (val + sgn * j.x) * x.x;
+        acc.y += (val + sgn * j.y) * x.y;
+      }
+    }
+    // double links, AR_K requests in flight
+    for (int base = 0; base < nd; base += CH) {
+      if (nd > CH) load_d(base);
+      const int m = nd - base < CH ? nd - base : CH;
+      for (int l = 0; l < m; l += AR_K) {
+        double2 x[AR_K];
+        double val[AR_K];
+#pragma unroll
+        for (int k = 0; k < AR_K; ++k) {
+          x[k] = make_double2(0.0, 0.0);
+          val[k] = 0.0;
+          if (l + k < m) {  // (uniform)
+            const uint32_t src = __builtin_amdgcn_readlane((int)v_dsrc, l + k);
+            val[k] = readlane_f64(v_dval, l + k);
+            x[k] = ArPair<WIDE>::ld(C + (int64_t)src * nb + cs, lane, left);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < AR_K; ++k) {
+          acc.x += val[k] * x[k].x;
+          acc.y += val[k] * x[k].y;
+        }
+      }
+    }
+    ArPair<WIDE>::st(out + A * nb + cs, lane, left, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // the list pass
 // ---------------------------------------------------------------------------------------------------------------
 struct ListsArgs {
@@ -287,23 +459,10 @@ struct ListsArgs {
   GPtr<const double> t4;      // compact single x single term [m_r][m_c] (beta side), null: none
   int64_t t4_ld;
   GPtr<const int> stop, vec_index;
-  int dbg;  // tuning hook (SQD_LISTS_DBG): bit 0 plain block order instead of the XCD-aware one, 1 no gathers, 2 no staging of the next row
+  int dbg;  // tuning hook (SQD_LISTS_DBG): bit 0 plain block order instead of the XCD-aware one, 1 no gathers, 2 no staging of the next
+            // row, 3 plain tile stores, 4 no tile flush
 };
 
-__device__ inline int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// element `i` (a lane's 32-bit index, i * 8 < 2^32) of an array whose base is wave-uniform: written so that the compiler
-// sees base + zext(32-bit BYTE offset) and emits the scalar-base form of global_load / global_store (one VGPR of offset);
-// indexed the usual way the offset is a 64-bit quantity per access -- ISA: a zero high dword kept in a VGPR for each of
-// the twenty loads of the next row's share
-__device__ inline double ldu(const double* base, unsigned i) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (i << 3));
-}
-__device__ inline double2 ldu2(const double* base, unsigned i) {  // 16-byte element i; base must be 16-byte aligned
-  return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + (i << 4));
-}
-__device__ inline void stu(double* base, unsigned i, double v) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (i << 3)) = v;
-}
 // The packed source addresses of a lane's links are loop invariants, and left alone the compiler unpacks them ONCE in
 // front of the row loop -- into one VGPR per link instead of one per two links (ISA: 24 v_lshl_add_u32 results kept
 // live), which is what pushed the kernel over its 128 registers.  Passing the word through an empty asm statement
@@ -436,6 +595,22 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
 #ifdef SQD_PHASE_CLOCK
   unsigned long long lclk_t = wall_clock64();
 #endif
+  // The column-block workgroups of a row chunk run in step and ask for the same 16 KB piece of the same row at the same
+  // moment; with SQD_LISTS_ROT piece u of block cb is piece (u + cb) mod NPF2 of the row, so that the blocks are spread
+  // over the row (and the L2 channels it is interleaved over) at any one time.
+#if SQD_LISTS_ROT
+  const int rot = uniform_int(cb % NPF2);
+#define SQD_PU(u) (((u) + rot) >= NPF2 ? ((u) + rot - NPF2) : ((u) + rot))
+#else
+#define SQD_PU(u) (u)
+#endif
+  // L2 prefetch (SQD_LISTS_L2PF = distance in rows): one lane per 128-byte line of a row further down the chunk, the
+  // lines shared out over the column blocks; the value is never used -- it is "consumed" (an empty asm) one iteration
+  // later, where the requests issued behind it have long landed
+#if SQD_LISTS_L2PF
+  const unsigned pf_lines = (unsigned)((n_c * 8 + 127) / 128), pf_lpb = (pf_lines + (unsigned)g.nblk - 1u) / (unsigned)g.nblk;
+  uint32_t pfx = 0;
+#endif
   for (int64_t r = r0; r < r1; ++r) {
     // -- 1. requests: the next row (it moves into LDS behind the barrier) and what the epilogue of THIS row adds.
     // Nothing here may be USED before the barrier: a use is a wait for every request issued before it.
@@ -455,9 +630,20 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
 #define SQD_LISTS_REQUEST(u)                                                                   \
   do {                                                                                         \
     pf[u] = make_double2(0.0, 0.0);                                                            \
-    if ((unsigned)((u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)((u) * NT))            \
-      pf[u] = ldu2(nimg + 2 * (u) * NT, (unsigned)tid);                                        \
+    if ((unsigned)(SQD_PU(u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(SQD_PU(u) * NT)) \
+      pf[u] = ldu2(nimg + 2 * SQD_PU(u) * NT, (unsigned)tid);                                  \
   } while (0)
+#if SQD_LISTS_L2PF
+#define SQD_LISTS_PREFETCH()                                                                   \
+  do {                                                                                         \
+    asm volatile("" ::"v"(pfx));                                                               \
+    if (r + SQD_LISTS_L2PF < r1 && (unsigned)tid < pf_lpb && (unsigned)cb * pf_lpb + (unsigned)tid < pf_lines) \
+      pfx = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(M + (r + SQD_LISTS_L2PF) * g.in_ld) + \
+                                               (((unsigned)cb * pf_lpb + (unsigned)tid) << 7));             \
+  } while (0)
+#else
+#define SQD_LISTS_PREFETCH()
+#endif
 #pragma unroll
     for (int u = 0; u < NPF2 / 2; ++u) SQD_LISTS_REQUEST(u);
     if (more) {
@@ -525,11 +711,13 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
         if (k0 == 0) {  // the second half of the next row's requests, behind the first round of gathers
 #pragma unroll
           for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+          SQD_LISTS_PREFETCH();
         }
       }
     } else {
 #pragma unroll
       for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+      SQD_LISTS_PREFETCH();
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -629,8 +817,8 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     if (more) {
 #pragma unroll
       for (int u = 0; u < NPF2; ++u)
-        if ((unsigned)(u * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(u * NT))
-          reinterpret_cast<double2*>(img)[tid + u * NT] = pf[u];
+        if ((unsigned)(SQD_PU(u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(SQD_PU(u) * NT))
+          reinterpret_cast<double2*>(img)[tid + SQD_PU(u) * NT] = pf[u];
       for (unsigned b = tid + NPF2 * NT; b < n2_n; b += NT)  // (rows beyond 2 NPF2 NT columns)
         reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * g.in_ld - sh_n, b);
       row = img + sh_n;
@@ -807,6 +995,27 @@ bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1
   return true;
 }
 
+// alpha side: 1 (default) by rows on C itself (k_alpha_rows), 0 as a list pass on C^T (SQD_LISTS_ALPHA)
+static bool alpha_by_rows() {
+  static const bool v = [] {
+    const char* env = std::getenv("SQD_LISTS_ALPHA");
+    return env ? std::atoi(env) != 0 : true;
+  }();
+  return v;
+}
+// columns of a panel of k_alpha_rows: na rows x pw columns within the share of the Infinity Cache that holds a panel
+static int alpha_panel_width(int64_t na, int64_t nb) {
+  static const double mb = [] {
+    const char* env = std::getenv("SQD_ALPHA_PANEL_MB");
+    return env ? std::atof(env) : 96.0;
+  }();
+  int64_t pw = (int64_t)(mb * 1048576.0 / (8.0 * (double)na)) / 128 * 128;
+  const int64_t full = (nb + 127) / 128 * 128;
+  if (pw < 128) pw = 128;
+  if (pw > full) pw = full;
+  return (int)pw;
+}
+
 template <class T>
 static int upload_vec(sqd_ctx* c, DevBuf& buf, const std::vector<T>& v) {
   SQD_TRY(buf.reserve(std::max<size_t>(v.size() * sizeof(T), 16)));
@@ -871,7 +1080,7 @@ int lists_build(sqd_ctx* c) {
       SQD_HIP_CHECK(hipGetLastError());
     }
   }
-  SQD_TRY(s->ct.reserve((size_t)((c->na + 1) & ~int64_t(1)) * c->nb * 8));  // (even pitch: 16-byte aligned rows)
+  if (!alpha_by_rows()) SQD_TRY(s->ct.reserve((size_t)((c->na + 1) & ~int64_t(1)) * c->nb * 8));  // (even pitch: 16-byte aligned rows)
   const int64_t ma = s->side[0].m, mb = s->side[1].m;
   SQD_TRY(s->cs.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
   SQD_TRY(s->t4.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
@@ -950,8 +1159,25 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     const char* env = std::getenv("SQD_LISTS_PASSES");
     return env ? std::atoi(env) : 15;
   }();
-  // pass 0: C^T (+ the compact matrix)
-  if ((alpha_pass || cross) && (pass_mask & 1)) {
+  const bool by_rows = alpha_by_rows();
+  // pass 0 (alpha side by rows): the compact matrix alone
+  if (by_rows && cross && (pass_mask & 1)) {
+    ListCompactArgs t;
+    t.c = d_c;
+    t.nb = nb;
+    t.c_stride = in_stride;
+    t.ma = ma;
+    t.mb = mb;
+    t.clist_a = s->side[0].clist.as<uint32_t>();
+    t.clist_b = s->side[1].clist.as<uint32_t>();
+    t.cs = s->cs.as<double>();
+    t.stop = c->sigma_stop;
+    t.vec_index = vec_index;
+    hipLaunchKernelGGL(k_lists_compact, dim3((unsigned)ma), dim3(256), 0, c->stream, t);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  // pass 0 (alpha side as a list pass): C^T (+ the compact matrix)
+  if (!by_rows && (alpha_pass || cross) && (pass_mask & 1)) {
     ListTransArgs t;
     t.c = d_c;
     t.ct = alpha_pass ? s->ct.as<double>() : nullptr;
@@ -1015,8 +1241,39 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     SQD_HIP_CHECK(hipGetLastError());
     return SQD_OK;
   };
-  // pass 1: alpha lists on C^T; the result lands in sigma (C's layout), 8 rows of C^T = 8 consecutive doubles at a time
-  if (alpha_pass && (pass_mask & 4)) {
+  // pass 1 (by rows): alpha lists on C, panel by panel
+  if (by_rows && alpha_pass && (pass_mask & 4)) {
+    AlphaRowsArgs a;
+    a.in = d_c;
+    a.out = d_sigma;
+    a.in_stride = in_stride;
+    a.out_stride = out_stride;
+    a.na = na;
+    a.nb = nb;
+    a.pw = alpha_panel_width(na, nb);
+    a.npanel = (int)((nb + a.pw - 1) / a.pw);
+    a.chunk = 64;
+    if (const char* env = std::getenv("SQD_ALPHA_CHUNK")) a.chunk = std::min(64, std::max(1, std::atoi(env)));
+    a.s_ptr = c->sp[0].s_ptr.as<int64_t>();
+    a.d_ptr = c->sp[0].d_ptr.as<int64_t>();
+    a.s_rec = c->sp[0].s_rec.as<SRec>();
+    a.s_val = c->sp[0].s_val.as<double>();
+    a.d_src = c->sp[0].d_src.as<uint32_t>();
+    a.d_val = c->sp[0].d_val.as<double>();
+    a.jT = c->sp[1].jT.as<double>();
+    a.stop = c->sigma_stop;
+    a.vec_index = vec_index;
+    const bool wide = ((nb & 1) == 0) && ((reinterpret_cast<uintptr_t>(d_c) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(d_sigma) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.jT.p) & 15) == 0) &&
+                      (!indexed || (((in_stride | out_stride) & 1) == 0));
+    const int64_t tasks = na * a.npanel;
+    const unsigned grid = (unsigned)((tasks + 3) / 4);
+    if (wide) hipLaunchKernelGGL((k_alpha_rows<true>), dim3(grid), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_alpha_rows<false>), dim3(grid), dim3(256), 0, c->stream, a);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  // pass 1 (list pass): alpha lists on C^T; the result lands in sigma (C's layout), 8 rows of C^T = 8 consecutive doubles at a time
+  if (!by_rows && alpha_pass && (pass_mask & 4)) {
     ListsArgs g;
     fill_pass_args(c, s, 0, mode, spin, ss, shift, &g);
     g.in = s->ct.as<double>();
