@@ -7,7 +7,7 @@ ROOT = Path(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 sys.path.insert(0, str(ROOT))
 import numpy as np
 from qiskit_addon_sqd_amd import _capi
-_capi.LIB_PATH = ROOT / 'profiles' / 'probes' / '_build' / 'libsqd_hip_clk.so'
+_capi.LIB_PATH = Path(os.environ.get('SQD_LIB', str(ROOT / 'profiles' / 'probes' / '_build' / 'libsqd_hip_clk.so')))
 from qiskit_addon_sqd_amd import synthetic as S, fermion as F
 
 lib = _capi.load_library()
@@ -26,7 +26,7 @@ lib.sqd_probe_clk_lists(buf, 0)
 c = np.array(buf[:], dtype=np.float64).reshape(4, 8)
 names = ['requests', 'row from LDS', 'barrier 1', 'next row -> LDS', 'epilogue', 'barrier 2']
 nwg = 240.0  # (8 XCDs x 3 row chunks x 10 column blocks at 10^4 x 10^4)
-for v, tag in ((0, 'alpha pass'), (1, 'beta pass')):
+for v, tag in ((1, 'list pass (beta side, H)'),):
     tot = c[v, :6].sum()
     print(f'{tag}: per workgroup and launch {tot / nwg / reps / 100.0:.1f} us  |  ' +
           '  '.join(f'{nm} {100.0 * c[v, i] / max(tot, 1):.1f}%' for i, nm in enumerate(names)), flush=True)

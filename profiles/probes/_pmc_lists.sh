@@ -17,7 +17,7 @@ res = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         kn = row['Kernel_Name']
-        if 'k_sigma_lists' in kn or 'k_lists_t' in kn or 'k_sigma_rows' in kn:
+        if 'k_sigma_lists' in kn or 'k_lists_' in kn or 'k_alpha_rows' in kn or 'k_sigma_rows' in kn:
             import re
             name = re.search(r'k_\w+(<[^>]*>)?', kn).group(0)
             k = (name, row['Counter_Name']); res[k][0] += float(row['Counter_Value']); res[k][1] += 1

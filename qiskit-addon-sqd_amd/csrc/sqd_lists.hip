@@ -2,28 +2,29 @@
 // per spin up: BASELINE config 2 read literally (10^4 x 10^4 strings, D = 10^8, 800 MB per vector) and the "subspace
 // dimensions of ~10^7" of the reference's README (README.md:78).  Replaces, like the other sigma kernels, pyscf
 // selected_ci.contract_2e + contract_ss behind kernel_fixed_space (reference qiskit_addon_sqd/fermion.py:721-723,
-// :810-818); the formulation is pyscf's own treatment of the same-spin halves -- "beta-beta on C, alpha-alpha on the
-// transpose"  -- with the link lists where the arithmetic is:
+// :810-818).  Four launches per sigma, each element of C leaving HBM once per side:
 //
-//   * Per spin, the merged same-spin list of a string (singles' one-body value, then doubles: ~11 links at 10^4
-//     strings) lives IN REGISTERS of the lane that owns the string: a workgroup of 1024 lanes owns a block of <= 1024
-//     columns, loads their lists ONCE and then walks a chunk of ~400 rows of the matrix.  Every row is staged in LDS
-//     (80 KB at 10^4 columns; the next row is prefetched into registers while this one is evaluated), so a link costs
-//     one LDS gather and one FMA: no pointer -> record -> operand chain, no record traffic per row at all.  (Round 3's
-//     k_sigma_rows re-read the 1.3 MB of beta records per row PAIR and streamed eleven 80 KB alpha source rows per
-//     target row: 14.8 GB through the memory pipes per sigma, 3.9 ms.)
-//   * The beta side runs on C (rows = alpha strings), the alpha side on C^T (rows = beta strings), which a tiled
-//     transpose pass writes first; the alpha pass hands its result back through 8-row tiles written in C's layout, the
-//     beta pass adds it in place.  Every element of C leaves HBM once per side.
-//   * Columns of a block are sorted by list length (wavefronts then run uniform trip counts without padding); the
-//     result row is un-permuted through LDS so that global loads and stores stay coalesced.  Lists longer than the
-//     register file's share (24 links / 4 single links) keep their tail in a small LDS table.
-//   * The diagonal term is formed in the (natural-order, coalesced) epilogue of the beta pass from hdiag.
+//   * BETA side, a list pass on C (k_sigma_lists): the merged same-spin list of a beta string (singles' one-body value,
+//     then doubles: ~11 links at 10^4 strings) lives IN REGISTERS of the lane that owns the string: a workgroup of 1024
+//     lanes owns a block of <= 1024 columns, loads their lists ONCE and then walks a chunk of ~400 rows of the matrix.
+//     Every row is staged in LDS (80 KB at 10^4 columns; the next row is prefetched into registers while this one is
+//     evaluated), so a link costs one LDS gather and one FMA: no pointer -> record -> operand chain, no record traffic per
+//     row at all.  Columns of a block are sorted by list length (wavefronts then run uniform trip counts without
+//     padding); the result row is un-permuted through LDS so that global loads and stores stay coalesced.  Lists longer
+//     than the register file's share (16 links / 4 single links) keep their tail in a small LDS table.  The diagonal
+//     term is formed in the (natural-order, coalesced) epilogue from hdiag, whose lines -- like the row's own -- are
+//     pulled into the L2 two rows ahead (the epilogue's operands are HBM misses otherwise, and the row loop of a
+//     workgroup cannot run faster than the latency of what it asks for and uses inside one iteration).  The ten
+//     column-block workgroups that read the same rows are placed on ONE XCD (block b runs on XCD b % 8): nine of ten
+//     row reads are L2 hits.
+//   * ALPHA side by rows, on C itself (k_alpha_rows): sigma[A][.] += sum over the list of A of value x C[A'][.] -- whole
+//     row segments streamed with 16 bytes per lane, panel by panel (see the kernel).  It adds onto the beta pass's
+//     result and brings the compact term with it, so the beta pass's row loop has no operand from HBM but hdiag.
+//     (Round 4's first half ran the alpha side as a second list pass on C^T between two transpositions: 1.59 + 0.40 ms
+//     against 0.8 ms; removed.)
 //   * The terms that pair a single link of each spin (2.7 % of the links, but a nested loop per element in the row
-//     kernel) are evaluated on the compact matrix of the strings that HAVE single links (gathered by the transpose
-//     pass; ~2600 x 2600 at 10^4 x 10^4) by a small kernel of their own, and added by the beta pass.
-//   * The ten column-block workgroups that read the same rows are placed on ONE XCD (block b runs on XCD b % 8), so
-//     nine of ten row reads are L2 hits.
+//     kernel) are evaluated on the compact matrix of the strings that HAVE single links (k_lists_compact gathers it;
+//     ~2600 x 2600 at 10^4 x 10^4) by a small kernel of their own (k_lists_t4).
 // Fixed order of accumulation everywhere: the same bits on every run.
 #include <algorithm>
 #include <atomic>
@@ -48,7 +49,10 @@ constexpr int LT = 1024;        // column slots of a workgroup
 #define SQD_LISTS_ROT 0
 #endif
 #ifndef SQD_LISTS_L2PF
-#define SQD_LISTS_L2PF 0
+#define SQD_LISTS_L2PF 2
+#endif
+#ifndef SQD_LISTS_SPREAD
+#define SQD_LISTS_SPREAD 0
 #endif
 constexpr int CPL = SQD_LISTS_CPL;  // columns per lane: the fixed per-lane state (addresses, masks, the next row's share) is paid
                                 // once per CPL columns, which is what lets 24 links per column stay in registers
@@ -58,7 +62,6 @@ constexpr int SCAP = 4;         // single links of a column held in registers (o
 constexpr int OVL_CAP = 512;    // per block: same-spin links beyond REGCAP (LDS)
 constexpr int OVS_CAP = 256;    // per block: single links beyond SCAP (LDS)
 constexpr int NPF2 = 5 * CPL;   // 16-byte pieces of the next row a lane prefetches (rows longer than 2 NPF2 NT: second phase)
-constexpr int TS = 64;          // transpose tile
 constexpr int RPC_MAX = 512;    // rows of a row chunk at most (their per-row scalars sit in LDS)
 
 typedef double lists_d2 __attribute__((ext_vector_type(2)));
@@ -140,99 +143,6 @@ __global__ void k_lists_fill(const ListFillArgs g) {
     const uint32_t w = (j < ns) ? pack_single(g.s_rec[s0 + j]) : 0u;
     if (j < SCAP) g.sing[((int64_t)b * SCAP + j) * LT + threadIdx.x] = w;
     else g.ovs[(int64_t)b * OVS_CAP + ovs0 + (j - SCAP)] = w;
-  }
-}
-
-// the row-major J table of a spin, J[I][pair] = sum_{k in I} (pair|kk) (jtable_body's order of operations): the alpha
-// pass stages rows of C^T -- beta strings -- and its single links need J_beta[B][.] as a row; the context keeps the beta
-// table transposed for the other kernels
-struct ListAuxArgs {
-  GPtr<const uint64_t> strs;
-  int64_t n;
-  int norb, nnorb;
-  GPtr<const double> jdiag;
-  GPtr<double> jrow;
-};
-__global__ void k_lists_aux(const ListAuxArgs g) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= g.n * g.nnorb) return;
-  const int64_t I = idx / g.nnorb, pair = idx - I * g.nnorb;
-  uint64_t occ = g.strs[I];
-  double v = 0.0;
-  while (occ) {
-    const int k = l_ctz64(occ);
-    occ &= occ - 1;
-    v += g.jdiag[pair * g.norb + k];
-  }
-  g.jrow[idx] = v;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// pass 0: C^T (64 x 64 tiles through LDS) + the compact matrix of the strings with single links
-// ---------------------------------------------------------------------------------------------------------------
-struct ListTransArgs {
-  GPtr<const double> c;
-  GPtr<double> ct;           // [nb][ld_t]; null: compact matrix only
-  int64_t na, nb, c_stride, ld_t;
-  GPtr<const int32_t> cidx_a, cidx_b;
-  GPtr<double> cs;           // [ma][mb]; null: none
-  int64_t mb;
-  GPtr<const int> stop, vec_index;
-};
-__global__ void __launch_bounds__(256) k_lists_transpose(const ListTransArgs g) {
-  __shared__ double tile[TS * (TS + 1)];
-  if (g.stop && *g.stop) return;
-  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
-  const double* __restrict__ C = g.c + vsel * g.c_stride;
-  const int64_t A0 = (int64_t)blockIdx.y * TS, B0 = (int64_t)blockIdx.x * TS;
-  // 16 bytes per lane both ways when rows of C and of C^T start on 16-byte boundaries (even nb; the scratch pitch is even)
-  const bool wide = ((g.nb & 1) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && A0 + TS <= g.na && B0 + TS <= g.nb;
-  if (wide) {
-    const int tp = threadIdx.x & 31, ty = threadIdx.x >> 5;  // pair index along the contiguous direction, row group
-#pragma unroll
-    for (int i = ty; i < TS; i += 8) {
-      const int64_t A = A0 + i;
-      const double2 v = *reinterpret_cast<const double2*>(C + A * g.nb + B0 + 2 * tp);
-      tile[i * (TS + 1) + 2 * tp] = v.x;
-      tile[i * (TS + 1) + 2 * tp + 1] = v.y;
-      if (g.cs) {
-        const int ca = g.cidx_a[A];
-        if (ca >= 0) {
-          const int cb0 = g.cidx_b[B0 + 2 * tp], cb1 = g.cidx_b[B0 + 2 * tp + 1];
-          if (cb0 >= 0) g.cs[(int64_t)ca * g.mb + cb0] = v.x;
-          if (cb1 >= 0) g.cs[(int64_t)ca * g.mb + cb1] = v.y;
-        }
-      }
-    }
-    if (!g.ct) return;
-    __syncthreads();
-#pragma unroll
-    for (int j = ty; j < TS; j += 8)
-      *reinterpret_cast<double2*>(g.ct + (B0 + j) * g.ld_t + A0 + 2 * tp) =
-          make_double2(tile[(2 * tp) * (TS + 1) + j], tile[(2 * tp + 1) * (TS + 1) + j]);
-    return;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int64_t B = B0 + tx;
-  const int cb = (g.cs && B < g.nb) ? g.cidx_b[B] : -1;
-#pragma unroll 4
-  for (int i = ty; i < TS; i += 4) {
-    const int64_t A = A0 + i;
-    if (A < g.na && B < g.nb) {
-      const double v = C[A * g.nb + B];
-      tile[i * (TS + 1) + tx] = v;
-      if (cb >= 0) {
-        const int ca = g.cidx_a[A];
-        if (ca >= 0) g.cs[(int64_t)ca * g.mb + cb] = v;
-      }
-    }
-  }
-  if (!g.ct) return;
-  __syncthreads();
-#pragma unroll 4
-  for (int j = ty; j < TS; j += 4) {
-    const int64_t Bo = B0 + j, Ao = A0 + tx;
-    if (Bo < g.nb && Ao < g.na) g.ct[Bo * g.ld_t + Ao] = tile[tx * (TS + 1) + j];
   }
 }
 
@@ -321,9 +231,19 @@ struct AlphaRowsArgs {
   GPtr<const uint32_t> d_src;
   GPtr<const double> d_val;
   GPtr<const double> jT;          // [nnorb][nb]
+  int accum;                      // out already holds the beta pass's part of the same elements: add onto it
+  GPtr<const double> t4;          // compact single x single term [ma][mb], null: none
+  int64_t t4_ld;
+  GPtr<const int32_t> cidx_a, cidx_b;
   GPtr<const int> stop, vec_index;
 };
-constexpr int AR_K = 8;           // requests in flight per lane
+#ifndef SQD_AR_K
+#define SQD_AR_K 8
+#endif
+#ifndef SQD_AR_WAVES
+#define SQD_AR_WAVES 7  // (8 wavefronts per SIMD spill two registers: 1.01 against 0.88 ms at 10^4 x 10^4)
+#endif
+constexpr int AR_K = SQD_AR_K;    // requests in flight per lane
 template <bool WIDE>
 struct ArPair {
   // the two columns of a lane inside a 128-column segment: WIDE (16-byte requests) 2 lane, 2 lane + 1; else lane, lane + 64
@@ -353,7 +273,7 @@ __device__ inline double readlane_f64(double v, int l) {
   return r;
 }
 template <bool WIDE>
-__global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
+__global__ void __launch_bounds__(256, SQD_AR_WAVES) k_alpha_rows(const AlphaRowsArgs g) {
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.in + vsel * g.in_stride;
@@ -367,6 +287,7 @@ __global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
   const int64_t s0 = g.s_ptr[A], d0 = g.d_ptr[A];
   const int ns = uniform_int((int)(g.s_ptr[A + 1] - s0)), nd = uniform_int((int)(g.d_ptr[A + 1] - d0));
   const int c_lo = p * g.pw, c_hi = (int)((int64_t)c_lo + g.pw < nb ? (int64_t)c_lo + g.pw : nb);
+  const int crow = g.t4 ? uniform_int(g.cidx_a[A]) : -1;  // compact row of A (strings with single links), -1: none
   // the lists, one link per lane (lists longer than 64: reloaded per segment, 64 at a time)
   const int CH = g.chunk;
   uint32_t v_ssrc = 0, v_smeta = 0, v_dsrc = 0;
@@ -390,6 +311,19 @@ __global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
   for (int cs = c_lo; cs < c_hi; cs += 128) {
     const int left = c_hi - cs;  // columns of this segment (and beyond) that exist
     double2 acc = make_double2(0.0, 0.0);
+    if (g.accum) acc = ArPair<WIDE>::ld(out + A * nb + cs, lane, left);
+    if (crow >= 0) {  // (uniform) single x single, from the compact matrix
+      const int ca = WIDE ? (int)(2 * lane) : (int)lane, cb2 = WIDE ? ca + 1 : ca + 64;
+      const double* trow = g.t4 + (int64_t)crow * g.t4_ld;
+      if (ca < left) {
+        const int ci = g.cidx_b[cs + ca];
+        if (ci >= 0) acc.x += trow[ci];
+      }
+      if (cb2 < left) {
+        const int ci = g.cidx_b[cs + cb2];
+        if (ci >= 0) acc.y += trow[ci];
+      }
+    }
     // single links: one-body value + sign x J_beta[column][pair]
     for (int base = 0; base < ns; base += CH) {
       if (ns > CH) load_s(base);
@@ -410,21 +344,21 @@ __global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
       const int m = nd - base < CH ? nd - base : CH;
       for (int l = 0; l < m; l += AR_K) {
         double2 x[AR_K];
-        double val[AR_K];
 #pragma unroll
         for (int k = 0; k < AR_K; ++k) {
           x[k] = make_double2(0.0, 0.0);
-          val[k] = 0.0;
           if (l + k < m) {  // (uniform)
             const uint32_t src = __builtin_amdgcn_readlane((int)v_dsrc, l + k);
-            val[k] = readlane_f64(v_dval, l + k);
             x[k] = ArPair<WIDE>::ld(C + (int64_t)src * nb + cs, lane, left);
           }
         }
 #pragma unroll
         for (int k = 0; k < AR_K; ++k) {
-          acc.x += val[k] * x[k].x;
-          acc.y += val[k] * x[k].y;
+          if (l + k < m) {  // (the values are broadcast where they are used: no registers held across the requests)
+            const double val = readlane_f64(v_dval, l + k);
+            acc.x += val * x[k].x;
+            acc.y += val * x[k].y;
+          }
         }
       }
     }
@@ -436,19 +370,15 @@ __global__ void __launch_bounds__(256) k_alpha_rows(const AlphaRowsArgs g) {
 // the list pass
 // ---------------------------------------------------------------------------------------------------------------
 struct ListsArgs {
-  GPtr<const double> in;      // [n_r][n_c]: the matrix whose rows are staged (C for the beta side, C^T for the alpha side)
-  GPtr<double> out;           // direct: [n_r][n_c]; transposed: [n_c][ldo]
-  int64_t in_stride, out_stride;  // added per selected vector (vec_index); 0 for scratch operands
-  int64_t n_r, n_c, ldo, in_ld;   // in_ld: pitch of the input rows (n_c, or the even pitch of the C^T scratch)
-  int transposed_out;         // alpha side: the result goes back in C's layout, G rows (= G consecutive doubles) at a time
-  int addin;                  // beta side: out already holds the alpha side's part of the same element
-  int diag;                   // beta side: diagonal term
-  int lists;                  // same-spin lists and single x occupation terms (mode 0)
+  GPtr<const double> in;      // C [n_r][n_c]: the matrix whose rows are staged
+  GPtr<double> out;           // [n_r][n_c]
+  int64_t in_stride, out_stride;  // added per selected vector (vec_index)
+  int64_t n_r, n_c;
   int mode, spin;
   double ss, shift, szterm;
-  int nblk, cpb, cpx, rpc, G; // column blocks, columns per block, row chunks per XCD, rows per chunk, tile rows
+  int nblk, cpb, cpx, rpc;    // column blocks, columns per block, row chunks per XCD, rows per chunk
   int norb, nnorb;
-  int pitch, o_jr, o_vr, o_ob, o_ovlv, o_ovli, o_ovs, o_tile, o_rs;  // LDS plan, in doubles
+  int pitch, o_jr, o_ob, o_ovlv, o_ovli, o_ovs, o_rs;  // LDS plan, in doubles
   GPtr<const int32_t> col;
   GPtr<const uint32_t> desc, ridx, sing, ovl_idx, ovs;
   GPtr<const double> rval, ovl_val;
@@ -456,11 +386,10 @@ struct ListsArgs {
   GPtr<const uint64_t> strs_c, strs_r;
   GPtr<const double> hdiag, jrow;
   GPtr<const int32_t> cidx_c, cidx_r;
-  GPtr<const double> t4;      // compact single x single term [m_r][m_c] (beta side), null: none
+  GPtr<const double> t4;      // compact single x single term [m_r][m_c] (pure S^2 operator: no alpha pass to bring it), null: none
   int64_t t4_ld;
   GPtr<const int> stop, vec_index;
-  int dbg;  // tuning hook (SQD_LISTS_DBG): bit 0 plain block order instead of the XCD-aware one, 1 no gathers, 2 no staging of the next
-            // row, 3 plain tile stores, 4 no tile flush
+  int dbg;  // tuning hook (SQD_LISTS_DBG): bit 0 plain block order instead of the XCD-aware one, 1 no gathers, 2 no staging of the next row
 };
 
 // The packed source addresses of a lane's links are loop invariants, and left alone the compiler unpacks them ONCE in
@@ -472,6 +401,15 @@ __device__ inline uint32_t opaque(uint32_t w) {
   asm volatile("" : "+v"(w));
 #endif
   return w;
+}
+// a value that was loaded only to pull its line into the L2: "used" here so that the load is neither dropped nor waited
+// for anywhere else
+__device__ inline void consume(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+  asm volatile("" ::"v"(w));
+#else
+  (void)w;
+#endif
 }
 
 // ---- phase clocks (probe builds only: -DSQD_PHASE_CLOCK; profiles/probes/_lists_clock.py): thread 0 of every workgroup
@@ -488,11 +426,10 @@ __device__ unsigned long long sqd_clk_lists[4 * LCLK_ROWS * LCLK_COLS];
 #else
 #define LCLK_MARK(slot)
 #endif
-// VAR 0: alpha pass (lists on C^T, result transposed back); 1: beta pass, H; 2: beta pass, H + shift (S^2 - ss);
-// 3: beta pass of the pure S^2 operator (diagonal + compact term only)
+// VAR 1: H; 2: H + shift (S^2 - ss); 3: the pure S^2 operator (diagonal + compact term only)
 template <int VAR>
 __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
-  constexpr bool BETA = VAR != 0, SPIN = VAR >= 2, lists = VAR != 3, HMODE = VAR != 3;
+  constexpr bool SPIN = VAR >= 2, lists = VAR != 3, HMODE = VAR != 3, T4 = VAR == 3;
   HIP_DYNAMIC_SHARED(double, smem)
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
@@ -513,8 +450,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
   double* __restrict__ ovlv = smem + g.o_ovlv;
   uint32_t* __restrict__ ovli = reinterpret_cast<uint32_t*>(smem + g.o_ovli);
   uint32_t* __restrict__ ovsl = reinterpret_cast<uint32_t*>(smem + g.o_ovs);
-  double* __restrict__ tile = smem + g.o_tile;
-  // per-row scalars of this workgroup's row chunk (beta pass): the alpha strings, their energies, compact indices
+  // per-row scalars of this workgroup's row chunk: the alpha strings, their compact indices
   uint64_t* __restrict__ rs_str = reinterpret_cast<uint64_t*>(smem + g.o_rs);
   int* __restrict__ rs_cid = reinterpret_cast<int*>(smem + g.o_rs + g.rpc);
 
@@ -557,9 +493,9 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     }
     sN[c] = 0;
     cidN[c] = -1;
-    if (BETA && c * NT + tid < ncol) {
+    if (c * NT + tid < ncol) {
       if (SPIN) sN[c] = g.strs_c[c0 + c * NT + tid];
-      if (g.t4) cidN[c] = g.cidx_c[c0 + c * NT + tid];
+      if (T4 && g.t4) cidN[c] = g.cidx_c[c0 + c * NT + tid];
     }
   }
   if (lists) {
@@ -577,7 +513,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
   double* __restrict__ img = smem;
   const double* __restrict__ row;
   {
-    const double* rp = M + r0 * g.in_ld;
+    const double* rp = M + r0 * g.n_c;
     const unsigned sh = (unsigned)((reinterpret_cast<uintptr_t>(rp) >> 3) & 1u);
     const unsigned n2 = ((unsigned)n_c + sh + 1u) >> 1;
     for (unsigned b = tid; b < n2; b += NT) reinterpret_cast<double2*>(img)[b] = ldu2(rp - sh, b);
@@ -585,11 +521,10 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
   }
   if (lists)
     for (int i = tid; i < g.nnorb; i += NT) jr[i] = g.jrow[r0 * g.nnorb + i];
-  if (BETA)
-    for (int i = tid; i < (int)(r1 - r0); i += NT) {
-      rs_str[i] = g.strs_r[r0 + i];
-      rs_cid[i] = g.t4 ? g.cidx_r[r0 + i] : -1;
-    }
+  for (int i = tid; i < (int)(r1 - r0); i += NT) {
+    rs_str[i] = g.strs_r[r0 + i];
+    rs_cid[i] = (T4 && g.t4) ? g.cidx_r[r0 + i] : -1;
+  }
   __syncthreads();
 
 #ifdef SQD_PHASE_CLOCK
@@ -604,12 +539,30 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
 #else
 #define SQD_PU(u) (u)
 #endif
-  // L2 prefetch (SQD_LISTS_L2PF = distance in rows): one lane per 128-byte line of a row further down the chunk, the
-  // lines shared out over the column blocks; the value is never used -- it is "consumed" (an empty asm) one iteration
-  // later, where the requests issued behind it have long landed
+  // L2 prefetch, SQD_LISTS_L2PF rows ahead: what an iteration asks for and uses -- the hdiag segment of the epilogue,
+  // the next row for whichever of the column blocks comes first -- is an HBM miss otherwise, and the loop's period
+  // cannot be shorter than the latency of that.  Wavefront 0: one lane per 128-byte line of this block's hdiag
+  // segment; wavefront 1: one lane per line of this block's tenth of the row of C.  The values are never used: they are
+  // "consumed" one iteration later, where the requests issued behind them have long landed.
 #if SQD_LISTS_L2PF
   const unsigned pf_lines = (unsigned)((n_c * 8 + 127) / 128), pf_lpb = (pf_lines + (unsigned)g.nblk - 1u) / (unsigned)g.nblk;
+  const unsigned hd_lines = (unsigned)((ncol * 8 + 127) / 128);
   uint32_t pfx = 0;
+#define SQD_LISTS_PREFETCH()                                                                                   \
+  do {                                                                                                         \
+    consume(pfx);                                                                                              \
+    if (r + SQD_LISTS_L2PF < r1) {                                                                             \
+      if (HMODE && (unsigned)tid < hd_lines)                                                                   \
+        pfx = *reinterpret_cast<const uint32_t*>(                                                              \
+            reinterpret_cast<const char*>(g.hdiag + (r + SQD_LISTS_L2PF) * n_c + c0) + ((unsigned)tid << 7));  \
+      const unsigned t1 = (unsigned)tid - 64u;                                                                 \
+      if (t1 < pf_lpb && t1 < 64u && (unsigned)cb * pf_lpb + t1 < pf_lines)                                    \
+        pfx = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(M + (r + SQD_LISTS_L2PF) * g.n_c) + \
+                                                 (((unsigned)cb * pf_lpb + t1) << 7));                         \
+    }                                                                                                          \
+  } while (0)
+#else
+#define SQD_LISTS_PREFETCH()
 #endif
   for (int64_t r = r0; r < r1; ++r) {
     // -- 1. requests: the next row (it moves into LDS behind the barrier) and what the epilogue of THIS row adds.
@@ -617,57 +570,45 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     const bool more = r + 1 < r1 && !(g.dbg & 4);
     double2 pf[NPF2];
     double pj = 0.0;
-    double addv[CPL], t4v[CPL], hd[CPL], own[CPL];
+    double t4v[CPL], hd[CPL], own[CPL];
     unsigned sh_n = 0, n2_n = 0;
     const double* __restrict__ nimg = M;
     if (more) {
-      const double* nrow = M + (r + 1) * g.in_ld;  // (uniform base + 32-bit lane offset: saddr loads)
+      const double* nrow = M + (r + 1) * g.n_c;  // (uniform base + 32-bit lane offset: saddr loads)
       sh_n = (unsigned)((reinterpret_cast<uintptr_t>(nrow) >> 3) & 1u);
       n2_n = ((unsigned)n_c + sh_n + 1u) >> 1;
       nimg = nrow - sh_n;
     }
     // (the group offset goes into the scalar base: ONE offset register; n2_n = 0 when there is no next row)
-#define SQD_LISTS_REQUEST(u)                                                                   \
-  do {                                                                                         \
-    pf[u] = make_double2(0.0, 0.0);                                                            \
+#define SQD_LISTS_REQUEST(u)                                                                    \
+  do {                                                                                          \
+    pf[u] = make_double2(0.0, 0.0);                                                             \
     if ((unsigned)(SQD_PU(u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(SQD_PU(u) * NT)) \
-      pf[u] = ldu2(nimg + 2 * SQD_PU(u) * NT, (unsigned)tid);                                  \
+      pf[u] = ldu2(nimg + 2 * SQD_PU(u) * NT, (unsigned)tid);                                   \
   } while (0)
-#if SQD_LISTS_L2PF
-#define SQD_LISTS_PREFETCH()                                                                   \
-  do {                                                                                         \
-    asm volatile("" ::"v"(pfx));                                                               \
-    if (r + SQD_LISTS_L2PF < r1 && (unsigned)tid < pf_lpb && (unsigned)cb * pf_lpb + (unsigned)tid < pf_lines) \
-      pfx = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(M + (r + SQD_LISTS_L2PF) * g.in_ld) + \
-                                               (((unsigned)cb * pf_lpb + (unsigned)tid) << 7));             \
-  } while (0)
-#else
-#define SQD_LISTS_PREFETCH()
-#endif
+    // SQD_LISTS_SPREAD: one piece up front, one behind each round of gathers (the address pipe works in the shadow of the
+    // LDS round trips) instead of two up front and three behind the first round
+    constexpr int UPF = SQD_LISTS_SPREAD ? (NPF2 > REGCAP / 4 ? NPF2 - REGCAP / 4 : 0) : NPF2 / 2;
 #pragma unroll
-    for (int u = 0; u < NPF2 / 2; ++u) SQD_LISTS_REQUEST(u);
+    for (int u = 0; u < UPF; ++u) SQD_LISTS_REQUEST(u);
     if (more) {
       if (lists && tid < g.nnorb) pj = ldu(g.jrow + (r + 1) * g.nnorb, (unsigned)tid);
     }
-    const int crow = BETA ? rs_cid[r - r0] : -1;  // (per-row scalars of the chunk come from LDS: a scalar load from
-                                                  // memory here would be a ~1 us wait for the whole workgroup per row)
+    const int crow = T4 ? rs_cid[r - r0] : -1;  // (per-row scalars of the chunk come from LDS: a scalar load from
+                                                // memory here would be a ~1 us wait for the whole workgroup per row)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      addv[c] = 0.0;
       t4v[c] = 0.0;
       hd[c] = 0.0;
       own[c] = 0.0;
-      if (BETA && c * NT + tid < ncol) {
+      if (c * NT + tid < ncol) {
         // the diagonal term is formed in the epilogue, in natural column order: hdiag is read coalesced (the bit loop
         // over a table of the row in LDS that round 4's first version used cost eight LDS reads per element -- the
         // LDS pipe is what this kernel is bound by) and the element itself comes from the staged row
         if (HMODE) hd[c] = ldu(g.hdiag + r * n_c + c0, (unsigned)(c * NT + tid));
         own[c] = row[c0 + c * NT + tid];
       }
-      if (BETA) {
-        if (g.addin && c * NT + tid < ncol) addv[c] = ldu(out + r * n_c + c0, (unsigned)(c * NT + tid));  // the alpha side's part
-        if (cidN[c] >= 0 && crow >= 0) t4v[c] = ldu(g.t4 + (int64_t)crow * g.t4_ld, (unsigned)cidN[c]);  // single x single (compact)
-      }
+      if (T4 && cidN[c] >= 0 && crow >= 0) t4v[c] = ldu(g.t4 + (int64_t)crow * g.t4_ld, (unsigned)cidN[c]);  // single x single (compact)
     }
     LCLK_MARK(0);
     // -- 2. this row from LDS
@@ -708,15 +649,18 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
             }
           }
         }
-        if (k0 == 0) {  // the second half of the next row's requests, behind the first round of gathers
+        if (SQD_LISTS_SPREAD) {
+          if (UPF + k0 / 4 < NPF2) SQD_LISTS_REQUEST(UPF + k0 / 4);
+          if (k0 + 4 >= REGCAP) SQD_LISTS_PREFETCH();
+        } else if (k0 == 0) {  // the second half of the next row's requests, behind the first round of gathers
 #pragma unroll
-          for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+          for (int u = UPF; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
           SQD_LISTS_PREFETCH();
         }
       }
     } else {
 #pragma unroll
-      for (int u = NPF2 / 2; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
+      for (int u = UPF; u < NPF2; ++u) SQD_LISTS_REQUEST(u);
       SQD_LISTS_PREFETCH();
     }
 #pragma unroll
@@ -763,53 +707,14 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     for (int c = 0; c < CPL; ++c) {
       const int lc = c * NT + tid;  // natural-order column of the block
       if (lc < ncol) {
-        double v = ob[lc] + addv[c] + t4v[c];
-        if (BETA) {
-          double d = hd[c];
-          if (SPIN) {
-            const double pop = (double)__popcll(sN[c] & ~rs_str[r - r0]);  // beta occupied, alpha empty
-            d = HMODE ? d + g.shift * (g.szterm + pop - g.ss) : g.szterm + pop;
-          }
-          v += d * own[c];
+        double v = ob[lc] + t4v[c];
+        double d = hd[c];
+        if (SPIN) {
+          const double pop = (double)__popcll(sN[c] & ~rs_str[r - r0]);  // beta occupied, alpha empty
+          d = HMODE ? d + g.shift * (g.szterm + pop - g.ss) : g.szterm + pop;
         }
-        if (BETA) {
-          stu(out + r * n_c + c0, (unsigned)lc, v);
-        } else {
-          tile[(int)((r - r0) % g.G) * LT + lc] = v;
-        }
-      }
-    }
-    if (!BETA) {
-      const int gi = (int)((r - r0) % g.G);
-      if ((gi == g.G - 1 || !more) && !(g.dbg & 16)) {  // (uniform)
-        // G (or the last few) consecutive rows of a column = consecutive doubles of the result in C's layout.  The
-        // pieces of one column's run go out from ADJACENT lanes (16 bytes each), so that a store instruction touches
-        // 64 / pieces runs instead of 64: lane-per-column stores -- every lane its own run, four instructions each --
-        // were what the whole alpha pass waited for (1.5 ms of it at 10^4 x 10^4 with nothing else left in the loop)
-        const int cnt = gi + 1;
-        const int64_t rbase = r - gi;
-        const bool even = ((g.ldo & 1) == 0) && ((cnt & 1) == 0) &&
-                          ((((reinterpret_cast<uintptr_t>(out) >> 3) + (uint64_t)c0 * (uint64_t)g.ldo + (uint64_t)rbase) & 1) == 0);
-        if (even) {
-          __syncthreads();
-          const int pieces = cnt >> 1;
-          for (int i = tid; i < ncol * pieces; i += NT) {
-            const int lc = i / pieces, pc = i - lc * pieces;
-            lists_d2 v2;
-            v2[0] = tile[(2 * pc) * LT + lc];
-            v2[1] = tile[(2 * pc + 1) * LT + lc];
-            lists_d2* dst = reinterpret_cast<lists_d2*>(out + (int64_t)(c0 + lc) * g.ldo + rbase + 2 * pc);
-            if (g.dbg & 8) *dst = v2;
-            else __builtin_nontemporal_store(v2, dst);  // (half lines that the next flush completes: keep them out of the L2)
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            const int lc = c * NT + tid;
-            if (lc < ncol)
-              for (int i = 0; i < cnt; ++i) out[(int64_t)(c0 + lc) * g.ldo + rbase + i] = tile[i * LT + lc];
-          }
-        }
+        v += d * own[c];
+        stu(out + r * n_c + c0, (unsigned)lc, v);
       }
     }
     LCLK_MARK(3);
@@ -820,7 +725,7 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
         if ((unsigned)(SQD_PU(u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(SQD_PU(u) * NT))
           reinterpret_cast<double2*>(img)[tid + SQD_PU(u) * NT] = pf[u];
       for (unsigned b = tid + NPF2 * NT; b < n2_n; b += NT)  // (rows beyond 2 NPF2 NT columns)
-        reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * g.in_ld - sh_n, b);
+        reinterpret_cast<double2*>(img)[b] = ldu2(M + (r + 1) * g.n_c - sh_n, b);
       row = img + sh_n;
       if (lists && tid < g.nnorb) jr[tid] = pj;
       if (lists)
@@ -830,6 +735,9 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     __syncthreads();
     LCLK_MARK(5);
   }
+#if SQD_LISTS_L2PF
+  consume(pfx);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -846,7 +754,7 @@ struct SidePlan {
 
 // columns of each block sorted by list length (longest first), 64 at a time dealt to the wavefronts so that the four
 // SIMDs of a CU carry the same load (a workgroup's wavefronts go to the SIMDs in cyclic order)
-void plan_side(const int64_t* s_ptr, const int64_t* d_ptr, int64_t n, SidePlan& p) {
+void plan_side(const int64_t* s_ptr, const int64_t* d_ptr, int64_t n, SidePlan& p, bool compact_only) {
   p.nblk = (int)((n + LT - 1) / LT);
   p.cpb = (int)((n + p.nblk - 1) / p.nblk);
   p.col.assign((size_t)p.nblk * LT, -1);
@@ -860,6 +768,12 @@ void plan_side(const int64_t* s_ptr, const int64_t* d_ptr, int64_t n, SidePlan& 
       p.cidx[(size_t)I] = (int32_t)p.clist.size();
       p.clist.push_back((uint32_t)I);
     }
+  if (compact_only) {  // (alpha side: k_alpha_rows reads the CSR lists as they are)
+    p.col.clear();
+    p.desc.clear();
+    p.wlen.clear();
+    return;
+  }
   std::vector<int> order;
   for (int b = 0; b < p.nblk; ++b) {
     const int64_t c0 = (int64_t)b * p.cpb, c1 = std::min<int64_t>(n, c0 + p.cpb);
@@ -904,34 +818,19 @@ void plan_side(const int64_t* s_ptr, const int64_t* d_ptr, int64_t n, SidePlan& 
 }
 
 struct LdsPlan {
-  int pitch, o_jr, o_vr, o_ob, o_ovlv, o_ovli, o_ovs, o_tile, o_rs, G;
+  int pitch, o_jr, o_ob, o_ovlv, o_ovli, o_ovs, o_rs;
   size_t bytes;
 };
-// LDS of a pass whose staged rows have n_c doubles; want_tile: transposed output (G rows of LT doubles)
-bool lds_plan(int64_t n_c, int nnorb, int lds_bytes, bool want_tile, LdsPlan& L) {
+// LDS of the pass whose staged rows have n_c doubles
+bool lds_plan(int64_t n_c, int nnorb, int lds_bytes, LdsPlan& L) {
   int off = (int)((n_c + 3) & ~int64_t(1));  // the aligned image of a row: up to one double in front, one behind
   L.pitch = off;
   L.o_jr = off, off += (nnorb + 1) & ~1;
-  L.o_vr = off;
   L.o_ob = off, off += LT;
   L.o_ovlv = off, off += OVL_CAP;
   L.o_ovli = off, off += OVL_CAP / 2;
   L.o_ovs = off, off += OVS_CAP / 2;
-  L.o_rs = off;
-  if (!want_tile) off += (3 * RPC_MAX + 1) / 2;  // beta pass: per-row scalars of a chunk (8 + 4 bytes a row)
-  L.o_tile = off;
-  L.G = 0;
-  if (want_tile) {
-    for (int G = 8; G >= 1; G >>= 1)
-      if ((size_t)(off + G * LT) * 8 <= (size_t)lds_bytes) {
-        L.G = G;
-        break;
-      }
-    if (!L.G) return false;
-    off += L.G * LT;
-  } else {
-    L.G = 1;
-  }
+  L.o_rs = off, off += (3 * RPC_MAX + 1) / 2;  // per-row scalars of a chunk (8 + 4 bytes a row)
   L.bytes = (size_t)off * 8;
   return L.bytes <= (size_t)lds_bytes;
 }
@@ -942,13 +841,13 @@ bool lds_plan(int64_t n_c, int nnorb, int lds_bytes, bool want_tile, LdsPlan& L)
 struct ListSideDev {
   int nblk = 0, cpb = 0;
   int64_t m = 0;  // strings with single links
-  DevBuf col, desc, wlen, ridx, rval, sing, ovl_idx, ovl_val, ovs, cidx, clist, aux;  // aux: row-major J table (beta)
+  DevBuf col, desc, wlen, ridx, rval, sing, ovl_idx, ovl_val, ovs, cidx, clist;  // (alpha side: cidx and clist only)
 };
 struct ListState {
   ListSideDev side[2];
   SidePlan plan[2];  // host copies (their uploads are asynchronous)
-  DevBuf ct, cs, t4;
-  LdsPlan lds_a, lds_b;  // alpha pass (rows of C^T: na doubles), beta pass (rows of C: nb doubles)
+  DevBuf cs, t4;
+  LdsPlan lds_b;     // the list pass (rows of C: nb doubles)
 };
 
 void lists_release(sqd_ctx* c) {
@@ -956,9 +855,8 @@ void lists_release(sqd_ctx* c) {
   ListState* s = static_cast<ListState*>(c->lists);
   for (auto& sd : s->side)
     for (DevBuf* b : {&sd.col, &sd.desc, &sd.wlen, &sd.ridx, &sd.rval, &sd.sing, &sd.ovl_idx, &sd.ovl_val, &sd.ovs,
-                      &sd.cidx, &sd.clist, &sd.aux})
+                      &sd.cidx, &sd.clist})
       b->release();
-  s->ct.release();
   s->cs.release();
   s->t4.release();
   delete s;
@@ -972,12 +870,11 @@ bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1
   const int forced = env ? std::atoi(env) : -1;
   if (forced == 0) return false;
   if (row0 != 0 || row1 != na) return false;                  // whole-subspace contexts only
-  if (na > 65535 || nb > 65535) return false;                 // 16-bit source addresses
+  if (nb > 65535) return false;                               // 16-bit source addresses in the beta pass's registers
   if (nocc[0] < 1 || nocc[1] < 1) return false;
   if (!c->lists) c->lists = new ListState();
   ListState* s = static_cast<ListState*>(c->lists);
-  if (!lds_plan(na, c->nnorb, c->lds_bytes, true, s->lds_a) || !lds_plan(nb, c->nnorb, c->lds_bytes, false, s->lds_b))
-    return false;
+  if (!lds_plan(nb, c->nnorb, c->lds_bytes, s->lds_b)) return false;
   if (forced != 1) {
     // Rows so long that k_sigma_rows keeps only two of them in LDS (8 500 strings per spin and more), lists short and
     // even enough for the registers to hold nearly all of them.  Measured on the MI355X (profiles/r04, uniform N x N,
@@ -988,26 +885,18 @@ bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1
     if (tot[0] + tot[1] > 16 * na || tot[2] + tot[3] > 16 * nb) return false;
     if (tot[0] > 2 * na || tot[2] > 2 * nb) return false;
   }
-  plan_side(c->h_sptr, c->h_dptr, na, s->plan[0]);
-  plan_side(c->h_sptr_b, c->h_dptr_b, nb, s->plan[1]);
+  plan_side(c->h_sptr, c->h_dptr, na, s->plan[0], true);
+  plan_side(c->h_sptr_b, c->h_dptr_b, nb, s->plan[1], false);
   if (!s->plan[0].ok || !s->plan[1].ok) return false;
   c->sig_lists = true;
   return true;
 }
 
-// alpha side: 1 (default) by rows on C itself (k_alpha_rows), 0 as a list pass on C^T (SQD_LISTS_ALPHA)
-static bool alpha_by_rows() {
-  static const bool v = [] {
-    const char* env = std::getenv("SQD_LISTS_ALPHA");
-    return env ? std::atoi(env) != 0 : true;
-  }();
-  return v;
-}
 // columns of a panel of k_alpha_rows: na rows x pw columns within the share of the Infinity Cache that holds a panel
 static int alpha_panel_width(int64_t na, int64_t nb) {
   static const double mb = [] {
     const char* env = std::getenv("SQD_ALPHA_PANEL_MB");
-    return env ? std::atof(env) : 96.0;
+    return env ? std::atof(env) : 16.0;
   }();
   int64_t pw = (int64_t)(mb * 1048576.0 / (8.0 * (double)na)) / 128 * 128;
   const int64_t full = (nb + 127) / 128 * 128;
@@ -1026,7 +915,6 @@ static int upload_vec(sqd_ctx* c, DevBuf& buf, const std::vector<T>& v) {
 // device tables of the list path; enqueued behind launch C of set_subspace (the CSR lists must be filled)
 int lists_build(sqd_ctx* c) {
   ListState* s = static_cast<ListState*>(c->lists);
-  const int64_t ns[2] = {c->na, c->nb};
   for (int sp = 0; sp < 2; ++sp) {
     const SidePlan& p = s->plan[sp];
     ListSideDev& d = s->side[sp];
@@ -1034,11 +922,12 @@ int lists_build(sqd_ctx* c) {
     d.nblk = p.nblk;
     d.cpb = p.cpb;
     d.m = (int64_t)p.clist.size();
+    SQD_TRY(upload_vec(c, d.cidx, p.cidx));
+    SQD_TRY(upload_vec(c, d.clist, p.clist));
+    if (sp == 0) continue;  // (alpha side: k_alpha_rows reads the CSR lists as they are)
     SQD_TRY(upload_vec(c, d.col, p.col));
     SQD_TRY(upload_vec(c, d.desc, p.desc));
     SQD_TRY(upload_vec(c, d.wlen, p.wlen));
-    SQD_TRY(upload_vec(c, d.cidx, p.cidx));
-    SQD_TRY(upload_vec(c, d.clist, p.clist));
     SQD_TRY(d.ridx.reserve((size_t)p.nblk * (REGCAP / 2) * LT * 4));
     SQD_TRY(d.rval.reserve((size_t)p.nblk * REGCAP * LT * 8));
     SQD_TRY(d.sing.reserve((size_t)p.nblk * SCAP * LT * 4));
@@ -1066,36 +955,21 @@ int lists_build(sqd_ctx* c) {
     f.ovs = d.ovs.as<uint32_t>();
     hipLaunchKernelGGL(k_lists_fill, dim3(p.nblk), dim3(LT), 0, c->stream, f);
     SQD_HIP_CHECK(hipGetLastError());
-    if (sp == 1) {  // row-major J table of the beta strings (the alpha J table of the context is row-major already)
-      ListAuxArgs a;
-      a.strs = t.strs.as<uint64_t>();
-      a.n = ns[sp];
-      a.norb = c->norb;
-      a.nnorb = c->nnorb;
-      a.jdiag = c->jdiag.as<double>();
-      const int64_t cnt = ns[sp] * c->nnorb;
-      SQD_TRY(d.aux.reserve((size_t)cnt * 8));
-      a.jrow = d.aux.as<double>();
-      hipLaunchKernelGGL(k_lists_aux, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, a);
-      SQD_HIP_CHECK(hipGetLastError());
-    }
   }
-  if (!alpha_by_rows()) SQD_TRY(s->ct.reserve((size_t)((c->na + 1) & ~int64_t(1)) * c->nb * 8));  // (even pitch: 16-byte aligned rows)
   const int64_t ma = s->side[0].m, mb = s->side[1].m;
   SQD_TRY(s->cs.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
   SQD_TRY(s->t4.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
   return SQD_OK;
 }
 
-static void fill_pass_args(sqd_ctx* c, ListState* s, int side, int mode, bool spin, double ss, double shift,
-                           ListsArgs* gp) {
-  // side 1: beta lists on C (rows = alpha strings); side 0: alpha lists on C^T (rows = beta strings)
+// arguments of the list pass: beta lists on C (rows = alpha strings)
+static void fill_pass_args(sqd_ctx* c, ListState* s, int mode, bool spin, double ss, double shift, ListsArgs* gp) {
   ListsArgs& g = *gp;
   std::memset(&g, 0, sizeof(g));
-  const ListSideDev& d = s->side[side];
-  const LdsPlan& L = side ? s->lds_b : s->lds_a;
-  g.n_r = side ? c->na : c->nb;
-  g.n_c = side ? c->nb : c->na;
+  const ListSideDev& d = s->side[1];
+  const LdsPlan& L = s->lds_b;
+  g.n_r = c->na;
+  g.n_c = c->nb;
   g.mode = mode;
   g.spin = spin ? 1 : 0;
   g.ss = ss;
@@ -1107,21 +981,18 @@ static void fill_pass_args(sqd_ctx* c, ListState* s, int side, int mode, bool sp
   // row chunks per XCD: the XCD's 32 CUs over the column blocks, but no chunk shorter than 8 rows
   g.cpx = (int)std::min<int64_t>(std::max(1, 32 / d.nblk), std::max<int64_t>(1, (g.n_r + 63) / 64));
   g.cpx = (int)std::max<int64_t>(g.cpx, (g.n_r + 8 * (RPC_MAX - 8) - 1) / (8 * (RPC_MAX - 8)));  // chunks of <= RPC_MAX rows
-  g.G = L.G;
   const int64_t nchunks = 8 * (int64_t)g.cpx;
   int64_t rpc = (g.n_r + nchunks - 1) / nchunks;
-  rpc = (rpc + 7) / 8 * 8;  // chunk starts on multiples of 8 rows: whole tiles, 16-byte aligned tile stores
+  rpc = (rpc + 7) / 8 * 8;
   g.rpc = (int)rpc;
   g.norb = c->norb;
   g.nnorb = c->nnorb;
   g.pitch = L.pitch;
   g.o_jr = L.o_jr;
-  g.o_vr = L.o_vr;
   g.o_ob = L.o_ob;
   g.o_ovlv = L.o_ovlv;
   g.o_ovli = L.o_ovli;
   g.o_ovs = L.o_ovs;
-  g.o_tile = L.o_tile;
   g.o_rs = L.o_rs;
   g.col = d.col.as<int32_t>();
   g.desc = d.desc.as<uint32_t>();
@@ -1132,12 +1003,12 @@ static void fill_pass_args(sqd_ctx* c, ListState* s, int side, int mode, bool sp
   g.rval = d.rval.as<double>();
   g.ovl_val = d.ovl_val.as<double>();
   g.wlen = d.wlen.as<int32_t>();
-  g.strs_c = c->sp[side].strs.as<uint64_t>();
-  g.strs_r = c->sp[1 - side].strs.as<uint64_t>();
+  g.strs_c = c->sp[1].strs.as<uint64_t>();
+  g.strs_r = c->sp[0].strs.as<uint64_t>();
   g.hdiag = c->hdiag.as<double>();
-  g.jrow = side ? c->sp[0].jrow.as<double>() : s->side[1].aux.as<double>();        // J of the staged rows' spin
+  g.jrow = c->sp[0].jrow.as<double>();  // J of the staged rows' spin
   g.cidx_c = d.cidx.as<int32_t>();
-  g.cidx_r = s->side[1 - side].cidx.as<int32_t>();
+  g.cidx_r = s->side[0].cidx.as<int32_t>();
   g.stop = c->sigma_stop;
   static const int dbg = [] {
     const char* env = std::getenv("SQD_LISTS_DBG");
@@ -1155,13 +1026,12 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
   const int64_t na = c->na, nb = c->nb, ma = s->side[0].m, mb = s->side[1].m;
   const bool cross = ma > 0 && mb > 0;     // single x single term exists
   const bool alpha_pass = (mode == 0);     // the pure S^2 operator has no same-spin part
-  static const int pass_mask = [] {        // profiling hook: bit 0 transpose, 1 compact term, 2 alpha pass, 3 beta pass
+  static const int pass_mask = [] {        // profiling hook: bit 0 compact matrix, 1 compact term, 2 alpha pass, 3 beta pass
     const char* env = std::getenv("SQD_LISTS_PASSES");
     return env ? std::atoi(env) : 15;
   }();
-  const bool by_rows = alpha_by_rows();
-  // pass 0 (alpha side by rows): the compact matrix alone
-  if (by_rows && cross && (pass_mask & 1)) {
+  // launch 1: the compact matrix
+  if (cross && (pass_mask & 1)) {
     ListCompactArgs t;
     t.c = d_c;
     t.nb = nb;
@@ -1176,25 +1046,7 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     hipLaunchKernelGGL(k_lists_compact, dim3((unsigned)ma), dim3(256), 0, c->stream, t);
     SQD_HIP_CHECK(hipGetLastError());
   }
-  // pass 0 (alpha side as a list pass): C^T (+ the compact matrix)
-  if (!by_rows && (alpha_pass || cross) && (pass_mask & 1)) {
-    ListTransArgs t;
-    t.c = d_c;
-    t.ct = alpha_pass ? s->ct.as<double>() : nullptr;
-    t.na = na;
-    t.nb = nb;
-    t.c_stride = in_stride;
-    t.ld_t = (na + 1) & ~int64_t(1);
-    t.cidx_a = s->side[0].cidx.as<int32_t>();
-    t.cidx_b = s->side[1].cidx.as<int32_t>();
-    t.cs = cross ? s->cs.as<double>() : nullptr;
-    t.mb = mb;
-    t.stop = c->sigma_stop;
-    t.vec_index = vec_index;
-    hipLaunchKernelGGL(k_lists_transpose, dim3((unsigned)((nb + TS - 1) / TS), (unsigned)((na + TS - 1) / TS)),
-                       dim3(256), 0, c->stream, t);
-    SQD_HIP_CHECK(hipGetLastError());
-  }
+  // launch 2: single x single on it
   if (cross && (pass_mask & 2)) {
     ListT4Args t;
     t.ma = ma;
@@ -1220,12 +1072,23 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     hipLaunchKernelGGL(k_lists_t4, dim3((unsigned)blocks), dim3(256), 0, c->stream, t);
     SQD_HIP_CHECK(hipGetLastError());
   }
-  auto launch = [&](const ListsArgs& g, size_t shmem, int var) -> int {
+  // launch 3, the list pass: diagonal + beta lists on C (the pure S^2 operator: + the compact term, no alpha pass follows)
+  if (pass_mask & 8) {
+    ListsArgs g;
+    fill_pass_args(c, s, mode, spin, ss, shift, &g);
+    g.in = d_c;
+    g.in_stride = in_stride;
+    g.out = d_sigma;
+    g.out_stride = out_stride;
+    g.t4 = (cross && !alpha_pass) ? s->t4.as<double>() : nullptr;
+    g.t4_ld = mb;
+    g.vec_index = vec_index;
+    const int var = mode == 1 ? 3 : (spin ? 2 : 1);
+    const size_t shmem = s->lds_b.bytes;
     const unsigned grid = 8u * (unsigned)g.cpx * (unsigned)g.nblk;
     static std::atomic<size_t> granted[4][64];
     const int dev = c->device & 63;
-    const void* fn = var == 0   ? reinterpret_cast<const void*>(&k_sigma_lists<0>)
-                     : var == 1 ? reinterpret_cast<const void*>(&k_sigma_lists<1>)
+    const void* fn = var == 1   ? reinterpret_cast<const void*>(&k_sigma_lists<1>)
                      : var == 2 ? reinterpret_cast<const void*>(&k_sigma_lists<2>)
                                 : reinterpret_cast<const void*>(&k_sigma_lists<3>);
     if (shmem > 64 * 1024 && shmem > granted[var][dev].load(std::memory_order_relaxed)) {
@@ -1233,17 +1096,16 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
       granted[var][dev].store(shmem, std::memory_order_relaxed);
     }
     switch (var) {
-      case 0: hipLaunchKernelGGL((k_sigma_lists<0>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
       case 1: hipLaunchKernelGGL((k_sigma_lists<1>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
       case 2: hipLaunchKernelGGL((k_sigma_lists<2>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
       default: hipLaunchKernelGGL((k_sigma_lists<3>), dim3(grid), dim3(NT), shmem, c->stream, g); break;
     }
     SQD_HIP_CHECK(hipGetLastError());
-    return SQD_OK;
-  };
-  // pass 1 (by rows): alpha lists on C, panel by panel
-  if (by_rows && alpha_pass && (pass_mask & 4)) {
+  }
+  // launch 4: alpha lists by rows, added onto the list pass's result together with the compact term
+  if (alpha_pass && (pass_mask & 4)) {
     AlphaRowsArgs a;
+    std::memset(&a, 0, sizeof(a));
     a.in = d_c;
     a.out = d_sigma;
     a.in_stride = in_stride;
@@ -1261,6 +1123,11 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     a.d_src = c->sp[0].d_src.as<uint32_t>();
     a.d_val = c->sp[0].d_val.as<double>();
     a.jT = c->sp[1].jT.as<double>();
+    a.accum = (pass_mask & 8) ? 1 : 0;
+    a.t4 = cross ? s->t4.as<double>() : nullptr;
+    a.t4_ld = mb;
+    a.cidx_a = s->side[0].cidx.as<int32_t>();
+    a.cidx_b = s->side[1].cidx.as<int32_t>();
     a.stop = c->sigma_stop;
     a.vec_index = vec_index;
     const bool wide = ((nb & 1) == 0) && ((reinterpret_cast<uintptr_t>(d_c) & 15) == 0) &&
@@ -1271,40 +1138,6 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     if (wide) hipLaunchKernelGGL((k_alpha_rows<true>), dim3(grid), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL((k_alpha_rows<false>), dim3(grid), dim3(256), 0, c->stream, a);
     SQD_HIP_CHECK(hipGetLastError());
-  }
-  // pass 1 (list pass): alpha lists on C^T; the result lands in sigma (C's layout), 8 rows of C^T = 8 consecutive doubles at a time
-  if (!by_rows && alpha_pass && (pass_mask & 4)) {
-    ListsArgs g;
-    fill_pass_args(c, s, 0, mode, spin, ss, shift, &g);
-    g.in = s->ct.as<double>();
-    g.in_stride = 0;
-    g.in_ld = (na + 1) & ~int64_t(1);
-    g.out = d_sigma;
-    g.out_stride = out_stride;
-    g.ldo = nb;
-    g.transposed_out = 1;
-    g.lists = 1;
-    g.vec_index = vec_index;
-    SQD_TRY(launch(g, s->lds_a.bytes, 0));
-  }
-  // pass 2: diagonal + beta lists on C + the alpha part (in place) + the compact single x single term
-  if (pass_mask & 8) {
-    ListsArgs g;
-    fill_pass_args(c, s, 1, mode, spin, ss, shift, &g);
-    g.in = d_c;
-    g.in_stride = in_stride;
-    g.in_ld = nb;
-    g.out = d_sigma;
-    g.out_stride = out_stride;
-    g.ldo = nb;
-    g.transposed_out = 0;
-    g.addin = alpha_pass ? 1 : 0;
-    g.diag = 1;
-    g.lists = (mode == 0) ? 1 : 0;
-    g.t4 = cross ? s->t4.as<double>() : nullptr;
-    g.t4_ld = mb;
-    g.vec_index = vec_index;
-    SQD_TRY(launch(g, s->lds_b.bytes, mode == 1 ? 3 : (spin ? 2 : 1)));
   }
   if (c->ev_after_sigma_kernel) {
     SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
