@@ -52,7 +52,7 @@ constexpr int LT = 1024;        // column slots of a workgroup
 #define SQD_LISTS_L2PF 2
 #endif
 #ifndef SQD_LISTS_SPREAD
-#define SQD_LISTS_SPREAD 0
+#define SQD_LISTS_SPREAD 1
 #endif
 constexpr int CPL = SQD_LISTS_CPL;  // columns per lane: the fixed per-lane state (addresses, masks, the next row's share) is paid
                                 // once per CPL columns, which is what lets 24 links per column stay in registers
@@ -103,7 +103,11 @@ struct ListFillArgs {
 __device__ inline uint32_t pack_single(const SRec r) {
   return (r.src & 0xffffu) | (srec_widx(r.meta) << 16) | (r.meta & 0x80000000u);
 }
-__global__ void k_lists_fill(const ListFillArgs g) {
+// One thread per column slot.  (A conflict-aware ORDER of the register-held links -- the lanes of an LDS service group
+// choosing in turn, round by round, the remaining link whose bank pair is least taken -- cut the list pass's conflict
+// cycles by 38 % and its LDS-active cycles by 17 % (profiles/r04b/alpha_rows_probe_5.txt), and its time by 0.7 %: the
+// pass is not bound by LDS throughput; the ordering cost 0.6 ms of table build.  Removed again.)
+__global__ void __launch_bounds__(LT) k_lists_fill(const ListFillArgs g) {
   const int b = blockIdx.x;
   const int64_t slot = (int64_t)b * LT + threadIdx.x;
   const int col = g.col[slot];
@@ -117,7 +121,8 @@ __global__ void k_lists_fill(const ListFillArgs g) {
   const int ns = (int)(s1 - s0), nl = ns + (int)(d1 - d0);
   const uint32_t ov = g.desc[2 * slot + 1];
   const int ovl0 = (int)(ov & 0xffffu), ovs0 = (int)(ov >> 16);
-  uint32_t pend = 0;
+  uint32_t lsrc[REGCAP];
+  double lval[REGCAP];
   for (int k = 0; k < (nl > REGCAP ? nl : REGCAP); ++k) {
     uint32_t src = 0;
     double val = 0.0;
@@ -131,13 +136,17 @@ __global__ void k_lists_fill(const ListFillArgs g) {
       }
     }
     if (k < REGCAP) {
-      g.rval[((int64_t)b * REGCAP + k) * LT + threadIdx.x] = val;
-      if (k & 1) g.ridx[((int64_t)b * (REGCAP / 2) + (k >> 1)) * LT + threadIdx.x] = pend | (src << 16);
-      else pend = src & 0xffffu;
+      lsrc[k] = src;
+      lval[k] = val;
     } else {
       g.ovl_idx[(int64_t)b * OVL_CAP + ovl0 + (k - REGCAP)] = src;
       g.ovl_val[(int64_t)b * OVL_CAP + ovl0 + (k - REGCAP)] = val;
     }
+  }
+  for (int k = 0; k < REGCAP; k += 2) {
+    g.rval[((int64_t)b * REGCAP + k) * LT + threadIdx.x] = lval[k];
+    g.rval[((int64_t)b * REGCAP + k + 1) * LT + threadIdx.x] = lval[k + 1];
+    g.ridx[((int64_t)b * (REGCAP / 2) + (k >> 1)) * LT + threadIdx.x] = (lsrc[k] & 0xffffu) | (lsrc[k + 1] << 16);
   }
   for (int j = 0; j < (ns > SCAP ? ns : SCAP); ++j) {
     const uint32_t w = (j < ns) ? pack_single(g.s_rec[s0 + j]) : 0u;
@@ -525,6 +534,11 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     rs_str[i] = g.strs_r[r0 + i];
     rs_cid[i] = (T4 && g.t4) ? g.cidx_r[r0 + i] : -1;
   }
+  // Every load so far -- the lists above all -- is waited for HERE: left pending into the loop, the compiler's wait
+  // counts inside it are sized for the first iteration (s_waitcnt vmcnt(0..4) in front of the first uses of the list
+  // registers in the first gather round: ISA), and in every later iteration such a count waits for the requests that
+  // iteration has just issued -- the next row's first piece, hdiag, the previous row's store.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
 #ifdef SQD_PHASE_CLOCK
@@ -541,25 +555,34 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
 #endif
   // L2 prefetch, SQD_LISTS_L2PF rows ahead: what an iteration asks for and uses -- the hdiag segment of the epilogue,
   // the next row for whichever of the column blocks comes first -- is an HBM miss otherwise, and the loop's period
-  // cannot be shorter than the latency of that.  Wavefront 0: one lane per 128-byte line of this block's hdiag
-  // segment; wavefront 1: one lane per line of this block's tenth of the row of C.  The values are never used: they are
-  // "consumed" one iteration later, where the requests issued behind them have long landed.
+  // cannot be shorter than the latency of that.  The ~126 lines (this block's hdiag segment, this block's tenth of the
+  // row of C) are dealt to the sixteen wavefronts, eight lines each: lanes 0..7 take one line each, the other lanes
+  // repeat lane 7's.  The values are never used: they are "consumed" one iteration later, where the requests issued
+  // behind them have long landed.
+  // EVERY load of the loop is unconditional (indices clamped, not predicated): a load under a lane predicate is a
+  // branch around it, the compiler then no longer knows how many loads follow the one it must wait for, and waits for
+  // all of them -- s_waitcnt vmcnt(0) in the epilogue: for the prefetch too, an HBM access per row (ISA).
 #if SQD_LISTS_L2PF
-  const unsigned pf_lines = (unsigned)((n_c * 8 + 127) / 128), pf_lpb = (pf_lines + (unsigned)g.nblk - 1u) / (unsigned)g.nblk;
-  const unsigned hd_lines = (unsigned)((ncol * 8 + 127) / 128);
+  const char* pfb;  // this lane's line in row r0 (advances by a row per iteration)
+  {
+    const unsigned row_lines = (unsigned)((n_c * 8 + 127) / 128), lpb = (row_lines + (unsigned)g.nblk - 1u) / (unsigned)g.nblk;
+    const unsigned hd_lines = HMODE ? (unsigned)((ncol * 8 + 127) / 128) : 0u;
+    unsigned my_lines = lpb;  // lines of the row's share that exist
+    if ((unsigned)cb * lpb >= row_lines) my_lines = 0;
+    else if ((unsigned)cb * lpb + lpb > row_lines) my_lines = row_lines - (unsigned)cb * lpb;
+    const unsigned total = hd_lines + my_lines;  // (>= 1: the block has columns)
+    const unsigned lane = (unsigned)tid & 63u, wv = (unsigned)tid >> 6;
+    unsigned L = wv * 8u + (lane < 8u ? lane : 7u);
+    if (L >= total) L = total - 1u;
+    pfb = (L < hd_lines) ? reinterpret_cast<const char*>(g.hdiag + r0 * n_c + c0) + ((size_t)L << 7)
+                         : reinterpret_cast<const char*>(M + r0 * n_c) + ((size_t)((unsigned)cb * lpb + (L - hd_lines)) << 7);
+  }
   uint32_t pfx = 0;
 #define SQD_LISTS_PREFETCH()                                                                                   \
   do {                                                                                                         \
     consume(pfx);                                                                                              \
-    if (r + SQD_LISTS_L2PF < r1) {                                                                             \
-      if (HMODE && (unsigned)tid < hd_lines)                                                                   \
-        pfx = *reinterpret_cast<const uint32_t*>(                                                              \
-            reinterpret_cast<const char*>(g.hdiag + (r + SQD_LISTS_L2PF) * n_c + c0) + ((unsigned)tid << 7));  \
-      const unsigned t1 = (unsigned)tid - 64u;                                                                 \
-      if (t1 < pf_lpb && t1 < 64u && (unsigned)cb * pf_lpb + t1 < pf_lines)                                    \
-        pfx = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(M + (r + SQD_LISTS_L2PF) * g.n_c) + \
-                                                 (((unsigned)cb * pf_lpb + t1) << 7));                         \
-    }                                                                                                          \
+    const int64_t ahead = (r + SQD_LISTS_L2PF < r1 ? r + SQD_LISTS_L2PF : r1 - 1) - r0;                        \
+    pfx = *reinterpret_cast<const uint32_t*>(pfb + ahead * (int64_t)n_c * 8);                                  \
   } while (0)
 #else
 #define SQD_LISTS_PREFETCH()
@@ -571,29 +594,22 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
     double2 pf[NPF2];
     double pj = 0.0;
     double t4v[CPL], hd[CPL], own[CPL];
-    unsigned sh_n = 0, n2_n = 0;
-    const double* __restrict__ nimg = M;
-    if (more) {
-      const double* nrow = M + (r + 1) * g.n_c;  // (uniform base + 32-bit lane offset: saddr loads)
-      sh_n = (unsigned)((reinterpret_cast<uintptr_t>(nrow) >> 3) & 1u);
-      n2_n = ((unsigned)n_c + sh_n + 1u) >> 1;
-      nimg = nrow - sh_n;
-    }
-    // (the group offset goes into the scalar base: ONE offset register; n2_n = 0 when there is no next row)
+    // (the last row of a chunk "asks" for itself again: the loads stay unconditional, the result is not stored)
+    const double* nrow = M + (more ? r + 1 : r) * g.n_c;  // (uniform base + 32-bit lane offset: saddr loads)
+    const unsigned sh_n = (unsigned)((reinterpret_cast<uintptr_t>(nrow) >> 3) & 1u);
+    const unsigned n2_n = ((unsigned)n_c + sh_n + 1u) >> 1;
+    const double* __restrict__ nimg = nrow - sh_n;
 #define SQD_LISTS_REQUEST(u)                                                                    \
   do {                                                                                          \
-    pf[u] = make_double2(0.0, 0.0);                                                             \
-    if ((unsigned)(SQD_PU(u) * NT) < n2_n && (unsigned)tid < n2_n - (unsigned)(SQD_PU(u) * NT)) \
-      pf[u] = ldu2(nimg + 2 * SQD_PU(u) * NT, (unsigned)tid);                                   \
+    const unsigned i_ = (unsigned)(SQD_PU(u) * NT) + (unsigned)tid;                             \
+    pf[u] = ldu2(nimg, i_ < n2_n ? i_ : n2_n - 1u);                                             \
   } while (0)
     // SQD_LISTS_SPREAD: one piece up front, one behind each round of gathers (the address pipe works in the shadow of the
     // LDS round trips) instead of two up front and three behind the first round
     constexpr int UPF = SQD_LISTS_SPREAD ? (NPF2 > REGCAP / 4 ? NPF2 - REGCAP / 4 : 0) : NPF2 / 2;
 #pragma unroll
     for (int u = 0; u < UPF; ++u) SQD_LISTS_REQUEST(u);
-    if (more) {
-      if (lists && tid < g.nnorb) pj = ldu(g.jrow + (r + 1) * g.nnorb, (unsigned)tid);
-    }
+    if (lists) pj = ldu(g.jrow + (more ? r + 1 : r) * g.nnorb, (unsigned)(tid < g.nnorb ? tid : g.nnorb - 1));
     const int crow = T4 ? rs_cid[r - r0] : -1;  // (per-row scalars of the chunk come from LDS: a scalar load from
                                                 // memory here would be a ~1 us wait for the whole workgroup per row)
 #pragma unroll
@@ -601,13 +617,12 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
       t4v[c] = 0.0;
       hd[c] = 0.0;
       own[c] = 0.0;
-      if (c * NT + tid < ncol) {
-        // the diagonal term is formed in the epilogue, in natural column order: hdiag is read coalesced (the bit loop
-        // over a table of the row in LDS that round 4's first version used cost eight LDS reads per element -- the
-        // LDS pipe is what this kernel is bound by) and the element itself comes from the staged row
-        if (HMODE) hd[c] = ldu(g.hdiag + r * n_c + c0, (unsigned)(c * NT + tid));
-        own[c] = row[c0 + c * NT + tid];
-      }
+      // the diagonal term is formed in the epilogue, in natural column order: hdiag is read coalesced (the bit loop
+      // over a table of the row in LDS that round 4's first version used cost eight LDS reads per element) and the
+      // element itself comes from the staged row
+      const int lcq = c * NT + tid < ncol ? c * NT + tid : ncol - 1;
+      if (HMODE) hd[c] = ldu(g.hdiag + r * n_c + c0, (unsigned)lcq);
+      own[c] = row[c0 + lcq];
       if (T4 && cidN[c] >= 0 && crow >= 0) t4v[c] = ldu(g.t4 + (int64_t)crow * g.t4_ld, (unsigned)cidN[c]);  // single x single (compact)
     }
     LCLK_MARK(0);
@@ -618,35 +633,34 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
       acc[c] = 0.0;
     }
     if (lists) {
-      // the gathers of a lane's CPL columns go out together, four links per column and round: 4 CPL LDS reads in
-      // flight per lane instead of four (two waves per SIMD hide nothing of a dependent LDS round trip)
+      // four links per round.  The single links come FIRST in a merged list and SCAP = 4 of them have their packed
+      // {source, pair, sign} in registers: their second term -- sign x J_alpha[row][pair] x the same operand -- is added in
+      // the first round, from the operand that round has just gathered (one LDS read for J instead of two per link)
+      static_assert(SCAP == 4, "the first gather round carries the single links' J term");
 #pragma unroll
       for (int k0 = 0; k0 < REGCAP; k0 += 4) {
-        if (CPL == 2 && k0 < trips[CPL - 1]) {
-          // both columns of the lane (the second one's list is never the longer: plan_side): eight gathers in flight
-          const uint32_t wa = opaque(ri[0][k0 / 2]), wb = opaque(ri[0][k0 / 2 + 1]);
-          const uint32_t wc = opaque(ri[CPL - 1][k0 / 2]), wd = opaque(ri[CPL - 1][k0 / 2 + 1]);
-          const double x0 = row[wa & 0xffffu], x1 = row[wa >> 16], x2 = row[wb & 0xffffu], x3 = row[wb >> 16];
-          const double y0 = row[wc & 0xffffu], y1 = row[wc >> 16], y2 = row[wd & 0xffffu], y3 = row[wd >> 16];
-          acc[0] += rv[0][k0] * x0;
-          acc[CPL - 1] += rv[CPL - 1][k0] * y0;
-          acc[0] += rv[0][k0 + 1] * x1;
-          acc[CPL - 1] += rv[CPL - 1][k0 + 1] * y1;
-          acc[0] += rv[0][k0 + 2] * x2;
-          acc[CPL - 1] += rv[CPL - 1][k0 + 2] * y2;
-          acc[0] += rv[0][k0 + 3] * x3;
-          acc[CPL - 1] += rv[CPL - 1][k0 + 3] * y3;
-        } else {
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            if (k0 < trips[c]) {
-              const uint32_t wa = opaque(ri[c][k0 / 2]), wb = opaque(ri[c][k0 / 2 + 1]);
-              const double x0 = row[wa & 0xffffu], x1 = row[wa >> 16], x2 = row[wb & 0xffffu], x3 = row[wb >> 16];
-              acc[c] += rv[c][k0] * x0;
-              acc[c] += rv[c][k0 + 1] * x1;
-              acc[c] += rv[c][k0 + 2] * x2;
-              acc[c] += rv[c][k0 + 3] * x3;
+        for (int c = 0; c < CPL; ++c) {
+          if (k0 < trips[c]) {
+            const uint32_t wa = opaque(ri[c][k0 / 2]), wb = opaque(ri[c][k0 / 2 + 1]);
+            const double x0 = row[wa & 0xffffu], x1 = row[wa >> 16], x2 = row[wb & 0xffffu], x3 = row[wb >> 16];
+            if (k0 == 0) {
+              const int ns = (int)(d0[c] >> 16);
+              const double xs[SCAP] = {x0, x1, x2, x3};
+#pragma unroll
+              for (int j = 0; j < SCAP; ++j) {
+                if (j < strips[c]) {
+                  const uint32_t w = opaque(sg[c][j]);
+                  const double sgn = (w >> 31) ? -1.0 : 1.0;
+                  const double coef = (j < ns) ? sgn * jr[(w >> 17) & 0xfffu] : 0.0;
+                  acc[c] += coef * xs[j];
+                }
+              }
             }
+            acc[c] += rv[c][k0] * x0;
+            acc[c] += rv[c][k0 + 1] * x1;
+            acc[c] += rv[c][k0 + 2] * x2;
+            acc[c] += rv[c][k0 + 3] * x3;
           }
         }
         if (SQD_LISTS_SPREAD) {
@@ -676,15 +690,6 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
           }
         }
         const int ns = (int)(d0[c] >> 16);
-#pragma unroll
-        for (int j = 0; j < SCAP; ++j) {
-          if (j < strips[c]) {
-            const uint32_t w = opaque(sg[c][j]);
-            const double sgn = (w >> 31) ? -1.0 : 1.0;
-            const double coef = (j < ns) ? sgn * jr[(w >> 17) & 0xfffu] : 0.0;
-            acc[c] += coef * row[w & 0xffffu];
-          }
-        }
         if (wtail_s[c] > 0) {
           const int ovs0 = (int)(d1[c] >> 16);
           for (int t = 0; t < wtail_s[c]; ++t) {
