@@ -603,9 +603,10 @@ def secondary_entries(args, h1, eri, device):
         if ctx.sigma_kernel() == "k_sigma_lists":
             res["sigma_uniform_1e4x1e4"]["roofline"]["launches_per_sigma"] = 4
             res["sigma_uniform_1e4x1e4"]["roofline"]["note_kernels"] = (
-                "one sigma = k_lists_transpose + k_lists_t4 + k_sigma_lists<0> (alpha lists on C^T) + k_sigma_lists<1> (beta "
-                "lists on C); avg_launch_ms is the whole application (HIP events around 5 of them); per-kernel times and "
-                "counters: profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
+                "one sigma = k_lists_compact + k_lists_t4 (single x single on the compact matrix) + k_sigma_lists<1> (diagonal + "
+                "beta lists on C, rows through LDS) + k_alpha_rows (alpha lists by rows on C, added onto it); avg_launch_ms is the "
+                "whole application (HIP events around 5 of them); per-kernel times and counters: "
+                "profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
         ctx.set_subspace(sa[:16], sb[:16])  # release nothing, but leave a small subspace behind
     except Exception as exc:
         res["sigma_uniform_1e4x1e4"] = {"error": repr(exc)}

@@ -227,6 +227,10 @@ __global__ void __launch_bounds__(256) k_lists_compact(const ListCompactArgs g) 
 // panel, so that the eleven reads of a row segment find it on the die and HBM sees every element once.
 // A wavefront owns (row, panel): its lists sit one link per lane and are broadcast with readlane (scalar base address +
 // 32-bit lane offset per request), eight requests in flight per lane.  Fixed order: the same bits on every run.
+// Measured at 10^4 x 10^4: 0.88 ms, 10.9 TB/s into the CUs whatever the number of requests in flight per lane (4 .. 12);
+// 19 TB/s at 3000 x 3000 where a panel fits the L2s.  A quarter of a wavefront per row with 32-column panels private to
+// an XCD's L2 (lists broadcast inside the 16-lane groups with ds_bpermute) ran 0.92 ms alone, 2.11 against 2.14 ms in the
+// whole sigma; with the lists read per lane from memory 1.2 ms (profiles/r04b/alpha_rows_probe_*.txt).  Not kept.
 // ---------------------------------------------------------------------------------------------------------------
 struct AlphaRowsArgs {
   GPtr<const double> in;
@@ -881,12 +885,12 @@ bool lists_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1
   ListState* s = static_cast<ListState*>(c->lists);
   if (!lds_plan(nb, c->nnorb, c->lds_bytes, s->lds_b)) return false;
   if (forced != 1) {
-    // Rows so long that k_sigma_rows keeps only two of them in LDS (8 500 strings per spin and more), lists short and
-    // even enough for the registers to hold nearly all of them.  Measured on the MI355X (profiles/r04, uniform N x N,
-    // ms per sigma, list passes | k_sigma_rows): 10 000: 3.34 | 3.85; 6 000: 0.90 | 0.81; 4 000: 0.35 | 0.29 -- a list
-    // pass costs ~2.5 us per staged row whatever the row's length (one row in flight per CU: the next row's requests
-    // have only this row's evaluation to land in), which R >= 3 rows per workgroup amortise better.
-    if (na < 8500 || nb < 8500) return false;
+    // Lists short and even enough for the registers to hold nearly all of them, sets large enough for the table build
+    // (a host sort of the columns + one fill launch: +0.8 ms of set_subspace) to pay within a Davidson solve.  Measured on
+    // the MI355X (profiles/r04b/alpha_rows_probe_5.txt, uniform N x N, ms per sigma, this path | k_sigma_rows):
+    // 10 000: 2.14 | 3.82; 7 000: 0.96 | 1.46; 5 000: 0.43 | 0.52; 4 000: 0.25 | 0.29; 3 000: 0.133 | 0.150;
+    // 2 000: 0.067 | 0.062.
+    if (na < 5000 || nb < 5000) return false;
     if (tot[0] + tot[1] > 16 * na || tot[2] + tot[3] > 16 * nb) return false;
     if (tot[0] > 2 * na || tot[2] > 2 * nb) return false;
   }

@@ -711,7 +711,7 @@ def test_config2_full_size_1e4_x_1e4(hip_lib):
 
 @pytest.mark.parametrize("na,nb", [(1500, 1111), (1111, 2050), (700, 4097)])
 def test_list_passes_forced_against_work_items(hip_lib, monkeypatch, na, nb):
-    """The list passes (sqd_lists.hip; the default from 8 500 strings per spin) forced at sizes where the work-item kernel
+    """The list passes (sqd_lists.hip; the default from 5 000 strings per spin) forced at sizes where the work-item kernel
     can be forced on the same inputs: ragged shapes (last column block and last row chunk partial, odd row lengths: the
     16-byte aligned image of a row starts one double early on every other row, unaligned tile stores), nalpha != nbeta,
     every operator form -- H, S^2 alone (kernel variant 3), the linear penalty (variant 2), the squared penalty -- and a
