@@ -601,9 +601,9 @@ def secondary_entries(args, h1, eri, device):
         res["sigma_uniform_1e4x1e4"] = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
                                         "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
         if ctx.sigma_kernel() == "k_sigma_lists":
-            res["sigma_uniform_1e4x1e4"]["roofline"]["launches_per_sigma"] = 4
+            res["sigma_uniform_1e4x1e4"]["roofline"]["launches_per_sigma"] = 3
             res["sigma_uniform_1e4x1e4"]["roofline"]["note_kernels"] = (
-                "one sigma = k_lists_compact + k_lists_t4 (single x single on the compact matrix) + k_sigma_lists<1> (diagonal + "
+                "one sigma = k_lists_t4 (single x single term of the strings that have single links) + k_sigma_lists<1> (diagonal + "
                 "beta lists on C, rows through LDS) + k_alpha_rows (alpha lists by rows on C, added onto it); avg_launch_ms is the "
                 "whole application (HIP events around 5 of them); per-kernel times and counters: "
                 "profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")

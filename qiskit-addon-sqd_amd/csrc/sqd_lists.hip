@@ -2,7 +2,7 @@
 // per spin up: BASELINE config 2 read literally (10^4 x 10^4 strings, D = 10^8, 800 MB per vector) and the "subspace
 // dimensions of ~10^7" of the reference's README (README.md:78).  Replaces, like the other sigma kernels, pyscf
 // selected_ci.contract_2e + contract_ss behind kernel_fixed_space (reference qiskit_addon_sqd/fermion.py:721-723,
-// :810-818).  Four launches per sigma, each element of C leaving HBM once per side:
+// :810-818).  Three launches per sigma, each element of C leaving HBM once per side:
 //
 //   * BETA side, a list pass on C (k_sigma_lists): the merged same-spin list of a beta string (singles' one-body value,
 //     then doubles: ~11 links at 10^4 strings) lives IN REGISTERS of the lane that owns the string: a workgroup of 1024
@@ -23,8 +23,8 @@
 //     (Round 4's first half ran the alpha side as a second list pass on C^T between two transpositions: 1.59 + 0.40 ms
 //     against 0.8 ms; removed.)
 //   * The terms that pair a single link of each spin (2.7 % of the links, but a nested loop per element in the row
-//     kernel) are evaluated on the compact matrix of the strings that HAVE single links (k_lists_compact gathers it;
-//     ~2600 x 2600 at 10^4 x 10^4) by a small kernel of their own (k_lists_t4).
+//     kernel) are evaluated for the strings that HAVE single links (~2600 x 2600 at 10^4 x 10^4) by a small kernel of
+//     their own (k_lists_t4; operands gathered from C in place, the lists from per-string records).
 // Fixed order of accumulation everywhere: the same bits on every run.
 #include <algorithm>
 #include <atomic>
@@ -156,66 +156,170 @@ __global__ void __launch_bounds__(LT) k_lists_fill(const ListFillArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// single x single (and the S^2 exchange term) on the compact matrix:
-//   T[ia][ib] = sum_{alpha singles (A <- A', wa, s)} s sum_{beta singles (B <- B', wb, t)} t W(wa, wb) Cs[A'][B'],
+// single x single (and the S^2 exchange term), for the strings that HAVE single links (compact lists clist_a / clist_b):
+//   T[ia][ib] = sum_{alpha singles (A <- A', wa, s)} s sum_{beta singles (B <- B', wb, t)} t W(wa, wb) C[A'][B'],
 //   W = (pq|rs)  (+ pen when the beta link undoes the alpha link's orbital move); direct_element's last loop
+// One launch, operands gathered from C itself.  Until the end of round 4 this was two: k_lists_compact gathered the
+// compact matrix C[clist_a][clist_b] (56 us at 10^4 x 10^4: per thread ten dependent pairs of round trips) and a
+// per-element kernel walked string -> CSR pointers -> records -> compact addresses -> operand for every element (a
+// 64-bit division and six dependent round trips each: 103 us); both were bound by the LENGTH of their chains, not by
+// bytes (the compact row staged in LDS changed nothing: 88 us).  Now the chains are walked once per subspace
+// (k_lists_t4_tab: per compact row / column the first two single links as one 16-byte record) and an element costs two
+// round trips: its records, then its operands -- C[A'][B'] read in place (the 8-byte gathers of a workgroup fall into the
+// 1250 lines of one or two rows of C, every line asked for 2.5 times at short distance: L2 hits after the first).
+// Order of accumulation unchanged (beta links inside alpha links): the same bits.
 // ---------------------------------------------------------------------------------------------------------------
 struct ListT4Args {
-  int64_t ma, mb;
+  int64_t ma, mb, nb, c_stride;
+  GPtr<const double> c;
   GPtr<const uint32_t> clist_a, clist_b;
-  GPtr<const int32_t> cidx_a, cidx_b;
   GPtr<const int64_t> sa_ptr, sb_ptr;
   GPtr<const SRec> sa_rec, sb_rec;
   GPtr<const double> eri_pp;
   int nnorb, mode, spin;
   double pen;
-  GPtr<const double> cs;
+  GPtr<const uint4> tab_a;  // [ma]: {meta 0, source string 0, meta 1, source string 1}
+  GPtr<const uint4> tab_b;  // [mb]: {meta 0, meta 1, source string 0 | source string 1 << 16, number of single links}
+  GPtr<const int32_t> cnt_a;  // [ma]: number of single links
   GPtr<double> t4;
-  GPtr<const int> stop;
-};
-__global__ void __launch_bounds__(256) k_lists_t4(const ListT4Args g) {
-  if (g.stop && *g.stop) return;
-  const int64_t n = g.ma * g.mb;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t ia = i / g.mb, ib = i - ia * g.mb;
-    const int64_t A = g.clist_a[ia], B = g.clist_b[ib];
-    const int64_t sa0 = g.sa_ptr[A], sa1 = g.sa_ptr[A + 1], sb0 = g.sb_ptr[B], sb1 = g.sb_ptr[B + 1];
-    double a = 0.0;
-    for (int64_t la = sa0; la < sa1; ++la) {
-      const SRec ra = g.sa_rec[la];
-      const double* srow = g.cs + (int64_t)g.cidx_a[ra.src] * g.mb;
-      const double* w = g.eri_pp + (int64_t)(srec_widx(ra.meta) >> 1) * g.nnorb;
-      const int partner = (int)srec_widx(ra.meta) ^ 1;
-      double t = 0.0;
-      for (int64_t lb = sb0; lb < sb1; ++lb) {
-        const SRec rb = g.sb_rec[lb];
-        double wv = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
-        if (g.spin) wv += ((int)srec_widx(rb.meta) == partner) ? g.pen : 0.0;
-        t += srec_sign(rb.meta) * wv * srow[g.cidx_b[rb.src]];
-      }
-      a += srec_sign(ra.meta) * t;
-    }
-    g.t4[i] = a;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// the compact matrix alone (alpha side by rows: no transposition pass to ride on): Cs[ia][ib] = C[clist_a[ia]][clist_b[ib]]
-// ---------------------------------------------------------------------------------------------------------------
-struct ListCompactArgs {
-  GPtr<const double> c;
-  int64_t nb, c_stride, ma, mb;
-  GPtr<const uint32_t> clist_a, clist_b;
-  GPtr<double> cs;
   GPtr<const int> stop, vec_index;
 };
-__global__ void __launch_bounds__(256) k_lists_compact(const ListCompactArgs g) {
+struct ListT4TabArgs {
+  int64_t ma, mb;
+  GPtr<const uint32_t> clist_a, clist_b;
+  GPtr<const int64_t> sa_ptr, sb_ptr;
+  GPtr<const SRec> sa_rec, sb_rec;
+  GPtr<uint4> tab_a, tab_b;
+  GPtr<int32_t> cnt_a;
+};
+__global__ void __launch_bounds__(256) k_lists_t4_tab(const ListT4TabArgs g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < g.ma) {
+    const int64_t A = g.clist_a[i];
+    const int64_t s0 = g.sa_ptr[A];
+    const int n = (int)(g.sa_ptr[A + 1] - s0);
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    if (n > 0) {
+      const SRec r = g.sa_rec[s0];
+      t.x = r.meta;
+      t.y = r.src;
+    }
+    if (n > 1) {
+      const SRec r = g.sa_rec[s0 + 1];
+      t.z = r.meta;
+      t.w = r.src;
+    }
+    g.tab_a[i] = t;
+    g.cnt_a[i] = n;
+  }
+  if (i < g.mb) {
+    const int64_t B = g.clist_b[i];
+    const int64_t s0 = g.sb_ptr[B];
+    const int n = (int)(g.sb_ptr[B + 1] - s0);
+    uint4 t = make_uint4(0u, 0u, 0u, (uint32_t)n);
+    if (n > 0) {
+      const SRec r = g.sb_rec[s0];
+      t.x = r.meta;
+      t.z = r.src & 0xffffu;  // (nb <= 65535 on this path: lists_select)
+    }
+    if (n > 1) {
+      const SRec r = g.sb_rec[s0 + 1];
+      t.y = r.meta;
+      t.z |= r.src << 16;
+    }
+    g.tab_b[i] = t;
+  }
+}
+constexpr int T4_CPT = 4;
+#ifndef SQD_T4_T
+#define SQD_T4_T 256
+#endif
+constexpr int T4_T = SQD_T4_T;
+// workgroup (x, y): compact row x, compact columns y * 4 T4_T ..., four per thread (a whole row per workgroup up to 4096
+// columns: the 8-byte gathers of a row meet again in the L2 -- with 1024 columns per workgroup every workgroup pulled
+// 60 % of the row's lines for itself: 93 us)
+__global__ void __launch_bounds__(T4_T) k_lists_t4(const ListT4Args g) {
+  HIP_DYNAMIC_SHARED(double, w_l)  // [nnorb]
   if (g.stop && *g.stop) return;
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
   const int64_t ia = blockIdx.x;
-  const double* __restrict__ row = g.c + vsel * g.c_stride + (int64_t)g.clist_a[ia] * g.nb;
-  double* __restrict__ dst = g.cs + ia * g.mb;
-  for (int64_t ib = threadIdx.x; ib < g.mb; ib += 256) dst[ib] = row[g.clist_b[ib]];
+  const uint4 ta = g.tab_a[ia];
+  const int na_l = g.cnt_a[ia];
+  const int mb = (int)g.mb;
+  uint4 tb[T4_CPT];
+  double acc[T4_CPT];
+#pragma unroll
+  for (int u = 0; u < T4_CPT; ++u) {
+    const int ib = (int)blockIdx.y * (T4_T * T4_CPT) + u * T4_T + (int)threadIdx.x;
+    tb[u] = (ib < mb) ? g.tab_b[ib] : make_uint4(0u, 0u, 0u, 0u);
+    acc[u] = 0.0;
+  }
+  for (int la = 0; la < na_l; ++la) {
+    uint32_t meta_a, src_a;
+    if (la == 0) {
+      meta_a = ta.x;
+      src_a = ta.y;
+    } else if (la == 1) {
+      meta_a = ta.z;
+      src_a = ta.w;
+    } else {  // longer lists: from the CSR tables
+      const SRec ra = g.sa_rec[g.sa_ptr[g.clist_a[ia]] + la];
+      meta_a = ra.meta;
+      src_a = ra.src;
+    }
+    const double* __restrict__ srow = C + (int64_t)src_a * g.nb;
+    const double* __restrict__ w = g.eri_pp + (int64_t)(srec_widx(meta_a) >> 1) * g.nnorb;
+    const int partner = (int)srec_widx(meta_a) ^ 1;
+    const double sgn_a = srec_sign(meta_a);
+    // the alpha link's row of (pq|rs) through LDS: gathered from memory it cost as much as the operands themselves --
+    // a 64-lane gather occupies the CU's address path for one clock per distinct line whether the line is in the L1 or not
+    if (la) __syncthreads();
+    for (int i = threadIdx.x; i < g.nnorb; i += T4_T) w_l[i] = w[i];
+    __syncthreads();
+    // every load unconditional (a link that does not exist reads element 0 and is not added): behind a branch each
+    // pair of loads was waited for before the next branch was even looked at -- eight round trips in sequence per alpha link
+    double wv[T4_CPT][2], cv[T4_CPT][2];
+#pragma unroll
+    for (int u = 0; u < T4_CPT; ++u)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool on = k < (int)tb[u].w;
+        const uint32_t meta = k ? tb[u].y : tb[u].x;
+        const uint32_t col = on ? (k ? (tb[u].z >> 16) : (tb[u].z & 0xffffu)) : 0u;
+        wv[u][k] = w_l[on ? (srec_widx(meta) >> 1) : 0u];
+        cv[u][k] = srow[col];
+      }
+#pragma unroll
+    for (int u = 0; u < T4_CPT; ++u) {
+      const int n = (int)tb[u].w;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t meta = k ? tb[u].y : tb[u].x;
+        double x = (g.mode == 0) ? wv[u][k] : 0.0;
+        if (g.spin) x += ((int)srec_widx(meta) == partner) ? g.pen : 0.0;
+        const double t1 = t + srec_sign(meta) * x * cv[u][k];
+        t = (k < n) ? t1 : t;
+      }
+      if (n > 2) {
+        const int ib = (int)blockIdx.y * (T4_T * T4_CPT) + u * T4_T + (int)threadIdx.x;
+        const int64_t sb0 = g.sb_ptr[g.clist_b[ib]];
+        for (int k = 2; k < n; ++k) {
+          const SRec rb = g.sb_rec[sb0 + k];
+          double x = (g.mode == 0) ? w[srec_widx(rb.meta) >> 1] : 0.0;
+          if (g.spin) x += ((int)srec_widx(rb.meta) == partner) ? g.pen : 0.0;
+          t += srec_sign(rb.meta) * x * srow[rb.src];
+        }
+      }
+      acc[u] += sgn_a * t;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < T4_CPT; ++u) {
+    const int ib = (int)blockIdx.y * (T4_T * T4_CPT) + u * T4_T + (int)threadIdx.x;
+    if (ib < mb) g.t4[ia * g.mb + ib] = acc[u];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -448,7 +552,13 @@ __global__ void __launch_bounds__(NT) k_sigma_lists(const ListsArgs g) {
   const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ M = g.in + vsel * g.in_stride;
   double* __restrict__ out = g.out + vsel * g.out_stride;
-  // block -> (row chunk, column block): the column blocks of one row chunk share an XCD (block b runs on XCD b % 8)
+  // block -> (row chunk, column block): the column blocks of one row chunk share an XCD (block b runs on XCD b % 8).
+  // (10^4 columns: 3 chunks x 10 column blocks fill 30 of an XCD's 32 CUs.  Giving the two idle CUs a short last chunk of
+  // the XCD's rows, its column blocks one after the other, was measured both ways: as a loop over column blocks inside
+  // the workgroup the pass gains 5.5 % on its rows but the loop costs the kernel its registers (119 -> 128 VGPRs, 43
+  // spilled SGPRs: +6 % per row); as ten more workgroups at the end of the grid, which start as CUs fall free, it is
+  // slower than without them -- 0.994 -> 1.034 ms at 48 rows: the late ones run behind the full chunks
+  // (profiles/r04b/extra_rows_probe.txt).  Not kept.)
   unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
   if (g.dbg & 1) xcd = 0, q = blockIdx.x;
   const int cb = (int)(q % (unsigned)g.nblk);
@@ -855,7 +965,7 @@ struct ListSideDev {
 struct ListState {
   ListSideDev side[2];
   SidePlan plan[2];  // host copies (their uploads are asynchronous)
-  DevBuf cs, t4;
+  DevBuf t4, t4tab_a, t4tab_b, t4cnt_a;
   LdsPlan lds_b;     // the list pass (rows of C: nb doubles)
 };
 
@@ -866,8 +976,10 @@ void lists_release(sqd_ctx* c) {
     for (DevBuf* b : {&sd.col, &sd.desc, &sd.wlen, &sd.ridx, &sd.rval, &sd.sing, &sd.ovl_idx, &sd.ovl_val, &sd.ovs,
                       &sd.cidx, &sd.clist})
       b->release();
-  s->cs.release();
   s->t4.release();
+  s->t4tab_a.release();
+  s->t4tab_b.release();
+  s->t4cnt_a.release();
   delete s;
   c->lists = nullptr;
 }
@@ -966,8 +1078,26 @@ int lists_build(sqd_ctx* c) {
     SQD_HIP_CHECK(hipGetLastError());
   }
   const int64_t ma = s->side[0].m, mb = s->side[1].m;
-  SQD_TRY(s->cs.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
   SQD_TRY(s->t4.reserve(std::max<size_t>((size_t)ma * mb * 8, 16)));
+  SQD_TRY(s->t4tab_a.reserve(std::max<size_t>((size_t)ma * 16, 16)));
+  SQD_TRY(s->t4tab_b.reserve(std::max<size_t>((size_t)mb * 16, 16)));
+  SQD_TRY(s->t4cnt_a.reserve(std::max<size_t>((size_t)ma * 4, 16)));
+  if (ma > 0 && mb > 0) {
+    ListT4TabArgs f;
+    f.ma = ma;
+    f.mb = mb;
+    f.clist_a = s->side[0].clist.as<uint32_t>();
+    f.clist_b = s->side[1].clist.as<uint32_t>();
+    f.sa_ptr = c->sp[0].s_ptr.as<int64_t>();
+    f.sb_ptr = c->sp[1].s_ptr.as<int64_t>();
+    f.sa_rec = c->sp[0].s_rec.as<SRec>();
+    f.sb_rec = c->sp[1].s_rec.as<SRec>();
+    f.tab_a = s->t4tab_a.as<uint4>();
+    f.tab_b = s->t4tab_b.as<uint4>();
+    f.cnt_a = s->t4cnt_a.as<int32_t>();
+    hipLaunchKernelGGL(k_lists_t4_tab, dim3((unsigned)((std::max(ma, mb) + 255) / 256)), dim3(256), 0, c->stream, f);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
   return SQD_OK;
 }
 
@@ -1035,35 +1165,20 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
   const int64_t na = c->na, nb = c->nb, ma = s->side[0].m, mb = s->side[1].m;
   const bool cross = ma > 0 && mb > 0;     // single x single term exists
   const bool alpha_pass = (mode == 0);     // the pure S^2 operator has no same-spin part
-  static const int pass_mask = [] {        // profiling hook: bit 0 compact matrix, 1 compact term, 2 alpha pass, 3 beta pass
+  static const int pass_mask = [] {        // profiling hook: bit 1 single x single term, 2 alpha pass, 3 beta pass (bit 0: unused)
     const char* env = std::getenv("SQD_LISTS_PASSES");
     return env ? std::atoi(env) : 15;
   }();
-  // launch 1: the compact matrix
-  if (cross && (pass_mask & 1)) {
-    ListCompactArgs t;
-    t.c = d_c;
-    t.nb = nb;
-    t.c_stride = in_stride;
-    t.ma = ma;
-    t.mb = mb;
-    t.clist_a = s->side[0].clist.as<uint32_t>();
-    t.clist_b = s->side[1].clist.as<uint32_t>();
-    t.cs = s->cs.as<double>();
-    t.stop = c->sigma_stop;
-    t.vec_index = vec_index;
-    hipLaunchKernelGGL(k_lists_compact, dim3((unsigned)ma), dim3(256), 0, c->stream, t);
-    SQD_HIP_CHECK(hipGetLastError());
-  }
-  // launch 2: single x single on it
+  // launch 1: the single x single term of the strings that have single links
   if (cross && (pass_mask & 2)) {
     ListT4Args t;
     t.ma = ma;
     t.mb = mb;
+    t.nb = nb;
+    t.c_stride = in_stride;
+    t.c = d_c;
     t.clist_a = s->side[0].clist.as<uint32_t>();
     t.clist_b = s->side[1].clist.as<uint32_t>();
-    t.cidx_a = s->side[0].cidx.as<int32_t>();
-    t.cidx_b = s->side[1].cidx.as<int32_t>();
     t.sa_ptr = c->sp[0].s_ptr.as<int64_t>();
     t.sb_ptr = c->sp[1].s_ptr.as<int64_t>();
     t.sa_rec = c->sp[0].s_rec.as<SRec>();
@@ -1073,12 +1188,14 @@ int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode,
     t.mode = mode;
     t.spin = sp ? 1 : 0;
     t.pen = (mode == 1) ? -1.0 : -shift;
-    t.cs = s->cs.as<double>();
+    t.tab_a = s->t4tab_a.as<uint4>();
+    t.tab_b = s->t4tab_b.as<uint4>();
+    t.cnt_a = s->t4cnt_a.as<int32_t>();
     t.t4 = s->t4.as<double>();
     t.stop = c->sigma_stop;
-    int64_t blocks = (ma * mb + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_lists_t4, dim3((unsigned)blocks), dim3(256), 0, c->stream, t);
+    t.vec_index = vec_index;
+    hipLaunchKernelGGL(k_lists_t4, dim3((unsigned)ma, (unsigned)((mb + T4_T * T4_CPT - 1) / (T4_T * T4_CPT))), dim3(T4_T),
+                       (size_t)c->nnorb * 8, c->stream, t);
     SQD_HIP_CHECK(hipGetLastError());
   }
   // launch 3, the list pass: diagonal + beta lists on C (the pure S^2 operator: + the compact term, no alpha pass follows)

@@ -32,8 +32,10 @@ struct dim3 {
 };
 struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
+struct uint4 { unsigned x, y, z, w; };
 struct double2 { double x, y; };
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 
 typedef int hipError_t;
