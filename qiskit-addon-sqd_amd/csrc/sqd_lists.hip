@@ -22,6 +22,9 @@
 //     result and brings the compact term with it, so the beta pass's row loop has no operand from HBM but hdiag.
 //     (Round 4's first half ran the alpha side as a second list pass on C^T between two transpositions: 1.59 + 0.40 ms
 //     against 0.8 ms; removed.)
+//     (The other order -- k_alpha_rows writes, the list pass adds onto it in its epilogue, the row of sigma prefetched
+//     into the L2 like hdiag's -- moves the 800 MB read from a bandwidth-bound kernel into this latency-bound loop:
+//     alpha rows 1.00 -> 0.88 ms, list pass 0.99 -> 1.09 ms; 2.074 -> 2.056 ms, not kept: profiles/r04b/order_swap_probe.txt.)
 //   * The terms that pair a single link of each spin (2.7 % of the links, but a nested loop per element in the row
 //     kernel) are evaluated for the strings that HAVE single links (~2600 x 2600 at 10^4 x 10^4) by a small kernel of
 //     their own (k_lists_t4; operands gathered from C in place, the lists from per-string records).
