@@ -452,8 +452,9 @@ def main():
                 F.solve_fermion((sa, sb), h1_rw, eri_rw, spin_sq=args.spin_sq, device=local_rank)
             out["ms_per_step_writeable_integrals"] = 1e3 * (time.perf_counter() - t_rw) / 40
             out["writeable_integrals_note"] = ("plain (writeable) numpy tensors, the reference user's call: the previous call's "
-                                               "solver context is taken at once and a worker thread re-hashes the tensors "
-                                               "while the solve runs; a mismatch repeats the solve (fermion._run_on_context)")
+                                               "solver context is taken at once and the library's hash threads digest the tensors "
+                                               "while the solve runs (sqd_hash_start / sqd_hash_finish); a mismatch repeats the solve "
+                                               "(fermion._run_on_context)")
             if args.spin_sq is not None:
                 # the oracle's Davidson here runs the bare operator; the penalised solve is compared with the
                 # reference flow in tests/test_gpu_parity.py (spin-penalty cases), not in the bench

@@ -358,6 +358,15 @@ int sqd_merge_rows(const uint8_t* bits, int64_t n, int nbits, const double* prob
 int sqd_choice_replay(const double* p, int64_t n, int64_t size, int64_t nbatches, const double* uniforms,
                       int64_t n_uniforms, int64_t* out, int64_t* n_used);
 
+/* Digests of the caller's integral tensors on native threads (no device work).  The reference's entry points take the
+ * tensors as plain arrays on every call (fermion.py:745-755) and never copy them; a solver context here is keyed by a hash
+ * of every byte, so that an in-place edit between two calls is seen.  sqd_hash_start returns at once (a small pool of
+ * native threads hashes fixed 512 KB pieces), sqd_hash_finish waits, helping, and returns one 64-bit digest per range
+ * (p1 == NULL, n1 == 0: one range) and releases the job.  The ranges must stay alive and unchanged in between; jobs of
+ * several host threads may be in flight at once.  The digest does not depend on the number of threads. */
+int sqd_hash_start(const void* p0, size_t n0, const void* p1, size_t n1, void** job);
+int sqd_hash_finish(void* job, unsigned long long* d0, unsigned long long* d1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,8 @@ EXPORTED_SYMBOLS = (
     "sqd_hamming_excess",
     "sqd_merge_rows",
     "sqd_choice_replay",
+    "sqd_hash_start",
+    "sqd_hash_finish",
 )
 
 
@@ -201,6 +203,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_hamming_excess.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p]
     lib.sqd_merge_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _i64p]
     lib.sqd_choice_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, _i64p]
+    lib.sqd_hash_start.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.sqd_hash_finish.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("sqd_last_error", "sqd_davidson_default_opts"):
@@ -740,9 +744,6 @@ class Context:
         occ = np.empty((2, self.norb))
         occ_a, occ_b = occ[0], occ[1]
         base = _addr(occ)
-        hook = getattr(self, "_before_native", None)
-        if hook is not None:  # (fermion._run_on_context: "the GIL is about to be released" -- the hash worker's cue)
-            hook()
         self._check(
             self._lib.sqd_solve_strings(self._h, _addr(a), a.size, _addr(b), b.size, C.byref(opts), ci0p,
                                         _addr(amps) if amps is not None else None, C.byref(stats), C.byref(e), C.byref(s2) if spin_square else None,

@@ -329,3 +329,231 @@ extern "C" __attribute__((visibility("default"))) int sqd_choice_replay(const do
   *n_used = pos;
   return SQD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Digest of the integral tensors on native threads.  A solver context is found by a hash of EVERY byte of the tensors the
+// caller passes (a writeable numpy array may have been edited in place since the last call); the Python layer launches
+// the solve on the previous call's context and verifies the bytes meanwhile (fermion._run_on_context).  A Python-side
+// hash holds the GIL for its whole pass and runs on one core: 0.2 ms for the 6.5 MB of norb = 30 beside a 0.16 ms solve.
+// Here the range is cut into fixed 512 KB pieces hashed by a small pool of native threads (four 64-bit lanes of
+// multiply-rotate rounds per piece, the piece digests folded in order: the result does not depend on the number of
+// threads); workers spin for a while after a job -- a solve loop hands them the next one within that time -- and sleep
+// on a condition variable otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+namespace sqd {
+namespace {
+
+constexpr uint64_t HP1 = 0x9E3779B185EBCA87ull, HP2 = 0xC2B2AE3D27D4EB4Full, HP3 = 0x165667B19E3779F9ull;
+constexpr size_t HASH_PIECE = 512 * 1024;
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t hround(uint64_t acc, uint64_t in) { return rotl64(acc + in * HP2, 31) * HP1; }
+inline uint64_t avalanche(uint64_t h) {
+  h ^= h >> 33;
+  h *= HP2;
+  h ^= h >> 29;
+  h *= HP3;
+  h ^= h >> 32;
+  return h;
+}
+// One 512 KB piece.  The bulk loop is the accumulate step of XXH3 (8 lanes of 64 bits per 64-byte stripe: the word is
+// added to the neighbouring lane, the product of the two halves of word ^ key to its own; every 16 stripes the lanes are
+// scrambled) written so that the compiler vectorises it: plain C++ compiled twice, for the baseline ISA and for AVX2
+// (chosen once at run time) -- 32 x 32 -> 64-bit multiplies, no 64-bit multiplier on the critical path.
+constexpr uint64_t HKEY[8] = {0xbe4ba423396cfeb8ull, 0x1cad21f72c81017cull, 0xdb979083e96dd4deull, 0x1f67b3b7a4a44072ull,
+                              0x78e5c0cc4ee679cbull, 0x2172ffcc7dd05a82ull, 0x8e2443f7744608b8ull, 0x4c263a81e69035e0ull};
+#define SQD_HASH_BULK_BODY                                                                   \
+  uint64_t acc[8];                                                                           \
+  for (int l = 0; l < 8; ++l) acc[l] = HKEY[l] ^ (seed + (uint64_t)l * HP1);                 \
+  size_t i = 0, stripe = 0;                                                                  \
+  for (; i + 64 <= n; i += 64, ++stripe) {                                                   \
+    uint64_t w[8];                                                                           \
+    std::memcpy(w, p + i, 64);                                                               \
+    for (int l = 0; l < 8; ++l) {                                                            \
+      const uint64_t k = w[l] ^ HKEY[l];                                                     \
+      acc[l ^ 1] += w[l];                                                                    \
+      acc[l] += (k & 0xffffffffull) * (k >> 32);                                             \
+    }                                                                                        \
+    if ((stripe & 15) == 15)                                                                 \
+      for (int l = 0; l < 8; ++l) acc[l] = ((acc[l] ^ (acc[l] >> 47)) ^ HKEY[7 - l]) * 0x9E3779B1ull; \
+  }                                                                                          \
+  for (int l = 0; l < 8; ++l) out[l] = acc[l];                                               \
+  return i;
+size_t hash_bulk_base(const unsigned char* p, size_t n, uint64_t seed, uint64_t* out) { SQD_HASH_BULK_BODY }
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) size_t hash_bulk_avx2(const unsigned char* p, size_t n, uint64_t seed, uint64_t* out) {
+  SQD_HASH_BULK_BODY
+}
+#endif
+uint64_t hash_piece(const unsigned char* p, size_t n, uint64_t seed) {
+  uint64_t acc[8];
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  size_t i = avx2 ? hash_bulk_avx2(p, n, seed, acc) : hash_bulk_base(p, n, seed, acc);
+#else
+  size_t i = hash_bulk_base(p, n, seed, acc);
+#endif
+  uint64_t h = (uint64_t)n * HP1;
+  for (int l = 0; l < 8; ++l) h = rotl64(h ^ avalanche(acc[l] + HKEY[l]), 23) * HP1 + HP2;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, p + i, 8);
+    h = rotl64(h ^ hround(0, w), 27) * HP1 + HP3;
+  }
+  for (; i < n; ++i) h = rotl64(h ^ (p[i] * HP3), 11) * HP1;
+  return avalanche(h);
+}
+
+struct HashJob {
+  const unsigned char* p[2] = {nullptr, nullptr};
+  size_t n[2] = {0, 0};
+  size_t pieces[2] = {0, 0};
+  std::vector<uint64_t> part;          // digests of the pieces, array 0 then array 1
+  std::atomic<size_t> next{0}, done{0};
+  std::atomic<int> active{0};          // workers that hold a pointer to this job
+  size_t total = 0;
+};
+
+struct HashPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::thread> workers;
+  std::vector<HashJob*> jobs;           // jobs in flight (guarded by mu)
+  std::atomic<uint64_t> epoch{0};       // bumped with every new job
+  bool quit = false;
+
+  static void run_pieces(HashJob* j) {
+    for (;;) {
+      const size_t k = j->next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= j->total) return;
+      const int a = k < j->pieces[0] ? 0 : 1;
+      const size_t q = a ? k - j->pieces[0] : k;
+      const size_t off = q * HASH_PIECE;
+      const size_t len = std::min(HASH_PIECE, j->n[a] - off);
+      j->part[k] = hash_piece(j->p[a] + off, len, (uint64_t)q);
+      j->done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::vector<HashJob*> mine;
+    for (;;) {
+      // spin briefly: the next job of a solve loop arrives within ~0.2 ms
+      const auto t0 = std::chrono::steady_clock::now();
+      while (epoch.load(std::memory_order_acquire) == seen) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return quit || epoch.load(std::memory_order_acquire) != seen; });
+          if (quit) return;
+          break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (quit) return;
+        seen = epoch.load(std::memory_order_acquire);
+        mine = jobs;
+        for (HashJob* j : mine) j->active.fetch_add(1, std::memory_order_relaxed);
+      }
+      for (HashJob* j : mine) {
+        run_pieces(j);
+        j->active.fetch_sub(1, std::memory_order_release);  // (the job may be freed from here on)
+      }
+    }
+  }
+  void ensure_started() {
+    if (!workers.empty()) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = hw >= 32 ? 6 : (hw >= 8 ? 3 : 1);
+    if (const char* env = std::getenv("SQD_HASH_THREADS")) nt = (unsigned)std::max(0, std::atoi(env));
+    for (unsigned i = 0; i < nt; ++i) workers.emplace_back([this] { worker(); });
+  }
+  void start(HashJob* j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ensure_started();
+      jobs.push_back(j);
+      epoch.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+  }
+  void finish(HashJob* j) {
+    run_pieces(j);  // the waiting thread helps
+    while (j->done.load(std::memory_order_acquire) < j->total) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < jobs.size(); ++i)
+        if (jobs[i] == j) {
+          jobs.erase(jobs.begin() + (long)i);  // (no worker can pick it up any more)
+          break;
+        }
+    }
+    while (j->active.load(std::memory_order_acquire) != 0) {  // a late worker that found nothing left to do
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+};
+HashPool& hash_pool() {
+  static HashPool* pool = new HashPool();  // (never destroyed: worker threads may outlive static destruction order)
+  return *pool;
+}
+uint64_t fold_parts(const HashJob& j, int a) {
+  const size_t b = a ? j.pieces[0] : 0;
+  uint64_t h = HP3 ^ (uint64_t)j.n[a];
+  for (size_t k = 0; k < j.pieces[a]; ++k) h = rotl64(h ^ j.part[b + k], 29) * HP1 + HP2;
+  return avalanche(h);
+}
+
+}  // namespace
+}  // namespace sqd
+
+// digests of one or two byte ranges (p1 may be NULL); sqd_hash_start returns at once with a job handle, sqd_hash_finish
+// waits (and helps) and releases the handle.  The ranges must stay unchanged and alive in between.  Jobs of several host
+// threads may be in flight at once.
+extern "C" __attribute__((visibility("default"))) int sqd_hash_start(const void* p0, size_t n0, const void* p1, size_t n1,
+                                                                     void** job) {
+  if ((!p0 && n0) || (!p1 && n1) || !job) {
+    set_error("sqd_hash_start: bad argument");
+    return SQD_ERR_INVALID;
+  }
+  HashJob* j = new HashJob();
+  j->p[0] = static_cast<const unsigned char*>(p0);
+  j->p[1] = static_cast<const unsigned char*>(p1);
+  j->n[0] = n0;
+  j->n[1] = n1;
+  j->pieces[0] = (n0 + HASH_PIECE - 1) / HASH_PIECE;
+  j->pieces[1] = (n1 + HASH_PIECE - 1) / HASH_PIECE;
+  j->total = j->pieces[0] + j->pieces[1];
+  j->part.assign(j->total, 0);
+  if (j->total > 1) hash_pool().start(j);  // (a single piece: the finishing thread hashes it itself)
+  *job = j;
+  return SQD_OK;
+}
+extern "C" __attribute__((visibility("default"))) int sqd_hash_finish(void* job, unsigned long long* d0,
+                                                                      unsigned long long* d1) {
+  HashJob* j = static_cast<HashJob*>(job);
+  if (!j) {
+    set_error("sqd_hash_finish: no job");
+    return SQD_ERR_INVALID;
+  }
+  if (j->total > 1) hash_pool().finish(j);
+  else HashPool::run_pieces(j);
+  if (d0) *d0 = fold_parts(*j, 0);
+  if (d1) *d1 = fold_parts(*j, 1);
+  delete j;
+  return SQD_OK;
+}

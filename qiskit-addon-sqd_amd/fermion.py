@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import os
 import threading
-import zlib
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
@@ -53,9 +52,9 @@ def _immutable(a: np.ndarray) -> bool:
 
 
 def _full_hash(arr: np.ndarray) -> int:
-    """Hash of EVERY byte of an integral array (xxh3).  Two tensors that differ anywhere get different hashes, hence
+    """Hash of EVERY byte of an integral array (``sqd_hash_start`` / ``sqd_hash_finish``: native threads, no GIL).  Two tensors that differ anywhere get different hashes, hence
     different solver contexts -- also after an IN-PLACE edit of a tensor that was used before: a writeable array is
-    hashed in full on every call (1 ms for the 6.5 MB of norb = 30; small tensors always are).  Only arrays that
+    hashed in full on every call (0.1 ms for the 6.5 MB of norb = 30; small tensors always are).  Only arrays that
     cannot change -- read-only, ``arr.setflags(write=False)``, with no writeable base -- are memoised by identity, so
     callers that solve many subspaces of one Hamiltonian freeze their integrals once (``freeze_integrals``; the SQD
     loop of this package does) and pay the pass once.  The memo holds a reference to the array, so its address cannot be
@@ -72,12 +71,7 @@ def _full_hash(arr: np.ndarray) -> int:
             hit = _HASH_MEMO.get(ident)
             if hit is not None and hit[0] is a:
                 return hit[1]
-    try:
-        import xxhash
-
-        digest = xxhash.xxh3_64_intdigest(flat.data)
-    except ImportError:  # pragma: no cover - xxhash ships with this image
-        digest = zlib.crc32(flat.data) | (zlib.adler32(flat.data) << 32)
+    digest = _native_digests(flat, None)[0]
     if ident is not None:
         with _HASH_LOCK:
             _HASH_MEMO[ident] = (a, digest)
@@ -109,54 +103,43 @@ def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int, digests=None):
 # since the last call, so their context can only be trusted once every byte has been hashed again -- a full xxh3 pass over
 # the 6.5 MB of norb = 30 per call, most of the time of a 0.2 ms solve.  Instead of waiting for it, the call SPECULATES:
 # tensors with the identity (object, address, size) of the previous call get the previous call's context at once, the
-# solve is launched, and a worker thread hashes the bytes meanwhile (the native call runs without the GIL).  When the
+# solve is launched, and the library's hash threads digest the bytes meanwhile (sqd_hash_start / sqd_hash_finish: native
+# threads, no GIL -- a Python-side xxh3 pass held the GIL and one core for 0.2 ms beside a 0.16 ms solve).  When the
 # solve returns the digests are compared; a mismatch -- the caller did edit the tensors -- discards the result and solves
 # again on the right context.  Never a wrong answer, and no hashing on the critical path when nothing changed.
 _SPEC_LOCK = threading.Lock()
 _SPEC: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of (hcore, eri, device, slot) -> (context key, hcore, eri)
 _SPEC_MAX = 4
-_HASH_QUEUE = None
+def _native_start(a0: np.ndarray, a1: "np.ndarray | None"):
+    """Start the digests of one or two C-contiguous arrays on the library's hash threads; returns (library, job)."""
+    import ctypes as C
+
+    lib = _capi.load_library()
+    job = C.c_void_p()
+    rc = lib.sqd_hash_start(a0.ctypes.data, a0.nbytes, a1.ctypes.data if a1 is not None else None,
+                            a1.nbytes if a1 is not None else 0, C.byref(job))
+    if rc != 0:
+        raise _capi.SQDNativeError(f"sqd_hash_start failed ({rc})")
+    return lib, job
 
 
-class _HashJob:
-    """Digests of two arrays, computed on the worker thread."""
+def _native_finish(handle) -> tuple[int, int]:
+    import ctypes as C
 
-    __slots__ = ("arrays", "digests", "done", "go")
-
-    def __init__(self, arrays):
-        self.arrays, self.digests, self.done, self.go = arrays, None, threading.Event(), threading.Event()
-
-    def result(self):
-        self.done.wait()
-        return self.digests
+    lib, job = handle
+    d0, d1 = C.c_ulonglong(), C.c_ulonglong()
+    rc = lib.sqd_hash_finish(job, C.byref(d0), C.byref(d1))
+    if rc != 0:
+        raise _capi.SQDNativeError(f"sqd_hash_finish failed ({rc})")
+    return int(d0.value), int(d1.value)
 
 
-def _hash_worker(q):
-    while True:
-        job = q.get()
-        # xxhash keeps the GIL for the whole pass: started at once it would hold up the calling thread's last Python steps
-        # in front of its native call.  The cue comes from the binding, right before that call releases the GIL.
-        job.go.wait(0.002)
-        try:
-            job.digests = tuple(_full_hash(a) for a in job.arrays)
-        except BaseException:  # noqa: BLE001 -- the caller falls back to the verified path
-            job.digests = None
-        job.done.set()
+def _native_digests(a0: np.ndarray, a1: "np.ndarray | None") -> tuple[int, int]:
+    return _native_finish(_native_start(a0, a1))
 
 
-def _submit_hash(arrays) -> _HashJob:
-    global _HASH_QUEUE
-    if _HASH_QUEUE is None:
-        import queue
-
-        with _SPEC_LOCK:
-            if _HASH_QUEUE is None:
-                q = queue.SimpleQueue()
-                threading.Thread(target=_hash_worker, args=(q,), daemon=True, name="sqd-hash").start()
-                _HASH_QUEUE = q
-    job = _HashJob(arrays)
-    _HASH_QUEUE.put(job)
-    return job
+def _plain(a) -> bool:
+    return isinstance(a, np.ndarray) and a.flags.c_contiguous and a.dtype == np.float64
 
 
 def _identity(hcore, eri, device, slot):
@@ -180,20 +163,17 @@ def _run_on_context(hcore, eri, device, slot, fn):
             with _CTX_LOCK:
                 ctx = _CTX_CACHE.get(hit[0])
     digests = None
-    if ctx is not None:
-        job = _submit_hash((hcore, eri))
-        ctx._before_native = job.go.set
+    if ctx is not None and _plain(hcore) and _plain(eri):
+        job = _native_start(hcore.reshape(-1), eri.reshape(-1))  # native threads hash while the solve runs
         try:
             out = fn(ctx)
         except Exception:  # noqa: BLE001 -- a failure on a context that may be the wrong one: decide below
             out = _FAILED
         finally:
-            ctx._before_native = None
-            job.go.set()
-        digests = job.result()
-        if digests is not None and _ham_key(hcore, eri, device, digests) + (slot,) == hit[0] and out is not _FAILED:
+            digests = _native_finish(job)
+        if _ham_key(hcore, eri, device, digests) + (slot,) == hit[0] and out is not _FAILED:
             return out, ctx
-        if digests is not None and _ham_key(hcore, eri, device, digests) + (slot,) == hit[0]:
+        if _ham_key(hcore, eri, device, digests) + (slot,) == hit[0]:
             return fn(ctx), ctx  # (the right context after all: let the exception surface from a clean call)
     if digests is None:
         digests = (_full_hash(hcore), _full_hash(eri))

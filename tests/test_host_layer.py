@@ -187,3 +187,47 @@ def test_writeable_integrals_speculation_is_safe(emu_backend):
     h1[0, 0] += 0.5
     eri /= 1.25
     assert abs(solve_fermion((sa, sb), h1, eri)[0] - e1) < 1e-10
+
+
+def test_native_digest_of_integral_tensors():
+    """``sqd_hash_start`` / ``sqd_hash_finish`` (host code of the library: no device work): every byte counts, whatever
+    the length class (tail bytes, whole stripes, several 512 KB pieces), jobs of several host threads may overlap, and the
+    digest does not depend on the number of hash threads."""
+    import subprocess
+    import sys
+    import threading
+
+    from qiskit_addon_sqd_amd import fermion as F
+
+    rng = np.random.default_rng(5)
+    for nbytes in (0, 1, 7, 8, 63, 64, 65, 1000, 512 * 1024 - 1, 512 * 1024, 512 * 1024 + 9, 3 * 512 * 1024 + 77):
+        a = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        d = F._native_digests(a, None)[0]
+        assert F._native_digests(a.copy(), None)[0] == d
+        for pos in {0, nbytes // 2, nbytes - 1} if nbytes else ():
+            b = a.copy()
+            b[pos] ^= 0x10
+            assert F._native_digests(b, None)[0] != d, (nbytes, pos)
+        if nbytes:
+            assert F._native_digests(a[:-1].copy(), None)[0] != d  # the length is part of the digest
+    big = rng.standard_normal(900_000)
+    small = rng.standard_normal(900)
+    want = F._native_digests(big, small)
+    assert want[0] == F._native_digests(big, None)[0] and want[1] == F._native_digests(small, None)[0]
+    # two jobs in flight at once, finished in the other order
+    j1, j2 = F._native_start(big, small), F._native_start(small, big)
+    assert F._native_finish(j2) == (want[1], want[0]) and F._native_finish(j1) == want
+    got = []
+    ts = [threading.Thread(target=lambda: got.append(F._native_digests(big, small))) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert got == [want] * 4
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from qiskit_addon_sqd_amd import fermion as F; "
+            "rng = np.random.default_rng(5); [rng.integers(0, 256, size=n, dtype=np.uint8) for n in "
+            "(0, 1, 7, 8, 63, 64, 65, 1000, 524287, 524288, 524297, 1572941)]; "
+            "print(*F._native_digests(rng.standard_normal(900_000), rng.standard_normal(900)))" % str(ROOT))
+    import os
+
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "SQD_HASH_THREADS": "0"}, capture_output=True,
+                         text=True, check=True).stdout.split()
+    assert (int(out[0]), int(out[1])) == want
