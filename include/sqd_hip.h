@@ -367,6 +367,11 @@ int sqd_choice_replay(const double* p, int64_t n, int64_t size, int64_t nbatches
 int sqd_hash_start(const void* p0, size_t n0, const void* p1, size_t n1, void** job);
 int sqd_hash_finish(void* job, unsigned long long* d0, unsigned long long* d1);
 
+/* _check_ci_strs (fermion.py:1075-1097) without a dozen numpy passes for the lists every SQD iteration produces: *ok = 1
+ * iff both lists are strictly ascending (= what np.sort(np.unique(.)) returns), non-negative as int64 and of one Hamming
+ * weight each; *ok = 0 sends the caller to the numpy path, which raises the reference's errors or normalises. */
+int sqd_check_strings(const uint64_t* a, int64_t na, const uint64_t* b, int64_t nb, int* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ EXPORTED_SYMBOLS = (
     "sqd_choice_replay",
     "sqd_hash_start",
     "sqd_hash_finish",
+    "sqd_check_strings",
 )
 
 
@@ -205,6 +206,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_choice_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, _i64p]
     lib.sqd_hash_start.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.sqd_hash_finish.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.sqd_check_strings.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("sqd_last_error", "sqd_davidson_default_opts"):
@@ -323,9 +325,12 @@ def _addr(a: np.ndarray) -> int:
     return a.__array_interface__["data"][0]
 
 
-def strings_to_u64(strs) -> np.ndarray:
-    """CI strings (int64 / uint64 / python ints) -> contiguous uint64 array (bit pattern preserved)."""
+def strings_to_u64(strs, validated: bool = False) -> np.ndarray:
+    """CI strings (int64 / uint64 / python ints) -> contiguous uint64 array (bit pattern preserved).  ``validated``: the
+    caller has checked the list (ascending, non-negative: ``fermion._check_ci_strs``) -- no pass over it here."""
     arr = np.asarray(strs)
+    if validated and arr.dtype in (np.int64, np.uint64) and arr.flags.c_contiguous:
+        return arr if arr.dtype == np.uint64 else arr.view(np.uint64)
     if arr.dtype == np.int64 and arr.flags.c_contiguous and (arr.size == 0 or (arr[0] >= 0 and arr[-1] >= 0 and arr.min() >= 0)):
         return arr.view(np.uint64)  # same bits, no copy
     if arr.dtype == object:
@@ -717,13 +722,17 @@ class Context:
     def solve(self, strs_a, strs_b, ci0=None, *, tol: float = 1e-9, tol_residual: float | None = None,
               lindep: float = 1e-14, max_cycle: int = 100, max_space: int = 12, spin_sq: float | None = None,
               shift: float = 0.2, verbose: int = 0, time_sigma_every: int = 0, spin_square: bool = True,
-              pageable_result: bool = False, fetch: bool = True):
+              pageable_result: bool = False, fetch: bool = True, validated: bool = False):
         """``set_subspace`` + ``davidson(observables=True)`` in one native call (``sqd_solve_strings``).
         Returns (amps, stats, (energy, spin_square | None, occ_a, occ_b))."""
-        a = strings_to_u64(strs_a)
-        b = strings_to_u64(strs_b)
-        opts = DavidsonOpts()
-        self._lib.sqd_davidson_default_opts(C.byref(opts))
+        a = strings_to_u64(strs_a, validated)
+        b = strings_to_u64(strs_b, validated)
+        tmpl = self.__dict__.get("_opts_template")
+        if tmpl is None:  # the library's defaults, asked for once per context
+            d0 = DavidsonOpts()
+            self._lib.sqd_davidson_default_opts(C.byref(d0))
+            tmpl = self._opts_template = bytes(d0)
+        opts = DavidsonOpts.from_buffer_copy(tmpl)
         opts.tol, opts.lindep, opts.max_cycle, opts.max_space = tol, lindep, int(max_cycle), int(max_space)
         opts.verbose = int(verbose)
         opts.time_sigma_every = int(time_sigma_every)

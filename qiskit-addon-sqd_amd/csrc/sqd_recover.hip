@@ -557,3 +557,23 @@ extern "C" __attribute__((visibility("default"))) int sqd_hash_finish(void* job,
   delete j;
   return SQD_OK;
 }
+
+// Are both string lists what np.sort(np.unique(.)) would return, non-negative as int64, and of one Hamming weight each?
+// (*ok = 1: the Python layer's _check_ci_strs -- reference fermion.py:1075-1097 -- has nothing to do or to raise; 0: it
+// takes its numpy path, which raises the reference's errors or normalises the lists.)  Host code, 10^2 .. 10^4 words.
+extern "C" __attribute__((visibility("default"))) int sqd_check_strings(const uint64_t* a, int64_t na, const uint64_t* b,
+                                                                        int64_t nb, int* ok) {
+  if (!ok || (!a && na) || (!b && nb) || na < 0 || nb < 0) {
+    set_error("sqd_check_strings: bad argument");
+    return SQD_ERR_INVALID;
+  }
+  auto good = [](const uint64_t* s, int64_t n) {
+    if (n < 1 || (s[n - 1] >> 63)) return false;
+    const int w = __builtin_popcountll(s[0]);
+    bool fine = true;
+    for (int64_t i = 1; i < n; ++i) fine &= (s[i] > s[i - 1]) & (__builtin_popcountll(s[i]) == w);
+    return fine;
+  };
+  *ok = (good(a, na) && good(b, nb)) ? 1 : 0;
+  return SQD_OK;
+}

@@ -11,6 +11,7 @@ CPU fallback.
 
 from __future__ import annotations
 
+import ctypes as _ctypes
 import os
 import threading
 from collections import OrderedDict
@@ -29,6 +30,8 @@ _PYSCF_KWARGS = {
     "verbose", "ecore", "pspace_size", "orbsym", "wfnsym", "tol_residual",
 }  # fmt: skip
 
+
+_C_INT, _BYREF = _ctypes.c_int, _ctypes.byref
 
 # --------------------------------------------------------------------------- contexts
 _CTX_LOCK = threading.Lock()
@@ -65,7 +68,7 @@ def _full_hash(arr: np.ndarray) -> int:
         a = np.ascontiguousarray(a, dtype=np.float64)
     flat = a.reshape(-1)
     ident = None
-    if own and a.size > _HASH_SMALL and _immutable(a):
+    if own and _immutable(a):
         ident = (id(a), a.__array_interface__["data"][0], a.size)
         with _HASH_LOCK:
             hit = _HASH_MEMO.get(ident)
@@ -96,7 +99,9 @@ def freeze_integrals(hcore, eri) -> tuple[np.ndarray, np.ndarray]:
 def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int, digests=None):
     if digests is None:
         digests = (_full_hash(hcore), _full_hash(eri))
-    return (device, int(np.asarray(hcore).shape[0]), int(np.asarray(eri).size), digests[0], digests[1])
+    h = hcore if type(hcore) is np.ndarray else np.asarray(hcore)
+    e = eri if type(eri) is np.ndarray else np.asarray(eri)
+    return (device, int(h.shape[0]), int(e.size), digests[0], digests[1])
 
 
 # ---- writeable integral tensors (what a reference user passes: plain numpy arrays).  They may have been edited in place
@@ -110,28 +115,25 @@ def _ham_key(hcore: np.ndarray, eri: np.ndarray, device: int, digests=None):
 _SPEC_LOCK = threading.Lock()
 _SPEC: "OrderedDict[tuple, tuple]" = OrderedDict()  # identity of (hcore, eri, device, slot) -> (context key, hcore, eri)
 _SPEC_MAX = 4
+_FAST: dict = {}  # (id(hcore), id(eri), device, slot) -> (hcore, eri, context key): immutable tensors only
 def _native_start(a0: np.ndarray, a1: "np.ndarray | None"):
     """Start the digests of one or two C-contiguous arrays on the library's hash threads; returns (library, job)."""
-    import ctypes as C
-
     lib = _capi.load_library()
-    job = C.c_void_p()
-    rc = lib.sqd_hash_start(a0.ctypes.data, a0.nbytes, a1.ctypes.data if a1 is not None else None,
-                            a1.nbytes if a1 is not None else 0, C.byref(job))
+    job = _ctypes.c_void_p()
+    rc = lib.sqd_hash_start(_capi._addr(a0), a0.nbytes, _capi._addr(a1) if a1 is not None else None,
+                            a1.nbytes if a1 is not None else 0, _BYREF(job))
     if rc != 0:
         raise _capi.SQDNativeError(f"sqd_hash_start failed ({rc})")
     return lib, job
 
 
 def _native_finish(handle) -> tuple[int, int]:
-    import ctypes as C
-
     lib, job = handle
-    d0, d1 = C.c_ulonglong(), C.c_ulonglong()
-    rc = lib.sqd_hash_finish(job, C.byref(d0), C.byref(d1))
+    d0, d1 = _ctypes.c_ulonglong(), _ctypes.c_ulonglong()
+    rc = lib.sqd_hash_finish(job, _BYREF(d0), _BYREF(d1))
     if rc != 0:
         raise _capi.SQDNativeError(f"sqd_hash_finish failed ({rc})")
-    return int(d0.value), int(d1.value)
+    return d0.value, d1.value
 
 
 def _native_digests(a0: np.ndarray, a1: "np.ndarray | None") -> tuple[int, int]:
@@ -143,46 +145,67 @@ def _plain(a) -> bool:
 
 
 def _identity(hcore, eri, device, slot):
-    h, e = np.asarray(hcore), np.asarray(eri)
-    return (id(hcore), h.__array_interface__["data"][0], h.size, id(eri), e.__array_interface__["data"][0], e.size,
+    """Identity of two writeable ndarrays: the objects, where their bytes live and how many there are (``resize`` can move
+    an array in place)."""
+    return (id(hcore), hcore.__array_interface__["data"][0], hcore.size, id(eri), eri.__array_interface__["data"][0], eri.size,
             device, slot)
 
 
 def _run_on_context(hcore, eri, device, slot, fn):
     """``fn(ctx)`` on the solver context of this Hamiltonian; returns (result, ctx).  Immutable tensors are recognised by
     identity (``_full_hash``'s memo); writeable ones take the speculative path described above."""
+    # frozen tensors seen before (the SQD loop's calls, a bench's steps): the context by the identity of the two array
+    # objects -- which this table keeps alive, so their ids cannot be recycled -- without building the hash key
+    fkey = (id(hcore), id(eri), device, slot)
+    fhit = _FAST.get(fkey)
+    if fhit is not None and fhit[0] is hcore and fhit[1] is eri and _immutable(hcore) and _immutable(eri):
+        with _CTX_LOCK:
+            ctx = _CTX_CACHE.get(fhit[2])
+            if ctx is not None:
+                _CTX_CACHE.move_to_end(fhit[2])
+        if ctx is not None:
+            return fn(ctx), ctx
     e_arr = np.asarray(eri)
     if e_arr.size <= _HASH_SMALL or (e_arr.flags.c_contiguous and e_arr.dtype == np.float64 and _immutable(e_arr)):
         ctx = _get_context(hcore, eri, device, slot)  # a full hash costs microseconds, or nothing
+        if (type(hcore) is np.ndarray and type(eri) is np.ndarray and _plain(hcore) and _plain(eri) and _immutable(hcore)
+                and _immutable(eri)):
+            with _SPEC_LOCK:
+                _FAST[fkey] = (hcore, eri, _ham_key(hcore, eri, device) + (slot,))
+                while len(_FAST) > 16:
+                    _FAST.pop(next(iter(_FAST)))
         return fn(ctx), ctx
-    ident = _identity(hcore, eri, device, slot)
-    with _SPEC_LOCK:
-        hit = _SPEC.get(ident)
-        ctx = None
+    spec_ok = type(hcore) is np.ndarray and type(eri) is np.ndarray and _plain(hcore) and _plain(eri)
+    ident = _identity(hcore, eri, device, slot) if spec_ok else None
+    hit = ctx = None
+    if spec_ok:
+        with _SPEC_LOCK:
+            hit = _SPEC.get(ident)
         if hit is not None and hit[1] is hcore and hit[2] is eri:
             with _CTX_LOCK:
                 ctx = _CTX_CACHE.get(hit[0])
     digests = None
-    if ctx is not None and _plain(hcore) and _plain(eri):
-        job = _native_start(hcore.reshape(-1), eri.reshape(-1))  # native threads hash while the solve runs
+    if ctx is not None:
+        job = _native_start(hcore, eri)  # native threads hash the tensors while the solve runs
         try:
             out = fn(ctx)
         except Exception:  # noqa: BLE001 -- a failure on a context that may be the wrong one: decide below
             out = _FAILED
         finally:
-            digests = _native_finish(job)
-        if _ham_key(hcore, eri, device, digests) + (slot,) == hit[0] and out is not _FAILED:
-            return out, ctx
+            digests = _native_finish(job)  # (the digests _full_hash gives: the keys must compare)
         if _ham_key(hcore, eri, device, digests) + (slot,) == hit[0]:
+            if out is not _FAILED:
+                return out, ctx
             return fn(ctx), ctx  # (the right context after all: let the exception surface from a clean call)
     if digests is None:
         digests = (_full_hash(hcore), _full_hash(eri))
     ctx = _get_context(hcore, eri, device, slot, digests=digests)
-    with _SPEC_LOCK:
-        _SPEC[ident] = (_ham_key(hcore, eri, device, digests) + (slot,), hcore, eri)
-        _SPEC.move_to_end(ident)
-        while len(_SPEC) > _SPEC_MAX:
-            _SPEC.popitem(last=False)
+    if spec_ok:
+        with _SPEC_LOCK:
+            _SPEC[ident] = (_ham_key(hcore, eri, device, digests) + (slot,), hcore, eri)
+            _SPEC.move_to_end(ident)
+            while len(_SPEC) > _SPEC_MAX:
+                _SPEC.popitem(last=False)
     return fn(ctx), ctx
 
 
@@ -209,6 +232,7 @@ def _get_context(hcore: np.ndarray, eri: np.ndarray, device: int = 0, slot: int 
 def clear_context_cache() -> None:
     with _SPEC_LOCK:
         _SPEC.clear()
+        _FAST.clear()
     with _CTX_LOCK:
         while _CTX_CACHE:
             _, old = _CTX_CACHE.popitem()
@@ -477,6 +501,9 @@ def _popcounts(strs) -> np.ndarray:
     return np.bitwise_count(arr.astype(np.uint64)).astype(np.int64)
 
 
+_INT64S = (np.dtype(np.int64), np.dtype(np.uint64))
+
+
 def _sorted_unique_int(a) -> bool:
     a = np.asarray(a)
     return a.ndim == 1 and a.dtype.kind in "iu" and a.size > 0 and bool((a[1:] > a[:-1]).all()) and a[0] >= 0
@@ -486,6 +513,15 @@ def _check_ci_strs(ci_strs: tuple[np.ndarray, np.ndarray]) -> tuple[np.ndarray, 
     """Make sure the hamming weight is consistent in all determinants (``fermion.py:1075-1097``;
     same error text, vectorised popcount instead of a Python loop over every string)."""
     addr_up, addr_dn = ci_strs
+    if (type(addr_up) is np.ndarray and type(addr_dn) is np.ndarray and addr_up.ndim == 1 and addr_dn.ndim == 1
+            and addr_up.dtype in _INT64S and addr_dn.dtype in _INT64S and addr_up.flags.c_contiguous
+            and addr_dn.flags.c_contiguous and addr_up.size and addr_dn.size):
+        # the lists every SQD iteration produces: one native pass says whether there is anything to do or to raise
+        ok = _C_INT()
+        lib = _capi.load_library()
+        if lib.sqd_check_strings(addr_up.ctypes.data, addr_up.size, addr_dn.ctypes.data, addr_dn.size, _BYREF(ok)) == 0 \
+                and ok.value:
+            return addr_up, addr_dn
     if _sorted_unique_int(addr_up) and _sorted_unique_int(addr_dn):
         # already what np.sort(np.unique(.)) would return: only the Hamming weights remain to be checked
         up, dn = np.asarray(addr_up), np.asarray(addr_dn)
@@ -559,7 +595,9 @@ def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True
         dk["time_sigma_every"] = _PROFILE["time_sigma_every"]
     if observables:  # tables + Davidson + observables: one native call
         ctx.set_async_state(_ASYNC_STATE)
-        out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square, **dk)
+        # (ci_strs went through _check_ci_strs: ascending, non-negative -- no second pass in the binding)
+        out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square, validated=True,
+                        **dk)
         _TLS.stats = out[1]
         ticket = out[1].get("state_ticket", 0)
         if ticket:  # the state is still landing in out[0]: wrapped, the first read of SCIState.amplitudes waits
