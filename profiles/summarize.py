@@ -32,7 +32,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
         real, early, alld = defaultdict(list), defaultdict(int), defaultdict(list)
         for r in csv.DictReader(open(f)):
             name = short(r["Kernel_Name"])
-            if "k_sigma" not in name and "k_same_spin" not in name and "k_lists" not in name:
+            if "k_sigma" not in name and "k_same_spin" not in name and "k_lists" not in name and "k_alpha_rows" not in name:
                 continue
             alld[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for name, ds in alld.items():
@@ -66,6 +66,13 @@ for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16"):
             w = out["WRITE_SIZE"].get(k, {"avg_KB": 0.0})
             hbm[k] = {"dispatches": v["dispatches"], "hbm_bytes_per_launch": (2.0 * v["avg_KB"] + w["avg_KB"]) * 1024.0}
         out["HBM_BYTES"] = hbm
+        if wl == "big":  # the list path's sigma is three launches: their sum is what one sigma moves
+            parts = {k: v["hbm_bytes_per_launch"] for k, v in hbm.items()
+                     if k.split("::")[-1].startswith(("k_lists_t4", "k_sigma_lists", "k_alpha_rows")) and "tab" not in k}
+            if parts:
+                out["LIST_PATH_SIGMA"] = {"kernels": parts, "hbm_bytes_per_sigma": sum(parts.values()),
+                                          "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (KB counters; the gfx950 "
+                                                  "correction for wide coalesced reads), summed over the launches of one sigma"}
         name = wl if wl != "big" else "uniform10000"
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{name}_pmc_summary.json"), "w"), indent=1)
         top = sorted(hbm.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]
