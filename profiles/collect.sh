@@ -60,7 +60,7 @@ CASE=hf16 REPS=3 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA --out
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_big -o p -- python $ROOT/profiles/probes/_big_sigma_probe.py > /dev/null 2>&1
 # keep only what travels back comfortably (the merge limit is 64 MiB)
-TAG=$R/pmc_lists bash profiles/probes/_pmc_lists.sh > $OUT/pmc_lists_probe.txt 2>&1
+TAG=$R/pmc_lists bash $ROOT/profiles/probes/_pmc_lists.sh > $OUT/pmc_lists_probe.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +12M -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT
