@@ -127,6 +127,21 @@ def _native_start(a0: np.ndarray, a1: "np.ndarray | None"):
     return lib, job
 
 
+_HASH_LIB = None
+
+
+def _native_start_at(addr0: int, nbytes0: int, addr1: int, nbytes1: int):
+    """``_native_start`` for two ranges whose addresses the caller has at hand."""
+    global _HASH_LIB
+    lib = _HASH_LIB
+    if lib is None:
+        lib = _HASH_LIB = _capi.load_library()
+    job = _ctypes.c_void_p()
+    if lib.sqd_hash_start(addr0, nbytes0, addr1, nbytes1, _BYREF(job)) != 0:
+        raise _capi.SQDNativeError("sqd_hash_start failed")
+    return lib, job
+
+
 def _native_finish(handle) -> tuple[int, int]:
     lib, job = handle
     d0, d1 = _ctypes.c_ulonglong(), _ctypes.c_ulonglong()
@@ -186,7 +201,8 @@ def _run_on_context(hcore, eri, device, slot, fn):
                 ctx = _CTX_CACHE.get(hit[0])
     digests = None
     if ctx is not None:
-        job = _native_start(hcore, eri)  # native threads hash the tensors while the solve runs
+        # native threads hash the tensors while the solve runs (addresses: the identity tuple has them already)
+        job = _native_start_at(ident[1], hcore.nbytes, ident[4], eri.nbytes)
         try:
             out = fn(ctx)
         except Exception:  # noqa: BLE001 -- a failure on a context that may be the wrong one: decide below
