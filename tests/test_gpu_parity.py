@@ -744,3 +744,41 @@ def test_list_passes_forced_against_work_items(hip_lib, monkeypatch, na, nb):
     assert a[5] == 1 and b[5] == 1 and abs(a[4] - b[4]) < 1e-9
     assert abs(a[6][0] - b[6][0]) < 1e-9 and abs(a[6][1] - b[6][1]) < 1e-8
     assert np.abs(a[6][2] - b[6][2]).max() < 1e-8 and np.abs(a[6][3] - b[6][3]).max() < 1e-8
+
+
+def test_list_path_default_selection_mid_size(hip_lib, monkeypatch):
+    """The list path where it becomes the DEFAULT (from 5 000 strings per spin; below, k_sigma_rows): 5 003 x 6 101
+    uniform strings, nalpha != nbeta, odd row length (k_alpha_rows' 8-byte form, unaligned row images).  H, the
+    linear spin penalty and S^2 alone against k_sigma_rows on the same input (SQD_SIGMA_LISTS=0); H on sampled rows and
+    columns against the row-restricted string-space oracle."""
+    from qiskit_addon_sqd_amd import synthetic as S
+
+    na, nb = 5003, 6101
+    h1, eri = S.synthetic_integrals(30)
+    sa, sb = S.uniform_strings(30, 8, na, 61), S.uniform_strings(30, 8, nb, 62)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((na, nb))
+    out = {}
+    for forced in ("default", "rows"):
+        if forced == "rows":
+            monkeypatch.setenv("SQD_SIGMA_LISTS", "0")
+        else:
+            monkeypatch.delenv("SQD_SIGMA_LISTS", raising=False)
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert (ctx.sigma_kernel() == "k_sigma_lists") == (forced == "default"), ctx.sigma_kernel()
+            out[forced] = (ctx.sigma(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.contract_ss(x))
+            if forced == "default":
+                assert np.array_equal(out[forced][0], ctx.sigma(x))  # fixed summation order
+                hd_max = np.abs(ctx.hdiag()).max()
+    for u, v in zip(out["default"], out["rows"]):
+        assert np.abs(u - v).max() < 1e-12 * max(1.0, np.abs(v).max())
+    sx = out["default"][0]
+    sl = O.single_links(sa, 30)
+    with_singles = np.unique(sl["tgt"])
+    rows = np.unique(np.concatenate(([0, na - 1], with_singles[:4], with_singles[-4:], rng.choice(na, 8, replace=False))))
+    ref = O.sigma_rows_string_space(h1, eri, sa, sb, x, 30, rows)
+    assert np.abs(sx[rows] - ref).max() < 1e-11 * hd_max * max(1.0, np.abs(x).max())
+    cols = np.unique(np.concatenate(([0, nb - 1], rng.choice(nb, 6, replace=False))))
+    refT = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), 30, cols)
+    assert np.abs(sx[:, cols].T - refT).max() < 1e-11 * hd_max * max(1.0, np.abs(x).max())
