@@ -10,4 +10,4 @@ Modules: ``fermion`` (solver surface), ``sqd`` (the configuration-recovery loop
 recovery, counts conversion), ``distributed`` (one-process-per-GPU batch-sharded ``sci_solver``),
 ``synthetic`` (seeded inputs, FCIDUMP I/O), ``_capi`` (ctypes binding).
 """
-__version__ = "0.1.0"
+from ._version import __version__  # noqa: F401
