@@ -44,7 +44,10 @@ __device__ unsigned long long sqd_clk[64 + 1024];  // [64 + 2 b], [65 + 2 b]: st
 
 
 constexpr int NV = 16;       // vectors per fused reduction launch (stand-alone dots)
-constexpr int RED_BLOCKS = 512;
+#ifndef SQD_RED_BLOCKS_MAX
+#define SQD_RED_BLOCKS_MAX 512
+#endif
+constexpr int RED_BLOCKS = SQD_RED_BLOCKS_MAX;
 constexpr int RED_T = 512;    // 8 waves per workgroup: half as many partials to fold as with 256
 
 // ---- loads over "the first nvec of up to N vectors" WITHOUT a branch per vector.  Written as
@@ -598,31 +601,20 @@ struct SplitRows {
 // the same bits.
 // (TOTALS -- row-sharded solves: the workgroup that arrives last folds the partials into tot_out, which the caller
 // all-reduces over the ranks before k_shard_eig; FUSED must be false)
-template <int MV, bool FUSED, bool TOTALS = false>
-__device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
-                                     double* __restrict__ partial, int width, unsigned* counter, DavState* st,
-                                     const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx,
-                                     double* __restrict__ tot_out = nullptr) {
-  __shared__ double red[16 * (MV + 1)];
-  __shared__ double tot[FUSED ? MV + 1 : 1];
-  __shared__ double sA[FUSED ? MV * MV : 1], sM[FUSED ? MV * MV : 1], sv_eig[FUSED ? MV + 1 : 1];
-  __shared__ unsigned long long s_head[FUSED ? DAV_HEAD_WORDS : 1];
-  __shared__ double s_heff[FUSED ? MV * MV : 1];
-  CLK(c0);
-  CLK_FIRST(63, c0);
-  if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
-                         // kernel before every workgroup has arrived)
-  const int nvec = st->m_next;
-  if (FUSED) dav_state_prefetch<MV>(st, s_head, s_heff);  // (for the workgroup that turns out to be the last one)
-  double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
-  double acc[MV + 1];
-#pragma unroll
-  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+// The element loop of the dot-product kernels with the basis slots bounded by K >= nvec instead of MV.  Slots past nvec
+// are loaded all the same (load_vectors: branch-free, an L1 hit) and multiplied by nothing -- free while a launch is a
+// chain of round trips (D = 1e5: one element per thread), but at D = 1e8 a thread walks ~400 elements and thirteen
+// loads and FMA pairs per element for a basis of two were most of the kernel: 0.81 ms for 1.6 GB at m = 1, growing by
+// only 0.06 ms per vector (profiles/r04b/big_davidson_probe.txt).  The arithmetic per element is the same for every K.
+template <int MV, int K>
+__device__ inline void dots_loop(int64_t n, const double* __restrict__ X, double* __restrict__ y, int64_t stride, int nvec,
+                                 const SplitRows& split, unsigned bx, unsigned nbx, double (&acc)[MV + 1]) {
+  static_assert(K <= MV, "slot bound");
   for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
     // every request that does not depend on another one first: the basis vectors, y, the row's split record -- the
     // partial rows of a split row are the only second round trip (they were the third)
-    double xv[MV];
-    load_vectors<MV>(X, stride, nvec, i, xv);
+    double xv[K];
+    load_vectors<K>(X, stride, nvec, i, xv);
     double yv = y[i];
     if (split.rowinfo) {
       const int64_t A = (n < (int64_t)1 << 31) ? (int64_t)((unsigned)i / (unsigned)split.nb) : i / split.nb;
@@ -650,11 +642,41 @@ __device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, do
       }
     }
 #pragma unroll
-    for (int v = 0; v < MV; ++v) {
+    for (int v = 0; v < K; ++v) {
       acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
       acc[0] += (v == nvec - 1) ? xv[v] * xv[v] : 0.0;
     }
   }
+}
+template <int MV>
+__device__ inline void dots_loop_select(int64_t n, const double* __restrict__ X, double* __restrict__ y, int64_t stride, int nvec,
+                                        const SplitRows& split, unsigned bx, unsigned nbx, double (&acc)[MV + 1]) {
+  if (nvec <= 2) dots_loop<MV, (2 < MV ? 2 : MV)>(n, X, y, stride, nvec, split, bx, nbx, acc);
+  else if (nvec <= 4) dots_loop<MV, (4 < MV ? 4 : MV)>(n, X, y, stride, nvec, split, bx, nbx, acc);
+  else if (nvec <= 8) dots_loop<MV, (8 < MV ? 8 : MV)>(n, X, y, stride, nvec, split, bx, nbx, acc);
+  else dots_loop<MV, MV>(n, X, y, stride, nvec, split, bx, nbx, acc);
+}
+template <int MV, bool FUSED, bool TOTALS = false>
+__device__ inline void dots_eig_body(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+                                     double* __restrict__ partial, int width, unsigned* counter, DavState* st,
+                                     const DavParams& prm, const SplitRows& split, unsigned bx, unsigned nbx,
+                                     double* __restrict__ tot_out = nullptr) {
+  __shared__ double red[16 * (MV + 1)];
+  __shared__ double tot[FUSED ? MV + 1 : 1];
+  __shared__ double sA[FUSED ? MV * MV : 1], sM[FUSED ? MV * MV : 1], sv_eig[FUSED ? MV + 1 : 1];
+  __shared__ unsigned long long s_head[FUSED ? DAV_HEAD_WORDS : 1];
+  __shared__ double s_heff[FUSED ? MV * MV : 1];
+  CLK(c0);
+  CLK_FIRST(63, c0);
+  if (st->stop) return;  // enqueued behind the iteration that ended the solve (nobody writes the flag during this
+                         // kernel before every workgroup has arrived)
+  const int nvec = st->m_next;
+  if (FUSED) dav_state_prefetch<MV>(st, s_head, s_heff);  // (for the workgroup that turns out to be the last one)
+  double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
+  double acc[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+  dots_loop_select<MV>(n, X, y, stride, nvec, split, bx, nbx, acc);
   block_sum_multi<MV + 1>(acc, nvec + 1, red);
   if constexpr (!FUSED && !TOTALS) {
     if ((int)threadIdx.x < nvec + 1) partial[(int64_t)bx * width + threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
@@ -711,6 +733,39 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
 // FOLD (row-sharded solves): the workgroup that arrives last folds the partials into tot_out (what the all-reduce over
 // the ranks reads) -- the single solver leaves the fold to every workgroup of k_orth_dev, which a collective in between
 // rules out, and a one-workgroup fold launch cost a dispatch and 3-4 us per iteration
+// (the element loop with the basis slots bounded by K >= nvec: see dots_loop)
+template <int MV, int K>
+__device__ inline void residual_loop(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride, int nvec,
+                                     double e, const double* __restrict__ hdiag, const PenaltyDiag& pd, const double* s_raw,
+                                     double* __restrict__ out, unsigned bx, unsigned nbx, double (&vals)[MV + 2]) {
+  static_assert(K <= MV, "slot bound");
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
+    double r = 0.0;
+    double xv[K];
+    const double hd = hdiag[i];
+    // eight (X_v, AX_v) pairs requested per round, branch-free (see load_vectors); X_v is kept for the overlaps
+#pragma unroll
+    for (int v0 = 0; v0 < K; v0 += 8) {
+      double a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < K) {
+          const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : 0) * stride + i;
+          xv[v0 + u] = X[off];
+          a8[u] = AX[off];
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u < K) r += (v0 + u < nvec) ? s_raw[v0 + u] * (a8[u] - e * xv[v0 + u]) : 0.0;
+    }
+    const double t = r / (hd + penalty_diag(pd, i) - e + 1e-4);
+    out[i] = t;
+    vals[0] += r * r;
+    vals[1] += t * t;
+#pragma unroll
+    for (int v = 0; v < K; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
+  }
+}
 template <int MV, bool FOLD = false>
 __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
                                              const DavState* __restrict__ st, const double* __restrict__ hdiag,
@@ -730,32 +785,10 @@ __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, 
   double vals[MV + 2];
 #pragma unroll
   for (int v = 0; v < MV + 2; ++v) vals[v] = 0.0;
-  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
-    double r = 0.0;
-    double xv[MV];
-    const double hd = hdiag[i];
-    // eight (X_v, AX_v) pairs requested per round, branch-free (see load_vectors); X_v is kept for the overlaps
-#pragma unroll
-    for (int v0 = 0; v0 < MV; v0 += 8) {
-      double a8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (v0 + u < MV) {
-          const int64_t off = (int64_t)(v0 + u < nvec ? v0 + u : 0) * stride + i;
-          xv[v0 + u] = X[off];
-          a8[u] = AX[off];
-        }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (v0 + u < MV) r += (v0 + u < nvec) ? s_raw[v0 + u] * (a8[u] - e * xv[v0 + u]) : 0.0;
-    }
-    const double t = r / (hd + penalty_diag(pd, i) - e + 1e-4);
-    out[i] = t;
-    vals[0] += r * r;
-    vals[1] += t * t;
-#pragma unroll
-    for (int v = 0; v < MV; ++v) vals[2 + v] += (v < nvec) ? xv[v] * t : 0.0;
-  }
+  if (nvec <= 2) residual_loop<MV, (2 < MV ? 2 : MV)>(n, X, AX, stride, nvec, e, hdiag, pd, s_raw, out, bx, nbx, vals);
+  else if (nvec <= 4) residual_loop<MV, (4 < MV ? 4 : MV)>(n, X, AX, stride, nvec, e, hdiag, pd, s_raw, out, bx, nbx, vals);
+  else if (nvec <= 8) residual_loop<MV, (8 < MV ? 8 : MV)>(n, X, AX, stride, nvec, e, hdiag, pd, s_raw, out, bx, nbx, vals);
+  else residual_loop<MV, MV>(n, X, AX, stride, nvec, e, hdiag, pd, s_raw, out, bx, nbx, vals);
   CLK(r2);
   block_sum_multi<MV + 2>(vals, nvec + 2, red);
   if constexpr (FOLD) {
@@ -780,8 +813,11 @@ __device__ inline void residual_precond_body(int64_t n, double* __restrict__ X, 
   }
 #endif
 }
+#ifndef SQD_RESID_WAVES
+#define SQD_RESID_WAVES 1
+#endif
 template <int MV>
-__global__ void __launch_bounds__(RED_T) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
+__global__ void __launch_bounds__(RED_T, SQD_RESID_WAVES) k_residual_precond(int64_t n, double* __restrict__ X, const double* __restrict__ AX, int64_t stride,
                                    const DavState* __restrict__ st, const double* __restrict__ hdiag,
                                    const PenaltyDiag pd, double* __restrict__ partial, int width) {
   residual_precond_body<MV>(n, X, AX, stride, st, hdiag, pd, partial, width, blockIdx.x, gridDim.x);
@@ -814,6 +850,22 @@ __device__ inline void post_progress(double* mail, long long seq, const DavState
 // enqueued behind) and posts the iteration's progress record to the host.
 // When the iteration is a restart (basis full), the same pass collapses the basis: X0 <- Ritz vector,
 // AX0 <- A * Ritz (linear combinations, element by element in place), X1 <- the correction.
+template <int G>
+__device__ inline void orth_loop(int64_t n, const double* __restrict__ X, int64_t stride, int nvec, double scale, const double* g,
+                                 double* __restrict__ t, double* __restrict__ send, unsigned bx, unsigned nbx) {
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
+    double s = scale * t[i];
+    for (int v0 = 0; v0 < nvec; v0 += G) {  // G vectors' loads in flight per round
+      double x[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
+#pragma unroll
+      for (int u = 0; u < G; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+    }
+    t[i] = s;
+    if (send) send[i] = s;
+  }
+}
 template <int MV>
 __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                                      const DavParams& prm, const double* __restrict__ partial, int nblocks, int width,
@@ -889,18 +941,11 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   const double scale = s_scale;
   double* __restrict__ t = X + (int64_t)nvec * stride;
   if (!restart) {
-    for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
-      double s = scale * t[i];
-      for (int v0 = 0; v0 < nvec; v0 += 8) {  // eight vectors' loads in flight per round
-        double x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s -= (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
-      }
-      t[i] = s;
-      if (send) send[i] = s;
-    }
+    // (rounds of G vectors' loads in flight; G = 2 / 4 for small bases: the slots past nvec of a round are loaded and
+    // dropped -- see dots_loop)
+    if (nvec <= 2) orth_loop<2>(n, X, stride, nvec, scale, g, t, send, bx, nbx);
+    else if (nvec <= 4) orth_loop<4>(n, X, stride, nvec, scale, g, t, send, bx, nbx);
+    else orth_loop<8>(n, X, stride, nvec, scale, g, t, send, bx, nbx);
 #ifdef SQD_PHASE_CLOCK
     __builtin_amdgcn_s_waitcnt(0);
     CLK(o3);
