@@ -618,9 +618,27 @@ def secondary_entries(args, h1, eri, device):
                 "beta lists on C, rows through LDS) + k_alpha_rows (alpha lists by rows on C, added onto it); avg_launch_ms is the "
                 "whole application (HIP events around 5 of them); per-kernel times and counters: "
                 "profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
+        # the whole Davidson solve at D = 1e8 (26 resident vectors of 0.8 GB): what an iteration costs beside its sigma
+        ctx.davidson(fetch=False)  # (first call at this size grows the arenas: not timed)
+        ctx.sync()
+        t0 = time.perf_counter()
+        _, st_big = ctx.davidson(fetch=False)
+        ctx.sync()
+        ms_big = 1e3 * (time.perf_counter() - t0)
+        nsb = max(int(st_big["n_sigma"]), 1)
+        # B_iter = B_sigma + 8 D (4 m + 6), m = 1 .. n_sigma in a run without restart
+        bytes_blas1 = sum(8.0 * n * n * (4.0 * m + 6.0) for m in range(1, nsb + 1))
+        ms_blas1 = ms_big - nsb * t_sig
+        res["sigma_uniform_1e4x1e4"]["davidson"] = {
+            "ms_per_solve": ms_big, "sigma_builds": nsb, "converged": int(st_big["converged"]),
+            "ms_per_iteration": ms_big / nsb, "ms_sigma_share": t_sig,
+            "blas1_gbs": bytes_blas1 / (ms_blas1 * 1e-3) / 1e9 if ms_blas1 > 0 else None,
+            "blas1_frac_of_hbm_peak": bytes_blas1 / (ms_blas1 * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_blas1 > 0 else None,
+            "note": "one whole Davidson solve (tol 1e-9) on the resident subspace, state left on the device; "
+                    "blas1 = (wall clock - sigma builds x the sigma time above) against SURVEY 8d's 8 D (4 m + 6) bytes per iteration"}
         ctx.set_subspace(sa[:16], sb[:16])  # release nothing, but leave a small subspace behind
     except Exception as exc:
-        res["sigma_uniform_1e4x1e4"] = {"error": repr(exc)}
+        res.setdefault("sigma_uniform_1e4x1e4", {})["error"] = repr(exc)
     return res
 
 
