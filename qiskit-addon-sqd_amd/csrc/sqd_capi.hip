@@ -776,10 +776,15 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
     SQD_HIP_CHECK(hipMemcpyAsync(amps, c->sol.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
   if (by_copy) SQD_STREAM_SYNC(c->copy_stream);
   if (staged) std::memcpy(amps, c->h_amps, bytes);
-  SQD_TRY(dev_observables_wait(c, /*whole_kernel=*/!late));
-  c->stage_pending = false;  // (the results are there: every upload in front of them in the stream has been consumed)
-  const int rc = solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
-  if (stats) stats->state_ticket = ticket;
+  int rc = dev_observables_wait(c, /*whole_kernel=*/!late);
+  if (rc == SQD_OK) {
+    c->stage_pending = false;  // (the results are there: every upload in front of them in the stream has been consumed)
+    rc = solve_collect(c, o, form, stats, e, s2, occ_a, occ_b);
+  }
+  // a call that fails hands no ticket back: the caller will recycle its page-locked block at once, so nothing may
+  // still be writing into it (k_state_copy on the copy stream)
+  if (rc != SQD_OK && late && ticket > 0) state_copy_wait(c, ticket);
+  if (stats) stats->state_ticket = (rc == SQD_OK) ? ticket : 0;
   return rc;
 }
 
@@ -1070,6 +1075,7 @@ SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double
   if (c->have_solution) {
     d = c->sol.as<double>();
   } else {
+    SQD_TRY(sol_writer_guard(c));
     SQD_TRY(c->sol.reserve((size_t)c->D * 8));
     SQD_HIP_CHECK(hipMemsetAsync(c->sol.p, 0, c->D * 8, c->stream));
     d = c->sol.as<double>();
@@ -1094,6 +1100,7 @@ SQD_API int sqd_time_dense(sqd_ctx* c, int reps, int copies, double* ms_per_laun
   NEED_ALL_ROWS(c);
   if (reps < 1 || !ms_per_launch || !flops_per_launch) return SQD_ERR_INVALID;
   if (!c->have_solution) {
+    SQD_TRY(sol_writer_guard(c));
     SQD_TRY(c->sol.reserve((size_t)c->D * 8));
     SQD_HIP_CHECK(hipMemsetAsync(c->sol.p, 0, c->D * 8, c->stream));
   }

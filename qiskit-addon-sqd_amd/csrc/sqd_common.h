@@ -415,6 +415,7 @@ int dev_observables_wait(sqd_ctx* c, bool whole_kernel = true);
 int state_copy_wait(sqd_ctx* c, long long ticket);
 int state_copy_enqueue(sqd_ctx* c, double* host_twin, long long* ticket);  // k_state_copy on the copy stream
 bool state_copy_landed(const sqd_ctx* c, long long ticket);
+int sol_writer_guard(sqd_ctx* c);  // wait until no k_state_copy reads c->sol any more (every writer of sol calls it)
 // batched (sqd_solve_batch)
 struct ObsBatchPlan {
   const char* args = nullptr;  // device array of ObsArgs

@@ -1240,6 +1240,9 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   const int nvecs = max_space + 1;
   SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
   SQD_TRY(c->AX.reserve((size_t)nvecs * D * 8));
+  // an earlier asynchronous solve's state may still be leaving `sol` on the copy stream (k_state_copy): every writer
+  // of `sol` waits for that copy first (a no-op behind sqd_solve's own buffer swap, which has checked the ticket)
+  SQD_TRY(sol_writer_guard(c));
   SQD_TRY(c->sol.reserve((size_t)D * 8));
   SQD_TRY(reserve_reduction_buffers(c));
   double* X = c->X.as<double>();
@@ -1644,6 +1647,7 @@ int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0) {
   const int nvecs = max_space + 1;
   SQD_TRY(c->X.reserve((size_t)nvecs * Dl * 8));
   SQD_TRY(c->AX.reserve((size_t)nvecs * Dl * 8));
+  SQD_TRY(sol_writer_guard(c));
   SQD_TRY(c->sol.reserve((size_t)Dl * 8));
   SQD_TRY(c->tmp1.reserve((size_t)Dl * 8));  // the send buffer of the all-gather
   SQD_TRY(reserve_reduction_buffers(c));

@@ -540,6 +540,14 @@ int dev_observables_wait(sqd_ctx* c, bool whole_kernel) {
 int state_copy_wait(sqd_ctx* c, long long ticket) {
   return spin_wait_word(c->h_mail + OBS_STATE_SEQ, ticket, c->copy_stream);
 }
+// Called by every writer of `sol` other than sqd_solve's asynchronous path (which alternates sol / sol_alt and checks
+// the other buffer's ticket itself): run_davidson reached through sqd_davidson or a solve whose state does not travel
+// late, the row-sharded run, the timing hooks' memset.  If the latest asynchronous solve's k_state_copy is still
+// reading `sol` on the copy stream, wait for it -- the earlier caller's SCIState would otherwise receive a mixture.
+int sol_writer_guard(sqd_ctx* c) {
+  if (c->sol_ticket > 0 && !state_copy_landed(c, c->sol_ticket)) SQD_TRY(state_copy_wait(c, c->sol_ticket));
+  return SQD_OK;
+}
 void dev_observables_collect(sqd_ctx* c, double* out_host) {
   const int nres = 3 + 2 * c->norb + 1;
   for (int i = 0; i < nres; ++i) out_host[i] = c->h_mail[OBS_MAIL + i];

@@ -111,6 +111,21 @@ def _exchange_buffers(group, tdev, nb: int, width: int, on_gpu: bool):
     return hit
 
 
+def _precheck_nelec(pairs, indices, nelec):
+    """Host-side check of this rank's batches against ``nelec`` (popcount of each list's first string -- the rule of
+    reference ``solve_fermion``, fermion.py:797-798); returns the exception to raise behind the exchange, or None."""
+    for i, (sa, sb) in zip(indices, pairs):
+        try:
+            got = (int(sa[0]).bit_count() if len(sa) else 0, int(sb[0]).bit_count() if len(sb) else 0)
+        except Exception as exc:  # noqa: BLE001 -- malformed input: reported like any other failure of the batch
+            return ValueError(f"batch {i}: cannot read the CI strings ({exc!r})")
+        if len(sa) == 0 or len(sb) == 0:
+            return ValueError(f"batch {i}: empty CI string list")
+        if got != tuple(nelec):
+            return ValueError(f"nelec={tuple(nelec)} does not match the Hamming weights {got} of the CI strings")
+    return None
+
+
 def shard_indices(num_batches: int, rank: int, world: int) -> list[int]:
     """Batches owned by ``rank``: round-robin, ``i % world == rank``."""
     return list(range(rank, num_batches, world))
@@ -215,8 +230,14 @@ def solve_sci_batch_distributed(
             dk = _davidson_kwargs(kwargs)
             dk.pop("verbose", None)
             dk.pop("ci0", None)
+            # What can be checked about this rank's batches is checked BEFORE the solve: once the solve's hook has
+            # enqueued the exchange, a failure can no longer be announced through it.  The native build
+            # validates order and a common Hamming weight per list before its first launch, i.e. also before the hook.
+            failure = _precheck_nelec([ci_strings[i] for i in mine], mine, nelec)
             try:
-                if len(mine) == 1:
+                if failure is not None:
+                    out = None
+                elif len(mine) == 1:
                     # one batch per rank (BASELINE config 3: 8 batches over 8 GPUs): the single solve.  The control
                     # process takes the state with the call (written by the observables kernel into page-locked memory);
                     # elsewhere it stays on the device -- it only ever leaves for rank 0, GPU to GPU
@@ -299,8 +320,14 @@ def solve_sci_batch_distributed(
     table = table.copy()
     if failure is not None:
         raise failure
-    if np.isnan(table[:, 0]).any():
-        bad = [int(i) for i in np.flatnonzero(np.isnan(table[:, 0]))]
+    # A record is unusable when its owner poisoned it (NaN energy: the owner failed before the exchange was enqueued) or
+    # when the kernels themselves produced no state (c.c not a positive finite number: the owner's solve_collect raises
+    # "zero norm" AFTER its hook has enqueued the exchange, so the record is the only messenger).  Every rank applies
+    # the same test to the same reduced table: all of them raise, none is left waiting in the state transfer below.
+    cc = table[:, 3]
+    unusable = np.isnan(table[:, 0]) | ~np.isfinite(cc) | ~(cc > 0.0)
+    if unusable.any():
+        bad = [int(i) for i in np.flatnonzero(unusable)]
         raise RuntimeError(f"solve_sci_batch_distributed: the solves of batches {bad} failed on ranks "
                            f"{sorted({i % world for i in bad})} (their own exceptions are raised there)")
     energies = np.empty(nb)

@@ -68,15 +68,59 @@ def main():
     s1 = solve_sci_batch(one, h1, eri, norb, nelec, compute_rdms=False, spin_sq=0.0)
     assert r1[0].energy == s1[0].energy, (rank, r1[0].energy, s1[0].energy)
     assert np.array_equal(r1[0].orbital_occupancies[1], s1[0].orbital_occupancies[1])
-    # a solve that fails on ONE rank (batch 1 has strings of the wrong Hamming weight) raises on EVERY rank, behind the
-    # exchange: nobody is left waiting in the collective
-    bad = [batches[0], (np.array([1, 2, 4]), np.array([1, 2, 4])), batches[2]]
+    # A solve that fails on ONE rank raises on EVERY rank, behind the exchange -- nobody is left waiting in the collective
+    # or in the state transfer that follows: the owner raises its own exception, the others the RuntimeError that names
+    # the failed batches.  Cases: the bad batch on rank 1, on the control process (rank 0), a batch whose strings are
+    # consistent among themselves (the native build accepts them) but carry the wrong electron number in either
+    # direction (4 electrons: it WOULD have been the lowest energy) -- caught on the host before the solve, i.e. before
+    # the solve's hook could enqueue the exchange.
+    def expect_failure(bad_batches, bad_index, owner_text):
+        owner = bad_index % world
+        try:
+            solve_sci_batch_distributed(bad_batches, h1, eri, norb, nelec, compute_rdms=False)
+        except ValueError as exc:
+            assert rank == owner, (rank, exc)
+            assert owner_text in str(exc), str(exc)
+        except RuntimeError as exc:
+            assert rank != owner, (rank, exc)
+            assert "failed on ranks" in str(exc) and f"[{bad_index}]" in str(exc) and f"[{owner}]" in str(exc), str(exc)
+        else:
+            raise AssertionError(f"rank {rank}: expected the failing batch {bad_index} to raise on every rank")
+        again = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False)  # the group still works
+        assert all(a.energy == s.energy for a, s in zip(again, serial))
+
+    mixed = (np.array([1, 2, 4]), np.array([1, 2, 4]))  # Hamming weight 1, nelec says 3
+    four = (O.random_strings(norb, 4, 6, 31), O.random_strings(norb, 4, 5, 32))
+    two = (O.random_strings(norb, 2, 6, 33), O.random_strings(norb, 2, 5, 34))
+    expect_failure([batches[0], mixed, batches[2]], 1, "Hamming")
+    expect_failure([mixed, batches[1], batches[2]], 0, "Hamming")
+    expect_failure([batches[0], four, batches[2]], 1, "Hamming")
+    expect_failure([two, batches[1], batches[2]], 0, "Hamming")
+    # ... and a failure the owner cannot announce: its kernels leave a record without a state (c.c = 0) and the call
+    # returns -- on a GPU the owner's "zero norm" error comes after its hook has enqueued the exchange.  Simulated by
+    # wiping the record behind rank 1's solve: every rank, the owner included, reads the same reduced table and raises.
+    if rank == 1:
+        ptrs = {}
+        orig_set, orig_solve = _capi.Context.set_record_out, _capi.Context.solve
+
+        def set_rec(self, ptr, stride=0):
+            if ptr:
+                ptrs["p"] = ptr
+            return orig_set(self, ptr, stride)
+
+        def solve_then_wipe(self, *a, **k):
+            out = orig_solve(self, *a, **k)
+            ctypes.memset(ptrs["p"], 0, 8 * _capi.record_width(norb))
+            return out
+
+        _capi.Context.set_record_out, _capi.Context.solve = set_rec, solve_then_wipe
     try:
-        solve_sci_batch_distributed(bad, h1, eri, norb, nelec, compute_rdms=False)
-        raise AssertionError("expected the failing batch to raise on every rank")
-    except (ValueError, RuntimeError) as exc:
-        assert "Hamming" in str(exc) or "failed on ranks" in str(exc) or "popcount" in str(exc).lower() or True
-    # ... and the group still works afterwards
+        solve_sci_batch_distributed(batches[:2], h1, eri, norb, nelec, compute_rdms=False)
+        raise AssertionError("expected the state-less record to raise on every rank")
+    except RuntimeError as exc:
+        assert "failed on ranks" in str(exc) and "[1]" in str(exc), str(exc)
+    if rank == 1:
+        _capi.Context.set_record_out, _capi.Context.solve = orig_set, orig_solve
     again = solve_sci_batch_distributed(batches, h1, eri, norb, nelec, compute_rdms=False)
     assert all(a.energy == s.energy for a, s in zip(again, serial))
     dist.barrier()
