@@ -12,7 +12,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from qiskit_addon_sqd_amd import _capi, synthetic as S  # noqa: E402
 
 sizes = [int(s) for s in os.environ.get("SIZES", "1000 2000 3000").split()]
-modes = os.environ.get("MODES", "default dense0 dense1").split()
+modes = os.environ.get("MODES", "default dense0 dense1 spmm0").split()
 reps = int(os.environ.get("REPS", "5"))
 check = os.environ.get("CHECK", "1") == "1"
 dav = os.environ.get("DAV", "1") == "1"
@@ -25,10 +25,15 @@ for n in sizes:
     for mode in modes:
         os.environ.pop("SQD_SIGMA_DENSE", None)
         os.environ.pop("SQD_SIGMA_CONN", None)
+        os.environ.pop("SQD_SIGMA_SPMM", None)
         if mode == "dense0":
             os.environ["SQD_SIGMA_DENSE"] = "0"
         elif mode == "dense1":
             os.environ["SQD_SIGMA_DENSE"] = "1"
+        elif mode == "spmm0":
+            os.environ["SQD_SIGMA_SPMM"] = "0"
+        elif mode == "spmm1":
+            os.environ["SQD_SIGMA_SPMM"] = "1"
         elif mode == "conn0":
             os.environ["SQD_SIGMA_CONN"] = "0"
         elif mode == "conn1":

@@ -246,6 +246,11 @@ struct sqd_ctx {
   bool sig_dense = false;
   int dense_pa = 0, dense_pb = 0;        // padded orders (multiples of 64) = leading dimensions
   sqd::DevBuf hdense_a, hdense_b, gdense;  // f64[pa*pa], f64[pb*pb], f64[rows*nb] (the product, added by the own-row items)
+  // connected sets of ~10^3 strings per spin and more (same-spin blocks 5-11 % dense): the same-spin part as a sparse
+  // product in row-AXPY form on C and on C^T (sqd_spmm.hip) instead of the matrix cores; sig_dense is set as well (the
+  // work items add ONE partial product, gdense) and hdense_a / hdense_b are not built
+  bool sig_spmm = false;
+  void* spmm = nullptr;          // sqd::SpmmState (sqd_spmm.hip), created on first use, released with the context
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
   // LDS capacity (in virtual rows) of the singles' / doubles' partial-sum arrays; a chunk with more
@@ -343,6 +348,13 @@ int lists_build(sqd_ctx* c);
 int launch_sigma_lists(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool spin, double ss, double shift,
                        int64_t in_stride, int64_t out_stride);
 void lists_release(sqd_ctx* c);
+// sparse-product same-spin part for connected sets of ~10^3 strings per spin and more (sqd_spmm.hip).  spmm_select:
+// phase 2 of set_subspace (sets sqd_ctx::sig_spmm); spmm_build: device tables, behind launch C; spmm_launch: G =
+// H_a C + C H_b into sqd_ctx::gdense, in front of the work items of the same sigma build
+bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1, const int64_t* tot, bool direct);
+int spmm_build(sqd_ctx* c);
+int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride);
+void spmm_release(sqd_ctx* c);
 // batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class
 struct SigmaBatchPlan {
   struct Launch {

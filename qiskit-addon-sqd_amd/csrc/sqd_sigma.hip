@@ -81,6 +81,7 @@ struct SigmaArgs {
   // add them in order s = 0, 1, ... and carry no same-spin link of their own.  nullptr: sparse same-spin links.
   GPtr<const double> gdense;
   int64_t gdense_stride;
+  int gsplit;  // partial products to add: DENSE_SPLIT (matrix cores) or 1 (the sparse product of sqd_spmm.hip)
   // launch geometry of THIS subspace: threads that work (a batched launch uses the largest workgroup of its class; the
   // surplus threads of a smaller subspace idle), work items, column chunks
   int T;
@@ -420,11 +421,15 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
           a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
           // dense same-spin mode: the whole same-spin part of this element, from the matrix-core product
           if (g.gdense) {
-            double gp[DENSE_SPLIT];
+            if (g.gsplit == 1) {  // (uniform)
+              a += g.gdense[(A - g.row0) * nb + B];
+            } else {
+              double gp[DENSE_SPLIT];
 #pragma unroll
-            for (int sp = 0; sp < DENSE_SPLIT; ++sp) gp[sp] = g.gdense[sp * g.gdense_stride + (A - g.row0) * nb + B];
+              for (int sp = 0; sp < DENSE_SPLIT; ++sp) gp[sp] = g.gdense[sp * g.gdense_stride + (A - g.row0) * nb + B];
 #pragma unroll
-            for (int sp = 0; sp < DENSE_SPLIT; ++sp) a += gp[sp];
+              for (int sp = 0; sp < DENSE_SPLIT; ++sp) a += gp[sp];
+            }
           }
         }
         acc[r] = a;
@@ -1219,6 +1224,7 @@ static void fill_sigma_args(sqd_ctx* c, const double* d_c, double* d_sigma, int 
   g.gy = (unsigned)c->sig_nchunks;
   g.gdense = (c->sig_dense && mode == 0) ? c->gdense.as<double>() : nullptr;
   g.gdense_stride = c->na * c->nb;
+  g.gsplit = c->sig_spmm ? 1 : DENSE_SPLIT;
 }
 // arguments of the matrix-core same-spin product for the vector the work items of the same sigma build will read
 static void fill_dense_args(sqd_ctx* c, const double* d_c, int64_t in_stride, DenseArgs* dp) {
@@ -1265,7 +1271,9 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   SigmaArgs g;
   fill_sigma_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);
-  if (g.gdense) {
+  if (g.gdense && c->sig_spmm) {
+    SQD_TRY(spmm_launch(c, d_c, in_stride));
+  } else if (g.gdense) {
     DenseArgs d;
     fill_dense_args(c, d_c, in_stride, &d);
     hipLaunchKernelGGL(k_same_spin_mfma, dim3(d.gx, DENSE_SPLIT), dim3(256), 0, c->stream, d);
@@ -1298,7 +1306,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
 // says so, and callers solve anything else one by one.
 bool sigma_batch_supported(const sqd_ctx* c) {
   if (c->sharded()) return false;
-  if (c->sig_rows > 0 || c->sig_lists) return false;
+  if (c->sig_rows > 0 || c->sig_lists || c->sig_spmm) return false;
   if (c->sig_direct) return true;
   return c->sig_lds_rows && !(c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max) && c->sig_R <= 16;
 }
@@ -1487,7 +1495,7 @@ int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan) {
 // workgroups at 317 x 317: latency, not throughput), copies = 16 fills the chip the way a batched solve of 16 subspaces
 // does (every copy reads the same operands and writes the same partial products: timing only)
 int time_dense_product(sqd_ctx* c, const double* d_c, int reps, int copies, double* ms, double* flops) {
-  if (!c->sig_dense) {
+  if (!c->sig_dense || c->sig_spmm) {
     set_error("the current subspace does not use the dense same-spin product");
     return SQD_ERR_STATE;
   }

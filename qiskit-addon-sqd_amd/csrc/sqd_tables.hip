@@ -1288,7 +1288,14 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
                  (double)(tot[2] + tot[3]) >= 0.08 * (double)nb * (double)nb;
     if (const char* env = std::getenv("SQD_SIGMA_DENSE"))
       dense = std::atoi(env) != 0 && !c->sig_direct && row0 == 0 && row1 == na && na <= 4096 && nb <= 4096;
-    c->sig_dense = dense;
+    // ... and from ~10^3 strings per spin, where the blocks have thinned out to 5-11 %, as a sparse product in
+    // row-AXPY form (sqd_spmm.hip); single builds only (the batched solve has no launch class for it).  An explicit
+    // SQD_SIGMA_DENSE wins over the default choice, SQD_SIGMA_SPMM=1 over both.
+    const bool spmm = !always_guess && spmm_select(c, na, nb, row0, row1, tot, c->sig_direct) &&
+                      (std::getenv("SQD_SIGMA_SPMM") || !std::getenv("SQD_SIGMA_DENSE"));
+    if (!spmm) c->sig_spmm = false;
+    if (spmm) dense = false;
+    c->sig_dense = dense || spmm;
     if (dense) {
       c->dense_pa = (int)((na + 63) / 64 * 64);
       c->dense_pb = (int)((nb + 63) / 64 * 64);
@@ -1556,6 +1563,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
     SQD_HIP_CHECK(hipGetLastError());
   }
   if (c->sig_lists) SQD_TRY(lists_build(c));
+  if (c->sig_spmm) SQD_TRY(spmm_build(c));
   if (b.have_dense) {
     hipLaunchKernelGGL(k_tables_dense, dim3(b.dense.gx, 2), dim3(256), 0, st, b.dense);
     SQD_HIP_CHECK(hipGetLastError());

@@ -254,3 +254,24 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
     # a set whose tails exceed the overflow tables (complete beta space: 261 links per string) is refused: another kernel
     ok, _, _ = selected(12, (2, 6), 3, 300, 19, False)
     assert not ok
+
+
+@pytest.mark.parametrize("xcd,J", [("0", "2"), ("1", "1"), ("1", "4")])
+def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J):
+    # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: merged CSR of both spins, C -> C^T, row
+    # AXPYs on C and C^T, G += G2T^T, work items add ONE partial product) that connected sets from ~10^3 strings per
+    # spin take by default.  Both task mappings (XCD split on / off), every panel width, ragged panels and tiles,
+    # nalpha != nbeta, rows without links, all operator forms, a Davidson solve and the observables.
+    monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
+    monkeypatch.setenv("SQD_SPMM_XCD", xcd)
+    monkeypatch.setenv("SQD_SPMM_J", J)
+    cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (8, (4, 4), 30, 28, 17, True),
+             (5, (1, 4), 5, 4, 9, False), (9, (2, 4), 7, 100, 29, True), (16, (4, 4), 66, 70, 23, True)]
+    for case in cases:
+        h1, eri, sa, sb = make_problem(*case)
+        with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == "k_spmm_rows+k_sigma", case
+    run_full_parity(emu_lib, *cases[0], variants=False)
+    for case in cases[1:]:
+        run_operator_parity(emu_lib, *case)
