@@ -158,10 +158,11 @@ int sqd_contract_ss(sqd_ctx* ctx, const double* c, double* out);
 
 typedef struct sqd_davidson_opts {
   double tol;        /* pyscf conv_tol, default 1e-9 (SelectedCI) */
-  double tol_residual; /* |r| threshold; <= 0 selects sqrt(tol)/32 (pyscf: sqrt(tol)).  Tighter here because the
-                          orbital occupancies, and with a spin penalty <c|H|c> itself, are FIRST order in the
-                          residual: 1e-6 instead of 1e-4, which keeps a seeded SQD run reproducible.  Pass
-                          sqrt(tol) for pyscf's rule (about a quarter fewer sigma builds). */
+  double tol_residual; /* |r| threshold; <= 0 selects pyscf's rule sqrt(tol) when use_spin == 0 (<c|H|c> is second
+                          order in the residual: the reference's own accuracy) and sqrt(tol)/32 with a spin penalty
+                          (the returned <c|H|c> = Ritz value - shift <penalty> is FIRST order in it).  Orbital
+                          occupancies are first order in the residual either way: pass sqrt(tol)/32 to have them at
+                          1e-6 instead of 1e-4 (about a third more sigma builds). */
   double lindep;     /* 1e-14 */
   int max_cycle;     /* 100 */
   int max_space;     /* 12 */

@@ -1220,6 +1220,16 @@ static int enqueue_init_guess_impl(sqd_ctx* c, double* x, DavState* st, unsigned
 }
 int enqueue_init_guess(sqd_ctx* c, double* x) { return enqueue_init_guess_impl(c, x, nullptr, nullptr); }
 
+// Residual threshold of a run.  Without a spin penalty: pyscf's rule, |r| < sqrt(tol) (lib.davidson1 as FCISolver.eig
+// calls it; reference qiskit_addon_sqd/fermion.py:713-723) -- <c|H|c> is second order in the residual, 1e-9 Ha at the
+// default tol, and a tighter rule buys accuracy the reference does not deliver (HF-centred 317^2: 29 instead of 40
+// sigma builds, energies 3e-10 Ha apart).  With a penalty (fix_spin_) the returned <c|H|c> = Ritz value - shift *
+// <penalty> is FIRST order in the residual: sqrt(tol)/32 keeps it inside 1e-6 Ha.  tol_residual overrides either.
+static double residual_threshold(const sqd_davidson_opts* o) {
+  if (o->tol_residual > 0.0) return o->tol_residual;
+  return o->use_spin ? std::sqrt(o->tol) / 32.0 : std::sqrt(o->tol);
+}
+
 int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host, sqd_davidson_stats* st,
                  bool defer_sync) {
   if (!c->have_subspace) {
@@ -1230,12 +1240,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   int max_space = o->max_space;
   if (max_space < 2) max_space = 2;
   if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
-  // residual threshold: sqrt(tol)/32 by default (pyscf: sqrt(tol)).  Energies would be fine with pyscf's
-  // value (second order in the residual without a penalty), but the orbital occupancies that steer the next
-  // configuration-recovery round are FIRST order in it: 1e-4 with pyscf's threshold, 1e-6 with this one, and
-  // a seeded SQD run only reproduces if they are stable.  tol_residual = sqrt(tol) restores pyscf's rule
-  // (HF-centred headline: 29 instead of 40 sigma builds, <c|H|c> 3e-10 Ha off).
-  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
+  const double toloose = residual_threshold(o);
   hipStream_t s = c->stream;
   const int nvecs = max_space + 1;
   SQD_TRY(c->X.reserve((size_t)nvecs * D * 8));
@@ -1458,7 +1463,7 @@ int davidson_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, c
   int max_space = o->max_space;
   if (max_space < 2) max_space = 2;
   if (max_space > SQD_MAX_SPACE) max_space = SQD_MAX_SPACE;
-  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
+  const double toloose = residual_threshold(o);
   const int nvecs = max_space + 1;
   const int width = SQD_MAX_SPACE + 4;
   plan->max_space = max_space;
@@ -1653,7 +1658,7 @@ int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0) {
   SQD_TRY(reserve_reduction_buffers(c));
   SQD_TRY(c->shard_tot.reserve((size_t)2 * (MAXB + 2) * 8));
   c->guess_x = nullptr;
-  const double toloose = (o->tol_residual > 0.0) ? o->tol_residual : std::sqrt(o->tol) / 32.0;
+  const double toloose = residual_threshold(o);
   c->shard_prm_tol = o->tol;
   c->shard_prm_tol2 = toloose * toloose;
   c->shard_prm_lindep = o->lindep;

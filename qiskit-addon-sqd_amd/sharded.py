@@ -275,7 +275,7 @@ def solve_sci_sharded(
     to every rank unless ``gather_state=False``, in which case ``sci_state.amplitudes`` holds the owned rows only).
 
     Davidson: pyscf's single-root flow -- start vector of ``get_init_guess`` (lower-triangle rule), residual
-    threshold ``sqrt(tol)/32`` as in the single-GPU solver (``tol_residual`` overrides), restart at ``max_space``.
+    threshold as in the single-GPU solver -- pyscf's ``sqrt(tol)``, ``sqrt(tol)/32`` with a spin penalty; ``tol_residual`` overrides --, restart at ``max_space``.
 
     ``driver="native"`` (default): the library's device-resident state machine on every rank (``sqd_shard_dav_*``) --
     projected matrix, eigenpair, restart and stop rule live on the GPU exactly as in the single-GPU solver; per iteration
@@ -294,7 +294,7 @@ def solve_sci_sharded(
         if spin_sq is not None:
             sz = 0.5 * abs(sub.nelec[0] - sub.nelec[1])
             use_spin, ss = (1 if spin_sq < sz * (sz + 1.0) + 0.1 else 2), float(spin_sq)
-        toloose = tol_residual if tol_residual else np.sqrt(tol) / 32.0
+        toloose = tol_residual if tol_residual else (np.sqrt(tol) / 32.0 if spin_sq is not None else np.sqrt(tol))
         hd = sub.hdiag
         # ---- pyscf get_init_guess on the sharded diagonal: global argmin (lower triangle when the sectors match)
         h_loc = hd.clone()

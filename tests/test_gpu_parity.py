@@ -291,8 +291,13 @@ def _full_size_checks(hip_lib, norb, nocc, n, hf, seeds, with_o2, e_tol=1e-8, ke
         hd = ctx.hdiag()
         s_gpu = ctx.sigma(x)
         x0 = ctx.init_guess()
-        amps, st = ctx.davidson()
+        # (occupancies and the state are compared at 5e-6 / 1e-9 below: first order in the residual, so the run uses
+        # the tight residual rule; the default rule -- pyscf's sqrt(tol) without a penalty -- is checked on the energy)
+        _, st_def = ctx.davidson(fetch=False)
+        e_def = st_def["e_davidson"]
+        amps, st = ctx.davidson(tol_residual=np.sqrt(1e-9) / 32.0)
         e, s2, occ_a, occ_b = ctx.observables()
+        assert st_def["converged"] == 1 and st_def["n_sigma"] <= st["n_sigma"] and abs(e_def - e) < 1e-8
     scale = np.abs(hd).max()
     assert np.allclose(hd, O.make_hdiag(h1, eri, sa, sb, norb), rtol=0, atol=1e-11 * scale)
     assert np.abs(s_gpu - O.sigma_string_space(h1, eri, sa, sb, x, norb)).max() < 1e-11 * scale
@@ -512,8 +517,11 @@ def test_python_api_solve_fermion(hip_lib):
         # <c|H|c> of a penalty-shifted eigenvector is first order in the Davidson residual (1e-6):
         # 5e-7 Ha here, inside the north_star bar of 1e-6 Ha
         assert abs(e - e_ref) < 5e-7, spin_sq
-        assert np.allclose(occ[0], occ_ref[0], atol=1e-5) and np.allclose(occ[1], occ_ref[1], atol=1e-5)
-        assert abs(s2 - s2_ref) < 1e-5
+        # occupancies and <S^2> are first order in the Davidson residual: sqrt(tol)/32 = 1e-6 with a penalty, pyscf's
+        # sqrt(tol) = 3e-5 without (the default rule follows the reference's solver)
+        otol = 1e-5 if spin_sq is not None else 3e-4
+        assert np.allclose(occ[0], occ_ref[0], atol=otol) and np.allclose(occ[1], occ_ref[1], atol=otol)
+        assert abs(s2 - s2_ref) < otol
         assert isinstance(state, SCIState) and state.amplitudes.shape == (20, 16)
         assert abs(state.spin_square() - s2) < 1e-9
     res = solve_sci((sa, sb), h1, eri, norb, nelec, spin_sq=0.75)
@@ -699,7 +707,7 @@ def test_config2_full_size_1e4_x_1e4(hip_lib):
         hc = ctx.sigma(amps)
         assert abs(np.vdot(amps, hc) - e0) < 1e-9  # Ritz value = Rayleigh quotient of the returned vector
         resid = np.linalg.norm((hc - e0 * amps).ravel())
-        assert resid < 2e-6 and abs(resid - st["residual"]) < 1e-7  # default rule: |r| < sqrt(tol)/32
+        assert resid < np.sqrt(1e-9) * 1.01 and abs(resid - st["residual"]) < 1e-7  # default rule: pyscf's |r| < sqrt(tol)
         assert e0 <= hd.min() + 1e-12  # variational: below the lowest diagonal element ...
         x0 = ctx.init_guess()
         assert e0 <= np.vdot(x0, ctx.sigma(x0)) + 1e-12  # ... and below the start vector's energy
@@ -782,3 +790,134 @@ def test_list_path_default_selection_mid_size(hip_lib, monkeypatch):
     cols = np.unique(np.concatenate(([0, nb - 1], rng.choice(nb, 6, replace=False))))
     refT = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), 30, cols)
     assert np.abs(sx[:, cols].T - refT).max() < 1e-11 * hd_max * max(1.0, np.abs(x).max())
+
+
+# ---- CONNECTED subspaces at D = 1e6 .. 1e7: what the SQD loop's carry-over produces and what
+# the reference advertises ("subspace dimensions of ~1e7", /root/reference/README.md:78).  HF-centred sets thin out as
+# they grow (same-spin blocks 11 % dense at 1000 strings, 5.6 % at 3000), and every same-spin formulation is run on the
+# same inputs: the matrix cores (k_same_spin_mfma), the sparse work items, the sparse product on C and C^T (sqd_spmm.hip).
+import functools  # noqa: E402
+
+_CONNECTED_MODES = {
+    "mfma": ({"SQD_SIGMA_DENSE": "1"}, "k_same_spin_mfma+k_sigma"),
+    "sparse": ({"SQD_SIGMA_DENSE": "0"}, "k_sigma"),
+    "spmm": ({"SQD_SIGMA_SPMM": "1"}, "k_spmm_rows+k_sigma"),
+}
+
+
+def _set_mode(monkeypatch, mode):
+    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM"):
+        monkeypatch.delenv(k, raising=False)
+    env, kernel = _CONNECTED_MODES[mode]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return kernel
+
+
+@functools.lru_cache(maxsize=None)
+def _connected_reference_1000():
+    """Oracle side of the 1000 x 1000 test, computed once for all modes: the full string-space sigma of a random vector
+    and the oracle's own Davidson (pyscf control flow) on the string-space operator (~3 minutes of numpy)."""
+    n, norb = 1000, 30
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, n, 11), O.hf_centred_strings(norb, 8, n, 13)
+    x = np.random.default_rng(17).standard_normal((n, n))
+    ref = O.sigma_string_space(h1, eri, sa, sb, x, norb)
+    hd = O.make_hdiag(h1, eri, sa, sb, norb)
+    op = O.StringSpaceOperator(h1, eri, sa, sb, norb)
+    conv, e_ref, x_ref, _ = O.davidson_pyscf(op, O.init_guess(hd.ravel(), n, n, nelec=(8, 8)), hd.ravel(), tol=1e-12, max_cycle=200)  # (|r| < 1e-6: the occupancies below are first order in it)
+    assert conv
+    return h1, eri, sa, sb, x, ref, hd, float(e_ref), x_ref / np.linalg.norm(x_ref)
+
+
+@pytest.mark.parametrize("mode", ["mfma", "spmm", "sparse"])
+def test_connected_1000x1000_full_sigma_and_solve(hip_lib, monkeypatch, mode):
+    """HF-centred 1000 x 1000 (D = 1e6, ~10 single + ~100 double links per string): the FULL sigma vector and hdiag
+    against O1s, bitwise reproducibility, then one whole solve -- E0 against the oracle's own Davidson (1e-8 Ha; the
+    north_star bar is 1e-6), the state's overlap, occupancies -- with the default residual rule (pyscf's) for the
+    energy and the tight rule for the first-order quantities."""
+    kernel = _set_mode(monkeypatch, mode)
+    h1, eri, sa, sb, x, ref, hd_ref, e_ref, x_ref = _connected_reference_1000()
+    n = len(sa)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == kernel
+        hd = ctx.hdiag()
+        scale = np.abs(hd).max()
+        assert np.allclose(hd, hd_ref, rtol=0, atol=1e-11 * scale)
+        sx = ctx.sigma(x)
+        assert np.abs(sx - ref).max() < 1e-11 * scale * max(1.0, np.abs(x).max())
+        assert np.array_equal(sx, ctx.sigma(x))  # fixed summation order: the same bits on every run
+        _, st = ctx.davidson(fetch=False)  # the default rule: |r| < sqrt(tol) without a penalty (pyscf's)
+        assert st["converged"] == 1 and abs(st["e_davidson"] - e_ref) < 1e-8 and st["residual"] < np.sqrt(1e-9)
+        amps, st2 = ctx.davidson(tol_residual=np.sqrt(1e-9) / 32.0)
+        assert st2["converged"] == 1 and abs(st2["e_davidson"] - e_ref) < 1e-8 and st2["n_sigma"] >= st["n_sigma"]
+        assert abs(abs(np.vdot(amps.ravel(), x_ref)) - 1.0) < 1e-9
+        e, s2, occ_a, occ_b = ctx.observables()
+        assert abs(e - e_ref) < 1e-8
+    r1a, r1b = O.make_rdm1s(x_ref.reshape(n, n), sa, sb, 30)
+    assert np.allclose(occ_a, np.diag(r1a), atol=5e-6) and np.allclose(occ_b, np.diag(r1b), atol=5e-6)
+
+
+@functools.lru_cache(maxsize=None)
+def _connected_reference_3000():
+    """Oracle side of the 3000 x 3000 test: sampled rows and sampled columns of the string-space sigma of a random vector."""
+    n, norb = 3000, 30
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, n, 11), O.hf_centred_strings(norb, 8, n, 13)
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((n, n), dtype=np.float32).astype(np.float64)
+    # rows / columns: the Hartree-Fock string itself (the longest lists: 176 single links), its neighbourhood, the last
+    # strings (highest excitation rank: the shortest lists), random ones
+    hf = int(np.flatnonzero(sa == (1 << 8) - 1)[0])
+    rows = np.unique(np.concatenate(([0, 1, hf, n - 2, n - 1], rng.choice(n, 9, replace=False))))
+    hfb = int(np.flatnonzero(sb == (1 << 8) - 1)[0])
+    cols = np.unique(np.concatenate(([0, hfb, n - 1], rng.choice(n, 7, replace=False))))
+    ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
+    ref_cols = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), norb, cols)
+    return h1, eri, sa, sb, x, rows, cols, ref_rows, ref_cols
+
+
+@pytest.mark.parametrize("mode", ["spmm", "mfma", "sparse"])
+def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode):
+    """HF-centred 3000 x 3000 (D = 9e6, 72 MB per vector; ~11 single + ~155 double links per string, same-spin blocks
+    5.6 % dense -- the default here is the sparse product of sqd_spmm.hip): sigma on sampled rows AND sampled columns
+    against the row-restricted string-space oracle, hermiticity, bitwise reproducibility; then one whole solve: converged,
+    Ritz value = Rayleigh quotient of the returned state (separate sigma call), true residual below the stopping rule,
+    variational bounds, observables consistent.  Every same-spin formulation gives the same energy."""
+    kernel = _set_mode(monkeypatch, mode)
+    h1, eri, sa, sb, x, rows, cols, ref_rows, ref_cols = _connected_reference_3000()
+    n = len(sa)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        if mode == "spmm":  # (what the default selection takes at this size)
+            monkeypatch.delenv("SQD_SIGMA_SPMM")
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == kernel
+        hd = ctx.hdiag()
+        scale = np.abs(hd).max() * max(1.0, np.abs(x).max())
+        sx = ctx.sigma(x)
+        assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
+        assert np.abs(sx[:, cols].T - ref_cols).max() < 1e-11 * scale
+        assert np.array_equal(sx, ctx.sigma(x))
+        y = np.random.default_rng(23).standard_normal((n, n), dtype=np.float32).astype(np.float64)
+        a, b = np.vdot(y, sx), np.vdot(ctx.sigma(y), x)
+        assert abs(a - b) < 1e-9 * abs(a)
+        del y, sx
+        amps, st = ctx.davidson()
+        assert st["converged"] == 1 and st["n_sigma"] >= 10
+        e0 = st["e_davidson"]
+        assert abs(np.vdot(amps, amps) - 1.0) < 1e-12
+        hc = ctx.sigma(amps)
+        assert abs(np.vdot(amps, hc) - e0) < 1e-9
+        resid = np.linalg.norm((hc - e0 * amps).ravel())
+        assert resid < np.sqrt(1e-9) * 1.01 and abs(resid - st["residual"]) < 1e-7  # default rule: pyscf's sqrt(tol)
+        assert e0 <= hd.min() + 1e-12
+        x0 = ctx.init_guess()
+        assert e0 <= np.vdot(x0, ctx.sigma(x0)) + 1e-12
+        e, s2, oa, ob = ctx.observables()
+        assert abs(e - e0) < 1e-9 and abs(oa.sum() - 8.0) < 1e-9 and abs(ob.sum() - 8.0) < 1e-9
+    _CONNECTED_E0.setdefault(3000, e0)
+    assert abs(e0 - _CONNECTED_E0[3000]) < 1e-8  # the same ground state whichever way the same-spin part is formed
+
+
+_CONNECTED_E0: dict = {}
