@@ -617,7 +617,7 @@ def secondary_entries(args, h1, eri, device):
             entry = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
                      "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
             entry["roofline"]["note_kernels"] = (
-                "one sigma = the same-spin product (sqd::k_spmm_rows between two k_spmm_transpose launches from ~1400 strings "
+                "one sigma = the same-spin product (sqd::k_spmm_grouped between two k_spmm_transpose launches from ~1000 strings "
                 "per spin, sqd::k_same_spin_mfma below) + sqd::k_sigma (opposite-spin work items); avg_launch_ms is the whole "
                 "application (HIP events around 5 of them); per-kernel times: profiles/r05/")
             ctx.davidson(fetch=False)  # (first call at this size grows the arenas: not timed)
@@ -648,7 +648,7 @@ def secondary_entries(args, h1, eri, device):
                         "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl1 / (ms1 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                         "note": f"G = H_a C + C H_b on the zero-padded orders ({(n + 63) // 64 * 64}): 2 pa^2 pb + 2 pa pb^2 flops; the "
                                 "blocks are 11 % (1000) / 5.6 % (3000) dense at these sizes, which is why the default same-spin "
-                                "formulation from ~1400 strings per spin is the sparse product, not this kernel"}
+                                "formulation from ~1000 strings per spin is the sparse product, not this kernel"}
                     entry["sigma_ms_with_matrix_cores"] = ctx.time_sigma(3)
             finally:
                 os.environ.pop("SQD_SIGMA_DENSE", None)

@@ -19,6 +19,7 @@
 // CU).  The work items of k_sigma then add G element by element exactly as they add the matrix-core product (dense
 // same-spin mode with ONE partial product).  Fixed order of accumulation: the same bits on every run.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <numeric>
 
@@ -26,7 +27,7 @@
 
 namespace sqd {
 
-constexpr int SPMM_U = 8;  // links per round; the merged lists are padded to whole rounds with zero-weight links
+constexpr int SPMM_U = 16;  // the merged lists are padded to multiples of 16 links with zero-weight links (rounds of 8 or 16)
 // element i (a 32-bit lane offset) of a row whose address is wave-uniform: scalar base + 32-bit byte offset, no 64-bit
 // address arithmetic per lane and load
 __device__ inline double spmm_ldu(const double* base, unsigned i) {
@@ -39,8 +40,27 @@ struct SpmmSide {
   std::vector<int64_t> h_ptr;     // padded row pointers
   int64_t n = 0, m = 0, links = 0;
 };
+// tiled form of the same lists (k_spmm_tiled): row t's links grouped by source chunk of TS rows, every group padded to a
+// multiple of 4 records {byte offset of the source row inside the staged tile, value}; beg / cnt [chunk][row]
+struct SpmmTiles {
+  DevBuf beg, cnt, off, val, rowbase;
+  std::vector<int64_t> h_rowbase;
+  int nch = 0;
+  int64_t npad = 0, cap = 0;
+};
+// row-grouped form (k_spmm_grouped): GR adjacent rows share ONE sorted list of sources (the union of their lists) with a
+// dense GR-vector of coefficients per source
+struct SpmmGroups {
+  DevBuf base, cnt, src, coef, order;
+  std::vector<int64_t> h_base;
+  std::vector<uint32_t> h_order;
+  int64_t ngroups = 0, cap = 0;
+};
 struct SpmmState {
   SpmmSide side[2];
+  SpmmTiles tiles[2];
+  SpmmGroups groups[2];
+  bool tiled = false, grouped = false;
   DevBuf ct, g2t;  // C^T (nb x na) and H_b C^T (nb x na)
 };
 
@@ -49,6 +69,10 @@ void spmm_release(sqd_ctx* c) {
   SpmmState* s = static_cast<SpmmState*>(c->spmm);
   for (auto& sd : s->side)
     for (DevBuf* b : {&sd.ptr, &sd.src, &sd.val, &sd.order}) b->release();
+  for (auto& tl : s->tiles)
+    for (DevBuf* b : {&tl.beg, &tl.cnt, &tl.off, &tl.val, &tl.rowbase}) b->release();
+  for (auto& gr : s->groups)
+    for (DevBuf* b : {&gr.base, &gr.cnt, &gr.src, &gr.coef, &gr.order}) b->release();
   s->ct.release();
   s->g2t.release();
   delete s;
@@ -167,7 +191,7 @@ struct SpmmArgs {
   GPtr<const int> stop, vec_index;
   int64_t in_stride;  // side 0's input: the vector selected on the device
 };
-template <int J>
+template <int J, int U>
 __global__ void __launch_bounds__(256) k_spmm_rows(const SpmmArgs g) {
   if (g.stop && *g.stop) return;
   const int side = blockIdx.y;
@@ -209,7 +233,6 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const SpmmArgs g) {
     acc[j] = 0.0;
   }
   in += c0;
-  constexpr int U = SPMM_U;
   // records of the NEXT round are requested (scalar loads) before this round's operand rows: their round trip hides
   // behind the vector loads.  (The arrays end with one round of padding, so the last prefetch stays inside them.)
   uint32_t sn[U];
@@ -250,6 +273,465 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const SpmmArgs g) {
     if (ok[j]) out[col[j]] = acc[j];
 }
 
+// ---- the product through LDS tiles (the default): the same sum, with the operand rows of a 64-column panel staged in LDS
+// TS = 128 source rows at a time and shared by the TB = 128 target rows of the workgroup (8 wavefronts x 16 targets, one
+// accumulator per target and lane), so that a staged element serves TB x density multiply-adds (7 at 3000 strings,
+// 14 at 1000) instead of one, and the vector L1 -- the bound of k_spmm_rows above -- carries 1/7 .. 1/14 of the bytes.
+// A link costs one scalar record (4-byte tile offset + 8-byte value, through the scalar cache, four records per
+// request), one conflict-free ds_read_b64 (64 lanes = 64 consecutive columns of one staged row) and one multiply-add.
+// The next tile's 16 elements per thread are requested before the current tile is consumed (register-staged double
+// buffering).  Fixed order (chunks ascending; inside a chunk singles, then doubles, by source): the same bits on every run.
+constexpr int TS = 128, TB = 128, TW = 8, TPANEL = 64, TTHREADS = 1024, TGRAN = 4;
+struct TileBuildArgs {
+  int64_t n[2];
+  int nch[2];
+  int64_t npad[2];
+  GPtr<const int64_t> s_ptr[2], d_ptr[2];
+  GPtr<const SRec> s_rec[2];
+  GPtr<const double> s_val[2], d_val[2];
+  GPtr<const uint32_t> d_src[2];
+  GPtr<const int64_t> rowbase[2];
+  GPtr<uint32_t> beg[2], cnt[2], off[2];
+  GPtr<double> val[2];
+};
+// one wavefront per row: histogram of the row's links over the source chunks (LDS), padded group sizes, their prefix
+// sums, then every link to its place: group start + rank inside the group (the CSR lists are sorted by source, so the
+// rank of a link is its index minus the index of the group's first link)
+__global__ void __launch_bounds__(256) k_spmm_tile_build(const TileBuildArgs g) {
+  __shared__ int hist[4][2][256];   // [wave][singles | doubles][chunk]: counts, then exclusive prefix (first link of the chunk)
+  __shared__ int gstart[4][256];    // group start (records, relative to the row's region)
+  __shared__ int gtot[4][256];      // unpadded group size
+  const int sd = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = g.n[sd];
+  const int nch = g.nch[sd];
+  const int64_t t = (int64_t)blockIdx.x * 4 + w;
+  const bool live = t < n;
+  for (int c = lane; c < 256; c += 64) hist[w][0][c] = hist[w][1][c] = 0;
+  __syncthreads();
+  const int64_t* __restrict__ sp = g.s_ptr[sd];
+  const int64_t* __restrict__ dp = g.d_ptr[sd];
+  const int64_t s0 = live ? sp[t] : 0, ns = live ? sp[t + 1] - s0 : 0, d0 = live ? dp[t] : 0, nd = live ? dp[t + 1] - d0 : 0;
+  const SRec* __restrict__ rec = g.s_rec[sd];
+  const uint32_t* __restrict__ ds = g.d_src[sd];
+  for (int64_t k = lane; k < ns; k += 64) atomicAdd(&hist[w][0][rec[s0 + k].src / TS], 1);
+  for (int64_t k = lane; k < nd; k += 64) atomicAdd(&hist[w][1][ds[d0 + k] / TS], 1);
+  __syncthreads();
+  // lane l owns chunks 4 l .. 4 l + 3: exclusive prefixes of the singles' counts, the doubles' counts, the padded sizes
+  int cs[4], cd[4], cp[4], as = 0, ad = 0, ap = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = 4 * lane + u;
+    cs[u] = hist[w][0][c];
+    cd[u] = hist[w][1][c];
+    cp[u] = (cs[u] + cd[u] + TGRAN - 1) / TGRAN * TGRAN;
+    as += cs[u];
+    ad += cd[u];
+    ap += cp[u];
+  }
+  int xs = as, xd = ad, xp = ap;  // inclusive scans over the lanes
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ys = __shfl(xs, lane - d), yd = __shfl(xd, lane - d), yp = __shfl(xp, lane - d);
+    if (lane >= d) {
+      xs += ys;
+      xd += yd;
+      xp += yp;
+    }
+  }
+  xs -= as;
+  xd -= ad;
+  xp -= ap;
+  __syncthreads();
+  const int64_t base = live ? g.rowbase[sd][t] : 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = 4 * lane + u;
+    hist[w][0][c] = xs;
+    hist[w][1][c] = xd;
+    gstart[w][c] = xp;
+    gtot[w][c] = cs[u] + cd[u];
+    if (live && c < nch) {
+      g.beg[sd][(int64_t)c * g.npad[sd] + t] = (uint32_t)(base + xp);
+      g.cnt[sd][(int64_t)c * g.npad[sd] + t] = (uint32_t)cp[u];
+    }
+    xs += cs[u];
+    xd += cd[u];
+    xp += cp[u];
+  }
+  __syncthreads();
+  if (!live) return;
+  uint32_t* __restrict__ off = g.off[sd] + base;
+  double* __restrict__ val = g.val[sd] + base;
+  const double* __restrict__ sv = g.s_val[sd];
+  const double* __restrict__ dv = g.d_val[sd];
+  for (int64_t k = lane; k < ns; k += 64) {
+    const uint32_t src = rec[s0 + k].src;
+    const int c = (int)(src / TS);
+    const int pos = gstart[w][c] + ((int)k - hist[w][0][c]);
+    off[pos] = (src % TS) * (uint32_t)(TPANEL * 8);
+    val[pos] = sv[s0 + k];
+  }
+  for (int64_t k = lane; k < nd; k += 64) {
+    const uint32_t src = ds[d0 + k];
+    const int c = (int)(src / TS);
+    const int nsc = (c + 1 < 256 ? hist[w][0][c + 1] : (int)ns) - hist[w][0][c];  // singles of this group
+    const int pos = gstart[w][c] + nsc + ((int)k - hist[w][1][c]);
+    off[pos] = (src % TS) * (uint32_t)(TPANEL * 8);
+    val[pos] = dv[d0 + k];
+  }
+  for (int c = lane; c < nch; c += 64) {
+    const int tot = gtot[w][c], pad = (tot + TGRAN - 1) / TGRAN * TGRAN;
+    for (int p = tot; p < pad; ++p) {
+      off[gstart[w][c] + p] = 0u;
+      val[gstart[w][c] + p] = 0.0;
+    }
+  }
+}
+
+struct TiledArgs {
+  GPtr<const uint32_t> beg[2], cnt[2], off[2];
+  GPtr<const double> val[2];
+  GPtr<const double> in[2];
+  GPtr<double> out[2];
+  int64_t n[2], m[2], npad[2];
+  int nch[2];
+  unsigned ntb[2], npanels[2];
+  GPtr<const int> stop, vec_index;
+  int64_t in_stride;
+};
+// Where the link records come from decides this kernel.  First version: scalar loads (s_load_dwordx4 / x8 per four links)
+// straight from the row-major lists -- every (target, chunk) group then starts with a scalar-cache miss that nothing
+// hides (groups hold 7 links on average): 2.24 ms at 3000 x 3000 against 1.35 ms for k_spmm_rows.  Now the records of a
+// wavefront's targets travel like the tile: one coalesced vector load per target (lane l = record l of the group, up to
+// TSL = 32 per pass), requested a chunk ahead, parked in the wavefront's own LDS slab, and read back with uniform-address
+// (broadcast) LDS reads -- four offsets per ds_read_b128, four values per two.  Per link: 3 LDS cycles of records, 2 of
+// operand, one address add, one multiply-add.
+constexpr int TSL = 32;  // records per target and pass in the LDS slab
+static_assert(TGRAN == 4, "the record reads of k_spmm_tiled are written for groups of four");
+__global__ void __launch_bounds__(TTHREADS) k_spmm_tiled(const TiledArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)  // [TS][TPANEL] tile | per wavefront: values [TW][TSL] | offsets [TW][TSL]
+  if (g.stop && *g.stop) return;
+  const int side = blockIdx.y;
+  // workgroup b runs on XCD b mod 8: the target blocks of one column panel share an XCD (its L2 holds the panel)
+  const unsigned x = blockIdx.x & 7u, q = blockIdx.x >> 3, ntb = g.ntb[side];
+  const unsigned panel = (q / ntb) * 8u + x, tb = q % ntb;
+  if (panel >= g.npanels[side]) return;
+  const int64_t n = g.n[side], m = g.m[side], npad = g.npad[side];
+  const int nch = g.nch[side];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t t0 = (int64_t)tb * TB + wave * TW;
+  const double* __restrict__ in = g.in[side];
+  if (side == 0 && g.vec_index) in += (int64_t)(*g.vec_index - 1) * g.in_stride;
+  const bool wave_on = t0 < n;  // (uniform; a wavefront past the last row still stages the tile and meets the barriers)
+  const uint32_t* __restrict__ beg = g.beg[side] + (wave_on ? t0 : 0);
+  const uint32_t* __restrict__ cnt = g.cnt[side] + (wave_on ? t0 : 0);
+  const uint32_t* __restrict__ off = g.off[side];
+  const double* __restrict__ val = g.val[side];
+  const int64_t col = (int64_t)panel * TPANEL + lane;
+  const bool col_ok = col < m;
+  const int64_t colc = col_ok ? col : m - 1;
+  double* tile = smem;
+  double* rval = smem + TS * TPANEL + wave * (TW * TSL);
+  uint32_t* roff = reinterpret_cast<uint32_t*>(smem + TS * TPANEL + (TTHREADS / 64) * (TW * TSL)) + wave * (TW * TSL);
+  constexpr int NL = TS * TPANEL / TTHREADS;  // tile elements per thread: rows (tid >> 6) + (TTHREADS / 64) i
+  double pf[NL];
+  auto fetch_tile = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int64_t r = (int64_t)c * TS + (tid >> 6) + (TTHREADS / 64) * i;
+      const double v = in[(r < n ? r : n - 1) * m + colc];
+      pf[i] = (r < n && col_ok) ? v : 0.0;
+    }
+  };
+  // link groups of this wavefront's TW targets in one chunk: first record and padded count (scalars); pass p of the
+  // records: lane l < TSL holds record TSL p + l of every target's group (zero weight past the group's end)
+  uint32_t bcur[TW], ncur[TW], bnxt[TW], nnxt[TW];
+  uint32_t po[TW];
+  double pv[TW];
+  auto fetch_heads = [&](int c, uint32_t* b, uint32_t* nn) {
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      b[i] = beg[(int64_t)c * npad + i];
+      const uint32_t cn = cnt[(int64_t)c * npad + i];
+      nn[i] = wave_on ? cn : 0u;
+    }
+  };
+  auto fetch_recs = [&](const uint32_t* b, const uint32_t* nn, uint32_t p) {
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      const uint32_t j = p * TSL + (uint32_t)(lane & (TSL - 1));
+      const bool on = j < nn[i];
+      const uint32_t a = b[i] + (on ? j : 0u);
+      const uint32_t ov = off[a];
+      const double vv = val[a];
+      po[i] = on ? ov : 0u;
+      pv[i] = on ? vv : 0.0;
+    }
+  };
+  auto park_recs = [&]() {
+    if (lane < TSL) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        roff[i * TSL + lane] = po[i];
+        rval[i * TSL + lane] = pv[i];
+      }
+    }
+  };
+  double acc[TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i) acc[i] = 0.0;
+  const char* tile_lane = reinterpret_cast<const char*>(tile) + lane * 8;
+  // records of `cn` (<= TSL, a multiple of TGRAN) links of target i from the slab
+  auto consume = [&](int i, uint32_t cn, double a) {
+    const uint32_t* ro = roff + i * TSL;
+    const double* rv = rval + i * TSL;
+    for (uint32_t k = 0; k < cn; k += TGRAN) {
+      // (16-byte reads: ds_read_b128 is 4 LDS cycles where the ds_read2_b64 the compiler picks for 8-byte-aligned
+      // pointers is 8; the slab and k are multiples of 16 bytes)
+      const uint4 o4 = *reinterpret_cast<const uint4*>(ro + k);
+      const double2 v01 = *reinterpret_cast<const double2*>(rv + k), v23 = *reinterpret_cast<const double2*>(rv + k + 2);
+      const uint32_t o[TGRAN] = {o4.x, o4.y, o4.z, o4.w};
+      const double v[TGRAN] = {v01.x, v01.y, v23.x, v23.y};
+      double xv[TGRAN];
+#pragma unroll
+      for (int u = 0; u < TGRAN; ++u) xv[u] = *reinterpret_cast<const double*>(tile_lane + o[u]);
+#pragma unroll
+      for (int u = 0; u < TGRAN; ++u) a += v[u] * xv[u];
+    }
+    return a;
+  };
+  fetch_tile(0);
+  fetch_heads(0, bcur, ncur);
+  fetch_recs(bcur, ncur, 0);
+  if (nch > 1) fetch_heads(1, bnxt, nnxt);
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) tile[((tid >> 6) + (TTHREADS / 64) * i) * TPANEL + lane] = pf[i];
+    park_recs();
+    __syncthreads();
+    // requests of the next chunk: its tile rows, the first pass of its records (heads already here), the heads after it
+    uint32_t nthis[TW], bthis[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      nthis[i] = ncur[i];
+      bthis[i] = bcur[i];
+    }
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int i = 0; i < TW; ++i) nmax = nthis[i] > nmax ? nthis[i] : nmax;
+    const bool single_pass = nmax <= TSL;  // (uniform; the rule, not the exception: groups hold 4-16 links)
+    if (c + 1 < nch) {
+      fetch_tile(c + 1);
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        bcur[i] = bnxt[i];
+        ncur[i] = nnxt[i];
+      }
+      if (single_pass) fetch_recs(bcur, ncur, 0);
+      if (c + 2 < nch) fetch_heads(c + 2, bnxt, nnxt);
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) acc[i] = consume(i, nthis[i] < (uint32_t)TSL ? nthis[i] : (uint32_t)TSL, acc[i]);
+    if (!single_pass) {
+      // long groups (rows of the Hartree-Fock neighbourhood): further passes over the same tile, their records loaded
+      // on the spot; the slab is private to the wavefront, so only its own LDS accesses need ordering
+      for (uint32_t p = 1; p * TSL < nmax; ++p) {
+        fetch_recs(bthis, nthis, p);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        park_recs();
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+          const uint32_t done = p * TSL, left = nthis[i] > done ? nthis[i] - done : 0u;
+          acc[i] = consume(i, left < (uint32_t)TSL ? left : (uint32_t)TSL, acc[i]);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (c + 1 < nch) fetch_recs(bcur, ncur, 0);  // (po / pv were in use: the next chunk's first pass only now)
+    }
+    __syncthreads();
+  }
+  if (col_ok) {
+    double* __restrict__ out = g.out[side];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+      if (t0 + i < n) out[(t0 + i) * m + col] = acc[i];
+  }
+}
+
+// ---- the product on ROW GROUPS (the default).  Strings that are neighbours in the sorted order differ in their low
+// orbitals only and are linked to nearly the same strings: the union of the source lists of GR = 8 adjacent rows is
+// 3.4 (1000 strings) to 4.1 (3000) times one list, not 8 times.  A group therefore walks ONE list -- the union, sorted --
+// with a dense 8-vector of coefficients per source (zeros where a row has no such link): an operand row segment that
+// k_spmm_rows reads once per link is read once per group and serves 8 multiply-adds, 2.4 / 1.9 of them useful.  The
+// bytes through the vector L1 per useful multiply-add drop to 0.42 / 0.52 of k_spmm_rows'; the extra multiply-adds by
+// zero are free (the vector units have an 8-fold margin over the L1 here).  Records travel through the scalar cache:
+// per round of GU sources one s_load of their addresses and GU x 8 coefficients, which enter v_fmac_f64 as scalar operands.
+constexpr int GR = 8, GPAD = 16;
+struct GroupBuildArgs {
+  int64_t n[2];
+  GPtr<const int64_t> s_ptr[2], d_ptr[2];
+  GPtr<const SRec> s_rec[2];
+  GPtr<const double> s_val[2], d_val[2];
+  GPtr<const uint32_t> d_src[2];
+  GPtr<const int64_t> base[2];  // first source slot of every group (host: an upper bound of the union sizes)
+  GPtr<uint32_t> cnt[2], src[2];
+  GPtr<double> coef[2];         // [slot][GR], zeroed beforehand
+};
+// one wavefront per group: bitmap of the sources of its rows (LDS), ranks from the per-word popcount prefix, then the
+// union's addresses and every link's value to coef[rank][row]
+__global__ void __launch_bounds__(256) k_spmm_group_build(const GroupBuildArgs g) {
+  __shared__ uint32_t bits[4][1024];   // up to 32 768 strings
+  __shared__ uint32_t rank0[4][1024];  // sources below the word
+  const int sd = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t n = g.n[sd];
+  const int64_t grp = (int64_t)blockIdx.x * 4 + w;
+  const int64_t ngroups = (n + GR - 1) / GR;
+  const bool live = grp < ngroups;
+  const int nwords = (int)((n + 31) / 32);
+  for (int i = lane; i < 1024; i += 64) bits[w][i] = 0u;
+  __syncthreads();
+  const int64_t* __restrict__ sp = g.s_ptr[sd];
+  const int64_t* __restrict__ dp = g.d_ptr[sd];
+  const SRec* __restrict__ rec = g.s_rec[sd];
+  const uint32_t* __restrict__ ds = g.d_src[sd];
+  const int64_t r0 = grp * GR, r1 = live ? (r0 + GR < n ? r0 + GR : n) : r0;
+  if (live) {
+    // (the rows of a group are consecutive: their single links, and their double links, are two contiguous ranges)
+    for (int64_t k = sp[r0] + lane; k < sp[r1]; k += 64) atomicOr(&bits[w][rec[k].src >> 5], 1u << (rec[k].src & 31u));
+    for (int64_t k = dp[r0] + lane; k < dp[r1]; k += 64) atomicOr(&bits[w][ds[k] >> 5], 1u << (ds[k] & 31u));
+  }
+  __syncthreads();
+  // lane l owns words 16 l .. 16 l + 15
+  uint32_t mine = 0;
+  for (int u = 0; u < 16; ++u) mine += __popc(bits[w][16 * lane + u]);
+  uint32_t incl = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl(incl, lane - d);
+    if (lane >= d) incl += y;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  uint32_t run = incl - mine;
+  for (int u = 0; u < 16; ++u) {
+    rank0[w][16 * lane + u] = run;
+    run += __popc(bits[w][16 * lane + u]);
+  }
+  __syncthreads();
+  if (!live) return;
+  const int64_t base = g.base[sd][grp];
+  const uint32_t padded = (total + GPAD - 1) / GPAD * GPAD;
+  if (lane == 0) g.cnt[sd][grp] = padded;
+  uint32_t* __restrict__ src = g.src[sd] + base;
+  double* __restrict__ coef = g.coef[sd] + base * GR;
+  for (int i = lane; i < nwords; i += 64) {
+    uint32_t b = bits[w][i], r = rank0[w][i];
+    while (b) {
+      const int bit = __ffs((int)b) - 1;
+      src[r++] = (uint32_t)(i * 32 + bit);
+      b &= b - 1u;
+    }
+  }
+  for (uint32_t p = total + lane; p < padded; p += 64) src[p] = 0u;  // (padding: any valid row, all-zero coefficients)
+  const double* __restrict__ sv = g.s_val[sd];
+  const double* __restrict__ dv = g.d_val[sd];
+  for (int64_t r = r0; r < r1; ++r) {
+    for (int64_t k = sp[r] + lane; k < sp[r + 1]; k += 64) {
+      const uint32_t a = rec[k].src;
+      const uint32_t rk = rank0[w][a >> 5] + __popc(bits[w][a >> 5] & ((1u << (a & 31u)) - 1u));
+      coef[(int64_t)rk * GR + (r - r0)] = sv[k];
+    }
+    for (int64_t k = dp[r] + lane; k < dp[r + 1]; k += 64) {
+      const uint32_t a = ds[k];
+      const uint32_t rk = rank0[w][a >> 5] + __popc(bits[w][a >> 5] & ((1u << (a & 31u)) - 1u));
+      coef[(int64_t)rk * GR + (r - r0)] = dv[k];
+    }
+  }
+}
+
+struct GroupedArgs {
+  GPtr<const int64_t> base[2];
+  GPtr<const uint32_t> cnt[2], src[2], order[2];
+  GPtr<const double> coef[2];
+  GPtr<const double> in[2];
+  GPtr<double> out[2];
+  int64_t n[2], m[2];
+  unsigned ngroups[2], npanels[2];
+  int xcd_split;
+  GPtr<const int> stop, vec_index;
+  int64_t in_stride;
+};
+template <int GX, int GU>
+__global__ void __launch_bounds__(256) k_spmm_grouped(const GroupedArgs g) {
+  if (g.stop && *g.stop) return;
+  const int side = blockIdx.y;
+  const unsigned ng = g.ngroups[side], np = g.npanels[side];
+  const int64_t n = g.n[side], m = g.m[side];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned panel, r;
+  if (g.xcd_split) {
+    const unsigned x = blockIdx.x & 7u, q = (blockIdx.x >> 3) * 4u + (unsigned)wave;
+    panel = (q / ng) * 8u + x;
+    r = q % ng;
+  } else {
+    const unsigned q = blockIdx.x * 4u + (unsigned)wave;
+    panel = q / ng;
+    r = q % ng;
+  }
+  if (panel >= np) return;  // (uniform over the wavefront)
+  panel = (unsigned)__builtin_amdgcn_readfirstlane((int)panel);
+  r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+  const int64_t grp = (int64_t)__builtin_amdgcn_readfirstlane((int)g.order[side][r]);
+  const double* __restrict__ in = g.in[side];
+  if (side == 0 && g.vec_index) in += (int64_t)(*g.vec_index - 1) * g.in_stride;
+  const int64_t base = g.base[side][grp];
+  const uint32_t cnt = g.cnt[side][grp];  // (a multiple of GPAD, itself a multiple of GX)
+  const uint32_t* __restrict__ src = g.src[side] + base;
+  const double* __restrict__ coef = g.coef[side] + base * GR;
+  const unsigned c0 = panel * 64u;
+  const bool ok = (int64_t)c0 + lane < m;
+  const unsigned col = ok ? (unsigned)lane : (unsigned)(m - 1 - c0);
+  in += c0;
+  double acc[GR];
+#pragma unroll
+  for (int i = 0; i < GR; ++i) acc[i] = 0.0;
+  // GX operand rows in flight per wavefront (what the kernel lives on: bytes in flight x the L2's latency under load),
+  // their addresses from one scalar load a chunk ahead; the coefficients stream behind them GU sources at a time
+  uint32_t sn[GX];
+#pragma unroll
+  for (int u = 0; u < GX; ++u) sn[u] = src[u];
+  for (uint32_t l = 0; l < cnt; l += GX, src += GX, coef += GX * GR) {
+    uint32_t s[GX];
+    double x[GX];
+#pragma unroll
+    for (int u = 0; u < GX; ++u) s[u] = sn[u];
+#pragma unroll
+    for (int u = 0; u < GX; ++u) sn[u] = src[GX + u];  // (the list ends with one chunk of padding)
+#pragma unroll
+    for (int u = 0; u < GX; ++u) x[u] = spmm_ldu(in + (int64_t)s[u] * m, col);
+#pragma unroll
+    for (int u0 = 0; u0 < GX; u0 += GU) {
+      double cf[GU][GR];
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int i = 0; i < GR; ++i) cf[u][i] = coef[(u0 + u) * GR + i];
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int i = 0; i < GR; ++i) acc[i] += cf[u][i] * x[u0 + u];
+    }
+  }
+  if (ok) {
+    double* __restrict__ out = g.out[side] + c0;
+#pragma unroll
+    for (int i = 0; i < GR; ++i)
+      if (grp * GR + i < n) out[(grp * GR + i) * m + col] = acc[i];
+  }
+}
+
 // ---- host side
 // Is this subspace taken by the sparse-product same-spin path?  (phase 2 of set_subspace; single builds, whole row
 // range.)  SQD_SIGMA_SPMM=1 / 0 forces / forbids (the tests run every same-spin formulation on the same inputs).
@@ -262,12 +744,12 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
   if (env) {
     on = std::atoi(env) != 0;
   } else {
-    // connected sets from ~1400 strings per spin.  Measured on the MI355X (profiles/r05/connected_probe_spmm.txt,
-    // HF-centred N x N, us per sigma, this path | matrix cores | sparse work items): 700: 160 | 111 | 125; 1000: 288 |
-    // 236 | 257; 2000: 1100 | 1305 | 1244; 3000: 2899 | 3747 | 5073.  Smaller sets stay with the matrix cores: one
-    // launch instead of three, and their blocks are 11-26 % dense.
+    // connected sets from ~10^3 strings per spin.  Measured on the MI355X (profiles/r05/connected_probe_*.txt, HF-centred
+    // N x N, us per sigma, this path (row groups) | matrix cores | sparse work items): 500: 98 | 67 | 73; 700: 145 | 111 |
+    // 125; 1000: 242 | 237 | 257; 2000: 1029 | 1305 | 1244; 3000: 2560 | 3747 | 5073.  Smaller sets stay with the matrix
+    // cores: one launch instead of three, and their blocks are 11-26 % dense.
     const int64_t same_a = tot[0] + tot[1], same_b = tot[2] + tot[3];
-    on = na >= 1400 && nb >= 1400 && same_a >= 8 * na && same_b >= 8 * nb;
+    on = na >= 1024 && nb >= 1024 && same_a >= 8 * na && same_b >= 8 * nb;
   }
   c->sig_spmm = on;
   return on;
@@ -339,6 +821,115 @@ int spmm_build(sqd_ctx* c) {
   const int64_t maxn = na > nb ? na : nb;
   hipLaunchKernelGGL(k_spmm_merge, dim3((unsigned)((maxn + 1 + 3) / 4), 2), dim3(256), 0, c->stream, ma);
   SQD_HIP_CHECK(hipGetLastError());
+  // the row-grouped form (default; SQD_SPMM_GROUPED=0 forbids): up to 32 768 strings per spin (the build kernel's bitmap)
+  static const bool grouped_env = [] {
+    const char* env = std::getenv("SQD_SPMM_GROUPED");
+    return !env || std::atoi(env) != 0;
+  }();
+  s->grouped = grouped_env && maxn <= 32768;
+  if (s->grouped) {
+    GroupBuildArgs gb;
+    for (int sp = 0; sp < 2; ++sp) {
+      const SpinTables& t = c->sp[sp];
+      SpmmGroups& gr = s->groups[sp];
+      const int64_t* ps = hptr[sp][0];
+      const int64_t* pd = hptr[sp][1];
+      gr.ngroups = (t.n + GR - 1) / GR;
+      gr.h_base.resize((size_t)gr.ngroups + 1);
+      gr.h_order.resize((size_t)gr.ngroups);
+      gr.h_base[0] = 0;
+      for (int64_t q = 0; q < gr.ngroups; ++q) {
+        const int64_t a = q * GR, b = (a + GR < t.n) ? a + GR : t.n;
+        int64_t len = (ps[b] - ps[a]) + (pd[b] - pd[a]);  // the union holds at most this many sources, and at most n
+        if (len > t.n) len = t.n;
+        gr.h_base[q + 1] = gr.h_base[q] + (len + GPAD - 1) / GPAD * GPAD + GPAD;
+      }
+      gr.cap = gr.h_base[gr.ngroups];
+      std::iota(gr.h_order.begin(), gr.h_order.end(), 0u);
+      std::stable_sort(gr.h_order.begin(), gr.h_order.end(), [&](uint32_t a, uint32_t b) {
+        return gr.h_base[a + 1] - gr.h_base[a] > gr.h_base[b + 1] - gr.h_base[b];
+      });
+      SQD_TRY(gr.base.reserve((size_t)(gr.ngroups + 1) * 8));
+      SQD_TRY(gr.cnt.reserve((size_t)gr.ngroups * 4 + 16));
+      SQD_TRY(gr.order.reserve((size_t)gr.ngroups * 4 + 16));
+      SQD_TRY(gr.src.reserve((size_t)(gr.cap + GPAD) * 4 + 64));
+      SQD_TRY(gr.coef.reserve((size_t)(gr.cap + GPAD) * GR * 8 + 64));
+      SQD_HIP_CHECK(hipMemcpyAsync(gr.base.p, gr.h_base.data(), (size_t)(gr.ngroups + 1) * 8, hipMemcpyHostToDevice, c->stream));
+      SQD_HIP_CHECK(hipMemcpyAsync(gr.order.p, gr.h_order.data(), (size_t)gr.ngroups * 4, hipMemcpyHostToDevice, c->stream));
+      SQD_HIP_CHECK(hipMemsetAsync(gr.coef.p, 0, (size_t)(gr.cap + GPAD) * GR * 8, c->stream));
+      gb.n[sp] = t.n;
+      gb.s_ptr[sp] = t.s_ptr.as<int64_t>();
+      gb.d_ptr[sp] = t.d_ptr.as<int64_t>();
+      gb.s_rec[sp] = t.s_rec.as<SRec>();
+      gb.s_val[sp] = t.s_val.as<double>();
+      gb.d_src[sp] = t.d_src.as<uint32_t>();
+      gb.d_val[sp] = t.d_val.as<double>();
+      gb.base[sp] = gr.base.as<int64_t>();
+      gb.cnt[sp] = gr.cnt.as<uint32_t>();
+      gb.src[sp] = gr.src.as<uint32_t>();
+      gb.coef[sp] = gr.coef.as<double>();
+    }
+    const int64_t maxg = (maxn + GR - 1) / GR;
+    hipLaunchKernelGGL(k_spmm_group_build, dim3((unsigned)((maxg + 3) / 4), 2), dim3(256), 0, c->stream, gb);
+    SQD_HIP_CHECK(hipGetLastError());
+    s->tiled = false;
+    return SQD_OK;
+  }
+  // the tiled form (SQD_SPMM_GROUPED=0 SQD_SPMM_TILED=1; otherwise k_spmm_rows on the merged lists above).  Chunks of TS source rows: at most
+  // 256 per side (the build kernel's histogram), i.e. 32 768 strings per spin.
+  static const bool tiled_env = [] {
+    const char* env = std::getenv("SQD_SPMM_TILED");
+    return env && std::atoi(env) != 0;
+  }();
+  s->tiled = tiled_env && maxn <= 256 * TS;
+  if (!s->tiled) return SQD_OK;
+  TileBuildArgs tb;
+  for (int sp = 0; sp < 2; ++sp) {
+    const SpinTables& t = c->sp[sp];
+    SpmmTiles& tl = s->tiles[sp];
+    const int64_t* ps = hptr[sp][0];
+    const int64_t* pd = hptr[sp][1];
+    tl.nch = (int)((t.n + TS - 1) / TS);
+    tl.npad = (t.n + TW - 1) / TW * TW + TW;
+    // a row's region: its links + the worst-case padding (TGRAN - 1 per non-empty group), cut on the host from the CSR
+    // pointers it holds anyway -- no device scan, no second synchronisation
+    tl.h_rowbase.resize((size_t)t.n + 1);
+    tl.h_rowbase[0] = 0;
+    for (int64_t i = 0; i < t.n; ++i) {
+      const int64_t len = (ps[i + 1] - ps[i]) + (pd[i + 1] - pd[i]);
+      const int64_t groups = len < tl.nch ? len : tl.nch;
+      tl.h_rowbase[i + 1] = tl.h_rowbase[i] + (len + (TGRAN - 1) * groups + TGRAN - 1) / TGRAN * TGRAN;
+    }
+    tl.cap = tl.h_rowbase[t.n];
+    if (tl.cap + TGRAN > 0xffffffffll) {
+      s->tiled = false;
+      return SQD_OK;
+    }
+    SQD_TRY(tl.rowbase.reserve((size_t)(t.n + 1) * 8));
+    SQD_TRY(tl.beg.reserve((size_t)tl.nch * tl.npad * 4 + 64));
+    SQD_TRY(tl.cnt.reserve((size_t)tl.nch * tl.npad * 4 + 64));
+    SQD_TRY(tl.off.reserve((size_t)(tl.cap + TGRAN) * 4 + 64));
+    SQD_TRY(tl.val.reserve((size_t)(tl.cap + TGRAN) * 8 + 64));
+    SQD_HIP_CHECK(hipMemcpyAsync(tl.rowbase.p, tl.h_rowbase.data(), (size_t)(t.n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    SQD_HIP_CHECK(hipMemsetAsync(tl.beg.p, 0, (size_t)tl.nch * tl.npad * 4, c->stream));
+    SQD_HIP_CHECK(hipMemsetAsync(tl.cnt.p, 0, (size_t)tl.nch * tl.npad * 4, c->stream));
+    tb.n[sp] = t.n;
+    tb.nch[sp] = tl.nch;
+    tb.npad[sp] = tl.npad;
+    tb.s_ptr[sp] = t.s_ptr.as<int64_t>();
+    tb.d_ptr[sp] = t.d_ptr.as<int64_t>();
+    tb.s_rec[sp] = t.s_rec.as<SRec>();
+    tb.s_val[sp] = t.s_val.as<double>();
+    tb.d_src[sp] = t.d_src.as<uint32_t>();
+    tb.d_val[sp] = t.d_val.as<double>();
+    tb.rowbase[sp] = tl.rowbase.as<int64_t>();
+    tb.beg[sp] = tl.beg.as<uint32_t>();
+    tb.cnt[sp] = tl.cnt.as<uint32_t>();
+    tb.off[sp] = tl.off.as<uint32_t>();
+    tb.val[sp] = tl.val.as<double>();
+  }
+  hipLaunchKernelGGL(k_spmm_tile_build, dim3((unsigned)((maxn + 3) / 4), 2), dim3(256), 0, c->stream, tb);
+  SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
 }
 
@@ -361,6 +952,76 @@ int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride) {
   t1.vec_index = vidx;
   t1.in_stride = in_stride;
   hipLaunchKernelGGL(k_spmm_transpose, dim3((unsigned)((nb + 63) / 64), (unsigned)((na + 63) / 64)), dim3(256), 0, c->stream, t1);
+  if (s->grouped) {
+    GroupedArgs gg;
+    unsigned gxg = 1;
+    gg.xcd_split = ((size_t)na * nb * 8 > (size_t(3) << 20)) ? 1 : 0;
+    if (const char* env = std::getenv("SQD_SPMM_XCD")) gg.xcd_split = std::atoi(env) != 0;  // tuning hook
+    for (int sp = 0; sp < 2; ++sp) {
+      const SpmmGroups& gr = s->groups[sp];
+      gg.base[sp] = gr.base.as<int64_t>();
+      gg.cnt[sp] = gr.cnt.as<uint32_t>();
+      gg.src[sp] = gr.src.as<uint32_t>();
+      gg.order[sp] = gr.order.as<uint32_t>();
+      gg.coef[sp] = gr.coef.as<double>();
+      gg.n[sp] = sp ? nb : na;
+      gg.m[sp] = sp ? na : nb;
+      gg.ngroups[sp] = (unsigned)gr.ngroups;
+      gg.npanels[sp] = (unsigned)((gg.m[sp] + 63) / 64);
+      uint64_t blocks;
+      if (gg.xcd_split) blocks = 8ull * (((uint64_t)((gg.npanels[sp] + 7) / 8) * (uint64_t)gr.ngroups + 3) / 4);
+      else blocks = ((uint64_t)gg.npanels[sp] * (uint64_t)gr.ngroups + 3) / 4;
+      gxg = blocks > gxg ? (unsigned)blocks : gxg;
+    }
+    gg.in[0] = d_c;
+    gg.in[1] = s->ct.as<double>();
+    gg.out[0] = c->gdense.as<double>();
+    gg.out[1] = s->g2t.as<double>();
+    gg.stop = c->sigma_stop;
+    gg.vec_index = vidx;
+    gg.in_stride = in_stride;
+    static const int gx = [] {  // tuning hook: operand rows in flight per wavefront
+      const char* env = std::getenv("SQD_SPMM_GX");
+      const int v = env ? std::atoi(env) : 16;
+      return (v == 4 || v == 8 || v == 16) ? v : 16;
+    }();
+    if (gx == 16) hipLaunchKernelGGL((k_spmm_grouped<16, 2>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+    else if (gx == 8) hipLaunchKernelGGL((k_spmm_grouped<8, 2>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+    else hipLaunchKernelGGL((k_spmm_grouped<4, 4>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+  } else if (s->tiled) {
+    TiledArgs tg;
+    unsigned gxt = 1;
+    for (int sp = 0; sp < 2; ++sp) {
+      const SpmmTiles& tl = s->tiles[sp];
+      tg.beg[sp] = tl.beg.as<uint32_t>();
+      tg.cnt[sp] = tl.cnt.as<uint32_t>();
+      tg.off[sp] = tl.off.as<uint32_t>();
+      tg.val[sp] = tl.val.as<double>();
+      tg.n[sp] = sp ? nb : na;
+      tg.m[sp] = sp ? na : nb;
+      tg.npad[sp] = tl.npad;
+      tg.nch[sp] = tl.nch;
+      tg.ntb[sp] = (unsigned)((tg.n[sp] + TB - 1) / TB);
+      tg.npanels[sp] = (unsigned)((tg.m[sp] + TPANEL - 1) / TPANEL);
+      const unsigned blocks = 8u * ((tg.npanels[sp] + 7u) / 8u) * tg.ntb[sp];
+      gxt = blocks > gxt ? blocks : gxt;
+    }
+    tg.in[0] = d_c;
+    tg.in[1] = s->ct.as<double>();
+    tg.out[0] = c->gdense.as<double>();
+    tg.out[1] = s->g2t.as<double>();
+    tg.stop = c->sigma_stop;
+    tg.vec_index = vidx;
+    tg.in_stride = in_stride;
+    constexpr size_t shmem = (size_t)TS * TPANEL * 8 + (size_t)(TTHREADS / 64) * TW * TSL * 12;
+    static std::atomic<bool> granted[64];
+    if (!granted[c->device & 63].load(std::memory_order_relaxed)) {
+      SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)shmem));
+      granted[c->device & 63].store(true, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(k_spmm_tiled, dim3(gxt, 2), dim3(TTHREADS), shmem, c->stream, tg);
+  } else {
   SpmmArgs g;
   unsigned gx = 1;
   // an XCD's L2 (4 MB) holds one panel of the larger side with room to spare: below that the whole vector is L2
@@ -389,9 +1050,15 @@ int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride) {
   g.stop = c->sigma_stop;
   g.vec_index = vidx;
   g.in_stride = in_stride;
-  if (J == 4) hipLaunchKernelGGL(k_spmm_rows<4>, dim3(gx, 2), dim3(256), 0, c->stream, g);
-  else if (J == 2) hipLaunchKernelGGL(k_spmm_rows<2>, dim3(gx, 2), dim3(256), 0, c->stream, g);
-  else hipLaunchKernelGGL(k_spmm_rows<1>, dim3(gx, 2), dim3(256), 0, c->stream, g);
+  static const int ru = [] {  // tuning hook: operand rows in flight per wavefront
+    const char* env = std::getenv("SQD_SPMM_U");
+    return (env && std::atoi(env) == 8) ? 8 : 16;
+  }();
+  if (J == 4) hipLaunchKernelGGL((k_spmm_rows<4, 8>), dim3(gx, 2), dim3(256), 0, c->stream, g);
+  else if (J == 2) hipLaunchKernelGGL((k_spmm_rows<2, 8>), dim3(gx, 2), dim3(256), 0, c->stream, g);
+  else if (ru == 8) hipLaunchKernelGGL((k_spmm_rows<1, 8>), dim3(gx, 2), dim3(256), 0, c->stream, g);
+  else hipLaunchKernelGGL((k_spmm_rows<1, 16>), dim3(gx, 2), dim3(256), 0, c->stream, g);
+  }
   TransArgs t2;
   t2.in = s->g2t.as<double>();
   t2.out = c->gdense.as<double>();

@@ -301,12 +301,17 @@ inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 inline double __longlong_as_double(long long x) { double d; std::memcpy(&d, &x, 8); return d; }
 
 template <class T> inline T atomicAdd(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());
   T old = *p; *p = old + v; return old;
+}
+template <class T> inline T atomicOr(T* p, T v) {
+  std::lock_guard<std::mutex> g(emu::atomic_mu());
+  T old = *p; *p = old | v; return old;
 }
 template <class T> inline T atomicExch(T* p, T v) {
   std::lock_guard<std::mutex> g(emu::atomic_mu());

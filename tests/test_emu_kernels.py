@@ -256,8 +256,9 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
     assert not ok
 
 
-@pytest.mark.parametrize("xcd,J", [("0", "2"), ("1", "1"), ("1", "4")])
-def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J):
+@pytest.mark.parametrize("xcd,J,tiled", [("0", "2", "0"), ("1", "1", "0"), ("1", "4", "0"), ("1", "1", "1"), ("0", "1", "g"),
+                                         ("1", "1", "g")])
+def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled):
     # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: merged CSR of both spins, C -> C^T, row
     # AXPYs on C and C^T, G += G2T^T, work items add ONE partial product) that connected sets from ~10^3 strings per
     # spin take by default.  Both task mappings (XCD split on / off), every panel width, ragged panels and tiles,
@@ -265,8 +266,17 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J):
     monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
     monkeypatch.setenv("SQD_SPMM_XCD", xcd)
     monkeypatch.setenv("SQD_SPMM_J", J)
+    # tiled = 1: the default product (k_spmm_tiled: operand rows through LDS tiles of 128 source rows, 16 targets per
+    # wavefront, link groups padded to 4 records); tiled = 0: k_spmm_rows on the merged lists
+    # tiled = g: the DEFAULT product (k_spmm_grouped: 8 adjacent rows share the sorted union of their source lists, a dense
+    # 8-vector of coefficients per source); the other two are reached with SQD_SPMM_GROUPED=0
+    monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if tiled == "g" else "0")
+    monkeypatch.setenv("SQD_SPMM_TILED", "1" if tiled == "1" else "0")
     cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (8, (4, 4), 30, 28, 17, True),
              (5, (1, 4), 5, 4, 9, False), (9, (2, 4), 7, 100, 29, True), (16, (4, 4), 66, 70, 23, True)]
+    if tiled != "0":  # more than one source chunk and more than one target block per side (TS = TB = 128); ragged last group
+        cases.append((12, (3, 3), 140, 24, 31, True))
+        cases.append((12, (3, 3), 18, 150, 33, True))
     for case in cases:
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
