@@ -925,10 +925,11 @@ class Context:
         (element gather), ``k_sigma_rows<R>`` (R whole rows of C per workgroup in LDS), ``k_same_spin_mfma+k_sigma``
         (dense same-spin blocks on the f64 matrix cores + work items for the opposite-spin terms), ``k_sigma_lists``
         (large sets with short lists: link lists in registers, one pass over C and one over its transpose) or
-        ``k_spmm_rows+k_sigma`` (connected sets from ~10^3 strings per spin: the same-spin part as a sparse product in
-        row-AXPY form on C and C^T + work items for the opposite-spin terms)."""
+        ``k_spmm_rows+k_sigma`` / ``k_spmm_rows+k_opp_rows`` (connected sets from ~10^3 strings per spin: the same-spin
+        part as a sparse product in row-AXPY form on C and C^T; the opposite-spin terms by work items, or -- the default
+        for the plain operator -- by whole rows with the beta link list in registers)."""
         kind, rows = C.c_int(), C.c_int()
         self._check(self._lib.sqd_sigma_kernel(self._h, C.byref(kind), C.byref(rows)))
         return ("k_sigma", "k_sigma_direct", f"k_sigma_rows<{rows.value}>", "k_same_spin_mfma+k_sigma",
-                "k_sigma_lists", "k_spmm_rows+k_sigma")[kind.value]
+                "k_sigma_lists", "k_spmm_rows+k_sigma", "k_spmm_rows+k_opp_rows")[kind.value]
 

@@ -257,6 +257,7 @@ SQD_API int sqd_ctx_destroy(sqd_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   lists_release(c);
   spmm_release(c);
+  opp_release(c);
   c->sp[0].release();
   c->sp[1].release();
   for (int i = 0; i < 4; ++i)
@@ -1124,7 +1125,7 @@ SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
 SQD_API int sqd_sigma_kernel(sqd_ctx* c, int* kind, int* rows_per_workgroup) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
-  if (kind) *kind = c->sig_lists ? 4 : c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_spmm ? 5 : (c->sig_dense ? 3 : 0)));
+  if (kind) *kind = c->sig_lists ? 4 : c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_opp ? 6 : (c->sig_spmm ? 5 : (c->sig_dense ? 3 : 0))));
   if (rows_per_workgroup) *rows_per_workgroup = c->sig_rows;
   return SQD_OK;
 }

@@ -251,6 +251,10 @@ struct sqd_ctx {
   // work items add ONE partial product, gdense) and hdense_a / hdense_b are not built
   bool sig_spmm = false;
   void* spmm = nullptr;          // sqd::SpmmState (sqd_spmm.hip), created on first use, released with the context
+  // ... and the opposite-spin part + diagonal by whole rows with the beta link list in registers (sqd_opp.hip) instead of
+  // the work items, for the plain operator (H without a spin penalty; S^2 and the penalty forms keep the work items)
+  bool sig_opp = false;
+  void* opp = nullptr;           // sqd::OppState (sqd_opp.hip)
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
   // LDS capacity (in virtual rows) of the singles' / doubles' partial-sum arrays; a chunk with more
@@ -355,6 +359,14 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
 int spmm_build(sqd_ctx* c);
 int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride);
 void spmm_release(sqd_ctx* c);
+// opposite-spin part + diagonal by whole rows for the subspaces of the sparse-product path (sqd_opp.hip).  opp_select:
+// phase 2 of set_subspace, behind spmm_select (sets sqd_ctx::sig_opp); opp_build: device tables, behind launch C;
+// opp_launch: sigma = (hdiag + opposite-spin part) c + gdense, behind spmm_launch of the same vector
+bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot);
+int opp_build(sqd_ctx* c);
+int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride);
+void opp_release(sqd_ctx* c);
+bool opp_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial);
 // batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class
 struct SigmaBatchPlan {
   struct Launch {

@@ -1323,7 +1323,17 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     form_sel = (o->ss < szh * (szh + 1.0) + 0.1) ? 1 : 2;
   }
   SplitRows split{nullptr, nullptr, c->nb};
-  if (c->n_multi > 0 && form_sel != 2 && !c->sig_direct) {
+  // (the whole-row opposite-spin kernel of sqd_opp.hip -- plain operator on the subspaces of the sparse-product path --
+  // writes complete rows: nothing to add)
+  if (c->sig_opp && form_sel == 0) {
+    const int32_t* ri = nullptr;
+    const double* pp = nullptr;
+    if (opp_split(c, &ri, &pp)) {
+      c->sigma_defer_reduce = true;
+      split.rowinfo = ri;
+      split.partial = pp;
+    }
+  } else if (c->n_multi > 0 && form_sel != 2 && !c->sig_direct) {
     c->sigma_defer_reduce = true;
     split.rowinfo = c->rowinfo.as<int32_t>();
     split.partial = c->sig_partial.as<double>();

@@ -1,0 +1,473 @@
+// Opposite-spin part of sigma (and the diagonal) for CONNECTED string sets of 10^3 strings per spin and more, in front of
+// which sqd_spmm.hip has formed the same-spin product G = H_a C + C H_b:
+//   sigma[A,B] = hdiag[A,B] C[A,B] + G[A,B]
+//     + sum_{(A',pq,s) in Sa(A)} s * Jb[B][pq] * C[A',B]            alpha single x beta occupation
+//     + sum_{(B',rs,t) in Sb(B)} t * Ja[A][rs] * C[A,B']            beta single x alpha occupation
+//     + sum_{Sa(A)} sum_{Sb(B)} s t (pq|rs) C[A',B']                single x single
+// -- what pyscf's selected_ci.contract_2e evaluates through SCIcontract_2e_bbaa (reference call sites
+// qiskit_addon_sqd/fermion.py:721-723, :810-818).  The last two terms are one sum over the "entries" of
+// row A -- the row itself (weights Ja[A][:]) and its alpha single links (weights (pq|:)) -- times the beta single links.
+//
+// Why a kernel of its own.  The work-item kernel (sqd_sigma.hip) spends 24 vector instructions per multiply-add at 3000
+// strings per spin (rocprofv3 counters, profiles/r05/pmc_spmm_hf3000_counters.txt: 422 M VALU instructions for 1.1e9
+// multiply-adds; waves parked 55 % of their life): every item of <= 3 alpha links re-reads and re-decodes all 33 000 beta
+// link records, runs them through virtual rows and LDS partial sums, and writes a partial row that a later launch adds.
+// Here ONE workgroup owns a target row A (and a range of columns):
+//   * every thread keeps its share of the beta link list -- S <= 20 consecutive links, one packed 32-bit record each
+//     {source column, orbital pair, sign, last-of-column} -- in registers for the whole row, and one accumulator per link;
+//   * the row's entries are staged four at a time, INTERLEAVED: Cst[B'][4] (signed source rows) and Wst[rs][4] (weight
+//     rows), so that a link costs two 16-byte LDS gathers per operand and four multiply-adds -- no address arithmetic
+//     per entry, no record traffic, no partial sums per entry batch;
+//   * after the last batch the per-link sums are folded to columns in a fixed order (runs inside a thread, then the
+//     threads a column spans, oldest first): one sigma row, written once.  No partial rows, no reduce launch.
+// Bound: LDS gather throughput (random 16-byte reads: ~3-way bank conflicts per 16-lane group).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <numeric>
+
+#include "sqd_common.h"
+
+namespace sqd {
+
+constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather each)
+constexpr int OPP_SMAX = 20;  // beta links per thread
+constexpr int OPP_RMAX = 4;   // columns per thread in the coalesced passes (nb <= OPP_RMAX * threads)
+constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30;
+
+// one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
+// link e - 1); slot < 0: the row has this one item and is written in place, else partial row `slot` (added in slot
+// order by the first reader of the vector -- k_dots_eig inside a Davidson run, k_opp_reduce otherwise)
+struct OppItem {
+  uint32_t A;
+  int32_t e0, ne, slot;
+};
+struct OppState {
+  DevBuf link, lcol, back, items, halves, rowinfo, partial, multi;
+  std::vector<OppItem> h_items;
+  std::vector<int32_t> h_rowinfo;
+  std::vector<MultiRow> h_multi;
+  std::vector<int64_t> h_halves;  // [H + 1] first link of every column range, then [H + 1] first column
+  int H = 1, S = 0, T = 0;
+  int64_t n_items = 0, n_slots = 0, n_multi = 0;
+  size_t shmem = 0;
+};
+
+void opp_release(sqd_ctx* c) {
+  if (!c->opp) return;
+  OppState* s = static_cast<OppState*>(c->opp);
+  for (DevBuf* b : {&s->link, &s->lcol, &s->back, &s->items, &s->halves, &s->rowinfo, &s->partial, &s->multi}) b->release();
+  delete s;
+  c->opp = nullptr;
+}
+
+// ---- tables: thread t of column range h owns the links l0[h] + t S .. + S - 1 (consecutive: a run of whole columns and
+// two partial ones); link[h][s][t] packed record, lcol[h][s][t] its target column, back[h][t] = how many preceding
+// threads hold earlier links of the column thread t starts in
+struct OppTabArgs {
+  GPtr<const int64_t> sb_ptr;
+  GPtr<const SRec> sb_rec;
+  GPtr<const uint32_t> sb_row;
+  GPtr<const int64_t> halves;  // [H + 1]
+  GPtr<uint32_t> link, lcol, back;
+  int H, S, T;
+};
+__global__ void __launch_bounds__(256) k_opp_tab(const OppTabArgs g) {
+  const int h = blockIdx.y;
+  const int64_t l0 = g.halves[h], l1 = g.halves[h + 1];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.T) return;
+  const int64_t base = ((int64_t)h * g.S) * g.T;
+  for (int s = 0; s < g.S; ++s) {
+    const int64_t l = l0 + (int64_t)t * g.S + s;
+    uint32_t rec = 0u, col = 0u;
+    if (l < l1) {
+      const SRec r = g.sb_rec[l];
+      col = g.sb_row[l];
+      rec = (r.src & 0xffffu) | ((srec_widx(r.meta) >> 1) << 16) | ((r.meta >> 31) ? OPP_SIGN : 0u) | OPP_LIVE |
+            ((l + 1 == g.sb_ptr[col + 1]) ? OPP_LAST : 0u);
+    }
+    g.link[base + (int64_t)s * g.T + t] = rec;
+    g.lcol[base + (int64_t)s * g.T + t] = col;
+  }
+  uint32_t bk = 0;
+  const int64_t lf = l0 + (int64_t)t * g.S;
+  if (lf < l1) {
+    const int64_t cstart = g.sb_ptr[g.sb_row[lf]];  // first link of the column thread t starts in (>= l0: ranges are cut at columns)
+    bk = (uint32_t)(t - (int)((cstart - l0) / g.S));
+  }
+  g.back[(int64_t)h * g.T + t] = bk;
+}
+
+struct OppArgs {
+  GPtr<const double> c;
+  GPtr<double> sigma, partial;
+  GPtr<const double> hdiag, gdense, ja_row, jbT, eri_pp;
+  GPtr<const int64_t> sa_ptr;
+  GPtr<const SRec> sa_rec;
+  GPtr<const uint32_t> link, lcol, back;
+  GPtr<const OppItem> items;
+  GPtr<const int64_t> colcut;  // [H + 1] first column of every range
+  int64_t na, nb;
+  int nnorb, S, T, H;
+  GPtr<const int> stop, vec_index;
+  int64_t c_stride, s_stride;
+};
+
+__global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
+  if (g.stop && *g.stop) return;
+  const int T = g.T, tid = threadIdx.x, h = blockIdx.y;
+  const OppItem it = g.items[blockIdx.x];
+  const int64_t A = it.A;
+  const int64_t nb = g.nb;
+  const int nn = g.nnorb;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  double* __restrict__ sig = g.sigma + vsel * g.s_stride;
+  const int64_t nbe = (nb + 1) & ~int64_t(1);
+  double* Cst = smem;
+  double* Wst = Cst + (nbe > (nb + T + 1) / 2 ? nbe : (nb + T + 2) / 2) * OPP_K;  // (room for outb + tailb in Cst's place)
+  double* outb = smem;
+  double* tailb = smem + nbe;
+  const int64_t B0 = g.colcut[h], B1 = g.colcut[h + 1];  // this workgroup writes the columns [B0, B1)
+  // this thread's links: packed records in registers for the whole item
+  uint32_t rec[OPP_SMAX];
+  const uint32_t* __restrict__ lk = g.link + ((int64_t)h * g.S) * T + tid;
+#pragma unroll
+  for (int s = 0; s < OPP_SMAX; ++s) rec[s] = (s < g.S) ? lk[(int64_t)s * T] : 0u;
+  double acc[OPP_SMAX];
+#pragma unroll
+  for (int s = 0; s < OPP_SMAX; ++s) acc[s] = 0.0;
+  double a3[OPP_RMAX];
+#pragma unroll
+  for (int r = 0; r < OPP_RMAX; ++r) a3[r] = 0.0;
+  const int64_t k0 = g.sa_ptr[A];
+  const int e_end = it.e0 + it.ne;
+  for (int e0 = it.e0; e0 < e_end; e0 += OPP_K) {
+    // the entries of this batch (uniform): source row, sign, weight row; a slot past the item's last entry is a zero row
+    const double* srow[OPP_K];
+    const double* wrow[OPP_K];
+    const double* jrow[OPP_K];
+    double sg[OPP_K];
+    bool lnk[OPP_K];
+#pragma unroll
+    for (int j = 0; j < OPP_K; ++j) {
+      const int e = e0 + j;
+      const bool valid = e < e_end;
+      lnk[j] = valid && e > 0;
+      SRec r = SRec{(uint32_t)A, 0u};
+      if (lnk[j]) r = g.sa_rec[k0 + e - 1];
+      const int64_t pair = (int64_t)(srec_widx(r.meta) >> 1);
+      srow[j] = C + (int64_t)r.src * nb;
+      sg[j] = valid ? (lnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
+      wrow[j] = lnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
+      jrow[j] = g.jbT + pair * nb;
+    }
+    // weight rows, then the source rows (signed), both interleaved; the alpha single x beta occupation term rides on
+    // the pass over the source rows (own columns)
+    for (int i = tid; i < nn; i += T)
+      *reinterpret_cast<double2*>(Wst + (int64_t)i * OPP_K) =
+          make_double2(sg[0] != 0.0 ? wrow[0][i] : 0.0, sg[1] != 0.0 ? wrow[1][i] : 0.0);
+    // (one column at a time: unrolled over r the operands in flight push the per-link accumulators out of the registers)
+#pragma unroll 1
+    for (int r = 0; r < OPP_RMAX; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      if (B < nb) {
+        double x[OPP_K], jb[OPP_K];
+#pragma unroll
+        for (int j = 0; j < OPP_K; ++j) {
+          x[j] = srow[j][B];
+          jb[j] = jrow[j][B];
+        }
+        double add = 0.0;
+#pragma unroll
+        for (int j = 0; j < OPP_K; ++j) {
+          x[j] *= sg[j];
+          add += lnk[j] ? jb[j] * x[j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < OPP_RMAX; ++q) a3[q] += (q == r) ? add : 0.0;
+        *reinterpret_cast<double2*>(Cst + B * OPP_K) = make_double2(x[0], x[1]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < OPP_SMAX; ++s) {
+      const uint32_t rc = rec[s];
+      const double2 cv = *reinterpret_cast<const double2*>(Cst + (rc & 0xffffu) * OPP_K);
+      const double2 wv2 = *reinterpret_cast<const double2*>(Wst + ((rc >> 16) & 0xfffu) * OPP_K);
+      acc[s] += wv2.x * cv.x;
+      acc[s] += wv2.y * cv.y;
+    }
+    __syncthreads();
+  }
+  // ---- per-link sums -> columns, fixed order.  Runs inside the thread; a column that spans threads is finished by the
+  // thread that holds its last link, which adds the open runs of the threads before it, oldest first.
+  for (int64_t B = tid; B < nb; B += T) outb[B] = 0.0;  // (Cst is done with: the loop's last barrier)
+  __syncthreads();
+  const uint32_t* __restrict__ lc = g.lcol + ((int64_t)h * g.S) * T + tid;
+  const uint32_t bk = g.back[(int64_t)h * T + tid];
+  double run = 0.0, firstrun = 0.0;
+  int firstcol = -1;
+  bool first = true, open = false;
+#pragma unroll
+  for (int s = 0; s < OPP_SMAX; ++s) {
+    const uint32_t rc = rec[s];
+    if (rc & OPP_LIVE) {
+      run += (rc & OPP_SIGN) ? -acc[s] : acc[s];
+      open = true;
+      if (rc & OPP_LAST) {
+        const uint32_t col = lc[(int64_t)s * T];
+        if (first && bk > 0) {
+          firstrun = run;
+          firstcol = (int)col;
+        } else {
+          outb[col] = run;
+        }
+        run = 0.0;
+        first = false;
+        open = false;
+      }
+    }
+  }
+  tailb[tid] = open ? run : 0.0;
+  __syncthreads();
+  if (firstcol >= 0) {
+    double sum = 0.0;
+    for (uint32_t j = bk; j >= 1; --j) sum += tailb[tid - (int)j];
+    outb[firstcol] = sum + firstrun;
+  }
+  __syncthreads();
+  const bool has0 = it.e0 == 0;  // the piece that holds the row itself also brings the diagonal and the same-spin product
+  const double* __restrict__ crow = C + A * nb;
+  const double* __restrict__ hd = g.hdiag + A * nb;
+  const double* __restrict__ gd = g.gdense + A * nb;
+  double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
+#pragma unroll
+  for (int r = 0; r < OPP_RMAX; ++r) {
+    const int64_t B = tid + (int64_t)r * T;
+    if (B >= B0 && B < B1) {
+      double v = a3[r] + outb[B];
+      if (has0) v += hd[B] * crow[B] + gd[B];
+      orow[B] = v;
+    }
+  }
+}
+
+// sigma[A, :] = sum of the partial rows of A in slot order, for the rows that were cut into several items (outside
+// Davidson runs; inside, k_dots_eig adds them as the first reader of the vector)
+struct OppReduceArgs {
+  GPtr<const MultiRow> rows;
+  GPtr<const double> partial;
+  GPtr<double> sigma;
+  int64_t nb;
+  GPtr<const int> stop, vec_index;
+  int64_t s_stride;
+};
+__global__ void __launch_bounds__(256) k_opp_reduce(const OppReduceArgs g) {
+  if (g.stop && *g.stop) return;
+  const MultiRow mr = g.rows[blockIdx.x];
+  double* __restrict__ sig = g.sigma + (g.vec_index ? (int64_t)(*g.vec_index - 1) * g.s_stride : 0) + (int64_t)mr.A * g.nb;
+  for (int64_t B = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; B < g.nb; B += (int64_t)gridDim.y * blockDim.x) {
+    double sacc = 0.0;
+    for (int j = 0; j < mr.nslots; ++j) sacc += g.partial[(int64_t)(mr.slot0 + j) * g.nb + B];
+    sig[B] = sacc;
+  }
+}
+
+// ---- host side
+static size_t opp_shmem(int64_t nb, int nn, int T) {
+  const int64_t nbe = (nb + 1) & ~int64_t(1);
+  const int64_t crows = nbe > (nb + T + 1) / 2 ? nbe : (nb + T + 2) / 2;  // Cst, or outb + tailb in its place
+  return (size_t)(crows * OPP_K + (int64_t)((nn + 1) & ~1) * OPP_K) * 8;
+}
+
+// phase 2 of set_subspace, behind spmm_select: is the opposite-spin part of this subspace taken by k_opp_rows?
+// (SQD_SIGMA_OPP=0 forbids: the work items then add G as they add the matrix-core product.)
+bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
+  c->sig_opp = false;
+  if (!c->sig_spmm) return false;
+  if (const char* env = std::getenv("SQD_SIGMA_OPP"))
+    if (std::atoi(env) == 0) return false;
+  const int64_t L = tot[2];  // beta single links
+  if (L < 1 || nb > 65535 || c->nnorb > 4095) return false;
+  if (!c->opp) c->opp = new OppState();
+  OppState* s = static_cast<OppState*>(c->opp);
+  // threads: 512 for short rows (four workgroups per CU), 1024 beyond (two); column ranges H so that a thread holds at
+  // most OPP_SMAX links
+  int T = (nb <= (int64_t)OPP_RMAX * 512 && L <= (int64_t)2 * OPP_SMAX * 512) ? 512 : 1024;
+  if (const char* env = std::getenv("SQD_OPP_T")) {  // tuning hook
+    const int v = std::atoi(env);
+    if ((v == 512 || v == 1024) && nb <= (int64_t)OPP_RMAX * v) T = v;
+  }
+  if (nb > (int64_t)OPP_RMAX * T) return false;
+  if (opp_shmem(nb, c->nnorb, T) + 1024 > (size_t)c->lds_bytes) return false;
+  const int H = (int)((L + (int64_t)OPP_SMAX * T - 1) / ((int64_t)OPP_SMAX * T));
+  if (H > 64) return false;
+  // cut the link list at column starts, as evenly as the columns allow
+  const int64_t* ps = c->h_sptr_b;
+  s->h_halves.assign((size_t)2 * (H + 1), 0);
+  int64_t B = 0, longest = 0;
+  for (int h = 1; h <= H; ++h) {
+    const int64_t want = (h == H) ? L : (L * h) / H;
+    while (B < nb && ps[B] < want) ++B;
+    if (h == H) B = nb;
+    s->h_halves[h] = ps[B];
+    s->h_halves[(size_t)(H + 1) + h] = B;
+    longest = std::max(longest, s->h_halves[h] - s->h_halves[h - 1]);
+  }
+  const int S = (int)((longest + T - 1) / T);
+  if (S > OPP_SMAX) return false;
+  s->H = H;
+  s->S = S < 1 ? 1 : S;
+  s->T = T;
+  s->shmem = opp_shmem(nb, c->nnorb, T);
+  // work items: a row's entries (itself + its alpha single links) in pieces of at most E, so that the rows of the
+  // Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain of 90 batches; a row in one
+  // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
+  // (measured, HF-centred N x N, us per sigma for E = 4 | 8 | 16 | 32: 1000: 260 | 222 | 202 | 195; 2000: 940 | 828 | 779 |
+  // 763; 3000: 2747 | 2437 | 2278 | 2209 -- profiles/r05/opp_probe.txt)
+  int E = 32;
+  if (const char* env = std::getenv("SQD_OPP_E")) {  // tuning hook
+    const int v = std::atoi(env);
+    if (v >= OPP_K && v <= 4096) E = v / OPP_K * OPP_K;
+  }
+  const int64_t* pa = c->h_sptr;
+  s->h_items.clear();
+  s->h_multi.clear();
+  s->h_rowinfo.assign((size_t)2 * na, 0);
+  int32_t nslots = 0;
+  for (int64_t A = 0; A < na; ++A) {
+    const int nent = 1 + (int)(pa[A + 1] - pa[A]);
+    const int pieces = (nent + E - 1) / E;
+    if (pieces == 1) {
+      s->h_items.push_back(OppItem{(uint32_t)A, 0, nent, -1});
+    } else {
+      s->h_multi.push_back(MultiRow{(uint32_t)A, nslots, pieces});
+      s->h_rowinfo[2 * A] = nslots;
+      s->h_rowinfo[2 * A + 1] = pieces;
+      for (int p = 0; p < pieces; ++p) {
+        const int e0 = p * E, ne = (nent - e0 < E) ? nent - e0 : E;
+        s->h_items.push_back(OppItem{(uint32_t)A, e0, ne, nslots++});
+      }
+    }
+  }
+  std::stable_sort(s->h_items.begin(), s->h_items.end(), [](const OppItem& a, const OppItem& b) { return a.ne > b.ne; });
+  s->n_items = (int64_t)s->h_items.size();
+  s->n_slots = nslots;
+  s->n_multi = (int64_t)s->h_multi.size();
+  c->sig_opp = true;
+  return true;
+}
+
+int opp_build(sqd_ctx* c) {
+  OppState* s = static_cast<OppState*>(c->opp);
+  const SpinTables& tb = c->sp[1];
+  const size_t nrec = (size_t)s->H * s->S * s->T;
+  SQD_TRY(s->link.reserve(nrec * 4 + 64));
+  SQD_TRY(s->lcol.reserve(nrec * 4 + 64));
+  SQD_TRY(s->back.reserve((size_t)s->H * s->T * 4 + 64));
+  SQD_TRY(s->items.reserve((size_t)s->n_items * sizeof(OppItem) + 64));
+  SQD_TRY(s->rowinfo.reserve((size_t)2 * c->na * 4 + 64));
+  SQD_TRY(s->multi.reserve((size_t)s->n_multi * sizeof(MultiRow) + 64));
+  SQD_TRY(s->partial.reserve((size_t)s->n_slots * c->nb * 8 + 64));
+  SQD_TRY(s->halves.reserve(s->h_halves.size() * 8));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->items.p, s->h_items.data(), (size_t)s->n_items * sizeof(OppItem), hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->rowinfo.p, s->h_rowinfo.data(), (size_t)2 * c->na * 4, hipMemcpyHostToDevice, c->stream));
+  if (s->n_multi)
+    SQD_HIP_CHECK(hipMemcpyAsync(s->multi.p, s->h_multi.data(), (size_t)s->n_multi * sizeof(MultiRow), hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->halves.p, s->h_halves.data(), s->h_halves.size() * 8, hipMemcpyHostToDevice, c->stream));
+  OppTabArgs a;
+  a.sb_ptr = tb.s_ptr.as<int64_t>();
+  a.sb_rec = tb.s_rec.as<SRec>();
+  a.sb_row = tb.s_row.as<uint32_t>();
+  a.halves = s->halves.as<int64_t>();
+  a.link = s->link.as<uint32_t>();
+  a.lcol = s->lcol.as<uint32_t>();
+  a.back = s->back.as<uint32_t>();
+  a.H = s->H;
+  a.S = s->S;
+  a.T = s->T;
+  hipLaunchKernelGGL(k_opp_tab, dim3((unsigned)((s->T + 255) / 256), (unsigned)s->H), dim3(256), 0, c->stream, a);
+  SQD_HIP_CHECK(hipGetLastError());
+  return SQD_OK;
+}
+
+// sigma = (hdiag + opposite-spin part) c + G, G = sqd_ctx::gdense as spmm_launch has just formed it for the same vector
+int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride) {
+  OppState* s = static_cast<OppState*>(c->opp);
+  if (!s) {
+    set_error("internal: opposite-spin row kernel without its tables");
+    return SQD_ERR_STATE;
+  }
+  OppArgs g;
+  const SpinTables& ta = c->sp[0];
+  const SpinTables& tb = c->sp[1];
+  g.c = d_c;
+  g.sigma = d_sigma;
+  g.hdiag = c->hdiag.as<double>();
+  g.gdense = c->gdense.as<double>();
+  g.ja_row = ta.jrow.as<double>();
+  g.jbT = tb.jT.as<double>();
+  g.eri_pp = c->eri_pp.as<double>();
+  g.sa_ptr = ta.s_ptr.as<int64_t>();
+  g.sa_rec = ta.s_rec.as<SRec>();
+  g.link = s->link.as<uint32_t>();
+  g.lcol = s->lcol.as<uint32_t>();
+  g.back = s->back.as<uint32_t>();
+  g.items = s->items.as<OppItem>();
+  g.partial = s->partial.as<double>();
+  g.colcut = s->halves.as<int64_t>() + (s->H + 1);
+  g.na = c->na;
+  g.nb = c->nb;
+  g.nnorb = c->nnorb;
+  g.S = s->S;
+  g.T = s->T;
+  g.H = s->H;
+  g.stop = c->sigma_stop;
+  const bool indexed = c->sigma_index && (in_stride || out_stride);
+  g.vec_index = indexed ? c->sigma_index : nullptr;
+  g.c_stride = in_stride;
+  g.s_stride = out_stride;
+  if (s->shmem > 64 * 1024) {
+    static std::atomic<size_t> granted[64];
+    const int dev = c->device & 63;
+    if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {
+      SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_opp_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)s->shmem));
+      granted[dev].store(s->shmem, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL(k_opp_rows, dim3((unsigned)s->n_items, (unsigned)s->H), dim3(s->T), s->shmem, c->stream, g);
+  SQD_HIP_CHECK(hipGetLastError());
+  // rows in several pieces: inside a Davidson run the first reader of the new vector adds the partial rows (opp_split)
+  if (s->n_multi > 0 && !(c->sigma_defer_reduce && indexed)) {
+    OppReduceArgs r;
+    r.rows = s->multi.as<MultiRow>();
+    r.partial = s->partial.as<double>();
+    r.sigma = d_sigma;
+    r.nb = c->nb;
+    r.stop = g.stop;
+    r.vec_index = g.vec_index;
+    r.s_stride = out_stride;
+    hipLaunchKernelGGL(k_opp_reduce, dim3((unsigned)s->n_multi, (unsigned)((c->nb + 1023) / 1024)), dim3(256), 0, c->stream, r);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (c->ev_after_sigma_kernel) {
+    SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+    c->ev_after_sigma_kernel = nullptr;
+  }
+  return SQD_OK;
+}
+
+// the split-row records of the latest opp_select (for k_dots_eig's deferred sum); false: every row is in one piece
+bool opp_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial) {
+  const OppState* s = static_cast<const OppState*>(c->opp);
+  if (!s || !c->sig_opp || s->n_multi == 0) return false;
+  *rowinfo = s->rowinfo.as<int32_t>();
+  *partial = s->partial.as<double>();
+  return true;
+}
+
+}  // namespace sqd

@@ -744,12 +744,13 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
   if (env) {
     on = std::atoi(env) != 0;
   } else {
-    // connected sets from ~10^3 strings per spin.  Measured on the MI355X (profiles/r05/connected_probe_*.txt, HF-centred
-    // N x N, us per sigma, this path (row groups) | matrix cores | sparse work items): 500: 98 | 67 | 73; 700: 145 | 111 |
-    // 125; 1000: 242 | 237 | 257; 2000: 1029 | 1305 | 1244; 3000: 2560 | 3747 | 5073.  Smaller sets stay with the matrix
-    // cores: one launch instead of three, and their blocks are 11-26 % dense.
+    // connected sets from ~900 strings per spin.  Measured on the MI355X (profiles/r05/, HF-centred N x N, us per sigma,
+    // this path with the whole-row opposite-spin kernel of sqd_opp.hip | matrix cores + work items | sparse work items):
+    // 1000: 195 | 237 | 257; 2000: 763 | 1305 | 1244; 3000: 2209 | 3747 | 5073 (500 / 700 with the work items behind the
+    // product: 98 | 67 | 73 and 145 | 111 | 125).  Smaller sets stay with the matrix cores: one launch instead of three,
+    // and their blocks are 11-26 % dense.
     const int64_t same_a = tot[0] + tot[1], same_b = tot[2] + tot[3];
-    on = na >= 1024 && nb >= 1024 && same_a >= 8 * na && same_b >= 8 * nb;
+    on = na >= 896 && nb >= 896 && same_a >= 8 * na && same_b >= 8 * nb;
   }
   c->sig_spmm = on;
   return on;

@@ -1295,6 +1295,7 @@ static int subspace_phase2_plan(sqd_ctx* c, SubspaceBuild& b, bool always_guess)
                       (std::getenv("SQD_SIGMA_SPMM") || !std::getenv("SQD_SIGMA_DENSE"));
     if (!spmm) c->sig_spmm = false;
     if (spmm) dense = false;
+    opp_select(c, na, nb, tot);  // (only with the sparse product: clears sig_opp otherwise)
     c->sig_dense = dense || spmm;
     if (dense) {
       c->dense_pa = (int)((na + 63) / 64 * 64);
@@ -1564,6 +1565,7 @@ int build_subspace(sqd_ctx* c, const uint64_t* sa, int64_t na, const uint64_t* s
   }
   if (c->sig_lists) SQD_TRY(lists_build(c));
   if (c->sig_spmm) SQD_TRY(spmm_build(c));
+  if (c->sig_opp) SQD_TRY(opp_build(c));
   if (b.have_dense) {
     hipLaunchKernelGGL(k_tables_dense, dim3(b.dense.gx, 2), dim3(256), 0, st, b.dense);
     SQD_HIP_CHECK(hipGetLastError());

@@ -258,12 +258,17 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
 
 @pytest.mark.parametrize("xcd,J,tiled", [("0", "2", "0"), ("1", "1", "0"), ("1", "4", "0"), ("1", "1", "1"), ("0", "1", "g"),
                                          ("1", "1", "g")])
-def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled):
+@pytest.mark.parametrize("opp", ["0", "1"])
+def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
     # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: merged CSR of both spins, C -> C^T, row
     # AXPYs on C and C^T, G += G2T^T, work items add ONE partial product) that connected sets from ~10^3 strings per
     # spin take by default.  Both task mappings (XCD split on / off), every panel width, ragged panels and tiles,
     # nalpha != nbeta, rows without links, all operator forms, a Davidson solve and the observables.
     monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
+    # opp = 1: the opposite-spin part and the diagonal by whole rows (sqd_opp.hip: beta links in registers, entries
+    # staged four at a time, per-link sums folded to columns) for the plain operator -- the default; the S^2 / penalty
+    # forms of the same tests still run the work items.  opp = 0: work items throughout.
+    monkeypatch.setenv("SQD_SIGMA_OPP", opp)
     monkeypatch.setenv("SQD_SPMM_XCD", xcd)
     monkeypatch.setenv("SQD_SPMM_J", J)
     # tiled = 1: the default product (k_spmm_tiled: operand rows through LDS tiles of 128 source rows, 16 targets per
@@ -281,7 +286,7 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled):
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == "k_spmm_rows+k_sigma", case
+            assert ctx.sigma_kernel() == ("k_spmm_rows+k_opp_rows" if opp == "1" else "k_spmm_rows+k_sigma"), case
     run_full_parity(emu_lib, *cases[0], variants=False)
     for case in cases[1:]:
         run_operator_parity(emu_lib, *case)

@@ -801,12 +801,13 @@ import functools  # noqa: E402
 _CONNECTED_MODES = {
     "mfma": ({"SQD_SIGMA_DENSE": "1"}, "k_same_spin_mfma+k_sigma"),
     "sparse": ({"SQD_SIGMA_DENSE": "0"}, "k_sigma"),
-    "spmm": ({"SQD_SIGMA_SPMM": "1"}, "k_spmm_rows+k_sigma"),
+    "spmm": ({"SQD_SIGMA_SPMM": "1"}, "k_spmm_rows+k_opp_rows"),
+    "spmm_items": ({"SQD_SIGMA_SPMM": "1", "SQD_SIGMA_OPP": "0"}, "k_spmm_rows+k_sigma"),
 }
 
 
 def _set_mode(monkeypatch, mode):
-    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM"):
+    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
         monkeypatch.delenv(k, raising=False)
     env, kernel = _CONNECTED_MODES[mode]
     for k, v in env.items():
@@ -830,7 +831,7 @@ def _connected_reference_1000():
     return h1, eri, sa, sb, x, ref, hd, float(e_ref), x_ref / np.linalg.norm(x_ref)
 
 
-@pytest.mark.parametrize("mode", ["mfma", "spmm", "sparse"])
+@pytest.mark.parametrize("mode", ["mfma", "spmm", "spmm_items", "sparse"])
 def test_connected_1000x1000_full_sigma_and_solve(hip_lib, monkeypatch, mode):
     """HF-centred 1000 x 1000 (D = 1e6, ~10 single + ~100 double links per string): the FULL sigma vector and hdiag
     against O1s, bitwise reproducibility, then one whole solve -- E0 against the oracle's own Davidson (1e-8 Ha; the
@@ -878,7 +879,7 @@ def _connected_reference_3000():
     return h1, eri, sa, sb, x, rows, cols, ref_rows, ref_cols
 
 
-@pytest.mark.parametrize("mode", ["spmm", "mfma", "sparse"])
+@pytest.mark.parametrize("mode", ["spmm", "spmm_items", "mfma", "sparse"])
 def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode):
     """HF-centred 3000 x 3000 (D = 9e6, 72 MB per vector; ~11 single + ~155 double links per string, same-spin blocks
     5.6 % dense -- the default here is the sparse product of sqd_spmm.hip): sigma on sampled rows AND sampled columns
