@@ -728,6 +728,32 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
   dots_eig_body<MV, true>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
 }
 
+// Single solves of large subspaces (D >= DOTS_SPLIT_D): dots and eigen step as two launches, as the batched solves run
+// them -- the eigen step's code holds the fused kernel at 232 VGPRs, i.e. ONE 512-thread workgroup per CU, and from
+// D ~ 5e5 on the launch is 512 workgroups of bandwidth-bound work (HF-centred 1000^2: 44 us of a 290 us iteration);
+// alone the dot products need 107 VGPRs.  The fold and the eigen step are the same code on the same partials: the same
+// bits as the fused kernel (tested).  Below that size the fused kernel saves a dispatch on a latency-bound chain.
+template <int MV>
+__global__ void __launch_bounds__(RED_T, 4) k_dots_s(int64_t n, const double* __restrict__ X, double* __restrict__ AX, int64_t stride,
+                                                      double* __restrict__ partial, int width, unsigned* counter, DavState* st,
+                                                      const DavParams prm, const SplitRows split) {
+  dots_eig_body<MV, false>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
+}
+template <int MV>
+__global__ void __launch_bounds__(RED_T) k_eig_s(const double* __restrict__ partial, int gb, int width, DavState* st,
+                                                  const DavParams prm) {
+  __shared__ double tot[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  __shared__ unsigned long long s_head[DAV_HEAD_WORDS];
+  __shared__ double s_heff[MV * MV];
+  if (st->stop) return;
+  const int nvec = st->m_next;
+  dav_state_prefetch<MV>(st, s_head, s_heff);
+  fold_partials<false>(partial, gb, width, nvec + 1, tot);
+  if (threadIdx.x >= 64) return;
+  wave_eig_step<MV>(st, s_head, s_heff, tot, prm, sA, sM, sv_eig);
+}
+
 // r = sum_v raw[v] (AX_v - e X_v);  t = r / (hdiag - e + 1e-4);  t stored to X[m].
 // partial[block*width + {0: |r|^2, 1: |t|^2, 2+v: X_v . t}]; k_orth_dev (next in the stream) folds them.
 // FOLD (row-sharded solves): the workgroup that arrives last folds the partials into tot_out (what the all-reduce over
@@ -1380,12 +1406,24 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     }
     return SQD_OK;
   };
+  static const int64_t dots_split_d = [] {  // tuning hook: subspace dimension from which dots and eigen step are two launches
+    const char* env = std::getenv("SQD_DOTS_SPLIT_D");
+    return env ? (int64_t)std::atoll(env) : (int64_t)500000;
+  }();
+  const bool split_dots = D >= dots_split_d;
   auto part_b = [&](int round) -> int {
     const long long seq = ++c->mail_seq;
     seq_of[round & 3] = seq;
     if (max_space <= 12) {
-      hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
-                         c->partial.as<double>(), width, counter, dst, prm, split);
+      if (split_dots) {
+        hipLaunchKernelGGL((k_dots_s<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                           c->partial.as<double>(), width, counter, dst, prm, split);
+        hipLaunchKernelGGL((k_eig_s<13>), dim3(1), dim3(RED_T), 0, s, (const double*)c->partial.as<double>(), (int)gb, width, dst,
+                           prm);
+      } else {
+        hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                           c->partial.as<double>(), width, counter, dst, prm, split);
+      }
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
                          (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
       hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,

@@ -344,6 +344,8 @@ extern "C" __attribute__((visibility("default"))) int sqd_choice_replay(const do
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <new>
+#include <pthread.h>
 #include <thread>
 
 namespace sqd {
@@ -439,14 +441,17 @@ struct HashPool {
       j->done.fetch_add(1, std::memory_order_release);
     }
   }
-  void worker() {
+  void worker(unsigned index) {
     uint64_t seen = 0;
     std::vector<HashJob*> mine;
     for (;;) {
-      // spin briefly: the next job of a solve loop arrives within ~0.2 ms
+      // ONE worker spins briefly (the next job of a solve loop arrives within ~0.2 ms, and the caller's thread hashes
+      // too); the others sleep on the condition variable at once: three to six threads spinning beside every solve
+      // took CPU from the HIP runtime's own threads
+      const auto spin = std::chrono::microseconds(index == 0 ? 300 : 0);
       const auto t0 = std::chrono::steady_clock::now();
       while (epoch.load(std::memory_order_acquire) == seen) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+        if (std::chrono::steady_clock::now() - t0 >= spin) {
           std::unique_lock<std::mutex> lk(mu);
           cv.wait(lk, [&] { return quit || epoch.load(std::memory_order_acquire) != seen; });
           if (quit) return;
@@ -474,8 +479,14 @@ struct HashPool {
     unsigned hw = std::thread::hardware_concurrency();
     unsigned nt = hw >= 32 ? 6 : (hw >= 8 ? 3 : 1);
     if (const char* env = std::getenv("SQD_HASH_THREADS")) nt = (unsigned)std::max(0, std::atoi(env));
-    for (unsigned i = 0; i < nt; ++i) workers.emplace_back([this] { worker(); });
+    for (unsigned i = 0; i < nt; ++i) workers.emplace_back([this, i] { worker(i); });
+    static std::once_flag once;
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, &HashPool::after_fork_in_child); });
   }
+  // fork(): the child has the pool's memory but none of its threads, and `mu` may have been held by one of them at the
+  // moment of the fork.  The child starts over with a fresh pool in the same storage (the old thread handles are
+  // abandoned, not destroyed: their threads do not exist here).
+  static void after_fork_in_child();
   void start(HashJob* j) {
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -511,6 +522,7 @@ HashPool& hash_pool() {
   static HashPool* pool = new HashPool();  // (never destroyed: worker threads may outlive static destruction order)
   return *pool;
 }
+void HashPool::after_fork_in_child() { new (&hash_pool()) HashPool(); }
 uint64_t fold_parts(const HashJob& j, int a) {
   const size_t b = a ? j.pieces[0] : 0;
   uint64_t h = HP3 ^ (uint64_t)j.n[a];

@@ -564,11 +564,12 @@ def _davidson_kwargs(kwargs: dict) -> dict:
         raise TypeError(f"unexpected keyword argument(s) for kernel_fixed_space: {sorted(unknown)}")
     nroots = kwargs.get("nroots")
     if nroots not in (None, 1):
-        # the reference forwards nroots to pyscf (fermion.py:722) but everything downstream of that call reads ONE
-        # state (amplitudes -> SCIState, RDMs, energy: :724-742): the lowest root is what a caller gets here too
-        import warnings
-
-        warnings.warn(f"nroots={nroots}: only the lowest root is computed and returned", stacklevel=3)
+        # pyscf returns lists of energies and vectors for nroots > 1; this solver computes one state.  Saying so beats
+        # handing back a ground state that looks like the answer to a different question.
+        raise NotImplementedError(f"nroots={nroots}: this solver computes the lowest root only (single-root Davidson)")
+    for k in ("orbsym", "wfnsym"):
+        if kwargs.get(k) is not None:
+            raise NotImplementedError(f"{k}: point-group symmetry restrictions are not implemented in this solver")
     out = {}
     for k in ("tol", "tol_residual", "lindep", "max_cycle", "max_space"):
         if kwargs.get(k) is not None:
@@ -602,7 +603,7 @@ def last_solve_stats() -> dict | None:
     return getattr(_TLS, "stats", None)
 
 
-def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True, spin_square=True):
+def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True, spin_square=True, validated=False):
     """Shared core: tables -> Davidson (-> energy, <S^2>, occupancies in the same native call), all on the
     device.  Returns (amps, stats, obs) with obs = (energy, spin_square, occ_a, occ_b) or None."""
     dk = _davidson_kwargs(kwargs)
@@ -611,9 +612,11 @@ def _solve(ctx: _capi.Context, ci_strs, spin_sq, shift, kwargs, observables=True
         dk["time_sigma_every"] = _PROFILE["time_sigma_every"]
     if observables:  # tables + Davidson + observables: one native call
         ctx.set_async_state(_ASYNC_STATE)
-        # (ci_strs went through _check_ci_strs: ascending, non-negative -- no second pass in the binding)
-        out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square, validated=True,
-                        **dk)
+        # (validated: ci_strs went through _check_ci_strs -- ascending, non-negative -- and the binding makes no second
+        # pass; caller-supplied lists (solve_sci) are checked for negative entries there, for order and Hamming weight
+        # by the native build)
+        out = ctx.solve(ci_strs[0], ci_strs[1], ci0, spin_sq=spin_sq, shift=shift, spin_square=spin_square,
+                        validated=validated, **dk)
         _TLS.stats = out[1]
         ticket = out[1].get("state_ticket", 0)
         if ticket:  # the state is still landing in out[0]: wrapped, the first read of SCIState.amplitudes waits
@@ -845,7 +848,7 @@ def solve_fermion(
     # one native call (sqd_solve): Davidson, then <c|H|c> (the quantity the reference rebuilds from
     # rdm1/rdm2, :825-827), <S^2> (:830) and the rdm1s diagonals (:821-822) while the amplitudes travel
     (amps, _stats, (e_sci, spin_squared, occ_a, occ_b)), ctx = _run_on_context(
-        hcore, eri, device, 0, lambda c: _solve(c, ci_strs, spin_sq, shift, kwargs))
+        hcore, eri, device, 0, lambda c: _solve(c, ci_strs, spin_sq, shift, kwargs, validated=True))
     num_up, num_dn = ctx.nelec
     avg_occupancy = (occ_a, occ_b)
     sci_state = SCIState(

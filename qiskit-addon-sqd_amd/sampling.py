@@ -158,19 +158,27 @@ def _choice_native(rng, probabilities, size: int, nbatches: int):
     p = np.ascontiguousarray(probabilities, dtype=np.float64)
     if p.ndim != 1 or size > p.size:
         return None
-    # (a batch takes `size` doubles plus a few per round with two draws on one element; beyond this bound: numpy's turn)
-    bound = int(nbatches) * (int(size) * (int(size) + 1) // 2 if size < 64 else 4 * int(size) + 64)
+    # A batch takes `size` doubles plus a few per round with two draws on one element.  The block of uniforms is drawn
+    # with a modest slack first (1.25 size + 64 per batch: 1 MB for ten batches of 1e4, not the 4 size + 64 worst case up
+    # front) and once more at the worst case if the replay ran out; beyond that: numpy's turn.
     state = bitgen.state
-    uniforms = rng.random(bound)
     out = np.empty((int(nbatches), int(size)), dtype=np.int64)
     used = capi.C.c_int64(0)
-    rc = lib.sqd_choice_replay(p.ctypes.data, p.size, int(size), int(nbatches), uniforms.ctypes.data, uniforms.size,
-                               out.ctypes.data, capi.C.byref(used))
-    if rc != 0:  # numpy raises on these inputs, or the block was too short (many collisions): numpy does the draw
-        bitgen.state = state
-        return None
-    bitgen.advance(-(bound - used.value))
-    return out
+    small = int(size) * (int(size) + 1) // 2
+    for per_batch in ((small,) if size < 64 else (int(size) + int(size) // 4 + 64, 4 * int(size) + 64)):
+        bound = int(nbatches) * per_batch
+        uniforms = rng.random(bound)
+        rc = lib.sqd_choice_replay(p.ctypes.data, p.size, int(size), int(nbatches), uniforms.ctypes.data, uniforms.size,
+                                   out.ctypes.data, capi.C.byref(used))
+        if rc == 0:
+            bitgen.advance(-(bound - used.value))
+            # (advance() clears PCG64's cached 32-bit half; numpy's own choice() draws doubles only and leaves it alone)
+            after = bitgen.state
+            after["has_uint32"], after["uinteger"] = state["has_uint32"], state["uinteger"]
+            bitgen.state = after
+            return out
+        bitgen.state = state  # numpy raises on these inputs, or the block was too short (many collisions)
+    return None
 
 
 # ----------------------------------------------------------------------------- configuration recovery

@@ -110,8 +110,13 @@ def test_python_api_through_emulator(emu_backend):
     import dataclasses
     assert [f.name for f in dataclasses.fields(SCIResult)] == ["energy", "sci_state", "orbital_occupancies", "rdm1", "rdm2"]
     assert len(dataclasses.astuple(lazy)) == 5 and dataclasses.replace(eager, energy=0.0).energy == 0.0
-    with pytest.warns(UserWarning, match="lowest root"):
-        assert abs(solve_sci((sa, sb), h1, eri, norb, nelec, nroots=2).energy - res.energy) < 1e-10
+    with pytest.raises(NotImplementedError, match="lowest root"):
+        solve_sci((sa, sb), h1, eri, norb, nelec, nroots=2)
+    with pytest.raises(NotImplementedError, match="symmetry"):
+        solve_sci((sa, sb), h1, eri, norb, nelec, wfnsym="A1g")
+    assert abs(solve_sci((sa, sb), h1, eri, norb, nelec, nroots=1, pspace_size=400).energy - res.energy) < 1e-10
+    with pytest.raises(ValueError, match="non-negative"):
+        solve_sci((np.array([-3, 1, 2]), sb), h1, eri, norb, nelec)
     assert abs(eager.energy - res.energy) < 1e-10
     assert np.allclose(eager.rdm1, res.rdm1, atol=1e-12) and np.allclose(eager.rdm2, res.rdm2, atol=1e-12)
     assert np.allclose(res.sci_state.orbital_occupancies()[0], res.orbital_occupancies[0], atol=1e-12)
