@@ -220,6 +220,11 @@ int sqd_davidson(sqd_ctx* ctx, const sqd_davidson_opts* opts, const double* ci0,
 int sqd_shard_dav_begin(sqd_ctx* ctx, const sqd_davidson_opts* opts, double** d_x0_rows);
 int sqd_shard_dav_pick(sqd_ctx* ctx, double** d_send_rows);
 int sqd_shard_dav_sigma(sqd_ctx* ctx, const double* d_c_full);
+/* The sigma stage in two calls around the all-gather, so that the gather overlaps the work that needs no remote row
+   (reference contract: docs/guides/hpc_acceleration.rst:52-57, the collective sci_solver): part 1 -- d_c_full may be
+   NULL -- right behind sqd_shard_dav_pick, on the rows in the send buffer; part 2 with the gathered vector.  part 0 =
+   sqd_shard_dav_sigma.  Bit-identical to the one-call stage. */
+int sqd_shard_dav_sigma_part(sqd_ctx* ctx, const double* d_c_full, int part);
 int sqd_shard_dav_dots(sqd_ctx* ctx, double** d_totals, int* count);
 int sqd_shard_dav_residual(sqd_ctx* ctx, double** d_totals, int* count);
 int sqd_shard_dav_orth(sqd_ctx* ctx, long long* ticket);

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "sqd_shard_dav_begin",
     "sqd_shard_dav_pick",
     "sqd_shard_dav_sigma",
+    "sqd_shard_dav_sigma_part",
     "sqd_shard_dav_dots",
     "sqd_shard_dav_residual",
     "sqd_shard_dav_orth",
@@ -153,6 +154,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_shard_dav_begin.argtypes = [_ctxp, C.POINTER(DavidsonOpts), C.POINTER(C.c_void_p)]
     lib.sqd_shard_dav_pick.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
     lib.sqd_shard_dav_sigma.argtypes = [_ctxp, C.c_void_p]
+    lib.sqd_shard_dav_sigma_part.argtypes = [_ctxp, C.c_void_p, C.c_int]
     lib.sqd_shard_dav_dots.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.sqd_shard_dav_residual.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.sqd_shard_dav_orth.argtypes = [_ctxp, C.POINTER(C.c_longlong)]
@@ -557,8 +559,8 @@ class Context:
                 check(rc)
             return out.value
 
-        def sigma(ptr):
-            rc = f_sigma(h, ptr)
+        def sigma(ptr, part=0):
+            rc = f_sigma(h, ptr) if part == 0 else lib.sqd_shard_dav_sigma_part(h, ptr, part)
             if rc:
                 check(rc)
 

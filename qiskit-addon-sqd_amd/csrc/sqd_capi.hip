@@ -379,6 +379,10 @@ SQD_API int sqd_shard_dav_sigma(sqd_ctx* c, const double* d_c_full) {
   if (!d_c_full) return SQD_ERR_INVALID;
   return shard_dav_sigma(c, d_c_full);
 }
+SQD_API int sqd_shard_dav_sigma_part(sqd_ctx* c, const double* d_c_full, int part) {
+  CTX_ENTER(c);
+  return shard_dav_sigma(c, d_c_full, part);
+}
 SQD_API int sqd_shard_dav_dots(sqd_ctx* c, double** d_totals, int* count) {
   CTX_ENTER(c);
   if (!d_totals || !count) return SQD_ERR_INVALID;

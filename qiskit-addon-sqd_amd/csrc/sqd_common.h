@@ -255,6 +255,10 @@ struct sqd_ctx {
   // the work items, for the plain operator (H without a spin penalty; S^2 and the penalty forms keep the work items)
   bool sig_opp = false;
   void* opp = nullptr;           // sqd::OppState (sqd_opp.hip)
+  // row-sharded Davidson, sigma in two launches around the all-gather (shard_dav_sigma_part): 0 = one launch, 1 = the part
+  // that needs only this rank's rows (input: sig_c_own), 2 = the rest; read by fill_sigma_args / launch_sigma
+  int sig_part = 0;
+  const double* sig_c_own = nullptr;
   int64_t sig_chunk = 0;         // columns per chunk (>= nb when there is one chunk)
   int sig_nchunks = 1;
   // LDS capacity (in virtual rows) of the singles' / doubles' partial-sum arrays; a chunk with more
@@ -398,7 +402,7 @@ int davidson_collect(sqd_ctx* c, sqd_davidson_stats* st);
 // row-sharded Davidson, stage by stage (sqd_shard_dav_* of the C ABI)
 int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0);
 int shard_dav_pick(sqd_ctx* c, double** d_send);
-int shard_dav_sigma(sqd_ctx* c, const double* d_full);
+int shard_dav_sigma(sqd_ctx* c, const double* d_full, int part = 0);
 int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count);
 int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count);
 int shard_dav_orth(sqd_ctx* c, long long* seq_out);

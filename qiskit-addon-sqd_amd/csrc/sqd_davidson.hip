@@ -1746,13 +1746,28 @@ int shard_dav_pick(sqd_ctx* c, double** d_send) {
 // split rows of the sigma vector are summed by the dots stage (as in the single solver: no k_sigma_reduce launch) unless the
 // squared-penalty form chains several sigma launches through scratch vectors
 static bool shard_defers_reduce(const sqd_ctx* c) { return c->n_multi > 0 && c->shard_form != 2 && !c->sig_direct && c->sig_rows == 0; }
-int shard_dav_sigma(sqd_ctx* c, const double* d_full) {
+// part 0: the whole sigma build on the gathered vector.  Parts 1 and 2 (both called, in this order, around the
+// all-gather): 1 needs only this rank's rows of the vector -- they lie in the send buffer the pick stage returned -- and
+// runs WHILE the gather is in flight: the own-row work items (diagonal, beta links, beta singles x alpha occupation)
+// without their folded alpha links; 2, behind the gather, everything that reads other ranks' rows.  The squared
+// penalty form chains three operators through scratch vectors and takes part 2 whole.  Same bits as part 0.
+int shard_dav_sigma(sqd_ctx* c, const double* d_full, int part) {
   SQD_TRY(shard_check(c));
+  if (part < 0 || part > 2) {
+    set_error("shard_dav_sigma: part must be 0, 1 or 2");
+    return SQD_ERR_INVALID;
+  }
+  const bool splittable = c->shard_form != 2;
+  if (part == 1 && !splittable) return SQD_OK;
   DavState* dst = state_ptr_dev(c);
   c->sigma_stop = &dst->stop;
   c->sigma_index = &dst->m_next;
   c->sigma_defer_reduce = shard_defers_reduce(c);
+  c->sig_part = splittable ? part : 0;
+  c->sig_c_own = (part == 1) ? c->tmp1.as<double>() : nullptr;
   const int rc = apply_h(c, d_full, c->AX.as<double>(), c->shard_form, c->shard_ss, c->shard_shift, 0, c->shard_Dl);
+  c->sig_part = 0;
+  c->sig_c_own = nullptr;
   c->sigma_stop = nullptr;
   c->sigma_index = nullptr;
   c->sigma_defer_reduce = false;

@@ -82,6 +82,14 @@ struct SigmaArgs {
   GPtr<const double> gdense;
   int64_t gdense_stride;
   int gsplit;  // partial products to add: DENSE_SPLIT (matrix cores) or 1 (the sparse product of sqd_spmm.hip)
+  // row-sharded solves, sigma in two launches around the all-gather of the input vector (sqd_shard_dav_sigma_part):
+  //   own_mode 1 -- in front of the gather: own-row items only, on the rows this rank owns (c_own: the rank's own rows of
+  //                 the vector, (row0 .. row1) x nb), without their folded alpha links;
+  //   own_mode 2 -- behind it: every other item, and the own-row items add their folded alpha links onto the element
+  //                 they have written (a_partial + chunk sum: the order of the one-launch kernel, the same bits).
+  // mask_skip: items outside type_mask return without writing (the profiling hook writes zeros instead).
+  GPtr<const double> c_own;
+  int own_mode, mask_skip;
   // launch geometry of THIS subspace: threads that work (a batched launch uses the largest workgroup of its class; the
   // surplus threads of a smaller subspace idle), work items, column chunks
   int T;
@@ -361,15 +369,26 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
 #endif
 
   if (!((g.type_mask >> it.type) & 1)) {
+    if (g.mask_skip) return;  // (uniform over the workgroup; nothing staged, no barrier met yet)
     // profiling hook only: skipped item classes write zeros
+  } else if (it.type == 0 && g.own_mode == 2) {
+    // behind the all-gather: the folded alpha links of an own-row item, added onto what the first launch wrote
+    if (it.count == 0) return;
+    double* __restrict__ o2 = (it.slot < 0) ? (sigma_out + (A - g.row0) * nb) : (g.partial + (int64_t)it.slot * nb);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t B = B0 + tid + (int64_t)r * T;
+      if (B < Bend) o2[B] += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
+    }
+    return;
   } else if (it.type == 0) {
     // ---- own row: slot 0 <- C[A,:], W2 slot 0 <- Ja[A][:]
     const uint64_t sA = g.strs_a[A];
     // the own row and the diagonal are touched exactly once per sigma: stream them past the L2
     // (non-temporal) so that the link lists, which every workgroup re-reads, stay resident
-    const double* crow0 = C + A * nb;
+    const double* crow0 = g.c_own ? (const double*)g.c_own + (A - g.row0) * nb : C + A * nb;
     if (LDSROW) {
-      for (int64_t i = tid; i < nb; i += T) Crow[i] = __builtin_nontemporal_load(&C[A * nb + i]);
+      for (int64_t i = tid; i < nb; i += T) Crow[i] = __builtin_nontemporal_load(&crow0[i]);
     }
     if (g.mode == 0)
       for (int i = tid; i < nnorb; i += T) {
@@ -418,7 +437,7 @@ __device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx,
           a += own_rows_sum(g.vs_own, B, part_s, vs0, s1);
           a += own_rows_sum(g.vd_own, B, part_d, vd0, d1);
           // first same-spin alpha links of this row: unit-stride row reads
-          a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
+          if (g.own_mode != 1) a += axpy_chunk(C, g.ha_src, g.ha_val, it.begin, it.count, nb, B);
           // dense same-spin mode: the whole same-spin part of this element, from the matrix-core product
           if (g.gdense) {
             if (g.gsplit == 1) {  // (uniform)
@@ -1225,6 +1244,19 @@ static void fill_sigma_args(sqd_ctx* c, const double* d_c, double* d_sigma, int 
   g.gdense = (c->sig_dense && mode == 0) ? c->gdense.as<double>() : nullptr;
   g.gdense_stride = c->na * c->nb;
   g.gsplit = c->sig_spmm ? 1 : DENSE_SPLIT;
+  g.c_own = nullptr;
+  g.own_mode = 0;
+  g.mask_skip = 0;
+  if (c->sig_part == 1) {  // in front of the all-gather: own-row items on the rank's own rows
+    g.c_own = c->sig_c_own;
+    g.own_mode = 1;
+    g.type_mask = 1;
+    g.mask_skip = 1;
+  } else if (c->sig_part == 2) {  // behind it: the rest
+    g.own_mode = 2;
+    g.type_mask = 7;
+    g.mask_skip = 1;
+  }
 }
 // arguments of the matrix-core same-spin product for the vector the work items of the same sigma build will read
 static void fill_dense_args(sqd_ctx* c, const double* d_c, int64_t in_stride, DenseArgs* dp) {
@@ -1267,6 +1299,10 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
     set_error("no subspace set");
     return SQD_ERR_STATE;
   }
+  // (two-launch sigma of a row shard: only the work-item kernel has a part that needs no remote row; the others run whole
+  // behind the gather)
+  const bool items_kernel = !c->sig_lists && !c->sig_direct;
+  if (c->sig_part == 1 && !items_kernel) return SQD_OK;
   if (c->sig_lists) return launch_sigma_lists(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_opp && mode == 0 && !spin) {
@@ -1294,7 +1330,7 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   else if (R <= 8) rc = launch_sigma_r<8>(c, g);
   else rc = launch_sigma_r<16>(c, g);
   if (rc != SQD_OK) return rc;
-  if (sigma_needs_reduce(c, mode, g.vec_index != nullptr)) {
+  if (c->sig_part != 1 && sigma_needs_reduce(c, mode, g.vec_index != nullptr)) {
     ReduceArgs r;
     fill_reduce_args(c, d_sigma, g, &r);
     hipLaunchKernelGGL(k_sigma_reduce, dim3(r.gx, r.gy), dim3(512), 0, c->stream, r);

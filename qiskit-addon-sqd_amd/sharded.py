@@ -30,10 +30,16 @@ projected matrix (one matrix-vector product + one all-reduce), and ``{|r|^2, |t|
 everything else (Ritz vector, residual, preconditioner, Gram-Schmidt) is a handful of device-side matrix-vector
 products with the coefficients uploaded once; the correction is orthogonalised with the known norm ``1 - sum g^2`` as
 the single-GPU solver does; the solver context is cached per (Hamiltonian, group); the squared spin penalty is applied
-through two gathers.  Still host-controlled, and the all-gather is not overlapped with the beta-side work.
+through two gathers.
+
+Round 5: the all-gather of a sigma build is overlapped with the work that needs no remote row -- the sigma stage is two
+native calls around it (``sqd_shard_dav_sigma_part``: own-row work items on the send buffer first, everything that
+reads gathered rows behind the collective), bit-identical to the one-call stage.
 """
 
 from __future__ import annotations
+
+import os as _os
 
 import numpy as np
 
@@ -169,6 +175,40 @@ class ShardedSubspace:
             for (lo, hi), buf in zip(self._sizes, bufs):
                 self._full[lo:hi] = buf[: hi - lo]
         return self._full
+
+    def gather_rows_async(self, shard):
+        """The same all-gather, started and not waited for: returns ``finish() -> full matrix``.  Between the two the caller
+        enqueues the part of the sigma build that reads only this rank's rows (``shard_dav_sigma_part(.., 1)``) -- on the GPU
+        the collective runs on RCCL's stream, ``finish`` makes the current stream wait for it."""
+        import torch
+
+        dist = _dist()
+        self.n_allgather += 1
+        if self.world == 1 and not self._force:
+            return lambda: shard
+        equal = all(hi - lo == self.nrows for lo, hi in self._sizes)
+        if self.on_gpu and equal:
+            work = dist.all_gather_into_tensor(self._full, shard.contiguous(), group=self.group, async_op=True)
+            bufs = None
+        elif self.on_gpu:
+            work = dist.all_gather([self._full[lo:hi] for lo, hi in self._sizes], shard.contiguous(), group=self.group,
+                                   async_op=True)
+            bufs = None
+        else:
+            rows = max(hi - lo for lo, hi in self._sizes)
+            pad = torch.zeros((rows, self.nb), dtype=torch.float64)
+            pad[: self.nrows] = shard
+            bufs = [torch.empty_like(pad) for _ in range(self.world)]
+            work = dist.all_gather(bufs, pad, group=self.group, async_op=True)
+
+        def finish():
+            work.wait()
+            if bufs is not None:
+                for (lo, hi), buf in zip(self._sizes, bufs):
+                    self._full[lo:hi] = buf[: hi - lo]
+            return self._full
+
+        return finish
 
     def allreduce(self, t):
         if self.world > 1 or self._force:
@@ -335,6 +375,7 @@ def solve_sci_sharded(
 
             st_pick, st_sigma, st_dots, st_residual, st_orth = sub.ctx.shard_dav_stages()
             alone = sub.world == 1 and not sub._force  # a group of one: every collective is the identity
+            overlap = _os.environ.get("SQD_SHARD_OVERLAP", "1") != "0"  # (probe switch)
 
             def enqueue_iteration() -> int:
                 p = st_pick()
@@ -344,8 +385,14 @@ def solve_sci_sharded(
                     st_dots()
                     st_residual()
                     return st_orth()
-                full = sub.gather_rows(view(p, (sub.nrows, sub.nb)))
-                st_sigma(full.data_ptr())
+                # the all-gather of the newest vector is started, the part of the sigma build that reads only this rank's
+                # rows (own-row work items: diagonal, beta links) runs while it is in flight, the rest behind it
+                finish = sub.gather_rows_async(view(p, (sub.nrows, sub.nb)))
+                if overlap:
+                    st_sigma(None, 1)
+                    st_sigma(finish().data_ptr(), 2)
+                else:
+                    st_sigma(finish().data_ptr())
                 p, n = st_dots()
                 sub.allreduce(view(p, (n,)))
                 p, n = st_residual()

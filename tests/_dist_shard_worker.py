@@ -88,6 +88,17 @@ def main():
     assert rn._sharded_stats["converged"] and rt._sharded_stats["converged"]
     assert abs(rn.energy - rt.energy) < 5e-7  # (with a penalty <c|H|c> is first order in the residual, 1e-6)
     assert abs(abs(np.vdot(rn.sci_state.amplitudes, rt.sci_state.amplitudes)) - 1.0) < 1e-6
+    # the sigma stage as two native calls around the all-gather (the default: the gather overlaps the own-row work items)
+    # against the one-call stage behind the gather: the same bits, energy and state, with and without the linear penalty
+    import qiskit_addon_sqd_amd.sharded as SH
+    for spin_sq in (None, 0.0):
+        outs = []
+        for ov in ("1", "0"):
+            os.environ["SQD_SHARD_OVERLAP"] = ov
+            r = solve_sci_sharded((sa, sb), h1, eri, norb, nelec, spin_sq=spin_sq, lib=emu)
+            outs.append((float(r.energy), r.sci_state.amplitudes.copy(), r._sharded_stats["n_sigma"]))
+        os.environ.pop("SQD_SHARD_OVERLAP")
+        assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2] and np.array_equal(outs[0][1], outs[1][1]), spin_sq
     # sharded state only
     part = solve_sci_sharded((sa, sb), h1, eri, norb, nelec, gather_state=False, lib=emu)
     assert part.sci_state.amplitudes.shape == (hi - lo, 11)

@@ -660,6 +660,44 @@ def test_row_sharded_sigma_on_gpu(hip_lib, monkeypatch):
     assert np.allclose(res.orbital_occupancies[0], ref.orbital_occupancies[0], atol=5e-6)
 
 
+def test_row_sharded_overlap_hf_1000_on_gpu(hip_lib, monkeypatch):
+    """The collective row-sharded solver on a CONNECTED subspace, HF-centred 1000 x 1000 (D = 1e6), with its collectives
+    really issued on an RCCL group of one (SQD_SHARD_FORCE_COLLECTIVES): the sigma stage runs as two native calls around
+    the asynchronous all-gather (own-row work items on the send buffer while the gather is in flight, the rest behind
+    it).  Same energy and state as the one-call stage (bit for bit) and as the single-GPU solver (1e-8)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from qiskit_addon_sqd_amd.fermion import solve_sci
+    from qiskit_addon_sqd_amd.sharded import solve_sci_sharded
+
+    norb, nelec = 30, (8, 8)
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, 1000, 11), O.hf_centred_strings(norb, 8, 1000, 13)
+    ref = solve_sci((sa, sb), h1, eri, norb, nelec, compute_rdms=False)
+    monkeypatch.setenv("SQD_SHARD_FORCE_COLLECTIVES", "1")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        out = {}
+        for ov in ("1", "0"):
+            monkeypatch.setenv("SQD_SHARD_OVERLAP", ov)
+            out[ov] = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+    finally:
+        dist.destroy_process_group()
+    a, b = out["1"], out["0"]
+    assert a._sharded_stats["converged"] and a._sharded_stats["n_allgather"] >= a._sharded_stats["n_sigma"]
+    assert a.energy == b.energy and np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
+    assert abs(a.energy - ref.energy) < 1e-8
+    assert abs(abs(np.vdot(a.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
+
+
 def test_config2_full_size_1e4_x_1e4(hip_lib):
     """BASELINE config 2 read literally: N2-sized (16e,30o), 10^4 uniform-random strings per spin, D = 10^8 (800 MB
     per vector) on one MI355X.  Kernel selection; sigma rows against the row-restricted string-space oracle (O1s,
