@@ -1301,8 +1301,15 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   }
   // (two-launch sigma of a row shard: only the work-item kernel has a part that needs no remote row; the others run whole
   // behind the gather)
-  const bool items_kernel = !c->sig_lists && !c->sig_direct;
-  if (c->sig_part == 1 && !items_kernel) return SQD_OK;
+  // (a context that holds ALL rows may also have chosen a dense / sparse-product same-spin formulation: whole as well)
+  const bool can_split = !c->sig_lists && !c->sig_direct && !c->sig_dense && !c->sig_opp;
+  if (c->sig_part == 1 && !can_split) return SQD_OK;
+  struct PartGuard {  // parts of a kernel that cannot be split: the second call runs everything
+    sqd_ctx* c;
+    int saved;
+    ~PartGuard() { c->sig_part = saved; }
+  } part_guard{c, c->sig_part};
+  if (!can_split) c->sig_part = 0;
   if (c->sig_lists) return launch_sigma_lists(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_opp && mode == 0 && !spin) {

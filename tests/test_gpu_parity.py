@@ -686,16 +686,27 @@ def test_row_sharded_overlap_hf_1000_on_gpu(hip_lib, monkeypatch):
                             device_id=torch.device("cuda", 0))
     try:
         out = {}
-        for ov in ("1", "0"):
-            monkeypatch.setenv("SQD_SHARD_OVERLAP", ov)
-            out[ov] = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+        # "items": the sparse work items, the kernel a real row shard runs and the one whose own-row items run in front of
+        # the gather; "default": a group of one holds all rows and takes the sparse-product path, which runs whole
+        # behind the gather (the two-call protocol must still be right)
+        for kern in ("items", "default"):
+            if kern == "items":
+                monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
+                monkeypatch.setenv("SQD_SIGMA_SPMM", "0")
+            else:
+                monkeypatch.delenv("SQD_SIGMA_DENSE")
+                monkeypatch.delenv("SQD_SIGMA_SPMM")
+            for ov in ("1", "0"):
+                monkeypatch.setenv("SQD_SHARD_OVERLAP", ov)
+                out[kern, ov] = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
     finally:
         dist.destroy_process_group()
-    a, b = out["1"], out["0"]
-    assert a._sharded_stats["converged"] and a._sharded_stats["n_allgather"] >= a._sharded_stats["n_sigma"]
-    assert a.energy == b.energy and np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
-    assert abs(a.energy - ref.energy) < 1e-8
-    assert abs(abs(np.vdot(a.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
+    for kern in ("items", "default"):
+        a, b = out[kern, "1"], out[kern, "0"]
+        assert a._sharded_stats["converged"] and a._sharded_stats["n_allgather"] >= a._sharded_stats["n_sigma"]
+        assert a.energy == b.energy and np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
+        assert abs(a.energy - ref.energy) < 1e-8
+        assert abs(abs(np.vdot(a.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
 
 
 def test_config2_full_size_1e4_x_1e4(hip_lib):
