@@ -30,7 +30,8 @@
 
 namespace sqd {
 
-constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather each)
+constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather per operand; 4 measured slower: 219 | 817 | 2319 us per sigma at 1000^2 | 2000^2 | 3000^2 against 195 | 763 | 2209)
+static_assert(OPP_K % 2 == 0, "entries are staged and gathered in pairs");
 constexpr int OPP_SMAX = 20;  // beta links per thread
 constexpr int OPP_RMAX = 4;   // columns per thread in the coalesced passes (nb <= OPP_RMAX * threads)
 constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30;
@@ -166,9 +167,15 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
     }
     // weight rows, then the source rows (signed), both interleaved; the alpha single x beta occupation term rides on
     // the pass over the source rows (own columns)
-    for (int i = tid; i < nn; i += T)
-      *reinterpret_cast<double2*>(Wst + (int64_t)i * OPP_K) =
-          make_double2(sg[0] != 0.0 ? wrow[0][i] : 0.0, sg[1] != 0.0 ? wrow[1][i] : 0.0);
+    for (int i = tid; i < nn; i += T) {
+      double w[OPP_K];
+#pragma unroll
+      for (int j = 0; j < OPP_K; ++j) w[j] = wrow[j][i];
+#pragma unroll
+      for (int j = 0; j < OPP_K; j += 2)
+        *reinterpret_cast<double2*>(Wst + (int64_t)i * OPP_K + j) =
+            make_double2(sg[j] != 0.0 ? w[j] : 0.0, sg[j + 1] != 0.0 ? w[j + 1] : 0.0);
+    }
     // (one column at a time: unrolled over r the operands in flight push the per-link accumulators out of the registers)
 #pragma unroll 1
     for (int r = 0; r < OPP_RMAX; ++r) {
@@ -188,17 +195,27 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
         }
 #pragma unroll
         for (int q = 0; q < OPP_RMAX; ++q) a3[q] += (q == r) ? add : 0.0;
-        *reinterpret_cast<double2*>(Cst + B * OPP_K) = make_double2(x[0], x[1]);
+#pragma unroll
+        for (int j = 0; j < OPP_K; j += 2) *reinterpret_cast<double2*>(Cst + B * OPP_K + j) = make_double2(x[j], x[j + 1]);
       }
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < OPP_SMAX; ++s) {
       const uint32_t rc = rec[s];
-      const double2 cv = *reinterpret_cast<const double2*>(Cst + (rc & 0xffffu) * OPP_K);
-      const double2 wv2 = *reinterpret_cast<const double2*>(Wst + ((rc >> 16) & 0xfffu) * OPP_K);
-      acc[s] += wv2.x * cv.x;
-      acc[s] += wv2.y * cv.y;
+      const double* cp = Cst + (rc & 0xffffu) * OPP_K;
+      const double* wp = Wst + ((rc >> 16) & 0xfffu) * OPP_K;
+      double2 cv[OPP_K / 2], wv2[OPP_K / 2];
+#pragma unroll
+      for (int j = 0; j < OPP_K / 2; ++j) {
+        cv[j] = *reinterpret_cast<const double2*>(cp + 2 * j);
+        wv2[j] = *reinterpret_cast<const double2*>(wp + 2 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < OPP_K / 2; ++j) {
+        acc[s] += wv2[j].x * cv[j].x;
+        acc[s] += wv2[j].y * cv[j].y;
+      }
     }
     __syncthreads();
   }
