@@ -5,7 +5,7 @@ profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traf
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
@@ -32,7 +32,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
         real, early, alld = defaultdict(list), defaultdict(int), defaultdict(list)
         for r in csv.DictReader(open(f)):
             name = short(r["Kernel_Name"])
-            if "k_sigma" not in name and "k_same_spin" not in name and "k_lists" not in name and "k_alpha_rows" not in name:
+            if "k_sigma" not in name and "k_same_spin" not in name and "k_lists" not in name and "k_alpha_rows" not in name and "k_spmm" not in name and "k_opp" not in name:
                 continue
             alld[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for name, ds in alld.items():
@@ -51,7 +51,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
             json.dump(out, open(os.path.join(dst, "final_" + os.path.basename(d)[5:] + "_sigma_launches.json"), "w"), indent=1)
 
 
-for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16"):
+for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16", "hf1000", "hf3000"):
     out = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
         acc = defaultdict(list)
@@ -73,6 +73,13 @@ for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16"):
                 out["LIST_PATH_SIGMA"] = {"kernels": parts, "hbm_bytes_per_sigma": sum(parts.values()),
                                           "note": "2 x FETCH_SIZE + WRITE_SIZE per launch (KB counters; the gfx950 "
                                                   "correction for wide coalesced reads), summed over the launches of one sigma"}
+        if wl in ("hf1000", "hf3000"):  # connected sets: one sigma = two transpositions + the sparse product + the whole-row kernel
+            parts = {k: v["hbm_bytes_per_launch"] * (2.0 if "transpose" in k else 1.0) for k, v in hbm.items()
+                     if k.split("::")[-1].startswith(("k_spmm_grouped", "k_spmm_transpose", "k_opp_rows", "k_opp_reduce"))}
+            if parts:
+                out["CONNECTED_SIGMA"] = {"kernels": parts, "hbm_bytes_per_sigma": sum(parts.values()),
+                                          "note": "2 x FETCH_SIZE + WRITE_SIZE per launch, summed over the launches of one sigma "
+                                                  "(k_spmm_transpose runs twice per sigma: counted twice)"}
         name = wl if wl != "big" else "uniform10000"
         json.dump(out, open(os.path.join(dst, "pmc", f"final_{name}_pmc_summary.json"), "w"), indent=1)
         top = sorted(hbm.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:6]
