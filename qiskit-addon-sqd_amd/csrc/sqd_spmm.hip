@@ -663,7 +663,7 @@ struct GroupedArgs {
   GPtr<const int> stop, vec_index;
   int64_t in_stride;
 };
-template <int GX, int GU>
+template <int GX, int GU, int GJ>
 __global__ void __launch_bounds__(256) k_spmm_grouped(const GroupedArgs g) {
   if (g.stop && *g.stop) return;
   const int side = blockIdx.y;
@@ -690,27 +690,38 @@ __global__ void __launch_bounds__(256) k_spmm_grouped(const GroupedArgs g) {
   const uint32_t cnt = g.cnt[side][grp];  // (a multiple of GPAD, itself a multiple of GX)
   const uint32_t* __restrict__ src = g.src[side] + base;
   const double* __restrict__ coef = g.coef[side] + base * GR;
-  const unsigned c0 = panel * 64u;
-  const bool ok = (int64_t)c0 + lane < m;
-  const unsigned col = ok ? (unsigned)lane : (unsigned)(m - 1 - c0);
-  in += c0;
-  double acc[GR];
+  // GJ columns per lane (panel = 64 GJ columns): a coefficient record fetched through the scalar cache serves GJ times
+  // the multiply-adds
+  const unsigned c0 = panel * (unsigned)(64 * GJ);
+  bool ok[GJ];
+  unsigned col[GJ];
 #pragma unroll
-  for (int i = 0; i < GR; ++i) acc[i] = 0.0;
-  // GX operand rows in flight per wavefront (what the kernel lives on: bytes in flight x the L2's latency under load),
-  // their addresses from one scalar load a chunk ahead; the coefficients stream behind them GU sources at a time
+  for (int j = 0; j < GJ; ++j) {
+    ok[j] = (int64_t)c0 + j * 64 + lane < m;
+    col[j] = ok[j] ? (unsigned)(j * 64 + lane) : (unsigned)(m - 1 - c0);
+  }
+  in += c0;
+  double acc[GR][GJ];
+#pragma unroll
+  for (int i = 0; i < GR; ++i)
+#pragma unroll
+    for (int j = 0; j < GJ; ++j) acc[i][j] = 0.0;
+  // GX operand rows in flight per wavefront (their addresses from one scalar load a chunk ahead); the coefficients
+  // stream behind them GU sources at a time
   uint32_t sn[GX];
 #pragma unroll
   for (int u = 0; u < GX; ++u) sn[u] = src[u];
   for (uint32_t l = 0; l < cnt; l += GX, src += GX, coef += GX * GR) {
     uint32_t s[GX];
-    double x[GX];
+    double x[GX][GJ];
 #pragma unroll
     for (int u = 0; u < GX; ++u) s[u] = sn[u];
 #pragma unroll
     for (int u = 0; u < GX; ++u) sn[u] = src[GX + u];  // (the list ends with one chunk of padding)
 #pragma unroll
-    for (int u = 0; u < GX; ++u) x[u] = spmm_ldu(in + (int64_t)s[u] * m, col);
+    for (int u = 0; u < GX; ++u)
+#pragma unroll
+      for (int j = 0; j < GJ; ++j) x[u][j] = spmm_ldu(in + (int64_t)s[u] * m, col[j]);
 #pragma unroll
     for (int u0 = 0; u0 < GX; u0 += GU) {
       double cf[GU][GR];
@@ -721,15 +732,18 @@ __global__ void __launch_bounds__(256) k_spmm_grouped(const GroupedArgs g) {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
 #pragma unroll
-        for (int i = 0; i < GR; ++i) acc[i] += cf[u][i] * x[u0 + u];
+        for (int i = 0; i < GR; ++i)
+#pragma unroll
+          for (int j = 0; j < GJ; ++j) acc[i][j] += cf[u][i] * x[u0 + u][j];
     }
   }
-  if (ok) {
-    double* __restrict__ out = g.out[side] + c0;
+  double* __restrict__ out = g.out[side] + c0;
 #pragma unroll
-    for (int i = 0; i < GR; ++i)
-      if (grp * GR + i < n) out[(grp * GR + i) * m + col] = acc[i];
-  }
+  for (int j = 0; j < GJ; ++j)
+    if (ok[j])
+#pragma unroll
+      for (int i = 0; i < GR; ++i)
+        if (grp * GR + i < n) out[(grp * GR + i) * m + col[j]] = acc[i][j];
 }
 
 // ---- host side
@@ -981,14 +995,26 @@ int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride) {
     gg.stop = c->sigma_stop;
     gg.vec_index = vidx;
     gg.in_stride = in_stride;
-    static const int gx = [] {  // tuning hook: operand rows in flight per wavefront
-      const char* env = std::getenv("SQD_SPMM_GX");
-      const int v = env ? std::atoi(env) : 16;
-      return (v == 4 || v == 8 || v == 16) ? v : 16;
+    // columns per lane.  Measured (profiles/r05/spmm_gj_probe.txt, HF-centred N x N, us per sigma, 1 | 2 | 4 columns):
+    // 1000: 194 | 195 | 283; 2000: 764 | 707 | 793; 3000: 2210 | 2026 | 2301 -- two from ~1000 strings on (a coefficient
+    // record through the scalar cache serves twice the multiply-adds; four leave the eight XCDs unevenly loaded)
+    static const int gj_env = [] {  // tuning hook
+      const char* env = std::getenv("SQD_SPMM_GJ");
+      const int v = env ? std::atoi(env) : 0;
+      return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
-    if (gx == 16) hipLaunchKernelGGL((k_spmm_grouped<16, 2>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
-    else if (gx == 8) hipLaunchKernelGGL((k_spmm_grouped<8, 2>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
-    else hipLaunchKernelGGL((k_spmm_grouped<4, 4>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+    const int gj = gj_env ? gj_env : ((na >= 1024 && nb >= 1024) ? 2 : 1);
+    gxg = 1;
+    for (int sp = 0; sp < 2; ++sp) {
+      gg.npanels[sp] = (unsigned)((gg.m[sp] + 64 * gj - 1) / (64 * gj));
+      uint64_t blocks;
+      if (gg.xcd_split) blocks = 8ull * (((uint64_t)((gg.npanels[sp] + 7) / 8) * (uint64_t)gg.ngroups[sp] + 3) / 4);
+      else blocks = ((uint64_t)gg.npanels[sp] * (uint64_t)gg.ngroups[sp] + 3) / 4;
+      gxg = blocks > gxg ? (unsigned)blocks : gxg;
+    }
+    if (gj == 4) hipLaunchKernelGGL((k_spmm_grouped<4, 2, 4>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+    else if (gj == 2) hipLaunchKernelGGL((k_spmm_grouped<8, 2, 2>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
+    else hipLaunchKernelGGL((k_spmm_grouped<16, 2, 1>), dim3(gxg, 2), dim3(256), 0, c->stream, gg);
   } else if (s->tiled) {
     TiledArgs tg;
     unsigned gxt = 1;

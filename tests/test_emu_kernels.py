@@ -256,32 +256,32 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
     assert not ok
 
 
-@pytest.mark.parametrize("xcd,J,tiled", [("0", "2", "0"), ("1", "1", "0"), ("1", "4", "0"), ("1", "1", "1"), ("0", "1", "g"),
-                                         ("1", "1", "g")])
-@pytest.mark.parametrize("opp", ["0", "1"])
+@pytest.mark.parametrize("xcd,J,tiled,opp", [("1", "1", "g", "1"), ("0", "1", "g", "0"), ("0", "2", "0", "1"), ("1", "4", "0", "0"),
+                                             ("1", "1", "1", "1")])
 def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
-    # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: merged CSR of both spins, C -> C^T, row
-    # AXPYs on C and C^T, G += G2T^T, work items add ONE partial product) that connected sets from ~10^3 strings per
-    # spin take by default.  Both task mappings (XCD split on / off), every panel width, ragged panels and tiles,
-    # nalpha != nbeta, rows without links, all operator forms, a Davidson solve and the observables.
+    # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: C -> C^T, the product on C and C^T, G +=
+    # G2T^T) that connected sets from ~900 strings per spin take by default.
+    #  tiled = g: the DEFAULT product (k_spmm_grouped: 8 adjacent rows share the sorted union of their source lists, a dense
+    #             8-vector of coefficients per source); 0: k_spmm_rows on the merged lists; 1: k_spmm_tiled (LDS tiles)
+    #  opp = 1:   the opposite-spin part and the diagonal by whole rows (sqd_opp.hip: beta links in registers, entries
+    #             staged interleaved, per-link sums folded to columns, long rows in pieces with partial rows) for the plain
+    #             operator -- the default; the S^2 / penalty forms of the same tests still run the work items.  opp = 0:
+    #             work items throughout (they add ONE partial product).
+    # Both task mappings (XCD split on / off), every panel width, ragged panels / tiles / groups, nalpha != nbeta, rows
+    # without links, all operator forms, a Davidson solve and the observables.
     monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
-    # opp = 1: the opposite-spin part and the diagonal by whole rows (sqd_opp.hip: beta links in registers, entries
-    # staged four at a time, per-link sums folded to columns) for the plain operator -- the default; the S^2 / penalty
-    # forms of the same tests still run the work items.  opp = 0: work items throughout.
     monkeypatch.setenv("SQD_SIGMA_OPP", opp)
     monkeypatch.setenv("SQD_SPMM_XCD", xcd)
     monkeypatch.setenv("SQD_SPMM_J", J)
-    # tiled = 1: the default product (k_spmm_tiled: operand rows through LDS tiles of 128 source rows, 16 targets per
-    # wavefront, link groups padded to 4 records); tiled = 0: k_spmm_rows on the merged lists
-    # tiled = g: the DEFAULT product (k_spmm_grouped: 8 adjacent rows share the sorted union of their source lists, a dense
-    # 8-vector of coefficients per source); the other two are reached with SQD_SPMM_GROUPED=0
     monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if tiled == "g" else "0")
     monkeypatch.setenv("SQD_SPMM_TILED", "1" if tiled == "1" else "0")
-    cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (8, (4, 4), 30, 28, 17, True),
-             (5, (1, 4), 5, 4, 9, False), (9, (2, 4), 7, 100, 29, True), (16, (4, 4), 66, 70, 23, True)]
-    if tiled != "0":  # more than one source chunk and more than one target block per side (TS = TB = 128); ragged last group
-        cases.append((12, (3, 3), 140, 24, 31, True))
-        cases.append((12, (3, 3), 18, 150, 33, True))
+    monkeypatch.setenv("SQD_OPP_E", "4")  # (pieces of 4 entries: rows in several pieces, partial rows, the deferred sum)
+    default = (tiled, opp) == ("g", "1")
+    cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (5, (1, 4), 5, 4, 9, False)]
+    if default:
+        cases += [(8, (4, 4), 30, 28, 17, True), (9, (2, 4), 7, 100, 29, True), (16, (4, 4), 66, 70, 23, True)]
+    if tiled != "0":  # more than one source chunk / target block (TS = TB = 128), more than one panel, a ragged last group
+        cases += [(12, (3, 3), 140, 24, 31, True), (12, (3, 3), 18, 150, 33, True)]
     for case in cases:
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
