@@ -13,7 +13,7 @@
 // multiply-adds; waves parked 55 % of their life): every item of <= 3 alpha links re-reads and re-decodes all 33 000 beta
 // link records, runs them through virtual rows and LDS partial sums, and writes a partial row that a later launch adds.
 // Here ONE workgroup owns a target row A (and a range of columns):
-//   * every thread keeps its share of the beta link list -- S <= 20 consecutive links, one packed 32-bit record each
+//   * every thread keeps its share of the beta link list -- S <= 12 consecutive links, one packed 32-bit record each
 //     {source column, orbital pair, sign, last-of-column} -- in registers for the whole row, and one accumulator per link;
 //   * the row's entries are staged four at a time, INTERLEAVED: Cst[B'][4] (signed source rows) and Wst[rs][4] (weight
 //     rows), so that a link costs two 16-byte LDS gathers per operand and four multiply-adds -- no address arithmetic
@@ -32,7 +32,7 @@ namespace sqd {
 
 constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather per operand; 4 measured slower: 219 | 817 | 2319 us per sigma at 1000^2 | 2000^2 | 3000^2 against 195 | 763 | 2209)
 static_assert(OPP_K % 2 == 0, "entries are staged and gathered in pairs");
-constexpr int OPP_SMAX = 20;  // beta links per thread
+constexpr int OPP_SMAX = 12;  // beta links per thread (registers: a packed record + an accumulator each, beside the staged batch)
 constexpr int OPP_RMAX = 4;   // columns per thread in the coalesced passes (nb <= OPP_RMAX * threads)
 constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30;
 
@@ -115,6 +115,7 @@ struct OppArgs {
   int64_t c_stride, s_stride;
 };
 
+template <int RM>
 __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
   if (g.stop && *g.stop) return;
@@ -140,66 +141,83 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   double acc[OPP_SMAX];
 #pragma unroll
   for (int s = 0; s < OPP_SMAX; ++s) acc[s] = 0.0;
-  double a3[OPP_RMAX];
+  double a3[RM];
 #pragma unroll
-  for (int r = 0; r < OPP_RMAX; ++r) a3[r] = 0.0;
+  for (int r = 0; r < RM; ++r) a3[r] = 0.0;
   const int64_t k0 = g.sa_ptr[A];
   const int e_end = it.e0 + it.ne;
-  for (int e0 = it.e0; e0 < e_end; e0 += OPP_K) {
-    // the entries of this batch (uniform): source row, sign, weight row; a slot past the item's last entry is a zero row
+  // Register-staged double buffering: the global loads of batch b + 1 (source rows, J rows, weight rows: everything a
+  // thread stages) are requested right behind the barrier that publishes batch b and land while batch b's links are
+  // gathered from LDS; a workgroup that fills the CU's registers runs alone on it, so nothing else hides that latency.
+  double px[RM][OPP_K], pjb[RM][OPP_K], pw[OPP_K];
+  double psg[OPP_K];
+  bool plnk[OPP_K];
+  const double* pwrow[OPP_K];
+  auto request = [&](int e0) {
     const double* srow[OPP_K];
-    const double* wrow[OPP_K];
     const double* jrow[OPP_K];
-    double sg[OPP_K];
-    bool lnk[OPP_K];
 #pragma unroll
     for (int j = 0; j < OPP_K; ++j) {
       const int e = e0 + j;
       const bool valid = e < e_end;
-      lnk[j] = valid && e > 0;
+      plnk[j] = valid && e > 0;
       SRec r = SRec{(uint32_t)A, 0u};
-      if (lnk[j]) r = g.sa_rec[k0 + e - 1];
+      if (plnk[j]) r = g.sa_rec[k0 + e - 1];
       const int64_t pair = (int64_t)(srec_widx(r.meta) >> 1);
       srow[j] = C + (int64_t)r.src * nb;
-      sg[j] = valid ? (lnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
-      wrow[j] = lnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
+      psg[j] = valid ? (plnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
+      pwrow[j] = plnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
       jrow[j] = g.jbT + pair * nb;
     }
-    // weight rows, then the source rows (signed), both interleaved; the alpha single x beta occupation term rides on
-    // the pass over the source rows (own columns)
-    for (int i = tid; i < nn; i += T) {
-      double w[OPP_K];
+    const int iw = tid < nn ? tid : nn - 1;
 #pragma unroll
-      for (int j = 0; j < OPP_K; ++j) w[j] = wrow[j][i];
+    for (int j = 0; j < OPP_K; ++j) pw[j] = pwrow[j][iw];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      const int64_t Bc = B < nb ? B : nb - 1;
+#pragma unroll
+      for (int j = 0; j < OPP_K; ++j) {
+        px[r][j] = srow[j][Bc];
+        pjb[r][j] = jrow[j][Bc];
+      }
+    }
+  };
+  // registers -> LDS (signed source rows and weight rows, interleaved); the alpha single x beta occupation term rides
+  // on the pass over the source rows (own columns)
+  auto park = [&]() {
+    if (tid < nn) {
+#pragma unroll
+      for (int j = 0; j < OPP_K; j += 2)
+        *reinterpret_cast<double2*>(Wst + (int64_t)tid * OPP_K + j) =
+            make_double2(psg[j] != 0.0 ? pw[j] : 0.0, psg[j + 1] != 0.0 ? pw[j + 1] : 0.0);
+    }
+    for (int i = tid + T; i < nn; i += T) {  // (more orbital pairs than threads: norb > 44 with 1024 threads)
 #pragma unroll
       for (int j = 0; j < OPP_K; j += 2)
         *reinterpret_cast<double2*>(Wst + (int64_t)i * OPP_K + j) =
-            make_double2(sg[j] != 0.0 ? w[j] : 0.0, sg[j + 1] != 0.0 ? w[j + 1] : 0.0);
+            make_double2(psg[j] != 0.0 ? pwrow[j][i] : 0.0, psg[j + 1] != 0.0 ? pwrow[j + 1][i] : 0.0);
     }
-    // (one column at a time: unrolled over r the operands in flight push the per-link accumulators out of the registers)
-#pragma unroll 1
-    for (int r = 0; r < OPP_RMAX; ++r) {
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
       const int64_t B = tid + (int64_t)r * T;
       if (B < nb) {
-        double x[OPP_K], jb[OPP_K];
+        double x[OPP_K];
 #pragma unroll
         for (int j = 0; j < OPP_K; ++j) {
-          x[j] = srow[j][B];
-          jb[j] = jrow[j][B];
+          x[j] = px[r][j] * psg[j];
+          a3[r] += plnk[j] ? pjb[r][j] * x[j] : 0.0;
         }
-        double add = 0.0;
-#pragma unroll
-        for (int j = 0; j < OPP_K; ++j) {
-          x[j] *= sg[j];
-          add += lnk[j] ? jb[j] * x[j] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < OPP_RMAX; ++q) a3[q] += (q == r) ? add : 0.0;
 #pragma unroll
         for (int j = 0; j < OPP_K; j += 2) *reinterpret_cast<double2*>(Cst + B * OPP_K + j) = make_double2(x[j], x[j + 1]);
       }
     }
+  };
+  request(it.e0);
+  for (int e0 = it.e0; e0 < e_end; e0 += OPP_K) {
+    park();
     __syncthreads();
+    if (e0 + OPP_K < e_end) request(e0 + OPP_K);
 #pragma unroll
     for (int s = 0; s < OPP_SMAX; ++s) {
       const uint32_t rc = rec[s];
@@ -262,7 +280,7 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   const double* __restrict__ gd = g.gdense + A * nb;
   double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
 #pragma unroll
-  for (int r = 0; r < OPP_RMAX; ++r) {
+  for (int r = 0; r < RM; ++r) {
     const int64_t B = tid + (int64_t)r * T;
     if (B >= B0 && B < B1) {
       double v = a3[r] + outb[B];
@@ -313,14 +331,19 @@ bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   OppState* s = static_cast<OppState*>(c->opp);
   // threads: 512 for short rows (four workgroups per CU), 1024 beyond (two); column ranges H so that a thread holds at
   // most OPP_SMAX links
-  int T = (nb <= (int64_t)OPP_RMAX * 512 && L <= (int64_t)2 * OPP_SMAX * 512) ? 512 : 1024;
-  if (const char* env = std::getenv("SQD_OPP_T")) {  // tuning hook
+  int T = (nb <= (int64_t)OPP_RMAX * 512 && L <= (int64_t)OPP_SMAX * 512) ? 512 : 1024;
+  if (const char* env = std::getenv("SQD_OPP_T")) {  // tuning / test hook (small workgroups: several column ranges on small sets)
     const int v = std::atoi(env);
-    if ((v == 512 || v == 1024) && nb <= (int64_t)OPP_RMAX * v) T = v;
+    if (v >= 64 && v <= 1024 && v % 64 == 0 && nb <= (int64_t)OPP_RMAX * v) T = v;
+  }
+  int smax = OPP_SMAX;
+  if (const char* env = std::getenv("SQD_OPP_S")) {  // test hook: links per thread
+    const int v = std::atoi(env);
+    if (v >= 1 && v <= OPP_SMAX) smax = v;
   }
   if (nb > (int64_t)OPP_RMAX * T) return false;
   if (opp_shmem(nb, c->nnorb, T) + 1024 > (size_t)c->lds_bytes) return false;
-  const int H = (int)((L + (int64_t)OPP_SMAX * T - 1) / ((int64_t)OPP_SMAX * T));
+  const int H = (int)((L + (int64_t)smax * T - 1) / ((int64_t)smax * T));
   if (H > 64) return false;
   // cut the link list at column starts, as evenly as the columns allow
   const int64_t* ps = c->h_sptr_b;
@@ -451,12 +474,18 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
     static std::atomic<size_t> granted[64];
     const int dev = c->device & 63;
     if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {
-      SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_opp_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)s->shmem));
+      for (const void* f : {reinterpret_cast<const void*>(&k_opp_rows<1>), reinterpret_cast<const void*>(&k_opp_rows<2>),
+                            reinterpret_cast<const void*>(&k_opp_rows<3>), reinterpret_cast<const void*>(&k_opp_rows<4>)})
+        SQD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));
       granted[dev].store(s->shmem, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL(k_opp_rows, dim3((unsigned)s->n_items, (unsigned)s->H), dim3(s->T), s->shmem, c->stream, g);
+  const int rm = (int)((c->nb + s->T - 1) / s->T);  // columns per thread in the coalesced passes (<= OPP_RMAX: opp_select)
+  const dim3 grid((unsigned)s->n_items, (unsigned)s->H), block((unsigned)s->T);
+  if (rm <= 1) hipLaunchKernelGGL(k_opp_rows<1>, grid, block, s->shmem, c->stream, g);
+  else if (rm == 2) hipLaunchKernelGGL(k_opp_rows<2>, grid, block, s->shmem, c->stream, g);
+  else if (rm == 3) hipLaunchKernelGGL(k_opp_rows<3>, grid, block, s->shmem, c->stream, g);
+  else hipLaunchKernelGGL(k_opp_rows<4>, grid, block, s->shmem, c->stream, g);
   SQD_HIP_CHECK(hipGetLastError());
   // rows in several pieces: inside a Davidson run the first reader of the new vector adds the partial rows (opp_split)
   if (s->n_multi > 0 && !(c->sigma_defer_reduce && indexed)) {

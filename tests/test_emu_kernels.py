@@ -276,6 +276,8 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
     monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if tiled == "g" else "0")
     monkeypatch.setenv("SQD_SPMM_TILED", "1" if tiled == "1" else "0")
     monkeypatch.setenv("SQD_OPP_E", "4")  # (pieces of 4 entries: rows in several pieces, partial rows, the deferred sum)
+    # the group records through LDS (k_spmm_grouped_lds, the default) or through the scalar cache (k_spmm_grouped)
+    monkeypatch.setenv("SQD_SPMM_LDS", "1" if xcd == "1" else "0")
     default = (tiled, opp) == ("g", "1")
     cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (5, (1, 4), 5, 4, 9, False)]
     if default:
@@ -290,3 +292,20 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
     run_full_parity(emu_lib, *cases[0], variants=False)
     for case in cases[1:]:
         run_operator_parity(emu_lib, *case)
+
+
+def test_emu_opp_rows_column_ranges(emu_lib, monkeypatch):
+    # the whole-row opposite-spin kernel with SEVERAL column ranges per row (what 3000 strings per spin take: the beta
+    # link list no longer fits one workgroup's registers) and columns whose links span several threads: 64-thread
+    # workgroups holding 1 link per thread; pieces of 4 entries (partial rows, the deferred sum inside the Davidson run)
+    monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
+    monkeypatch.setenv("SQD_OPP_T", "64")
+    monkeypatch.setenv("SQD_OPP_S", "1")
+    monkeypatch.setenv("SQD_OPP_E", "4")
+    for case in ((7, (3, 3), 20, 20, 7, True), (8, (4, 4), 30, 28, 17, True), (9, (2, 4), 7, 100, 29, True)):
+        h1, eri, sa, sb = make_problem(*case)
+        with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and ctx.link_counts(1)[0] > 64
+        run_operator_parity(emu_lib, *case)
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
