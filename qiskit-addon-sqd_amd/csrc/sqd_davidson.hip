@@ -1745,7 +1745,20 @@ int shard_dav_pick(sqd_ctx* c, double** d_send) {
 }
 // split rows of the sigma vector are summed by the dots stage (as in the single solver: no k_sigma_reduce launch) unless the
 // squared-penalty form chains several sigma launches through scratch vectors
-static bool shard_defers_reduce(const sqd_ctx* c) { return c->n_multi > 0 && c->shard_form != 2 && !c->sig_direct && c->sig_rows == 0; }
+// (a "shard" that holds all rows -- a group of one -- may run the whole-row opposite-spin kernel of sqd_opp.hip for the
+// plain operator: its rows in several pieces are then the split rows, not the work items')
+static bool shard_split_rows(const sqd_ctx* c, const int32_t** rowinfo, const double** partial) {
+  if (c->sig_opp && c->shard_form == 0) return opp_split(c, rowinfo, partial);
+  if (!(c->n_multi > 0 && c->shard_form != 2 && !c->sig_direct && c->sig_rows == 0)) return false;
+  *rowinfo = c->rowinfo.as<int32_t>();
+  *partial = c->sig_partial.as<double>();
+  return true;
+}
+static bool shard_defers_reduce(const sqd_ctx* c) {
+  const int32_t* ri = nullptr;
+  const double* pp = nullptr;
+  return shard_split_rows(c, &ri, &pp);
+}
 // part 0: the whole sigma build on the gathered vector.  Parts 1 and 2 (both called, in this order, around the
 // all-gather): 1 needs only this rank's rows of the vector -- they lie in the send buffer the pick stage returned -- and
 // runs WHILE the gather is in flight: the own-row work items (diagonal, beta links, beta singles x alpha occupation)
@@ -1780,9 +1793,13 @@ int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count) {
   const int width = SQD_MAX_SPACE + 4;
   double* tot = c->shard_tot.as<double>();
   SplitRows split{nullptr, nullptr, c->nb};
-  if (shard_defers_reduce(c)) {  // (the sigma stage left split rows in pieces: this pass adds them, as k_dots_eig does)
-    split.rowinfo = c->rowinfo.as<int32_t>();
-    split.partial = c->sig_partial.as<double>();
+  {  // (the sigma stage left split rows in pieces: this pass adds them, as k_dots_eig does)
+    const int32_t* ri = nullptr;
+    const double* pp = nullptr;
+    if (shard_split_rows(c, &ri, &pp)) {
+      split.rowinfo = ri;
+      split.partial = pp;
+    }
   }
   if (c->shard_max_space <= 12)
     hipLaunchKernelGGL((k_shard_dots<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),

@@ -1112,9 +1112,12 @@ int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride) {
       else blocks = ((uint64_t)gg.npanels[sp] * (uint64_t)gg.ngroups[sp] + 3) / 4;
       gxg = blocks > gxg ? (unsigned)blocks : gxg;
     }
-    static const bool lds_records = [] {  // SQD_SPMM_LDS=0: the records through the scalar cache (k_spmm_grouped)
+    // SQD_SPMM_LDS=1: the group records through an LDS slab shared by four panels (k_spmm_grouped_lds) instead of the
+    // scalar cache.  Measured SLOWER (profiles/r05/variants_probe.txt: the product alone 117 vs 97 us at 1000^2, 1017 vs
+    // 855 at 3000^2): three uniform-address LDS reads and a barrier per slab cost more than the scalar stream they replace.
+    static const bool lds_records = [] {
       const char* env = std::getenv("SQD_SPMM_LDS");
-      return !env || std::atoi(env) != 0;
+      return env && std::atoi(env) != 0;
     }();
     if (lds_records && gj <= 2) {
       unsigned gxl = 1;

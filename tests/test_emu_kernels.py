@@ -276,7 +276,7 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
     monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if tiled == "g" else "0")
     monkeypatch.setenv("SQD_SPMM_TILED", "1" if tiled == "1" else "0")
     monkeypatch.setenv("SQD_OPP_E", "4")  # (pieces of 4 entries: rows in several pieces, partial rows, the deferred sum)
-    # the group records through LDS (k_spmm_grouped_lds, the default) or through the scalar cache (k_spmm_grouped)
+    # the group records through the scalar cache (k_spmm_grouped, the default) or through LDS (k_spmm_grouped_lds)
     monkeypatch.setenv("SQD_SPMM_LDS", "1" if xcd == "1" else "0")
     default = (tiled, opp) == ("g", "1")
     cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (5, (1, 4), 5, 4, 9, False)]

@@ -703,9 +703,10 @@ def test_row_sharded_overlap_hf_1000_on_gpu(hip_lib, monkeypatch):
         dist.destroy_process_group()
     for kern in ("items", "default"):
         a, b = out[kern, "1"], out[kern, "0"]
-        assert a._sharded_stats["converged"] and a._sharded_stats["n_allgather"] >= a._sharded_stats["n_sigma"]
-        assert a.energy == b.energy and np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes)
-        assert abs(a.energy - ref.energy) < 1e-8
+        assert a._sharded_stats["converged"] and b._sharded_stats["converged"], (kern, a._sharded_stats, b._sharded_stats)
+        assert a._sharded_stats["n_allgather"] >= a._sharded_stats["n_sigma"], (kern, a._sharded_stats)
+        assert a.energy == b.energy and np.array_equal(a.sci_state.amplitudes, b.sci_state.amplitudes), (kern, a.energy, b.energy)
+        assert abs(a.energy - ref.energy) < 1e-8, (kern, a.energy, ref.energy)
         assert abs(abs(np.vdot(a.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
 
 
