@@ -553,7 +553,7 @@ def secondary_entries(args, h1, eri, device):
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl1 / (ms1 * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                     "note": "G = H_a C + C H_b on the zero-padded orders (320): 2 pa^2 pb + 2 pa pb^2 flops per problem; "
                             "v_mfma_f64_16x16x4_f64; peak = dense f64 matrix rate (public spec, SURVEY 8d); counters: "
-                            "profiles/r04/pmc/final_mfma_batch_hf16_summary.json",
+                            "profiles/r05/pmc/final_mfma_batch_hf16_summary.json",
                 }
     except Exception as exc:
         res["hf_centred_317x317"]["roofline_mfma"] = {"error": repr(exc)}
@@ -669,7 +669,7 @@ def secondary_entries(args, h1, eri, device):
                 "one sigma = k_lists_t4 (single x single term of the strings that have single links) + k_sigma_lists<1> (diagonal + "
                 "beta lists on C, rows through LDS) + k_alpha_rows (alpha lists by rows on C, added onto it); avg_launch_ms is the "
                 "whole application (HIP events around 5 of them); per-kernel times and counters: "
-                "profiles/r04/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
+                "profiles/r05/final_lists_passes_probe.txt, profiles/r04/pmc/final_lists_uniform10000_counters.txt")
         # the whole Davidson solve at D = 1e8 (26 resident vectors of 0.8 GB): what an iteration costs beside its sigma
         ctx.davidson(fetch=False)  # (first call at this size grows the arenas: not timed)
         ctx.sync()

@@ -11,6 +11,11 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from qiskit_addon_sqd_amd import _capi, synthetic as S  # noqa: E402
 
+if os.environ.get("SQD_LIB"):  # A/B against another build of the library (profiles/probes/build_variant.sh)
+    from pathlib import Path
+
+    _capi.LIB_PATH = Path(os.environ.get("GRAFT_REPO_ROOT", "/root/repo")) / os.environ["SQD_LIB"]
+
 sizes = [int(s) for s in os.environ.get("SIZES", "1000 2000 3000").split()]
 modes = os.environ.get("MODES", "default dense0 dense1 spmm0").split()
 reps = int(os.environ.get("REPS", "5"))

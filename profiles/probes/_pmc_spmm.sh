@@ -19,7 +19,7 @@ for f in glob.glob('$OUT/pass*/**/*counter_collection.csv', recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:60]
-        if 'spmm' not in k and 'k_sigma' not in k and 'mfma' not in k: continue
+        if 'spmm' not in k and 'k_sigma' not in k and 'mfma' not in k and 'k_opp' not in k: continue
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         key = (k, r['Counter_Name'], r['Dispatch_Id'])
         if (k, r['Dispatch_Id'], r['Counter_Name']) not in seen:
@@ -27,7 +27,7 @@ for f in glob.glob('$OUT/pass*/**/*counter_collection.csv', recursive=True):
     # dispatch counts per kernel per counter
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:60]
-        if 'spmm' not in k and 'k_sigma' not in k and 'mfma' not in k: continue
+        if 'spmm' not in k and 'k_sigma' not in k and 'mfma' not in k and 'k_opp' not in k: continue
         calls[(k, r['Counter_Name'])] += 1
 for k in agg:
     print('==', k)

@@ -570,7 +570,10 @@ __global__ void __launch_bounds__(TTHREADS) k_spmm_tiled(const TiledArgs g) {
 // bytes through the vector L1 per useful multiply-add drop to 0.42 / 0.52 of k_spmm_rows'; the extra multiply-adds by
 // zero are free (the vector units have an 8-fold margin over the L1 here).  Records travel through the scalar cache:
 // per round of GU sources one s_load of their addresses and GU x 8 coefficients, which enter v_fmac_f64 as scalar operands.
-constexpr int GR = 8, GPAD = 16;
+#ifndef SQD_SPMM_GR
+#define SQD_SPMM_GR 8  // (probe builds: 4 / 16 -- profiles/r05/spmm_group_size_probe.txt)
+#endif
+constexpr int GR = SQD_SPMM_GR, GPAD = 16;
 struct GroupBuildArgs {
   int64_t n[2];
   GPtr<const int64_t> s_ptr[2], d_ptr[2];
