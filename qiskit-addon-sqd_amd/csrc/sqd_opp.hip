@@ -111,6 +111,7 @@ struct OppArgs {
   GPtr<const int64_t> colcut;  // [H + 1] first column of every range
   int64_t na, nb;
   int nnorb, S, T, H;
+  unsigned n_items;
   GPtr<const int> stop, vec_index;
   int64_t c_stride, s_stride;
 };
@@ -119,8 +120,14 @@ template <int RM>
 __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
   if (g.stop && *g.stop) return;
-  const int T = g.T, tid = threadIdx.x, h = blockIdx.y;
-  const OppItem it = g.items[blockIdx.x];
+  // workgroup b runs on XCD b mod 8: the H column ranges of one item -- they stage the same source rows and J rows --
+  // take ids 8 apart, i.e. the same XCD at the same time, so that its L2 serves all but the first of them
+  const unsigned xcd = blockIdx.x & 7u, kq = blockIdx.x >> 3;
+  const int h = (int)(kq % (unsigned)g.H);
+  const unsigned item_index = (kq / (unsigned)g.H) * 8u + xcd;
+  if (item_index >= g.n_items) return;
+  const int T = g.T, tid = threadIdx.x;
+  const OppItem it = g.items[item_index];
   const int64_t A = it.A;
   const int64_t nb = g.nb;
   const int nn = g.nnorb;
@@ -481,7 +488,8 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
     }
   }
   const int rm = (int)((c->nb + s->T - 1) / s->T);  // columns per thread in the coalesced passes (<= OPP_RMAX: opp_select)
-  const dim3 grid((unsigned)s->n_items, (unsigned)s->H), block((unsigned)s->T);
+  g.n_items = (unsigned)s->n_items;
+  const dim3 grid(8u * (unsigned)((s->n_items + 7) / 8) * (unsigned)s->H), block((unsigned)s->T);
   if (rm <= 1) hipLaunchKernelGGL(k_opp_rows<1>, grid, block, s->shmem, c->stream, g);
   else if (rm == 2) hipLaunchKernelGGL(k_opp_rows<2>, grid, block, s->shmem, c->stream, g);
   else if (rm == 3) hipLaunchKernelGGL(k_opp_rows<3>, grid, block, s->shmem, c->stream, g);

@@ -972,3 +972,43 @@ def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode)
 
 
 _CONNECTED_E0: dict = {}
+
+
+def test_connected_ragged_fes_sized_sparse_product_path(hip_lib, monkeypatch):
+    """The sparse-product + whole-row path away from the round numbers it was tuned on: Fe-S-sized orbital space (40
+    orbitals: 820 orbital pairs per weight row), nalpha != nbeta electrons (15, 14) and strings (1153 x 931: ragged row
+    groups, panels, column ranges and transposition tiles), HF-centred.  Kernel selection by default; H on sampled rows and
+    columns against the row-restricted string-space oracle; H + the linear spin penalty and S^2 (work items behind the
+    product) against the forced work-item kernel; one whole solve against the work-item solve."""
+    norb, nelec = 40, (15, 14)
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, nelec[0], 1153, 21), O.hf_centred_strings(norb, nelec[1], 931, 22)
+    na, nb = len(sa), len(sb)
+    rng = np.random.default_rng(29)
+    x = rng.standard_normal((na, nb))
+    out = {}
+    for forced in ("default", "items"):
+        for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
+            monkeypatch.delenv(k, raising=False)
+        if forced == "items":
+            monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
+            monkeypatch.setenv("SQD_SIGMA_SPMM", "0")
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == ("k_spmm_rows+k_opp_rows" if forced == "default" else "k_sigma"), ctx.sigma_kernel()
+            ops = (ctx.sigma(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.contract_ss(x))
+            assert np.array_equal(ops[0], ctx.sigma(x))
+            _, st = ctx.davidson(fetch=False)
+            out[forced] = ops + (st["e_davidson"], st["converged"], np.abs(ctx.hdiag()).max())
+    a, b = out["default"], out["items"]
+    scale = a[5] * max(1.0, np.abs(x).max())
+    for u, v in zip(a[:3], b[:3]):
+        assert np.abs(u - v).max() < 1e-11 * scale
+    assert a[4] == 1 and b[4] == 1 and abs(a[3] - b[3]) < 1e-8
+    hfa = int(np.flatnonzero(sa == (1 << nelec[0]) - 1)[0])
+    rows = np.unique(np.concatenate(([0, hfa, na - 1], rng.choice(na, 7, replace=False))))
+    ref = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
+    assert np.abs(a[0][rows] - ref).max() < 1e-11 * scale
+    cols = np.unique(np.concatenate(([0, nb - 1], rng.choice(nb, 6, replace=False))))
+    refT = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), norb, cols)
+    assert np.abs(a[0][:, cols].T - refT).max() < 1e-11 * scale
