@@ -354,13 +354,14 @@ int sqd_recover_rows(uint8_t* bits, int64_t n_total, int norb, const int64_t* ro
  *   (configuration_recovery.py:231-241 computes the same sums row by row);
  * sqd_merge_rows -- duplicates merged in first-occurrence order, probabilities added in row order (the running dictionary
  *   of configuration_recovery.py:112-126): first[k] = row of the k-th distinct bitstring, freq[k] its summed probability;
+ *   compact != 0 also moves the distinct rows to the front of `bits`, in that order;
  * sqd_choice_replay -- the `nbatches` calls Generator.choice(n, size, replace=False, p=p) of subsampling.py:200-207
  *   replayed one after the other on a block of uniforms, out[nbatches][size] (SQD_ERR_STATE: an input numpy raises on,
  *   SQD_ERR_LIMIT: stream too short). */
 int sqd_hamming_excess(const uint8_t* bits, int64_t n, int norb, int target_left, int target_right, int64_t* bound,
                        int64_t* nbad);
-int sqd_merge_rows(const uint8_t* bits, int64_t n, int nbits, const double* probs, int64_t* first, double* freq,
-                   int64_t* n_unique);
+int sqd_merge_rows(uint8_t* bits, int64_t n, int nbits, const double* probs, int64_t* first, double* freq,
+                   int64_t* n_unique, int compact);
 int sqd_choice_replay(const double* p, int64_t n, int64_t size, int64_t nbatches, const double* uniforms,
                       int64_t n_uniforms, int64_t* out, int64_t* n_used);
 

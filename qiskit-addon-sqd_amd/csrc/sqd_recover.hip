@@ -123,6 +123,101 @@ static int repair_half(uint8_t* b, int n, const double* w_up, const double* w_do
   return 0;
 }
 
+// ---- The same selection without a single division (round 5).  The draw only needs to know WHERE x falls among the
+// cumulative probabilities, and the normalisations cancel: cdf[i] = (sum_{k<=i} w_k) / (sum_k w_k) up to rounding, whatever
+// `s` and `ps` were.  Every cdf[i] the reference forms is within (2m + 22) * 2^-53 < 2e-14 (m <= 64 candidates) of that
+// real number, and so is the plain running sum R[i] / R[m-1] of the raw weights.  So x is located among R[i] against
+// x * R[m-1], and unless it lies within 1e-11 (relative to the total) of a boundary -- 500x the two error bounds together
+// -- the index is the reference's.  Anything else (a near tie, bytes that are not 0 / 1, inputs numpy raises on) returns
+// -1 with nothing consumed or changed, and the operation-by-operation replay above decides.  A half costs its popcount,
+// m additions and a binary search per draw instead of 30 + 3m divisions, two pairwise sums and a branchy compaction.
+static inline bool half_mask(const uint8_t* b, int n, uint64_t* out) {
+  uint64_t m = 0, odd = 0;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, b + i, 8);
+    odd |= w & 0xFEFEFEFEFEFEFEFEull;
+    // eight 0 / 1 bytes -> eight bits with one multiplication (byte j lands on bit 56 + j of the product)
+    m |= (((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << i;
+  }
+  for (; i < n; ++i) {
+    odd |= b[i] & 0xFEu;
+    m |= (uint64_t)(b[i] & 1) << i;
+  }
+  *out = m;
+  return odd == 0;
+}
+
+struct FlipWeights {  // one half's clipped weights and which of them are nonzero
+  const double *up, *down;
+  uint64_t nz_up, nz_down;
+};
+
+static int repair_half_fast(uint8_t* b, int n, const FlipWeights& fw, int target, UniformStream& us) {
+  uint64_t mask;
+  if (!half_mask(b, n, &mask)) return -1;
+  const uint64_t full = n >= 64 ? ~0ull : ((1ull << n) - 1);
+  const int excess = __builtin_popcountll(mask) - target;
+  if (excess == 0) return 0;
+  if (((mask & fw.nz_down) | (~mask & full & fw.nz_up)) == 0) return 0;  // every flip weight zero: nothing is drawn
+  const bool down = excess > 0;  // flip occupied bits down, or empty bits up
+  const int size = down ? excess : -excess;
+  const uint64_t cmask = down ? mask : (~mask & full);
+  const double* wt = down ? fw.down : fw.up;
+  const int m = __builtin_popcountll(cmask);
+  if (size > m || __builtin_popcountll(cmask & (down ? fw.nz_down : fw.nz_up)) < size) return -1;
+  double wv[SQD_MAX_NORB], R[SQD_MAX_NORB];
+  int cand[SQD_MAX_NORB], found[SQD_MAX_NORB], fresh[SQD_MAX_NORB];
+  {
+    int k = 0;
+    for (uint64_t t = cmask; t; t &= t - 1, ++k) {
+      cand[k] = __builtin_ctzll(t);
+      wv[k] = wt[cand[k]];
+    }
+  }
+  const int64_t pos0 = us.pos;
+  int nf = 0;
+  while (nf < size) {
+    const int k = size - nf;
+    if (us.pos + k > us.n) return 1;
+    const double* x = us.u + us.pos;
+    us.pos += k;
+    for (int f = 0; f < nf; ++f) wv[found[f]] = 0.0;
+    double acc = 0.0;
+    for (int i = 0; i < m; ++i) {
+      acc += wv[i];
+      R[i] = acc;
+    }
+    const double W = R[m - 1];
+    if (!(W > 0.0)) {
+      us.pos = pos0;
+      return -1;
+    }
+    const double tol = W * 1e-11;
+    int nfresh = 0;
+    for (int j = 0; j < k; ++j) {
+      const double t = x[j] * W;
+      int lo = 0, hi = m;  // lo = #{i : R[i] <= t}
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (R[mid] <= t) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo >= m || R[lo] - t <= tol || (lo > 0 && t - R[lo - 1] <= tol)) {
+        us.pos = pos0;
+        return -1;
+      }
+      bool seen = false;
+      for (int q = 0; q < nfresh; ++q) seen = seen || (fresh[q] == lo);
+      if (!seen) fresh[nfresh++] = lo;
+    }
+    for (int q = 0; q < nfresh; ++q) found[nf++] = fresh[q];
+  }
+  for (int f = 0; f < size; ++f) b[cand[found[f]]] = down ? 0 : 1;
+  return 0;
+}
+
 }  // namespace sqd
 
 using namespace sqd;
@@ -148,6 +243,12 @@ extern "C" __attribute__((visibility("default"))) int sqd_recover_rows(
       cl[t][i] = std::fmin(1.0, std::fmax(0.0, src[t][i]));
     }
   up_left = cl[0], down_left = cl[1], up_right = cl[2], down_right = cl[3];
+  FlipWeights fw[2] = {{up_left, down_left, 0, 0}, {up_right, down_right, 0, 0}};
+  for (int i = 0; i < norb; ++i) {
+    fw[0].nz_up |= (uint64_t)(up_left[i] != 0.0) << i, fw[0].nz_down |= (uint64_t)(down_left[i] != 0.0) << i;
+    fw[1].nz_up |= (uint64_t)(up_right[i] != 0.0) << i, fw[1].nz_down |= (uint64_t)(down_right[i] != 0.0) << i;
+  }
+  static const bool exact_only = std::getenv("SQD_RECOVER_EXACT") != nullptr;  // (test hook: the replay alone)
   for (int64_t r = 0; r < nrows; ++r) {
     const int64_t i = rows ? rows[r] : r;
     if (i < 0 || i >= n_total) {
@@ -156,8 +257,12 @@ extern "C" __attribute__((visibility("default"))) int sqd_recover_rows(
     }
     uint8_t* row = bits + i * 2 * (int64_t)norb;
     // left (spin-down) half first, then right (spin-up): the reference's stream order
-    int rc = repair_half(row, norb, up_left, down_left, target_left, us);
-    if (rc == 0) rc = repair_half(row + norb, norb, up_right, down_right, target_right, us);
+    int rc = exact_only ? -1 : repair_half_fast(row, norb, fw[0], target_left, us);
+    if (rc < 0) rc = repair_half(row, norb, up_left, down_left, target_left, us);
+    if (rc == 0) {
+      rc = exact_only ? -1 : repair_half_fast(row + norb, norb, fw[1], target_right, us);
+      if (rc < 0) rc = repair_half(row + norb, norb, up_right, down_right, target_right, us);
+    }
     if (rc == 1) {
       set_error("sqd_recover_rows: uniform stream exhausted");
       return SQD_ERR_LIMIT;
@@ -198,16 +303,20 @@ extern "C" __attribute__((visibility("default"))) int sqd_hamming_excess(const u
 
 // sqd_merge_rows: duplicates of a bool matrix merged in FIRST-OCCURRENCE order, their probabilities added one by one in
 // row order (what the reference's running dictionary does, configuration_recovery.py:112-126).  first[k] = row index of
-// the k-th distinct row, freq[k] = its summed probability (not normalised); *n_unique.  nbits <= 128.
-extern "C" __attribute__((visibility("default"))) int sqd_merge_rows(const uint8_t* bits, int64_t n, int nbits,
+// the k-th distinct row, freq[k] = its summed probability (not normalised); *n_unique.  nbits <= 128.  With compact != 0
+// the distinct rows are also moved to the front of `bits` in that order (first[k] >= k: in place), which saves the caller a
+// gather.  Keys and home slots are formed in a first pass so that the insertion can prefetch the slot of the row eight
+// ahead (the table of 1e5 rows lives in L2: every probe is a dependent miss otherwise).
+extern "C" __attribute__((visibility("default"))) int sqd_merge_rows(uint8_t* bits, int64_t n, int nbits,
                                                                       const double* probs, int64_t* first, double* freq,
-                                                                      int64_t* n_unique) {
-  if (!bits || !probs || !first || !freq || !n_unique || nbits < 1 || nbits > 128) return SQD_ERR_INVALID;
+                                                                      int64_t* n_unique, int compact) {
+  if (!bits || !probs || !first || !freq || !n_unique || nbits < 1 || nbits > 128 || n < 0) return SQD_ERR_INVALID;
+  if (n > 0x3fffffff) return SQD_ERR_LIMIT;
   size_t cap = 16;
   while (cap < (size_t)n * 2 + 16) cap <<= 1;
-  std::vector<int64_t> slot(cap, -1);  // -> index into first / freq
-  std::vector<uint64_t> keys((size_t)n * 2);
-  int64_t nu = 0;
+  std::vector<int32_t> slot(cap, -1);  // -> index into first / freq / ukeys
+  std::vector<uint64_t> keys((size_t)n * 2), ukeys((size_t)n * 2);  // (k0, k1) per row / per distinct row
+  std::vector<uint32_t> home((size_t)n);
   for (int64_t r = 0; r < n; ++r) {
     const uint8_t* row = bits + r * (int64_t)nbits;
     // eight 0 / 1 bytes -> eight bits with one multiplication (byte j lands on bit 56 + j of the product)
@@ -226,25 +335,36 @@ extern "C" __attribute__((visibility("default"))) int sqd_merge_rows(const uint8
     }
     uint64_t h = (k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
-    size_t pos = (size_t)h & (cap - 1);
+    keys[2 * (size_t)r] = k0;
+    keys[2 * (size_t)r + 1] = k1;
+    home[(size_t)r] = (uint32_t)((size_t)h & (cap - 1));
+  }
+  int64_t nu = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    if (r + 8 < n) __builtin_prefetch(&slot[home[(size_t)r + 8]]);
+    const uint64_t k0 = keys[2 * (size_t)r], k1 = keys[2 * (size_t)r + 1];
+    size_t pos = home[(size_t)r];
     for (;;) {
-      const int64_t e = slot[pos];
+      const int32_t e = slot[pos];
       if (e < 0) {
-        slot[pos] = nu;
-        keys[2 * (size_t)nu] = k0;
-        keys[2 * (size_t)nu + 1] = k1;
+        slot[pos] = (int32_t)nu;
+        ukeys[2 * (size_t)nu] = k0;
+        ukeys[2 * (size_t)nu + 1] = k1;
         first[nu] = r;
         freq[nu] = probs[r];
         ++nu;
         break;
       }
-      if (keys[2 * (size_t)e] == k0 && keys[2 * (size_t)e + 1] == k1) {
+      if (ukeys[2 * (size_t)e] == k0 && ukeys[2 * (size_t)e + 1] == k1) {
         freq[e] += probs[r];
         break;
       }
       pos = (pos + 1) & (cap - 1);
     }
   }
+  if (compact)
+    for (int64_t k = 0; k < nu; ++k)
+      if (first[k] != k) std::memcpy(bits + k * (int64_t)nbits, bits + first[k] * (int64_t)nbits, (size_t)nbits);
   *n_unique = nu;
   return SQD_OK;
 }

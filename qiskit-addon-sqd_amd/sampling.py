@@ -314,11 +314,11 @@ def _recover_all_native(out, probabilities, norb, up_l, dn_l, up_r, dn_r, target
     freq = np.empty(n, dtype=np.float64)
     nu = C.c_int64(0)
     if lib.sqd_merge_rows(work.ctypes.data, n, int(2 * norb), probs.ctypes.data, first.ctypes.data, freq.ctypes.data,
-                          C.byref(nu)) != 0:
+                          C.byref(nu), 1) != 0:
         raise RuntimeError("sqd_merge_rows failed")  # (cannot happen behind the checks above; the stream has moved)
-    first, freq = first[: nu.value], freq[: nu.value]
+    freq = freq[: nu.value]
     freq = np.abs(freq) / np.sum(np.abs(freq))
-    return out[first], freq
+    return out[: nu.value], freq  # (the distinct rows were moved to the front of `out`, a private copy)
 
 
 def _recover_rows_native(out, rows, sum_l, sum_r, norb, up_l, dn_l, up_r, dn_r, target_l, target_r, rng) -> bool:

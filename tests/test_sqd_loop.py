@@ -153,12 +153,13 @@ def test_recover_configurations_native_replay_matches_numpy_stream():
             occ[1][-2:] = 1.0
         g_fast, g_slow = np.random.default_rng(900 + trial), np.random.default_rng(900 + trial)
         m_fast, p_fast = sampling.recover_configurations(bits, probs, occ, na, nb, g_fast)
-        orig = sampling._recover_rows_native
+        orig = sampling._recover_rows_native, sampling._recover_all_native
         sampling._recover_rows_native = lambda *a, **k: False  # force the per-row numpy path
+        sampling._recover_all_native = lambda *a, **k: None
         try:
             m_slow, p_slow = sampling.recover_configurations(bits, probs, occ, na, nb, g_slow)
         finally:
-            sampling._recover_rows_native = orig
+            sampling._recover_rows_native, sampling._recover_all_native = orig
         assert np.array_equal(m_fast, m_slow) and np.array_equal(p_fast, p_slow)
         assert g_fast.random() == g_slow.random()  # same stream position
         assert (m_fast[:, :norb].sum(axis=1) == nb).all() and (m_fast[:, norb:].sum(axis=1) == na).all()
@@ -221,3 +222,118 @@ def test_native_sample_processing_matches_numpy():
         SP._recover_all_native = real
     assert np.array_equal(m1, m2) and np.array_equal(f1, f2)
     assert a.bit_generator.state == b.bit_generator.state
+
+
+def test_native_repair_without_divisions_equals_the_replay_and_numpy():
+    """`sqd_recover_rows` locates every draw among running sums of the raw flip weights (no divisions) and falls back to
+    the operation-by-operation replay of numpy only near a tie.  At the loop's own shape (30 orbitals, 2e4 noisy samples,
+    several wrong bits per half, exact zeros among the weights): rows and stream consumption equal the replay's
+    (``SQD_RECOVER_EXACT`` in a fresh process) and, on a slice, the per-row numpy path's."""
+    import subprocess
+    import sys
+
+    code = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from qiskit_addon_sqd_amd import sampling
+rng0 = np.random.default_rng(77)
+norb, na, nb, n = 30, 8, 7, 20000
+bits = np.zeros((n, 2 * norb), dtype=bool)
+cols = np.argsort(rng0.random((n, norb)), axis=1)
+np.put_along_axis(bits[:, :norb], cols[:, :nb], True, axis=1)
+cols = np.argsort(rng0.random((n, norb)), axis=1)
+np.put_along_axis(bits[:, norb:], cols[:, :na], True, axis=1)
+bits ^= rng0.random(bits.shape) < 0.04
+bits[::9] = bits[3]
+probs = rng0.random(n); probs /= probs.sum()
+occ = (rng0.random(norb), rng0.random(norb))
+occ[0][:4] = 0.0; occ[1][-3:] = 1.0; occ[1][5] = occ[1][6]  # zero weights, equal weights
+g = np.random.default_rng(5)
+m, p = sampling.recover_configurations(bits, probs, occ, na, nb, g)
+print(hashlib.sha256(m.tobytes()).hexdigest(), hashlib.sha256(p.tobytes()).hexdigest(), g.random(), len(m))
+g = np.random.default_rng(6)
+m, p = sampling.recover_configurations(bits[:1500], probs[:1500] / probs[:1500].sum(), occ, na, nb, g)
+print(hashlib.sha256(m.tobytes()).hexdigest(), hashlib.sha256(p.tobytes()).hexdigest(), g.random(), len(m))
+""" % str(Path(__file__).resolve().parent.parent)
+    import os
+
+    outs = []
+    for exact in (False, True):
+        env = dict(os.environ)
+        env.pop("SQD_RECOVER_EXACT", None)
+        if exact:
+            env["SQD_RECOVER_EXACT"] = "1"
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) == 2
+    # the slice against the per-row numpy path, in this process
+    import hashlib
+
+    from qiskit_addon_sqd_amd import sampling
+
+    rng0 = np.random.default_rng(77)
+    norb, na, nb, n = 30, 8, 7, 20000
+    bits = np.zeros((n, 2 * norb), dtype=bool)
+    cols = np.argsort(rng0.random((n, norb)), axis=1)
+    np.put_along_axis(bits[:, :norb], cols[:, :nb], True, axis=1)
+    cols = np.argsort(rng0.random((n, norb)), axis=1)
+    np.put_along_axis(bits[:, norb:], cols[:, :na], True, axis=1)
+    bits ^= rng0.random(bits.shape) < 0.04
+    bits[::9] = bits[3]
+    probs = rng0.random(n)
+    probs /= probs.sum()
+    occ = (rng0.random(norb), rng0.random(norb))
+    occ[0][:4] = 0.0
+    occ[1][-3:] = 1.0
+    occ[1][5] = occ[1][6]
+    orig = sampling._recover_rows_native, sampling._recover_all_native
+    sampling._recover_rows_native = lambda *a, **k: False
+    sampling._recover_all_native = lambda *a, **k: None
+    try:
+        g = np.random.default_rng(6)
+        m, p = sampling.recover_configurations(bits[:1500], probs[:1500] / probs[:1500].sum(), occ, na, nb, g)
+    finally:
+        sampling._recover_rows_native, sampling._recover_all_native = orig
+    line = f"{hashlib.sha256(m.tobytes()).hexdigest()} {hashlib.sha256(p.tobytes()).hexdigest()} {g.random()} {len(m)}"
+    assert outs[0].splitlines()[1] == line
+
+
+def test_batch_strings_union_shortcut_and_carryover_mask():
+    """Without ``max_dim`` the ordered merge of `_batch_strings` reduces to a sorted union (the order only decides what a
+    truncation drops); `_carryover` finds the rows / columns holding a large amplitude from one mask.  Both against the
+    formulations they replace (reference ``fermion.py:520-553``, ``:607-631``)."""
+    from qiskit_addon_sqd_amd import sqd as L
+
+    rng = np.random.default_rng(2)
+    norb = 9
+    for sym in (False, True):
+        for trial in range(4):
+            samples = rng.random((60, 2 * norb)) < 0.4
+            inc_a, inc_b = np.unique(rng.integers(0, 1 << norb, 3)), np.unique(rng.integers(0, 1 << norb, 2))
+            car_a, car_b = rng.permutation(1 << norb)[:7].astype(np.int64), rng.permutation(1 << norb)[:5].astype(np.int64)
+            if sym:
+                car_b = car_a
+            fast = L._batch_strings(samples, norb, sym, inc_a, inc_b, car_a, car_b, None, None)
+            slow = L._batch_strings(samples, norb, sym, inc_a, inc_b, car_a, car_b, 10**9, 10**9)
+            assert np.array_equal(fast[0], slow[0]) and np.array_equal(fast[1], slow[1])
+    for sym in (False, True):
+        na, nb = 23, 17
+        amps = rng.standard_normal((na, nb)) * np.exp(-rng.random((na, nb)) * 3) * np.outer(0.5 ** np.arange(na), 0.6 ** np.arange(nb))
+        amps /= np.linalg.norm(amps)
+        sa, sb = np.sort(rng.permutation(1 << norb)[:na]), np.sort(rng.permutation(1 << norb)[:nb])
+        res = SCIResult(-1.0, SCIState(amps, sa, sb, norb, (3, 3)), (np.zeros(norb), np.zeros(norb)))
+        thr = 1e-3
+        got = L._carryover(res, thr, sym)
+        mag = np.abs(amps.reshape(-1))
+        order = np.argsort(mag)
+        big = order[np.searchsorted(mag, thr, sorter=order):]
+        ia, ib = np.divmod(big, nb)
+        ia, ib = np.unique(ia), np.unique(ib)
+        wa, wb = np.sum(np.abs(amps[ia]) ** 2, axis=1), np.sum(np.abs(amps[:, ib]) ** 2, axis=0)
+        if sym:
+            both = np.concatenate((sa[ia], sb[ib]))[np.argsort(np.concatenate((wa, wb)))[::-1]]
+            _, idx = np.unique(both, return_index=True)
+            want = (both[np.sort(idx)],) * 2
+        else:
+            want = (sa[ia][np.argsort(wa)[::-1]], sb[ib][np.argsort(wb)[::-1]])
+        assert 0 < len(ia) < na and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
