@@ -362,6 +362,10 @@ int sqd_hamming_excess(const uint8_t* bits, int64_t n, int norb, int target_left
                        int64_t* nbad);
 int sqd_merge_rows(uint8_t* bits, int64_t n, int nbits, const double* probs, int64_t* first, double* freq,
                    int64_t* n_unique, int compact);
+/* np.unique(bool_matrix, axis=0, return_counts=True) as counts.py:45-61 applies it to the shots of a BitArray: first[k] =
+ * smallest row index of the k-th distinct row in lexicographic row order, counts[k] its multiplicity (host code; nbits <=
+ * 128, else SQD_ERR_LIMIT; bytes other than 0 / 1: SQD_ERR_STATE). */
+int sqd_unique_rows(const uint8_t* bits, int64_t n, int nbits, int64_t* first, int64_t* counts, int64_t* n_unique);
 int sqd_choice_replay(const double* p, int64_t n, int64_t size, int64_t nbatches, const double* uniforms,
                       int64_t n_uniforms, int64_t* out, int64_t* n_used);
 

@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = (
     "sqd_recover_rows",
     "sqd_hamming_excess",
     "sqd_merge_rows",
+    "sqd_unique_rows",
     "sqd_choice_replay",
     "sqd_hash_start",
     "sqd_hash_finish",
@@ -204,6 +205,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_recover_rows.argtypes = [C.POINTER(C.c_uint8), C.c_int64, C.c_int, _i64p, C.c_int64, _dp, _dp, _dp, _dp,
                                      C.c_int, C.c_int, _dp, C.c_int64, _i64p]
     lib.sqd_hamming_excess.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _i64p, _i64p]
+    lib.sqd_unique_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, _i64p]
     lib.sqd_merge_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _i64p, C.c_int]
     lib.sqd_choice_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, _i64p]
     lib.sqd_hash_start.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

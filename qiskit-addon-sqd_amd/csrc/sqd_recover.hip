@@ -14,6 +14,7 @@
 // used, and the caller rewinds the PCG64 stream by the rest (BitGenerator.advance).  Floating point is
 // replayed operation by operation, including numpy's pairwise summation, so that every cdf is bit-identical
 // to the reference's; tests/test_sqd_loop.py replays a recorded run of the reference against it.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -365,6 +366,76 @@ extern "C" __attribute__((visibility("default"))) int sqd_merge_rows(uint8_t* bi
   if (compact)
     for (int64_t k = 0; k < nu; ++k)
       if (first[k] != k) std::memcpy(bits + k * (int64_t)nbits, bits + first[k] * (int64_t)nbits, (size_t)nbits);
+  *n_unique = nu;
+  return SQD_OK;
+}
+
+// sqd_unique_rows: np.unique(bool_matrix, axis=0, return_counts=True) of counts.py:45-61 (the 1e5 shots of a BitArray ->
+// distinct bitstrings in lexicographic row order + how often each occurred): rows packed MSB-first into one or two 64-bit
+// keys, a stable LSD radix sort of (key, row index) on 16-bit digits (digits every row agrees on are skipped), runs
+// counted.  first[k] = smallest row index of the k-th distinct row, counts[k] its multiplicity.  nbits <= 128; bytes
+// other than 0 / 1 -> SQD_ERR_STATE (the caller then asks numpy).
+extern "C" __attribute__((visibility("default"))) int sqd_unique_rows(const uint8_t* bits, int64_t n, int nbits,
+                                                                       int64_t* first, int64_t* counts,
+                                                                       int64_t* n_unique) {
+  if (!bits || !first || !counts || !n_unique || nbits < 1 || n < 0) return SQD_ERR_INVALID;
+  if (nbits > 128 || n > 0x7fffffff) return SQD_ERR_LIMIT;
+  const int words = nbits > 64 ? 2 : 1;
+  std::vector<uint64_t> key[2] = {std::vector<uint64_t>((size_t)n * words), std::vector<uint64_t>((size_t)n * words)};
+  std::vector<uint32_t> idx[2] = {std::vector<uint32_t>((size_t)n), std::vector<uint32_t>((size_t)n)};
+  uint64_t odd = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const uint8_t* row = bits + r * (int64_t)nbits;
+    uint64_t k[2] = {0, 0};  // column c -> bit 63 - (c mod 64) of word c / 64: integer order = row order
+    int c = 0;
+    for (; c + 8 <= nbits; c += 8) {
+      uint64_t w;
+      std::memcpy(&w, row + c, 8);
+      odd |= w & 0xFEFEFEFEFEFEFEFEull;
+      // eight 0 / 1 bytes -> one byte, FIRST column in the top bit (byte j lands on bit 63 - j of the product)
+      k[c >> 6] |= (((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56) << (56 - (c & 63));
+    }
+    for (; c < nbits; ++c) {
+      odd |= row[c] & 0xFEu;
+      k[c >> 6] |= (uint64_t)(row[c] & 1) << (63 - (c & 63));
+    }
+    for (int w = 0; w < words; ++w) key[0][(size_t)r * words + w] = k[w];
+    idx[0][(size_t)r] = (uint32_t)r;
+  }
+  if (odd) return SQD_ERR_STATE;
+  int cur = 0;
+  std::vector<uint32_t> hist(65536);
+  for (int w = words - 1; w >= 0; --w)  // least significant word first
+    for (int shift = 0; shift < 64; shift += 16) {
+      std::fill(hist.begin(), hist.end(), 0u);
+      const uint64_t* kc = key[cur].data();
+      for (int64_t r = 0; r < n; ++r) ++hist[(kc[(size_t)r * words + w] >> shift) & 0xFFFF];
+      if (n && hist[(kc[(size_t)w] >> shift) & 0xFFFF] == (uint32_t)n) continue;  // every row agrees on this digit
+      uint32_t run = 0;
+      for (auto& h : hist) {
+        const uint32_t c0 = h;
+        h = run;
+        run += c0;
+      }
+      uint64_t* kn = key[cur ^ 1].data();
+      const uint32_t* ic = idx[cur].data();
+      uint32_t* in = idx[cur ^ 1].data();
+      for (int64_t r = 0; r < n; ++r) {
+        const uint32_t to = hist[(kc[(size_t)r * words + w] >> shift) & 0xFFFF]++;
+        for (int q = 0; q < words; ++q) kn[(size_t)to * words + q] = kc[(size_t)r * words + q];
+        in[to] = ic[r];
+      }
+      cur ^= 1;
+    }
+  const uint64_t* ks = key[cur].data();
+  const uint32_t* is = idx[cur].data();
+  int64_t nu = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    bool same = r > 0;
+    for (int q = 0; q < words && same; ++q) same = ks[(size_t)r * words + q] == ks[(size_t)(r - 1) * words + q];
+    if (same) ++counts[nu - 1];
+    else first[nu] = is[r], counts[nu] = 1, ++nu;  // (stable sort: the first of a run is its smallest row index)
+  }
   *n_unique = nu;
   return SQD_OK;
 }

@@ -47,6 +47,14 @@ def _unique_rows(bools: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     (sorts one key per row, see ``_row_keys``, instead of comparing rows column by column)."""
     if bools.ndim != 2 or bools.shape[0] == 0 or bools.shape[1] == 0:
         return np.unique(bools, axis=0, return_counts=True)
+    if bools.dtype == np.bool_ and bools.shape[1] <= 128 and bools.shape[0] >= 4096:
+        lib, capi = _native_lib()  # packed keys + radix sort natively (``sqd_unique_rows``); numpy below otherwise
+        if lib is not None:
+            rows = np.ascontiguousarray(bools)
+            n = rows.shape[0]
+            first, counts, nu = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64), capi.C.c_int64(0)
+            if lib.sqd_unique_rows(rows.ctypes.data, n, rows.shape[1], first.ctypes.data, counts.ctypes.data, capi.C.byref(nu)) == 0:
+                return rows[first[: nu.value]], counts[: nu.value].copy()
     _, first, counts = np.unique(_row_keys(bools), return_index=True, return_counts=True)
     return bools[first], counts
 
