@@ -1408,7 +1408,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   };
   static const int64_t dots_split_d = [] {  // tuning hook: subspace dimension from which dots and eigen step are two launches
     const char* env = std::getenv("SQD_DOTS_SPLIT_D");
-    return env ? (int64_t)std::atoll(env) : (int64_t)500000;
+    return env ? (int64_t)std::atoll(env) : (int64_t)200000;  // (profiles/r05/dots_split_probe.txt)
   }();
   const bool split_dots = D >= dots_split_d;
   auto part_b = [&](int round) -> int {

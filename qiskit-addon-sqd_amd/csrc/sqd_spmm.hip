@@ -866,8 +866,10 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
     // 1000: 195 | 237 | 257; 2000: 763 | 1305 | 1244; 3000: 2209 | 3747 | 5073 (500 / 700 with the work items behind the
     // product: 98 | 67 | 73 and 145 | 111 | 125).  Smaller sets stay with the matrix cores: one launch instead of three,
     // and their blocks are 11-26 % dense.
+    // Blocks more than a quarter full (near-complete string sets of few orbitals) go back to the matrix cores: all 1001
+    // strings of (14o, 4e), 31 % dense, 911 us here against 699 us there (profiles/r05/dense_small_orbital_probe.txt).
     const int64_t same_a = tot[0] + tot[1], same_b = tot[2] + tot[3];
-    on = na >= 896 && nb >= 896 && same_a >= 8 * na && same_b >= 8 * nb;
+    on = na >= 896 && nb >= 896 && same_a >= 8 * na && same_b >= 8 * nb && 4 * same_a <= na * na && 4 * same_b <= nb * nb;
   }
   c->sig_spmm = on;
   return on;
