@@ -151,6 +151,15 @@ def _native_lib():
         return None, None
 
 
+def _rewind(bitgen, before: dict, count: int) -> None:
+    """Step a PCG64 back by ``count`` doubles.  ``advance()`` also clears the cached 32-bit half numpy keeps for 32-bit
+    draws; numpy's own ``choice`` / ``random`` draw doubles only and leave it alone, so it is put back as it was."""
+    bitgen.advance(-int(count))
+    after = bitgen.state
+    after["has_uint32"], after["uinteger"] = before["has_uint32"], before["uinteger"]
+    bitgen.state = after
+
+
 def _choice_native(rng, probabilities, size: int, nbatches: int):
     """``nbatches`` calls ``rng.choice(n, size, replace=False, p=probabilities)`` replayed natively (``sqd_choice_replay``) on
     uniforms drawn from the same generator, which is rewound by what was not consumed: the indices and the stream position
@@ -179,11 +188,7 @@ def _choice_native(rng, probabilities, size: int, nbatches: int):
         rc = lib.sqd_choice_replay(p.ctypes.data, p.size, int(size), int(nbatches), uniforms.ctypes.data, uniforms.size,
                                    out.ctypes.data, capi.C.byref(used))
         if rc == 0:
-            bitgen.advance(-(bound - used.value))
-            # (advance() clears PCG64's cached 32-bit half; numpy's own choice() draws doubles only and leaves it alone)
-            after = bitgen.state
-            after["has_uint32"], after["uinteger"] = state["has_uint32"], state["uinteger"]
-            bitgen.state = after
+            _rewind(bitgen, state, bound - used.value)
             return out
         bitgen.state = state  # numpy raises on these inputs, or the block was too short (many collisions)
     return None
@@ -316,7 +321,7 @@ def _recover_all_native(out, probabilities, norb, up_l, dn_l, up_r, dn_r, target
         if rc != 0:
             bitgen.state = state
             return None
-        bitgen.advance(-(bound.value - used.value))
+        _rewind(bitgen, state, bound.value - used.value)
     probs = np.ascontiguousarray(probabilities, dtype=np.float64)
     first = np.empty(n, dtype=np.int64)
     freq = np.empty(n, dtype=np.float64)
@@ -358,5 +363,5 @@ def _recover_rows_native(out, rows, sum_l, sum_r, norb, up_l, dn_l, up_r, dn_r, 
     if rc != 0:  # the caller restores the rows from its input; the stream goes back to where it was
         bitgen.state = state
         return False
-    bitgen.advance(-(bound - used.value))
+    _rewind(bitgen, state, bound - used.value)
     return True

@@ -213,6 +213,8 @@ def test_native_sample_processing_matches_numpy():
     probs /= probs.sum()
     occ = (rng0.random(norb), rng0.random(norb))
     a, b = np.random.default_rng(7), np.random.default_rng(7)
+    a.integers(0, 10, dtype=np.uint32), b.integers(0, 10, dtype=np.uint32)  # leaves a cached 32-bit half in the generator
+    assert a.bit_generator.state["has_uint32"] == 1
     m1, f1 = SP.recover_configurations(bits, probs, occ, 4, 3, rand_seed=a)
     real = SP._recover_all_native
     SP._recover_all_native = lambda *args, **kw: None  # force the numpy path
