@@ -33,7 +33,15 @@ namespace sqd {
 constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather per operand; 4 measured slower: 219 | 817 | 2319 us per sigma at 1000^2 | 2000^2 | 3000^2 against 195 | 763 | 2209)
 static_assert(OPP_K % 2 == 0, "entries are staged and gathered in pairs");
 constexpr int OPP_SMAX = 12;  // beta links per thread (registers: a packed record + an accumulator each, beside the staged batch)
-constexpr int OPP_RMAX = 4;   // columns per thread in the coalesced passes (nb <= OPP_RMAX * threads)
+constexpr int OPP_RMAX = 8;   // columns per thread in the coalesced passes (nb <= OPP_RMAX * threads)
+#ifndef SQD_OPP_RREG
+#define SQD_OPP_RREG 3
+#endif
+constexpr int OPP_RREG = SQD_OPP_RREG;   // ... up to which the J rows of the next batch ride in registers with the source rows; beyond
+                              // (nb > 3072) they ride for the OWN column range only, and the term is formed behind the
+                              // barrier from the staged source values (4000^2: 4227 -> 4056 us per sigma; 3000^2 unchanged)
+constexpr int OPP_RFULL = 4;  // ... up to which the first form exists at all (the fallback when a column range is too wide)
+constexpr int OPP_ROWN = 2;   // own columns per thread in that mode (a range is <= OPP_ROWN * threads columns wide)
 constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30;
 
 // one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
@@ -50,6 +58,7 @@ struct OppState {
   std::vector<MultiRow> h_multi;
   std::vector<int64_t> h_halves;  // [H + 1] first link of every column range, then [H + 1] first column
   int H = 1, S = 0, T = 0;
+  bool own_j = false;  // J rows on the own column range only (k_opp_rows<RM, true>)
   int64_t n_items = 0, n_slots = 0, n_multi = 0;
   size_t shmem = 0;
 };
@@ -116,8 +125,9 @@ struct OppArgs {
   int64_t c_stride, s_stride;
 };
 
-template <int RM>
+template <int RM, bool BIG>
 __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
+  constexpr int RA = BIG ? OPP_ROWN : RM;  // accumulators of the alpha single x beta occupation term (own columns)
   HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
   if (g.stop && *g.stop) return;
   // workgroup b runs on XCD b mod 8: the H column ranges of one item -- they stage the same source rows and J rows --
@@ -148,15 +158,15 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   double acc[OPP_SMAX];
 #pragma unroll
   for (int s = 0; s < OPP_SMAX; ++s) acc[s] = 0.0;
-  double a3[RM];
+  double a3[RA];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) a3[r] = 0.0;
+  for (int r = 0; r < RA; ++r) a3[r] = 0.0;
   const int64_t k0 = g.sa_ptr[A];
   const int e_end = it.e0 + it.ne;
   // Register-staged double buffering: the global loads of batch b + 1 (source rows, J rows, weight rows: everything a
   // thread stages) are requested right behind the barrier that publishes batch b and land while batch b's links are
   // gathered from LDS; a workgroup that fills the CU's registers runs alone on it, so nothing else hides that latency.
-  double px[RM][OPP_K], pjb[RM][OPP_K], pw[OPP_K];
+  double px[RM][OPP_K], pjb[BIG ? OPP_ROWN : RM][OPP_K], pw[OPP_K];
   double psg[OPP_K];
   bool plnk[OPP_K];
   const double* pwrow[OPP_K];
@@ -186,7 +196,16 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
 #pragma unroll
       for (int j = 0; j < OPP_K; ++j) {
         px[r][j] = srow[j][Bc];
-        pjb[r][j] = jrow[j][Bc];
+        if constexpr (!BIG) pjb[r][j] = jrow[j][Bc];
+      }
+    }
+    if constexpr (BIG) {  // rows beyond 4096 columns: the J rows on the OWN column range only
+#pragma unroll
+      for (int r = 0; r < OPP_ROWN; ++r) {
+        const int64_t B = B0 + tid + (int64_t)r * T;
+        const int64_t Bc = B < B1 ? B : B0;
+#pragma unroll
+        for (int j = 0; j < OPP_K; ++j) pjb[r][j] = jrow[j][Bc];
       }
     }
   };
@@ -213,7 +232,7 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
 #pragma unroll
         for (int j = 0; j < OPP_K; ++j) {
           x[j] = px[r][j] * psg[j];
-          a3[r] += plnk[j] ? pjb[r][j] * x[j] : 0.0;
+          if constexpr (!BIG) a3[r] += plnk[j] ? pjb[r][j] * x[j] : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < OPP_K; j += 2) *reinterpret_cast<double2*>(Cst + B * OPP_K + j) = make_double2(x[j], x[j + 1]);
@@ -224,6 +243,15 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   for (int e0 = it.e0; e0 < e_end; e0 += OPP_K) {
     park();
     __syncthreads();
+    if constexpr (BIG) {  // alpha single x beta occupation on the own columns: the staged (signed) source values from LDS
+#pragma unroll
+      for (int r = 0; r < OPP_ROWN; ++r) {
+        const int64_t B = B0 + tid + (int64_t)r * T;
+        const int64_t Bc = B < B1 ? B : B0;
+        const double2 xv = *reinterpret_cast<const double2*>(Cst + Bc * OPP_K);
+        a3[r] += (plnk[0] ? pjb[r][0] * xv.x : 0.0) + (plnk[1] ? pjb[r][1] * xv.y : 0.0);
+      }
+    }
     if (e0 + OPP_K < e_end) request(e0 + OPP_K);
 #pragma unroll
     for (int s = 0; s < OPP_SMAX; ++s) {
@@ -287,8 +315,8 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   const double* __restrict__ gd = g.gdense + A * nb;
   double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    const int64_t B = tid + (int64_t)r * T;
+  for (int r = 0; r < RA; ++r) {
+    const int64_t B = BIG ? B0 + tid + (int64_t)r * T : tid + (int64_t)r * T;
     if (B >= B0 && B < B1) {
       double v = a3[r] + outb[B];
       if (has0) v += hd[B] * crow[B] + gd[B];
@@ -366,6 +394,11 @@ bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   }
   const int S = (int)((longest + T - 1) / T);
   if (S > OPP_SMAX) return false;
+  s->own_j = nb > (int64_t)OPP_RREG * T;  // long rows: a thread holds its OWN range's J values, <= OPP_ROWN columns
+  if (s->own_j)
+    for (int h = 1; h <= H; ++h)
+      if (s->h_halves[(size_t)(H + 1) + h] - s->h_halves[(size_t)(H + 1) + h - 1] > (int64_t)OPP_ROWN * T) s->own_j = false;
+  if (!s->own_j && nb > (int64_t)OPP_RFULL * T) return false;
   s->H = H;
   s->S = S < 1 ? 1 : S;
   s->T = T;
@@ -481,8 +514,12 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
     static std::atomic<size_t> granted[64];
     const int dev = c->device & 63;
     if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {
-      for (const void* f : {reinterpret_cast<const void*>(&k_opp_rows<1>), reinterpret_cast<const void*>(&k_opp_rows<2>),
-                            reinterpret_cast<const void*>(&k_opp_rows<3>), reinterpret_cast<const void*>(&k_opp_rows<4>)})
+      for (const void* f :
+           {reinterpret_cast<const void*>(&k_opp_rows<1, false>), reinterpret_cast<const void*>(&k_opp_rows<2, false>),
+            reinterpret_cast<const void*>(&k_opp_rows<3, false>), reinterpret_cast<const void*>(&k_opp_rows<4, false>),
+            reinterpret_cast<const void*>(&k_opp_rows<4, true>), reinterpret_cast<const void*>(&k_opp_rows<5, true>),
+            reinterpret_cast<const void*>(&k_opp_rows<6, true>), reinterpret_cast<const void*>(&k_opp_rows<7, true>),
+            reinterpret_cast<const void*>(&k_opp_rows<8, true>)})
         SQD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));
       granted[dev].store(s->shmem, std::memory_order_relaxed);
     }
@@ -490,10 +527,20 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   const int rm = (int)((c->nb + s->T - 1) / s->T);  // columns per thread in the coalesced passes (<= OPP_RMAX: opp_select)
   g.n_items = (unsigned)s->n_items;
   const dim3 grid(8u * (unsigned)((s->n_items + 7) / 8) * (unsigned)s->H), block((unsigned)s->T);
-  if (rm <= 1) hipLaunchKernelGGL(k_opp_rows<1>, grid, block, s->shmem, c->stream, g);
-  else if (rm == 2) hipLaunchKernelGGL(k_opp_rows<2>, grid, block, s->shmem, c->stream, g);
-  else if (rm == 3) hipLaunchKernelGGL(k_opp_rows<3>, grid, block, s->shmem, c->stream, g);
-  else hipLaunchKernelGGL(k_opp_rows<4>, grid, block, s->shmem, c->stream, g);
+#define SQD_OPP_GO(RM_, BIG_) hipLaunchKernelGGL((k_opp_rows<RM_, BIG_>), grid, block, s->shmem, c->stream, g)
+  if (!s->own_j) {
+    if (rm <= 1) SQD_OPP_GO(1, false);
+    else if (rm == 2) SQD_OPP_GO(2, false);
+    else if (rm == 3) SQD_OPP_GO(3, false);
+    else SQD_OPP_GO(4, false);
+  } else {
+    if (rm <= 4) SQD_OPP_GO(4, true);
+    else if (rm == 5) SQD_OPP_GO(5, true);
+    else if (rm == 6) SQD_OPP_GO(6, true);
+    else if (rm == 7) SQD_OPP_GO(7, true);
+    else SQD_OPP_GO(8, true);
+  }
+#undef SQD_OPP_GO
   SQD_HIP_CHECK(hipGetLastError());
   // rows in several pieces: inside a Davidson run the first reader of the new vector adds the partial rows (opp_split)
   if (s->n_multi > 0 && !(c->sigma_defer_reduce && indexed)) {

@@ -309,3 +309,12 @@ def test_emu_opp_rows_column_ranges(emu_lib, monkeypatch):
             assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and ctx.link_counts(1)[0] > 64
         run_operator_parity(emu_lib, *case)
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
+    # rows longer than four columns per thread (what more than 4096 strings take with 1024 threads): the J rows ride for
+    # the workgroup's own column range only and the alpha single x beta occupation term is formed from the staged values
+    for s_hook, case in (("2", (11, (2, 5), 6, 230, 29, True)), ("2", (11, (2, 5), 6, 300, 31, True)), ("5", (11, (3, 5), 5, 460, 33, True))):
+        monkeypatch.setenv("SQD_OPP_S", s_hook)
+        h1, eri, sa, sb = make_problem(*case)
+        with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and len(sb) > 3 * 64
+        run_operator_parity(emu_lib, *case)

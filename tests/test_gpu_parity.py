@@ -974,6 +974,47 @@ def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode)
 _CONNECTED_E0: dict = {}
 
 
+@pytest.mark.parametrize("na,nb", [(1000, 5003), (901, 3500)])
+def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
+    """Rows of more than 3072 columns in the whole-row opposite-spin kernel (k_opp_rows<RM, true>: 4 ... 8 columns per
+    thread, the J rows held for the workgroup's own column range only): HF-centred 1000 x 5003 and 901 x 3500 by default
+    selection -- sigma on sampled rows and sampled columns against the row-restricted string-space oracle,
+    reproducibility, the work-item formulation on the whole vector, one whole solve (Rayleigh quotient, residual)."""
+    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
+        monkeypatch.delenv(k, raising=False)
+    norb = 30
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, na, 31), O.hf_centred_strings(norb, 8, nb, 37)
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((na, nb), dtype=np.float32).astype(np.float64)
+    hf = int(np.flatnonzero(sa == (1 << 8) - 1)[0])
+    rows = np.unique(np.concatenate(([0, hf, na - 1], rng.choice(na, 4, replace=False))))
+    hfb = int(np.flatnonzero(sb == (1 << 8) - 1)[0])
+    cols = np.unique(np.concatenate(([0, hfb, nb - 1, 3071, 3072, 3073], rng.choice(nb, 3, replace=False))))
+    ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
+    ref_cols = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), norb, cols)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows"
+        scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
+        sx = ctx.sigma(x)
+        assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
+        assert np.abs(sx[:, cols].T - ref_cols).max() < 1e-11 * scale
+        assert np.array_equal(sx, ctx.sigma(x))
+        amps, st = ctx.davidson()
+        e0 = st["e_davidson"]
+        hc = ctx.sigma(amps)
+        assert st["converged"] == 1 and abs(np.vdot(amps, hc) - e0) < 1e-9
+        assert np.linalg.norm((hc - e0 * amps).ravel()) < np.sqrt(1e-9) * 1.01
+    monkeypatch.setenv("SQD_SIGMA_SPMM", "0")
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_sigma"
+        assert np.abs(ctx.sigma(x) - sx).max() < 1e-11 * scale
+
+
+
 def test_connected_ragged_fes_sized_sparse_product_path(hip_lib, monkeypatch):
     """The sparse-product + whole-row path away from the round numbers it was tuned on: Fe-S-sized orbital space (40
     orbitals: 820 orbital pairs per weight row), nalpha != nbeta electrons (15, 14) and strings (1153 x 931: ragged row
