@@ -20,7 +20,11 @@
 //     per entry, no record traffic, no partial sums per entry batch;
 //   * after the last batch the per-link sums are folded to columns in a fixed order (runs inside a thread, then the
 //     threads a column spans, oldest first): one sigma row, written once.  No partial rows, no reduce launch.
-// Bound: LDS gather throughput (random 16-byte reads: ~3-way bank conflicts per 16-lane group).
+// Rows of more than 3072 columns (k_opp_rows<RM, true>, RM = 4 .. 8 staged columns per thread, sets of up to 8192 strings):
+// the J rows ride in registers for the workgroup's OWN column range only (<= 2 columns per thread) and the alpha single x
+// beta occupation term is formed behind the barrier from the staged, signed source values.
+// Bound: latency of a one-workgroup-per-CU batch loop (profiles/r05/opp_probe.txt: neither the LDS gathers nor the
+// request latency of a batch alone).
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
