@@ -50,6 +50,9 @@ for case in range(ncases):
     neb = nea if rng.random() < 0.5 else int(rng.integers(2, min(10, norb // 2) + 1))
     na = int(rng.choice([300, 880, 896, 900, 1023, 1024, 1025, 1400, 2100]))
     nb = na if rng.random() < 0.4 else int(rng.choice([200, 890, 896, 1000, 1024, 1300, 1900]))
+    if os.environ.get("NA_LIST"):  # unequal sides: env NA_LIST / NB_LIST
+        na = int(rng.choice([int(v) for v in os.environ["NA_LIST"].split()]))
+        nb = int(rng.choice([int(v) for v in os.environ["NB_LIST"].split()]))
     kind = "hf" if rng.random() < 0.7 else "mixed"
     h1, eri = S.synthetic_integrals(norb)
     sa, sb = strings(norb, nea, na, kind, 100 + case), strings(norb, neb, nb, kind, 200 + case)

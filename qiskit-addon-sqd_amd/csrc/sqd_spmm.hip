@@ -856,6 +856,11 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
   c->sig_spmm = false;
   if (direct || row0 != 0 || row1 != na) return false;
   if (na > 0xfffffffell / 64 || nb > 0xfffffffell / 64) return false;
+  // More than 8192 beta strings: the whole-row opposite-spin kernel does not take such rows, and the work items behind the
+  // product (nine or more columns per thread) do not come back on the MI355X at nb = 8193 while they do at 8192
+  // (profiles/r05/long_rows_hang_probe.txt; the emulator runs the same configuration clean).  Not understood yet: such sets
+  // keep the work-item formulation of rounds 1-4, hooks included.
+  if (nb > 8192) return false;
   const char* env = std::getenv("SQD_SIGMA_SPMM");
   bool on = false;
   if (env) {
@@ -869,7 +874,15 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
     // Blocks more than a quarter full (near-complete string sets of few orbitals) go back to the matrix cores: all 1001
     // strings of (14o, 4e), 31 % dense, 911 us here against 699 us there (profiles/r05/dense_small_orbital_probe.txt).
     const int64_t same_a = tot[0] + tot[1], same_b = tot[2] + tot[3];
-    on = na >= 896 && nb >= 896 && same_a >= 8 * na && same_b >= 8 * nb && 4 * same_a <= na * na && 4 * same_b <= nb * nb;
+    // Unequal sides (profiles/r05/shape_probe*.txt, us per sigma, this path | matrix cores + work items | work items): a long
+    // beta side carries it from ~300 alpha strings (300 x 3000: 325 | 324 | 535; 500 x 2000: 269 | 299 | 310; 600 x 6000:
+    // 1396 | - | 3132), a long alpha side from ~450 beta strings (4000 x 500: 481 | 693 | 612; 2500 x 700: 412 | 471 | 445;
+    // 6000 x 600: 1164 | - | 1377); short sides below that stay where they were (200 x 2000: 196 | 131 | 157).
+    // ... for well-connected sets only (>= 4 single links per string on both sides: half-uniform sets of 300 x 1800 lose,
+    // 134 us against 75)
+    const bool unequal = ((nb >= 1800 && na >= 280) || (na >= 2500 && nb >= 450)) && tot[0] >= 4 * na && tot[2] >= 4 * nb;
+    const bool sized = (na >= 896 && nb >= 896) || unequal;
+    on = sized && same_a >= 8 * na && same_b >= 8 * nb && 4 * same_a <= na * na && 4 * same_b <= nb * nb;
   }
   c->sig_spmm = on;
   return on;

@@ -974,6 +974,33 @@ def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode)
 _CONNECTED_E0: dict = {}
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("na,nb,force", [(900, 8193, False), (900, 8193, True), (1000, 10000, False)])
+def test_connected_more_than_8192_beta_strings_keep_the_work_items(hip_lib, monkeypatch, na, nb, force):
+    """HF-centred sets with more than 8192 beta strings: the sparse product is not selected (spmm_select; with the work
+    items behind it the sigma build did not return at nb = 8193, profiles/r05/long_rows_hang_probe.txt), hooks or not;
+    sigma on sampled rows against the row-restricted string-space oracle, and it comes back."""
+    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
+        monkeypatch.delenv(k, raising=False)
+    if force:
+        monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
+    norb = 30
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, na, 31), O.hf_centred_strings(norb, 8, nb, 37)
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((na, nb), dtype=np.float32).astype(np.float64)
+    rows = np.unique(np.concatenate(([0, na - 1], rng.choice(na, 3, replace=False))))
+    ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_sigma"
+        scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
+        sx = ctx.sigma(x)
+        assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
+        assert np.array_equal(sx, ctx.sigma(x))
+
+
+
 @pytest.mark.parametrize("na,nb", [(1000, 5003), (901, 3500)])
 def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
     """Rows of more than 3072 columns in the whole-row opposite-spin kernel (k_opp_rows<RM, true>: 4 ... 8 columns per
