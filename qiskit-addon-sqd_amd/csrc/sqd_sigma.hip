@@ -1059,7 +1059,10 @@ static int launch_sigma_rs(sqd_ctx* c, const SigmaArgs& g) {
 template <int R>
 static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
   const bool spin = (g.mode == 1 || g.spin);
-  if (c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max)  // multi-pass walk of the beta lists
+  // multi-pass walk of the beta lists -- also for rows of more than eight columns per thread (R = 16) whose lists fit one
+  // pass: k_sigma<16, ., true, false> does not return on the MI355X (profiles/r05/long_rows_hang_probe.txt) while the
+  // multi-pass instantiation, here with zero extra passes, is the one every set of ~10^4 strings has run since round 2
+  if (R > 8 || c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max)
     return spin ? launch_sigma_rs<R, true, true, true>(c, g) : launch_sigma_rs<R, false, true, true>(c, g);
   return spin ? launch_sigma_rs<R, true, true, false>(c, g) : launch_sigma_rs<R, false, true, false>(c, g);
 }

@@ -856,11 +856,8 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
   c->sig_spmm = false;
   if (direct || row0 != 0 || row1 != na) return false;
   if (na > 0xfffffffell / 64 || nb > 0xfffffffell / 64) return false;
-  // More than 8192 beta strings: the whole-row opposite-spin kernel does not take such rows, and the work items behind the
-  // product (nine or more columns per thread) do not come back on the MI355X at nb = 8193 while they do at 8192
-  // (profiles/r05/long_rows_hang_probe.txt; the emulator runs the same configuration clean).  Not understood yet: such sets
-  // keep the work-item formulation of rounds 1-4, hooks included.
-  if (nb > 8192) return false;
+  // (More than 8192 beta strings: the whole-row opposite-spin kernel does not take such rows; the work items run behind the
+  // product -- through the multi-pass instantiation of k_sigma, see launch_sigma_r.)
   const char* env = std::getenv("SQD_SIGMA_SPMM");
   bool on = false;
   if (env) {

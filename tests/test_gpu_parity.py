@@ -975,15 +975,15 @@ _CONNECTED_E0: dict = {}
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("na,nb,force", [(900, 8193, False), (900, 8193, True), (1000, 10000, False)])
-def test_connected_more_than_8192_beta_strings_keep_the_work_items(hip_lib, monkeypatch, na, nb, force):
-    """HF-centred sets with more than 8192 beta strings: the sparse product is not selected (spmm_select; with the work
-    items behind it the sigma build did not return at nb = 8193, profiles/r05/long_rows_hang_probe.txt), hooks or not;
-    sigma on sampled rows against the row-restricted string-space oracle, and it comes back."""
+@pytest.mark.parametrize("na,nb", [(900, 8193), (1000, 10000)])
+def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
+    """HF-centred sets with more than 8192 beta strings (nine and more columns per thread in the work-item kernel, which
+    runs behind the sparse product there: the whole-row kernel does not take such rows).  The single-pass instantiation
+    k_sigma<16, ., true, false> did not return on the MI355X at nb = 8193 (profiles/r05/long_rows_hang_probe.txt); such rows
+    go through the multi-pass instantiation.  Sigma on sampled rows against the row-restricted string-space oracle, the
+    work items alone on the whole vector, and it comes back."""
     for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
         monkeypatch.delenv(k, raising=False)
-    if force:
-        monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
     norb = 30
     h1, eri = O.synthetic_integrals(norb)
     sa, sb = O.hf_centred_strings(norb, 8, na, 31), O.hf_centred_strings(norb, 8, nb, 37)
@@ -993,11 +993,18 @@ def test_connected_more_than_8192_beta_strings_keep_the_work_items(hip_lib, monk
     ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
-        assert ctx.sigma_kernel() == "k_sigma"
+        assert ctx.sigma_kernel() == "k_spmm_rows+k_sigma"
         scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
         sx = ctx.sigma(x)
         assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
         assert np.array_equal(sx, ctx.sigma(x))
+        assert np.abs(ctx.sigma(x, use_spin=1, ss=0.75, shift=0.3)[rows]).max() > 0.0  # (the penalty form returns as well)
+    monkeypatch.setenv("SQD_SIGMA_SPMM", "0")
+    monkeypatch.setenv("SQD_SIGMA_DENSE", "0")
+    with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+        ctx.set_subspace(sa, sb)
+        assert ctx.sigma_kernel() == "k_sigma"
+        assert np.abs(ctx.sigma(x) - sx).max() < 1e-11 * scale
 
 
 
