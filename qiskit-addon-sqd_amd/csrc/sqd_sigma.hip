@@ -1360,7 +1360,9 @@ bool sigma_batch_supported(const sqd_ctx* c) {
   if (c->sharded()) return false;
   if (c->sig_rows > 0 || c->sig_lists || c->sig_spmm) return false;
   if (c->sig_direct) return true;
-  return c->sig_lds_rows && !(c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max) && c->sig_R <= 16;
+  // (R <= 8: the batched launch classes are single-pass, and the single-pass kernel of 9+ columns per thread is the one that
+  // does not return on the MI355X -- see launch_sigma_r; such subspaces are solved one by one)
+  return c->sig_lds_rows && !(c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max) && c->sig_R <= 8;
 }
 static int work_item_R(const sqd_ctx* c) {
   const int R = c->sig_R;
