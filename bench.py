@@ -604,10 +604,10 @@ def secondary_entries(args, h1, eri, device):
             res[key] = entry
         except Exception as exc:
             res[key] = {"error": repr(exc)}
-    # --- CONNECTED subspaces at D = 1e6 and 9e6 (HF-centred 1000^2, 3000^2): the regime the reference advertises
+    # --- CONNECTED subspaces at D = 1e6, 9e6 and 2.5e7 (HF-centred 1000^2, 3000^2, 5000^2): the regime the reference advertises
     # (README.md:78, "subspace dimensions of ~1e7") -- sigma against the HBM roofline, the whole Davidson iteration, and
     # the dense same-spin product of the same subspace on the matrix cores (orders 1024 / 3072) against the f64 MFMA peak
-    for n in (1000, 3000):
+    for n in (1000, 3000, 5000):
         key = f"hf_centred_{n}x{n}"
         try:
             sa, sb = S.hf_centred_strings(30, 8, n, 11), S.hf_centred_strings(30, 8, n, 13)
@@ -617,9 +617,10 @@ def secondary_entries(args, h1, eri, device):
             entry = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
                      "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
             entry["roofline"]["note_kernels"] = (
-                "one sigma = the same-spin product (sqd::k_spmm_grouped between two k_spmm_transpose launches from ~1000 strings "
-                "per spin, sqd::k_same_spin_mfma below) + sqd::k_sigma (opposite-spin work items); avg_launch_ms is the whole "
-                "application (HIP events around 5 of them); per-kernel times: profiles/r05/")
+                "one sigma = the same-spin product (sqd::k_spmm_grouped between two k_spmm_transpose launches) + sqd::k_opp_rows "
+                "(opposite-spin part + diagonal by whole rows, the beta link list in registers; rows of more than 3072 columns "
+                "in its 4-8-columns-per-thread form); avg_launch_ms is the whole application (HIP events around 5 of them); "
+                "per-kernel times: profiles/r05/final_hf1000_kernel_stats.csv, final_hf3000_kernel_stats.csv")
             ctx.davidson(fetch=False)  # (first call at this size grows the arenas: not timed)
             ctx.sync()
             t0 = time.perf_counter()
