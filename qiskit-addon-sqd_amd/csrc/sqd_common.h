@@ -368,7 +368,8 @@ void spmm_release(sqd_ctx* c);
 // opp_launch: sigma = (hdiag + opposite-spin part) c + gdense, behind spmm_launch of the same vector
 bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot);
 int opp_build(sqd_ctx* c);
-int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride);
+int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride, bool spin = false,
+               double ss = 0.0, double shift = 0.0);
 void opp_release(sqd_ctx* c);
 bool opp_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial);
 // batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class

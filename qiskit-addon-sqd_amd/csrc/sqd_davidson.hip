@@ -1351,7 +1351,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   SplitRows split{nullptr, nullptr, c->nb};
   // (the whole-row opposite-spin kernel of sqd_opp.hip -- plain operator on the subspaces of the sparse-product path --
   // writes complete rows: nothing to add)
-  if (c->sig_opp && form_sel == 0) {
+  if (c->sig_opp && form_sel != 2) {  // (plain operator and the linear penalty form: both by whole rows)
     const int32_t* ri = nullptr;
     const double* pp = nullptr;
     if (opp_split(c, &ri, &pp)) {
@@ -1748,7 +1748,7 @@ int shard_dav_pick(sqd_ctx* c, double** d_send) {
 // (a "shard" that holds all rows -- a group of one -- may run the whole-row opposite-spin kernel of sqd_opp.hip for the
 // plain operator: its rows in several pieces are then the split rows, not the work items')
 static bool shard_split_rows(const sqd_ctx* c, const int32_t** rowinfo, const double** partial) {
-  if (c->sig_opp && c->shard_form == 0) return opp_split(c, rowinfo, partial);
+  if (c->sig_opp && c->shard_form != 2) return opp_split(c, rowinfo, partial);
   if (!(c->n_multi > 0 && c->shard_form != 2 && !c->sig_direct && c->sig_rows == 0)) return false;
   *rowinfo = c->rowinfo.as<int32_t>();
   *partial = c->sig_partial.as<double>();

@@ -46,7 +46,7 @@ constexpr int OPP_RREG = SQD_OPP_RREG;   // ... up to which the J rows of the ne
                               // barrier from the staged source values (4000^2: 4227 -> 4056 us per sigma; 3000^2 unchanged)
 constexpr int OPP_RFULL = 4;  // ... up to which the first form exists at all (the fallback when a column range is too wide)
 constexpr int OPP_ROWN = 2;   // own columns per thread in that mode (a range is <= OPP_ROWN * threads columns wide)
-constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30;
+constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30, OPP_DIR = 1u << 31;  // DIR: low bit of the link's widx
 
 // one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
 // link e - 1); slot < 0: the row has this one item and is written in place, else partial row `slot` (added in slot
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_opp_tab(const OppTabArgs g) {
       const SRec r = g.sb_rec[l];
       col = g.sb_row[l];
       rec = (r.src & 0xffffu) | ((srec_widx(r.meta) >> 1) << 16) | ((r.meta >> 31) ? OPP_SIGN : 0u) | OPP_LIVE |
-            ((l + 1 == g.sb_ptr[col + 1]) ? OPP_LAST : 0u);
+            ((l + 1 == g.sb_ptr[col + 1]) ? OPP_LAST : 0u) | ((srec_widx(r.meta) & 1u) ? OPP_DIR : 0u);
     }
     g.link[base + (int64_t)s * g.T + t] = rec;
     g.lcol[base + (int64_t)s * g.T + t] = col;
@@ -127,9 +127,14 @@ struct OppArgs {
   unsigned n_items;
   GPtr<const int> stop, vec_index;
   int64_t c_stride, s_stride;
+  // the linear spin penalty, sigma = (H + shift (S^2 - ss)) c (pyscf's fix_spin_ form for ss < sz(sz+1) + 0.1; SPIN
+  // instantiations): S^2 = sz(sz+1) + sum_p n_pb (1 - n_pa) - sum_{p != q} Ea_qp Eb_pq -- a diagonal term on the own row
+  // and -shift on the weight of the ONE beta link with the alpha link's orbital pair and the opposite direction
+  double ss, shift, szterm;
+  GPtr<const uint64_t> strs_a, strs_b;
 };
 
-template <int RM, bool BIG>
+template <int RM, bool BIG, bool SPIN>
 __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   constexpr int RA = BIG ? OPP_ROWN : RM;  // accumulators of the alpha single x beta occupation term (own columns)
   HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
@@ -173,6 +178,8 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
   double px[RM][OPP_K], pjb[BIG ? OPP_ROWN : RM][OPP_K], pw[OPP_K];
   double psg[OPP_K];
   bool plnk[OPP_K];
+  uint32_t ppart[OPP_K];  // SPIN: {pair, direction, LIVE} of the beta link an entry's alpha link pairs with in S^2, in the
+                          // bit layout of the link records (0: none -- no live record matches it)
   const double* pwrow[OPP_K];
   auto request = [&](int e0) {
     const double* srow[OPP_K];
@@ -185,6 +192,8 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
       SRec r = SRec{(uint32_t)A, 0u};
       if (plnk[j]) r = g.sa_rec[k0 + e - 1];
       const int64_t pair = (int64_t)(srec_widx(r.meta) >> 1);
+      if constexpr (SPIN)
+        ppart[j] = plnk[j] ? (((uint32_t)pair << 16) | ((srec_widx(r.meta) & 1u) ? 0u : OPP_DIR) | OPP_LIVE) : 0u;
       srow[j] = C + (int64_t)r.src * nb;
       psg[j] = valid ? (plnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
       pwrow[j] = plnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
@@ -256,6 +265,11 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
         a3[r] += (plnk[0] ? pjb[r][0] * xv.x : 0.0) + (plnk[1] ? pjb[r][1] * xv.y : 0.0);
       }
     }
+    uint32_t cpart[OPP_K];
+    if constexpr (SPIN) {
+#pragma unroll
+      for (int j = 0; j < OPP_K; ++j) cpart[j] = ppart[j];
+    }
     if (e0 + OPP_K < e_end) request(e0 + OPP_K);
 #pragma unroll
     for (int s = 0; s < OPP_SMAX; ++s) {
@@ -267,6 +281,15 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
       for (int j = 0; j < OPP_K / 2; ++j) {
         cv[j] = *reinterpret_cast<const double2*>(cp + 2 * j);
         wv2[j] = *reinterpret_cast<const double2*>(wp + 2 * j);
+      }
+      if constexpr (SPIN) {
+        constexpr uint32_t KEY = OPP_DIR | OPP_LIVE | 0x0fff0000u;  // (a dead slot, rc = 0, matches "none": its sum is never read)
+        const double pen = -g.shift;
+#pragma unroll
+        for (int j = 0; j < OPP_K / 2; ++j) {
+          wv2[j].x += (((rc ^ cpart[2 * j]) & KEY) == 0u) ? pen : 0.0;
+          wv2[j].y += (((rc ^ cpart[2 * j + 1]) & KEY) == 0u) ? pen : 0.0;
+        }
       }
 #pragma unroll
       for (int j = 0; j < OPP_K / 2; ++j) {
@@ -323,7 +346,11 @@ __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
     const int64_t B = BIG ? B0 + tid + (int64_t)r * T : tid + (int64_t)r * T;
     if (B >= B0 && B < B1) {
       double v = a3[r] + outb[B];
-      if (has0) v += hd[B] * crow[B] + gd[B];
+      if (has0) {
+        double d = hd[B];
+        if constexpr (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
+        v += d * crow[B] + gd[B];
+      }
       orow[B] = v;
     }
   }
@@ -479,7 +506,8 @@ int opp_build(sqd_ctx* c) {
 }
 
 // sigma = (hdiag + opposite-spin part) c + G, G = sqd_ctx::gdense as spmm_launch has just formed it for the same vector
-int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride) {
+int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride, bool spin, double ss,
+               double shift) {
   OppState* s = static_cast<OppState*>(c->opp);
   if (!s) {
     set_error("internal: opposite-spin row kernel without its tables");
@@ -514,16 +542,22 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   g.vec_index = indexed ? c->sigma_index : nullptr;
   g.c_stride = in_stride;
   g.s_stride = out_stride;
+  g.ss = ss;
+  g.shift = shift;
+  {
+    const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+    g.szterm = sz * (sz + 1.0);
+  }
+  g.strs_a = c->sp[0].strs.as<uint64_t>();
+  g.strs_b = c->sp[1].strs.as<uint64_t>();
   if (s->shmem > 64 * 1024) {
     static std::atomic<size_t> granted[64];
     const int dev = c->device & 63;
     if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {
-      for (const void* f :
-           {reinterpret_cast<const void*>(&k_opp_rows<1, false>), reinterpret_cast<const void*>(&k_opp_rows<2, false>),
-            reinterpret_cast<const void*>(&k_opp_rows<3, false>), reinterpret_cast<const void*>(&k_opp_rows<4, false>),
-            reinterpret_cast<const void*>(&k_opp_rows<4, true>), reinterpret_cast<const void*>(&k_opp_rows<5, true>),
-            reinterpret_cast<const void*>(&k_opp_rows<6, true>), reinterpret_cast<const void*>(&k_opp_rows<7, true>),
-            reinterpret_cast<const void*>(&k_opp_rows<8, true>)})
+#define SQD_OPP_F(RM_, BIG_) reinterpret_cast<const void*>(&k_opp_rows<RM_, BIG_, false>), reinterpret_cast<const void*>(&k_opp_rows<RM_, BIG_, true>)
+      for (const void* f : {SQD_OPP_F(1, false), SQD_OPP_F(2, false), SQD_OPP_F(3, false), SQD_OPP_F(4, false), SQD_OPP_F(4, true),
+                            SQD_OPP_F(5, true), SQD_OPP_F(6, true), SQD_OPP_F(7, true), SQD_OPP_F(8, true)})
+#undef SQD_OPP_F
         SQD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));
       granted[dev].store(s->shmem, std::memory_order_relaxed);
     }
@@ -531,7 +565,11 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   const int rm = (int)((c->nb + s->T - 1) / s->T);  // columns per thread in the coalesced passes (<= OPP_RMAX: opp_select)
   g.n_items = (unsigned)s->n_items;
   const dim3 grid(8u * (unsigned)((s->n_items + 7) / 8) * (unsigned)s->H), block((unsigned)s->T);
-#define SQD_OPP_GO(RM_, BIG_) hipLaunchKernelGGL((k_opp_rows<RM_, BIG_>), grid, block, s->shmem, c->stream, g)
+#define SQD_OPP_GO(RM_, BIG_)                                                                            \
+  do {                                                                                                   \
+    if (spin) hipLaunchKernelGGL((k_opp_rows<RM_, BIG_, true>), grid, block, s->shmem, c->stream, g);    \
+    else hipLaunchKernelGGL((k_opp_rows<RM_, BIG_, false>), grid, block, s->shmem, c->stream, g);        \
+  } while (0)
   if (!s->own_j) {
     if (rm <= 1) SQD_OPP_GO(1, false);
     else if (rm == 2) SQD_OPP_GO(2, false);

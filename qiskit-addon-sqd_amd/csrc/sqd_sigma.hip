@@ -1315,11 +1315,11 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   if (!can_split) c->sig_part = 0;
   if (c->sig_lists) return launch_sigma_lists(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
   if (c->sig_direct) return launch_sigma_direct(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride);
-  if (c->sig_opp && mode == 0 && !spin) {
-    // connected sets of ~10^3 strings per spin and more, plain operator: same-spin product, then the opposite-spin part
-    // and the diagonal by whole rows -- no work items, no partial rows
+  if (c->sig_opp && mode == 0) {
+    // connected sets of ~10^3 strings per spin and more, the operator with or without the linear spin penalty: same-spin
+    // product, then the opposite-spin part and the diagonal by whole rows -- no work items, no partial rows
     SQD_TRY(spmm_launch(c, d_c, in_stride));
-    return opp_launch(c, d_c, d_sigma, in_stride, out_stride);
+    return opp_launch(c, d_c, d_sigma, in_stride, out_stride, spin, ss, shift);
   }
   SigmaArgs g;
   fill_sigma_args(c, d_c, d_sigma, mode, spin, ss, shift, in_stride, out_stride, &g);

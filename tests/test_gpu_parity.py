@@ -1035,6 +1035,7 @@ def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
         assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
         assert np.abs(sx[:, cols].T - ref_cols).max() < 1e-11 * scale
         assert np.array_equal(sx, ctx.sigma(x))
+        sp = ctx.sigma(x, use_spin=1, ss=0.75, shift=0.3)  # (the linear penalty form: the same kernel, SPIN instantiation)
         amps, st = ctx.davidson()
         e0 = st["e_davidson"]
         hc = ctx.sigma(amps)
@@ -1046,6 +1047,7 @@ def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
         ctx.set_subspace(sa, sb)
         assert ctx.sigma_kernel() == "k_sigma"
         assert np.abs(ctx.sigma(x) - sx).max() < 1e-11 * scale
+        assert np.abs(ctx.sigma(x, use_spin=1, ss=0.75, shift=0.3) - sp).max() < 1e-11 * scale
 
 
 
