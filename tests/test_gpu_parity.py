@@ -699,8 +699,13 @@ def test_row_sharded_overlap_hf_1000_on_gpu(hip_lib, monkeypatch):
             for ov in ("1", "0"):
                 monkeypatch.setenv("SQD_SHARD_OVERLAP", ov)
                 out[kern, ov] = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+        # the linear spin penalty on the default path (the whole-row kernel's SPIN form; its split rows in the sharded dots)
+        pen = solve_sci_sharded((sa, sb), h1, eri, norb, nelec, spin_sq=0.0)
     finally:
         dist.destroy_process_group()
+    monkeypatch.delenv("SQD_SHARD_FORCE_COLLECTIVES")
+    pen_ref = solve_sci((sa, sb), h1, eri, norb, nelec, spin_sq=0.0, compute_rdms=False)
+    assert pen._sharded_stats["converged"] and abs(pen.energy - pen_ref.energy) < 1e-6, (pen.energy, pen_ref.energy)
     for kern in ("items", "default"):
         a, b = out[kern, "1"], out[kern, "0"]
         assert a._sharded_stats["converged"] and b._sharded_stats["converged"], (kern, a._sharded_stats, b._sharded_stats)
