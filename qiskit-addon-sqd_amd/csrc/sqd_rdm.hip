@@ -7,7 +7,10 @@
 // Conventions: dm1s[p,q] = <a+_p a_q>;  dm2[p,q,r,s] = sum_{st} <p+_s r+_t s_t q_s>.
 // Orbital occupancies (the diagonal of dm1s, the only part that feeds back into the SQD loop) are
 // reduced in a fixed order and are bitwise reproducible; off-diagonal bins use f64 atomics.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "sqd_common.h"
 #include "sqd_device.h"
@@ -191,6 +194,106 @@ __global__ void k_rdm2_ab(const double* __restrict__ C, int64_t nb, int64_t la, 
     const int p = a.pq & 63, q = (a.pq >> 6) & 63;
     const double v = (double)(a.sign * b.sign) * C[(int64_t)a.tgt * nb + b.tgt] * C[(int64_t)a.src * nb + b.src];
     if (v != 0.0) atomicAdd(&G[i4(norb, p, q, r, s)], v);
+  }
+}
+// ---- the same sum for CONNECTED sets (la x lb ~ 3e9 pairs at 3000 strings per spin: 132 ms of one global atomic per pair
+// above).  The pairs factorise like the single x single term of sigma (sqd_opp.hip): for an alpha xlink a, every beta xlink
+// b contributes sa sb u[tgt_b] v[src_b] with u = C[tgt_a, :], v = C[src_a, :] to G[pq_a][rs_b].  Both lists are sorted by
+// their orbital pair on the device (counting sort: k_xl_hist / k_xl_scan / k_xl_scatter); a workgroup owns a chunk of <= E
+// alpha xlinks of ONE pair pq and a range of the beta list: every thread keeps S consecutive beta xlinks (packed, in
+// registers) and one sum per xlink over the whole chunk, the two rows are staged in LDS per alpha xlink; at the end the
+// sums fold over the runs of equal rs inside the thread and go to G[pq][rs] with one atomic per run.
+constexpr int RAB_S = 12, RAB_E = 32;
+__global__ void k_xl_hist(const XLink* __restrict__ x, int64_t n, unsigned* __restrict__ hist) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&hist[x[i].pq & 4095u], 1u);
+}
+__global__ void __launch_bounds__(1024) k_xl_scan(const unsigned* __restrict__ hist, unsigned* __restrict__ cursor) {  // 4096 bins, one workgroup
+  __shared__ unsigned part[1024];
+  const int t = threadIdx.x;
+  unsigned v[4], sum = 0;
+  for (int k = 0; k < 4; ++k) v[k] = hist[4 * t + k], sum += v[k];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned y = t >= d ? part[t - d] : 0u;
+    __syncthreads();
+    part[t] += y;
+    __syncthreads();
+  }
+  unsigned run = part[t] - sum;
+  for (int k = 0; k < 4; ++k) cursor[4 * t + k] = run, run += v[k];
+}
+__global__ void k_xl_scatter(const XLink* __restrict__ x, int64_t n, unsigned* __restrict__ cursor, XLink* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[atomicAdd(&cursor[x[i].pq & 4095u], 1u)] = x[i];
+}
+struct RabItem {
+  uint32_t a0, na;  // alpha xlinks [a0, a0 + na) of the sorted list: one orbital pair
+};
+struct RabArgs {
+  GPtr<const double> c;
+  int64_t nb, lb;
+  GPtr<const XLink> xa, xb;  // sorted by pq
+  GPtr<const RabItem> items;
+  unsigned n_items;
+  int H, T, norb;
+  GPtr<double> G;
+};
+__global__ void __launch_bounds__(1024) k_rdm2_ab_rows(const RabArgs g) {
+  HIP_DYNAMIC_SHARED(double, smem)  // u[nb] | v[nb]
+  const int T = g.T, tid = threadIdx.x;
+  const unsigned item = blockIdx.x / (unsigned)g.H;
+  const int h = (int)(blockIdx.x % (unsigned)g.H);
+  if (item >= g.n_items) return;
+  const RabItem it = g.items[item];
+  const int64_t nb = g.nb;
+  double* u = smem;
+  double* v = smem + ((nb + 1) & ~int64_t(1));
+  // this thread's beta xlinks: {tgt | src << 16}, {rs | live << 30 | negative << 31}
+  uint32_t w0[RAB_S], w1[RAB_S];
+  double acc[RAB_S];
+  const int64_t l0 = ((int64_t)h * T + tid) * RAB_S;
+#pragma unroll
+  for (int s = 0; s < RAB_S; ++s) {
+    const int64_t l = l0 + s;
+    w0[s] = 0u, w1[s] = 0u, acc[s] = 0.0;
+    if (l < g.lb) {
+      const XLink b = g.xb[l];
+      w0[s] = (b.tgt & 0xffffu) | (b.src << 16);
+      w1[s] = (b.pq & 4095u) | (1u << 30) | (b.sign < 0.0f ? (1u << 31) : 0u);
+    }
+  }
+  for (uint32_t k = 0; k < it.na; ++k) {
+    const XLink a = g.xa[it.a0 + k];
+    const double* __restrict__ ru = g.c + (int64_t)a.tgt * nb;
+    const double* __restrict__ rv = g.c + (int64_t)a.src * nb;
+    const double sa = (double)a.sign;
+    __syncthreads();  // (the previous pair of rows has been read)
+    for (int64_t B = tid; B < nb; B += T) {
+      u[B] = sa * ru[B];
+      v[B] = rv[B];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < RAB_S; ++s) acc[s] += u[w0[s] & 0xffffu] * v[w0[s] >> 16];
+  }
+  // runs of equal rs inside the thread -> one atomic each (dead slots carry no live bit)
+  const XLink a0 = g.xa[it.a0];
+  const int p = a0.pq & 63, q = (a0.pq >> 6) & 63;
+  double run = 0.0;
+#pragma unroll
+  for (int s = 0; s < RAB_S; ++s) {
+    if (w1[s] & (1u << 30)) {
+      run += (w1[s] >> 31) ? -acc[s] : acc[s];
+      const bool last = (s == RAB_S - 1) || !(w1[s + 1 < RAB_S ? s + 1 : s] & (1u << 30)) ||
+                        ((w1[s + 1 < RAB_S ? s + 1 : s] ^ w1[s]) & 4095u);
+      if (last) {
+        const int r = w1[s] & 63, sq = (w1[s] >> 6) & 63;
+        if (run != 0.0) atomicAdd(&g.G[i4(g.norb, p, q, r, sq)], run);
+        run = 0.0;
+      }
+    }
   }
 }
 // dm2 += G + G^T(2,3,0,1)
@@ -675,7 +778,10 @@ static int rdm2_impl(sqd_ctx* c, const double* d_c, bool resolved, double* const
     xl[s] = c->sp[s].n_s + c->sp[s].n * c->sp[s].nocc;
   }
   const size_t xbytes = (size_t)(xl[0] + xl[1]) * sizeof(XLink);
-  SQD_TRY(c->scratch.reserve((size_t)need * 8 + xbytes + 256));
+  // (+ the row form of the opposite-spin block: the lists once more, sorted; 2 x 2 x 4096 counters; its work items)
+  const size_t max_items = 4096 + (size_t)xl[0] / RAB_E + 1;
+  const size_t rbytes = xbytes + 4 * 4096 * sizeof(unsigned) + max_items * sizeof(RabItem) + 256;
+  SQD_TRY(c->scratch.reserve((size_t)need * 8 + xbytes + rbytes + 256));
   double* base = c->scratch.as<double>();
   double* same[2] = {base, resolved ? base + n4 : base};
   double* G = base + nhead - n4;
@@ -706,9 +812,67 @@ static int rdm2_impl(sqd_ctx* c, const double* d_c, bool resolved, double* const
     SQD_HIP_CHECK(hipGetLastError());
   }
   if (xl[0] > 0 && xl[1] > 0) {
-    unsigned gy = (unsigned)(xl[0] < 1024 ? xl[0] : 1024);
-    hipLaunchKernelGGL(k_rdm2_ab, dim3(nblk(xl[1], 256), gy), dim3(256), 0, st, d_c, c->nb, xl[0], xl[1],
-                       (const XLink*)xlink[0], (const XLink*)xlink[1], norb, G);
+    // connected sets: sorted lists + staged rows (k_rdm2_ab_rows); small or very long-rowed ones: a thread per beta xlink
+    bool rows = (double)xl[0] * (double)xl[1] >= 2e8 && c->nb <= 65535 && c->na <= 0x7fffffff;
+    int T = 1024;
+    if (const char* env = std::getenv("SQD_RDM2_ROWS")) {  // test hook: "T" forces the row form with T threads, "0" forbids
+      const int v = std::atoi(env);
+      rows = v >= 64 && v <= 1024 && v % 64 == 0 && c->nb <= 65535;
+      if (rows) T = v;
+    }
+    const size_t shmem = (size_t)(((c->nb + 1) & ~int64_t(1)) * 2) * 8;
+    const int64_t H = (xl[1] + (int64_t)RAB_S * T - 1) / ((int64_t)RAB_S * T);
+    if (shmem + 1024 > (size_t)c->lds_bytes || H > 4096) rows = false;
+    if (rows) {
+      // sort both lists by orbital pair (order inside a pair: as the atomics fall -- the sums below are atomic anyway)
+      XLink* xs[2] = {xlink[1] + xl[1], xlink[1] + xl[1] + xl[0]};
+      unsigned* hist = reinterpret_cast<unsigned*>(xs[1] + xl[1]);  // [2][4096] counts, then [2][4096] cursors
+      unsigned* cursor = hist + 2 * 4096;
+      RabItem* d_items = reinterpret_cast<RabItem*>(cursor + 2 * 4096);
+      SQD_HIP_CHECK(hipMemsetAsync(hist, 0, 2 * 4096 * sizeof(unsigned), st));
+      for (int sd = 0; sd < 2; ++sd) {
+        hipLaunchKernelGGL(k_xl_hist, dim3(nblk(xl[sd], 256)), dim3(256), 0, st, (const XLink*)xlink[sd], xl[sd], hist + sd * 4096);
+        hipLaunchKernelGGL(k_xl_scan, dim3(1), dim3(1024), 0, st, (const unsigned*)(hist + sd * 4096), cursor + sd * 4096);
+        hipLaunchKernelGGL(k_xl_scatter, dim3(nblk(xl[sd], 256)), dim3(256), 0, st, (const XLink*)xlink[sd], xl[sd], cursor + sd * 4096, xs[sd]);
+      }
+      SQD_HIP_CHECK(hipGetLastError());
+      std::vector<unsigned> h_hist(4096);
+      SQD_HIP_CHECK(hipMemcpyAsync(h_hist.data(), hist, 4096 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      SQD_STREAM_SYNC(st);
+      std::vector<RabItem> items;
+      uint32_t at = 0;
+      for (int b = 0; b < 4096; ++b) {
+        for (uint32_t o = 0; o < h_hist[b]; o += RAB_E) items.push_back(RabItem{at + o, std::min<uint32_t>(RAB_E, h_hist[b] - o)});
+        at += h_hist[b];
+      }
+      if (items.size() > max_items) {
+        set_error("internal: more opposite-spin rdm2 work items than planned");
+        return SQD_ERR_STATE;
+      }
+      SQD_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(RabItem), hipMemcpyHostToDevice, st));
+      RabArgs ra;
+      ra.c = d_c;
+      ra.nb = c->nb;
+      ra.lb = xl[1];
+      ra.xa = xs[0];
+      ra.xb = xs[1];
+      ra.items = d_items;
+      ra.n_items = (unsigned)items.size();
+      ra.H = (int)H;
+      ra.T = T;
+      ra.norb = norb;
+      ra.G = G;
+      if (shmem > 64 * 1024)
+        SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rdm2_ab_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)shmem));
+      hipLaunchKernelGGL(k_rdm2_ab_rows, dim3((unsigned)(items.size() * (size_t)H)), dim3((unsigned)T), shmem, st, ra);
+      SQD_HIP_CHECK(hipGetLastError());
+      SQD_STREAM_SYNC(st);  // (the item list is a host vector copied asynchronously)
+    } else {
+      unsigned gy = (unsigned)(xl[0] < 1024 ? xl[0] : 1024);
+      hipLaunchKernelGGL(k_rdm2_ab, dim3(nblk(xl[1], 256), gy), dim3(256), 0, st, d_c, c->nb, xl[0], xl[1],
+                         (const XLink*)xlink[0], (const XLink*)xlink[1], norb, G);
+    }
   }
   if (!resolved) {
     hipLaunchKernelGGL(k_rdm2_symm_add, dim3(nblk(n4, 256)), dim3(256), 0, st, norb, (const double*)G, same[0]);

@@ -318,3 +318,29 @@ def test_emu_opp_rows_column_ranges(emu_lib, monkeypatch):
             ctx.set_subspace(sa, sb)
             assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and len(sb) > 3 * 64
         run_operator_parity(emu_lib, *case)
+
+
+def test_emu_rdm2_opposite_spin_row_form(emu_lib, monkeypatch):
+    # SQD_RDM2_ROWS=64 forces the row form of the opposite-spin block of rdm2 (sqd_rdm.hip: both extended link lists sorted
+    # by orbital pair on the device, an alpha chunk's rows staged in LDS, the beta list in registers) that sets with 2e8
+    # and more link pairs take by default -- here with 64-thread workgroups: one and several beta ranges, chunks of one
+    # pair cut at 32 links, against the oracle's rdm2 and against the thread-per-link form ("0")
+    from oracle import sqd_oracle as O
+
+    for case in ((7, (3, 3), 20, 20, 7, True), (11, (2, 5), 6, 300, 31, True), (10, (4, 2), 120, 9, 3, False)):
+        norb = case[0]
+        h1, eri, sa, sb = make_problem(*case)
+        amps = np.random.default_rng(case[4]).standard_normal((len(sa), len(sb)))
+        amps /= np.linalg.norm(amps)
+        out = {}
+        for hook in ("64", "0"):
+            monkeypatch.setenv("SQD_RDM2_ROWS", hook)
+            with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+                ctx.set_subspace(sa, sb)
+                out[hook] = ctx.rdm2(amps)
+                if hook == "64":
+                    aa, ab, bb = ctx.rdm2s(amps)
+        ref = O.make_rdm2(amps, sa, sb, norb)
+        assert np.allclose(out["64"], ref, atol=1e-12) and np.allclose(out["0"], ref, atol=1e-12), case
+        # resolved form: dm2 = aa + bb + ab + ab^T(2,3,0,1)
+        assert np.allclose(aa + bb + ab + ab.transpose(2, 3, 0, 1), ref, atol=1e-12), case

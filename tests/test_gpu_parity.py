@@ -979,6 +979,37 @@ def test_connected_3000x3000_sampled_sigma_and_solve(hip_lib, monkeypatch, mode)
 _CONNECTED_E0: dict = {}
 
 
+def test_rdm2_row_form_on_a_connected_set(hip_lib, monkeypatch):
+    """rdm2 of a state on HF-centred 1000 x 1100 (3e9 opposite-spin link pairs: the row form of sqd_rdm.hip by default)
+    against the thread-per-link form of rounds 1-4 on the same state, the resolved blocks, the trace, and E = <c|H|c>
+    from the RDMs contracted as the reference does (fermion.py:730-732)."""
+    norb = 30
+    h1, eri = O.synthetic_integrals(norb)
+    sa, sb = O.hf_centred_strings(norb, 8, 1000, 11), O.hf_centred_strings(norb, 7, 1100, 13)
+    amps = np.random.default_rng(3).standard_normal((len(sa), len(sb))) * np.exp(-np.add.outer(np.arange(len(sa)), np.arange(len(sb))) / 400.0)
+    amps /= np.linalg.norm(amps)
+    out = {}
+    for hook in (None, "0"):
+        if hook is None:
+            monkeypatch.delenv("SQD_RDM2_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("SQD_RDM2_ROWS", hook)
+        with _capi.Context(h1, eri, lib=hip_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            out[hook] = ctx.rdm2(amps)
+            if hook is None:
+                aa, ab, bb = ctx.rdm2s(amps)
+                d1a, d1b = ctx.rdm1s(amps)
+                e_sigma = float(np.vdot(amps, ctx.sigma(amps)))
+    d2 = out[None]
+    assert np.abs(d2 - out["0"]).max() < 1e-12
+    assert np.abs(aa + bb + ab + ab.transpose(2, 3, 0, 1) - d2).max() < 1e-12
+    assert abs(np.einsum("ppqq->", d2) - 15.0 * 14.0) < 1e-9
+    e_rdm = np.einsum("pq,pq->", h1, d1a + d1b) + 0.5 * np.einsum("prqs,prqs->", eri, d2)
+    assert abs(e_rdm - e_sigma) < 1e-9 * max(1.0, abs(e_sigma))
+
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("na,nb", [(900, 8193), (1000, 10000)])
 def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
