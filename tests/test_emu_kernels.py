@@ -249,7 +249,7 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
     # to 3 links every list of these cases is walked in several reloads (the path lists longer than 64 links take)
     monkeypatch.setenv("SQD_ALPHA_CHUNK", "3")
     run_operator_parity(emu_lib, *cases[1])
-    run_operator_parity(emu_lib, *cases[-1])
+    run_operator_parity(emu_lib, *cases[4])
     monkeypatch.delenv("SQD_ALPHA_CHUNK")
     # a set whose tails exceed the overflow tables (complete beta space: 261 links per string) is refused: another kernel
     ok, _, _ = selected(12, (2, 6), 3, 300, 19, False)
