@@ -381,6 +381,8 @@ SQD_API int sqd_shard_dav_sigma(sqd_ctx* c, const double* d_c_full) {
 }
 SQD_API int sqd_shard_dav_sigma_part(sqd_ctx* c, const double* d_c_full, int part) {
   CTX_ENTER(c);
+  if (part < 0 || part > 2) return SQD_ERR_INVALID;
+  if (part != 1 && !d_c_full) return SQD_ERR_INVALID;  // only part 1 (own rows, in front of the gather) reads no full vector
   return shard_dav_sigma(c, d_c_full, part);
 }
 SQD_API int sqd_shard_dav_dots(sqd_ctx* c, double** d_totals, int* count) {

@@ -426,7 +426,7 @@ __device__ inline bool rqi_dispatch(int m, const double (&a)[MV], double& ci, do
 // dot products, the linear-dependence test, the lowest eigenpair, the Ritz coefficients, the restart decision.
 // tot[0] = |X_{m-1}|^2, tot[1+v] = X_v . A X_{m-1}.  w / wh: the LDS working copy (dav_state_prefetch).
 template <int MV>
-__device__ inline void wave_eig_step(DavState* st, unsigned long long* s_head, double* wh, const double* tot, const DavParams prm,
+__device__ __attribute__((always_inline)) inline void wave_eig_step(DavState* st, unsigned long long* s_head, double* wh, const double* tot, const DavParams prm,
                                      double* sA, double* sM, double* sv_eig) {
   const int lane = threadIdx.x & 63;
   DavState* w = reinterpret_cast<DavState*>(s_head);  // (head fields only)

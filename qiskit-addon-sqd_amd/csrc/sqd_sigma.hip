@@ -327,8 +327,19 @@ __device__ inline unsigned sclk_row() {
 // (bx, by) = work item and column chunk of this workgroup within ITS subspace; T threads work, the others (a batched
 // launch is sized for the largest workgroup of its class) park on an index no loop reaches -- they still meet every
 // barrier
+// ALWAYS inlined into its two kernels (round 6).  As an out-of-line function -- what the compiler chose for the R = 8 / 16
+// single-pass instantiations, whose bodies exceed its inline threshold -- the argument record travels through scratch, every
+// field is re-loaded per lane with flat loads, the compiler has to treat the workgroup-uniform branches (item type, stop
+// flag) as divergent, and the body needs a 400-byte stack frame per thread: the form in which k_sigma<16, ., true, false>
+// never returned on the MI355X (profiles/r06/hang_root_cause.txt; tests/test_codeobj_audit.py pins "no kernel of the
+// library calls out of line or owns a stack frame").  -DSQD_SIGMA_BODY_NOINLINE rebuilds the old form for the probe.
+#ifdef SQD_SIGMA_BODY_NOINLINE
+#define SQD_SIGMA_BODY_INLINE __attribute__((noinline))
+#else
+#define SQD_SIGMA_BODY_INLINE __attribute__((always_inline))
+#endif
 template <int R, bool SPIN, bool LDSROW, bool PASS>
-__device__ inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx, unsigned by) {
+__device__ SQD_SIGMA_BODY_INLINE inline void sigma_body(const SigmaArgs& g, double* smem, unsigned bx, unsigned by) {
   if (g.stop && *g.stop) return;  // uniform over the subspace
   SCLK(k0);
   const int T = g.T, tid = ((int)threadIdx.x < T) ? (int)threadIdx.x : (1 << 30);
@@ -1062,7 +1073,11 @@ static int launch_sigma_r(sqd_ctx* c, const SigmaArgs& g) {
   // multi-pass walk of the beta lists -- also for rows of more than eight columns per thread (R = 16) whose lists fit one
   // pass: k_sigma<16, ., true, false> does not return on the MI355X (profiles/r05/long_rows_hang_probe.txt) while the
   // multi-pass instantiation, here with zero extra passes, is the one every set of ~10^4 strings has run since round 2
-  if (R > 8 || c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max)
+  static const bool r16_single = [] {  // probe / test hook: rows of more than eight columns per thread in the single-pass form
+    const char* env = std::getenv("SQD_SIGMA_R16_SINGLE");
+    return env && std::atoi(env) != 0;
+  }();
+  if ((R > 8 && !r16_single) || c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max)
     return spin ? launch_sigma_rs<R, true, true, true>(c, g) : launch_sigma_rs<R, false, true, true>(c, g);
   return spin ? launch_sigma_rs<R, true, true, false>(c, g) : launch_sigma_rs<R, false, true, false>(c, g);
 }
@@ -1305,7 +1320,10 @@ int launch_sigma(sqd_ctx* c, const double* d_c, double* d_sigma, int mode, bool 
   // (two-launch sigma of a row shard: only the work-item kernel has a part that needs no remote row; the others run whole
   // behind the gather)
   // (a context that holds ALL rows may also have chosen a dense / sparse-product same-spin formulation: whole as well)
-  const bool can_split = !c->sig_lists && !c->sig_direct && !c->sig_dense && !c->sig_opp;
+  // (and subspaces whose beta lists need extra passes: one launch rounds ((d c + sums + axpy) + extra-pass sums), two
+  // launches ((d c + sums) + extra-pass sums) + axpy -- the split promises the same bits, so those run whole too)
+  const bool multi_pass = c->sig_ps < c->hv_s.nv_max || c->sig_pd < c->hv_d.nv_max;
+  const bool can_split = !c->sig_lists && !c->sig_direct && !c->sig_dense && !c->sig_opp && !multi_pass;
   if (c->sig_part == 1 && !can_split) return SQD_OK;
   struct PartGuard {  // parts of a kernel that cannot be split: the second call runs everything
     sqd_ctx* c;

@@ -160,6 +160,9 @@ def _rewind(bitgen, before: dict, count: int) -> None:
     bitgen.state = after
 
 
+_SQD_ERR_LIMIT = -4  # include/sqd_hip.h: the block of uniforms was too short
+
+
 def _choice_native(rng, probabilities, size: int, nbatches: int):
     """``nbatches`` calls ``rng.choice(n, size, replace=False, p=probabilities)`` replayed natively (``sqd_choice_replay``) on
     uniforms drawn from the same generator, which is rewound by what was not consumed: the indices and the stream position
@@ -190,7 +193,10 @@ def _choice_native(rng, probabilities, size: int, nbatches: int):
         if rc == 0:
             _rewind(bitgen, state, bound - used.value)
             return out
-        bitgen.state = state  # numpy raises on these inputs, or the block was too short (many collisions)
+        bitgen.state = state
+        if rc != _SQD_ERR_LIMIT:  # inputs numpy raises on (SQD_ERR_STATE): a longer block cannot help -- numpy's turn
+            return None
+        # SQD_ERR_LIMIT: the block was too short (many collisions) -- once more at the worst case
     return None
 
 
