@@ -332,11 +332,10 @@ def main():
     nsig = 0
     ms_sigma = ms_apply = ms_empty = 0.0
     n_timed = 0
-    step_marks = [] if os.environ.get("SQD_BENCH_DEBUG") else None
+    step_marks = []  # (one perf_counter per step: the median of the steps is reported beside the mean)
     for _ in range(args.steps):
         e, st = one_step()
-        if step_marks is not None:
-            step_marks.append(time.perf_counter())
+        step_marks.append(time.perf_counter())
         nsig += st["n_sigma"]
         n_timed += st["n_sigma_timed"]
         ms_sigma += st["ms_sigma_kernel"]
@@ -360,8 +359,9 @@ def main():
             ms_empty += stx["ms_event_overhead"]
         nsig = nsig_keep
     F.set_profiling(0)
-    if step_marks is not None and rank == 0:
-        d = np.diff([t0] + step_marks) * 1e3
+    step_ms = np.diff([t0] + step_marks) * 1e3
+    if os.environ.get("SQD_BENCH_DEBUG") and rank == 0:
+        d = step_ms
         print("step ms:", " ".join(f"{x:.3f}" for x in d), "| closing sync %.3f" % ((t0 + elapsed - step_marks[-1]) * 1e3),
               file=sys.stderr)
     # device time of the two phases of a solve (HIP events around the table build and around the Davidson run): five
@@ -387,6 +387,10 @@ def main():
     if rank == 0:
         ctx = F._get_context(h1, eri, local_rank)  # the context the timed solves used (cache hit)
         t_sigma_ms = ms_sigma / max(n_timed, 1)
+        # The roofline leg's launch duration: 200 launches of the sigma kernel BEHIND the timed region, every one inside
+        # its own HIP-event bracket with an empty bracket behind it, medians of both (round 5's line carried 5 samples
+        # taken inside the region: 0.060 <-> 0.096 from box to box).  The in-region samples stay as a cross-check.
+        br = ctx.time_sigma_brackets(200, 0 if args.spin_sq is None else 0)
         ns_a, nd_a = ctx.link_counts(0)
         ns_b, nd_b = ctx.link_counts(1)
         traffic, source = pmc_traffic(args)
@@ -426,9 +430,15 @@ def main():
             "tables_ms_per_solve": ms_setup,
             "energy": float(e), "converged": int(st["converged"]), "residual": float(st["residual"]),
             "links": {"alpha_single": ns_a, "alpha_double": nd_a, "beta_single": ns_b, "beta_double": nd_b},
-            "roofline": roofline_entry(ctx, t_sigma_ms, ms_apply / max(n_timed, 1), n_timed, traffic, source,
-                                       ms_empty / max(n_timed, 1)),
+            "roofline": roofline_entry(ctx, br["kernel_median_ms"], ms_apply / max(n_timed, 1), br["launches"], traffic, source,
+                                       br["empty_median_ms"]),
+            "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_min": float(np.min(step_ms)),
         }
+        out["roofline"]["bracket_source"] = ("200 launches behind the timed region, one HIP-event bracket each + an empty bracket; "
+                                             "medians (means: %.4f / %.4f ms)" % (br["kernel_mean_ms"], br["empty_mean_ms"]))
+        out["roofline"]["in_region_samples"] = {"launches": n_timed, "event_bracket_ms": t_sigma_ms,
+                                                "empty_bracket_ms": ms_empty / max(n_timed, 1)}
         # SURVEY 8d's second unit: one Davidson ITERATION, B_iter = B_sigma + 8 D (4 m + 6) at basis size m (the mean
         # m of this solve: sigma builds 1..n), over the device time of the Davidson run per sigma build
         n_it = max(nsig / args.steps, 1.0)

@@ -296,6 +296,9 @@ int sqd_rdm2s(sqd_ctx* ctx, const double* amps, double* dm2aa, double* dm2ab, do
 /* Benchmark hooks: run `reps` sigma builds on the resident solution buffer and report the
  * average device time per launch of the dominant sigma kernel (HIP events on the context stream). */
 int sqd_time_sigma(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift, double* ms_per_sigma);
+/* ... with a HIP-event bracket around every launch of the dominant sigma kernel and an empty bracket behind it:
+ * out4 = {mean, median kernel bracket, mean, median empty bracket} in ms over `reps` (<= 4096) launches. */
+int sqd_time_sigma_brackets(sqd_ctx* ctx, int reps, int use_spin, double ss, double shift, double* out4);
 /* ... and of the matrix-core same-spin product alone (subspaces in dense mode, sqd_sigma_kernel kind 3): `copies` identical
  * problems per launch (1 = what a single solve launches, 16 = a batched solve's full chip), average device time per
  * launch and the flops of one launch on the padded orders (2 pa^2 pb + 2 pa pb^2 per copy) -- the MFMA roofline entry of
@@ -310,7 +313,9 @@ int sqd_sigma_bytes_needed(sqd_ctx* ctx, double* bytes);
 /* Which sigma kernel the current subspace selected (benchmark / test hook, no reference counterpart):
  * kind 0 = work items (k_sigma), 1 = element gather (k_sigma_direct), 2 = whole rows in LDS (k_sigma_rows),
  * 3 = dense same-spin blocks on the f64 matrix cores (k_same_spin_mfma) + work items for the opposite-spin terms,
- * 4 = list passes for large sets with short lists (k_sigma_lists: link lists in registers, rows of C and C^T through LDS);
+ * 4 = list passes for large sets with short lists (k_sigma_lists: link lists in registers, rows of C and C^T through LDS),
+ * 5 = sparse same-spin product (k_spmm_*) + work items, 6 = sparse product + whole-row opposite-spin kernel (k_opp_rows,
+ * rows of <= 3072 columns), 7 = sparse product + the source-range form of it (k_opp_src, longer rows);
  * rows_per_workgroup is set for kind 2, else 0. */
 int sqd_sigma_kernel(sqd_ctx* ctx, int* kind, int* rows_per_workgroup);
 

@@ -11,7 +11,7 @@ FILES=${@:-sqd_lists.hip}
 mkdir -p $B/obj
 CC="hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -I$CS"
 OBJS=""
-for f in sqd_tables sqd_sigma sqd_lists sqd_spmm sqd_opp sqd_davidson sqd_rdm sqd_pauli sqd_recover sqd_capi; do
+for f in sqd_tables sqd_sigma sqd_lists sqd_spmm sqd_opp sqd_oppsrc sqd_davidson sqd_rdm sqd_pauli sqd_recover sqd_capi; do
   if echo " $FILES " | grep -q " $f.hip "; then
     $CC $FLAGS -c $CS/$f.hip -o $B/obj/${f}_$NAME.o; OBJS="$OBJS $B/obj/${f}_$NAME.o"
   else

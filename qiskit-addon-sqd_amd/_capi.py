@@ -71,6 +71,7 @@ EXPORTED_SYMBOLS = (
     "sqd_rdm2",
     "sqd_rdm2s",
     "sqd_time_sigma",
+    "sqd_time_sigma_brackets",
     "sqd_time_dense",
     "sqd_sigma_bytes",
     "sqd_sigma_bytes_needed",
@@ -194,6 +195,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_rdm2.argtypes = [_ctxp, _dp, _dp]
     lib.sqd_rdm2s.argtypes = [_ctxp, _dp, _dp, _dp, _dp]
     lib.sqd_time_sigma.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+    lib.sqd_time_sigma_brackets.argtypes = [_ctxp, C.c_int, C.c_int, C.c_double, C.c_double, _dp]
     lib.sqd_time_dense.argtypes = [_ctxp, C.c_int, C.c_int, _dp, _dp]
     lib.sqd_sigma_bytes.argtypes = [_ctxp, _dp]
     lib.sqd_sigma_bytes_needed.argtypes = [_ctxp, _dp]
@@ -908,6 +910,13 @@ class Context:
         self._check(self._lib.sqd_time_sigma(self._h, reps, use_spin, ss, shift, C.byref(out)))
         return float(out.value)
 
+    def time_sigma_brackets(self, reps: int = 200, use_spin: int = 0, ss: float = 0.0, shift: float = 0.0) -> dict:
+        """HIP-event bracket around every one of ``reps`` launches of the dominant sigma kernel, an empty bracket behind each:
+        mean / median of both in ms (the roofline leg of bench.py, run behind the timed region)."""
+        out = (C.c_double * 4)()
+        self._check(self._lib.sqd_time_sigma_brackets(self._h, reps, use_spin, ss, shift, out))
+        return {"kernel_mean_ms": out[0], "kernel_median_ms": out[1], "empty_mean_ms": out[2], "empty_median_ms": out[3], "launches": reps}
+
     def time_dense(self, reps: int = 10, copies: int = 1):
         """(ms per launch, flops per launch) of the matrix-core same-spin product alone, ``copies`` problems per launch."""
         ms, fl = C.c_double(), C.c_double()
@@ -931,9 +940,10 @@ class Context:
         (large sets with short lists: link lists in registers, one pass over C and one over its transpose) or
         ``k_spmm_rows+k_sigma`` / ``k_spmm_rows+k_opp_rows`` (connected sets from ~10^3 strings per spin: the same-spin
         part as a sparse product in row-AXPY form on C and C^T; the opposite-spin terms by work items, or -- the default
-        for the plain operator -- by whole rows with the beta link list in registers)."""
+        for the plain operator -- by whole rows with the beta link list in registers: ``k_opp_rows`` up to 3072 columns,
+        ``k_opp_src``, passes over ranges of the source column, beyond)."""
         kind, rows = C.c_int(), C.c_int()
         self._check(self._lib.sqd_sigma_kernel(self._h, C.byref(kind), C.byref(rows)))
         return ("k_sigma", "k_sigma_direct", f"k_sigma_rows<{rows.value}>", "k_same_spin_mfma+k_sigma",
-                "k_sigma_lists", "k_spmm_rows+k_sigma", "k_spmm_rows+k_opp_rows")[kind.value]
+                "k_sigma_lists", "k_spmm_rows+k_sigma", "k_spmm_rows+k_opp_rows", "k_spmm_rows+k_opp_src")[kind.value]
 

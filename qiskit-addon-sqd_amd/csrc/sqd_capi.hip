@@ -7,6 +7,8 @@
 #include <mutex>
 #include <thread>
 
+#include <algorithm>
+
 #include "sqd_common.h"
 
 namespace sqd {
@@ -1102,6 +1104,74 @@ SQD_API int sqd_time_sigma(sqd_ctx* c, int reps, int use_spin, double ss, double
   return SQD_OK;
 }
 
+// ... with a HIP-event bracket around EVERY launch of the dominant sigma kernel and an empty bracket right behind it:
+// out[0] / out[1] = mean / median kernel bracket, out[2] / out[3] = mean / median empty bracket (ms).  `reps` samples of a
+// 6 us kernel average the jitter of a 5 us event record away; bench.py's roofline leg runs it BEHIND the timed region.
+SQD_API int sqd_time_sigma_brackets(sqd_ctx* c, int reps, int use_spin, double ss, double shift, double* out4) {
+  CTX_ENTER(c);
+  NEED_SUBSPACE(c);
+  NEED_ALL_ROWS(c);
+  if (reps < 1 || reps > 4096 || !out4) return SQD_ERR_INVALID;
+  const double* d = nullptr;
+  if (c->have_solution) {
+    d = c->sol.as<double>();
+  } else {
+    SQD_TRY(sol_writer_guard(c));
+    SQD_TRY(c->sol.reserve((size_t)c->D * 8));
+    SQD_HIP_CHECK(hipMemsetAsync(c->sol.p, 0, c->D * 8, c->stream));
+    d = c->sol.as<double>();
+  }
+  SQD_TRY(c->tmp1.reserve((size_t)c->D * 8));
+  std::vector<hipEvent_t> ev((size_t)3 * reps, nullptr);
+  int rc = SQD_OK;
+  auto cleanup = [&]() {
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
+  };
+  for (hipEvent_t& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      cleanup();
+      set_error("sqd_time_sigma_brackets: hipEventCreate failed");
+      return SQD_ERR_HIP;
+    }
+  rc = apply_h(c, d, c->tmp1.as<double>(), use_spin, ss, shift);  // warm-up
+  for (int i = 0; i < reps && rc == SQD_OK; ++i) {
+    if (hipEventRecord(ev[3 * i], c->stream) != hipSuccess) rc = SQD_ERR_HIP;
+    c->ev_after_sigma_kernel = ev[3 * i + 1];  // recorded by the launcher right behind the dominant kernel
+    if (rc == SQD_OK) rc = apply_h(c, d, c->tmp1.as<double>(), use_spin, ss, shift);
+    if (c->ev_after_sigma_kernel) {  // (a formulation that does not record it: bracket the whole application)
+      c->ev_after_sigma_kernel = nullptr;
+      if (rc == SQD_OK && hipEventRecord(ev[3 * i + 1], c->stream) != hipSuccess) rc = SQD_ERR_HIP;
+    }
+    if (rc == SQD_OK && hipEventRecord(ev[3 * i + 2], c->stream) != hipSuccess) rc = SQD_ERR_HIP;
+  }
+  if (rc == SQD_OK) rc = spin_stream_sync(c->stream);
+  c->stage_pending = false;
+  if (rc == SQD_OK) {
+    std::vector<double> k((size_t)reps), e((size_t)reps);
+    for (int i = 0; i < reps; ++i) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, ev[3 * i], ev[3 * i + 1]) != hipSuccess || hipEventElapsedTime(&b, ev[3 * i + 1], ev[3 * i + 2]) != hipSuccess) {
+        rc = SQD_ERR_HIP;
+        break;
+      }
+      k[i] = a;
+      e[i] = b;
+    }
+    if (rc == SQD_OK) {
+      auto mean = [](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return s / (double)v.size(); };
+      auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      out4[0] = mean(k);
+      out4[1] = median(k);
+      out4[2] = mean(e);
+      out4[3] = median(e);
+    }
+  }
+  cleanup();
+  if (rc == SQD_ERR_HIP) set_error("sqd_time_sigma_brackets: HIP event failure");
+  return rc;
+}
+
 SQD_API int sqd_time_dense(sqd_ctx* c, int reps, int copies, double* ms_per_launch, double* flops_per_launch) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
@@ -1131,7 +1201,7 @@ SQD_API int sqd_sigma_bytes(sqd_ctx* c, double* bytes) {
 SQD_API int sqd_sigma_kernel(sqd_ctx* c, int* kind, int* rows_per_workgroup) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
-  if (kind) *kind = c->sig_lists ? 4 : c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_opp ? 6 : (c->sig_spmm ? 5 : (c->sig_dense ? 3 : 0))));
+  if (kind) *kind = c->sig_lists ? 4 : c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_opp ? (c->opp_src ? 7 : 6) : (c->sig_spmm ? 5 : (c->sig_dense ? 3 : 0))));
   if (rows_per_workgroup) *rows_per_workgroup = c->sig_rows;
   return SQD_OK;
 }

@@ -255,6 +255,8 @@ struct sqd_ctx {
   // the work items, for the plain operator (H without a spin penalty; S^2 and the penalty forms keep the work items)
   bool sig_opp = false;
   void* opp = nullptr;           // sqd::OppState (sqd_opp.hip)
+  bool opp_src = false;          // ... by passes over source-column ranges (k_opp_src) instead of k_opp_rows
+  void* oppsrc = nullptr;        // sqd::OppSrcState (sqd_oppsrc.hip)
   // row-sharded Davidson, sigma in two launches around the all-gather (shard_dav_sigma_part): 0 = one launch, 1 = the part
   // that needs only this rank's rows (input: sig_c_own), 2 = the rest; read by fill_sigma_args / launch_sigma
   int sig_part = 0;
@@ -372,6 +374,14 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
                double ss = 0.0, double shift = 0.0);
 void opp_release(sqd_ctx* c);
 bool opp_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial);
+// ... for rows of more than 3072 columns: passes over ranges of the SOURCE column (sqd_oppsrc.hip); reached through the
+// opp_* entry points above (sqd_ctx::opp_src)
+bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot);
+int oppsrc_build(sqd_ctx* c);
+int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride, bool spin, double ss, double shift);
+void oppsrc_release(sqd_ctx* c);
+bool oppsrc_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial);
+int oppsrc_passes(const sqd_ctx* c);
 // batched sigma (sqd_solve_batch): per launch class one launch over all subspaces of the class
 struct SigmaBatchPlan {
   struct Launch {

@@ -8,49 +8,38 @@
 // qiskit_addon_sqd/fermion.py:721-723, :810-818).  The last two terms are one sum over the "entries" of
 // row A -- the row itself (weights Ja[A][:]) and its alpha single links (weights (pq|:)) -- times the beta single links.
 //
-// Round 6 formulation (k_opp_rows; the round-5 kernel of the same name kept the beta links by TARGET column range, every
-// range staging whole source rows: 4.7 GB per sigma at 3000 x 3000 out of the Infinity Cache, two LDS gathers per
-// multiply-add, 6-40 spilled registers on rows of more than 4096 columns).  ONE workgroup owns a piece of a target row A
-// (<= E of its entries) and walks the beta link list in PASSES over ranges of the SOURCE column B':
-//   * a pass stages only its range [q0, q1) of every source row -- each element of a source row is staged once per item,
-//     not once per range -- two entries at a time, interleaved (Cst[B' - q0][2], signed) and double-buffered in LDS;
-//   * inside a range the links are grouped by excitation operator (widx = orbital pair and direction) in sub-runs of four:
-//     a thread holds <= NSUB sub-runs -- per link ONE register, the byte offset of its source column in Cst, and one
-//     accumulator -- and per sub-run the byte offset of its weight pair in Wst[widx][2]: a link costs one 16-byte LDS
-//     gather and two multiply-adds, a sub-run one more gather; no address arithmetic, no record decoding, and the linear
-//     spin penalty is one addition to a staged weight (Wst[partner of the alpha link][entry] -= shift);
-//   * the alpha single x beta occupation term rides on the staging pass (the staged columns' J values in registers);
-//   * at the end of a pass the per-link sums go through LDS to the threads that own the target columns (positions in
-//     target order precomputed per range; runs summed in that order), and a thread carries its columns' sums over the
-//     passes in registers: one sigma row per item, written once, same bits on every run.
-// Rows in one piece are written in place; the others as partial rows that the first reader of the vector adds in slot
-// order (k_dots_s inside a Davidson run, k_opp_reduce otherwise).
+// Why a kernel of its own.  The work-item kernel (sqd_sigma.hip) spends 24 vector instructions per multiply-add at 3000
+// strings per spin (rocprofv3 counters, profiles/r05/pmc_spmm_hf3000_counters.txt: 422 M VALU instructions for 1.1e9
+// multiply-adds; waves parked 55 % of their life): every item of <= 3 alpha links re-reads and re-decodes all 33 000 beta
+// link records, runs them through virtual rows and LDS partial sums, and writes a partial row that a later launch adds.
+// Here ONE workgroup owns a target row A (and a range of columns):
+//   * every thread keeps its share of the beta link list -- S <= 12 consecutive links, one packed 32-bit record each
+//     {source column, orbital pair, sign, last-of-column} -- in registers for the whole row, and one accumulator per link;
+//   * the row's entries are staged four at a time, INTERLEAVED: Cst[B'][4] (signed source rows) and Wst[rs][4] (weight
+//     rows), so that a link costs two 16-byte LDS gathers per operand and four multiply-adds -- no address arithmetic
+//     per entry, no record traffic, no partial sums per entry batch;
+//   * after the last batch the per-link sums are folded to columns in a fixed order (runs inside a thread, then the
+//     threads a column spans, oldest first): one sigma row, written once.  No partial rows, no reduce launch.
+// Rows of more than 3072 columns (k_opp_rows<RM, true>, RM = 4 .. 8 staged columns per thread, sets of up to 8192 strings):
+// the J rows ride in registers for the workgroup's OWN column range only (<= 2 columns per thread) and the alpha single x
+// beta occupation term is formed behind the barrier from the staged, signed source values.
+// Bound: latency of a one-workgroup-per-CU batch loop (profiles/r05/opp_probe.txt: neither the LDS gathers nor the
+// request latency of a batch alone).
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
-#include <cstring>
 #include <numeric>
 
 #include "sqd_common.h"
 
 namespace sqd {
 
-constexpr int OPP_SUB = 4;       // links per sub-run (one weight gather serves four links)
-constexpr int OPP_NSUB_MAX = 2;  // sub-runs per thread (8 links: 8 + 16 registers; three sub-runs spill at 1024 threads' 128 registers)
-constexpr int OPP_JR_MAX = 2;    // staged columns per thread and pass (a range is <= JR * threads columns wide)
-constexpr int OPP_RMAX = 8;      // target columns per thread (nb <= OPP_RMAX * threads)
-// LDS plan (bytes; compile-time offsets so that the buffer of a batch is an immediate of the gather instruction):
-//   Cst[2][COLS][2] | Wst[2][ROWS][2] -- the staging buffers; accb[links of a pass] takes their place at the end of a pass
-//   and jbuf[JR * T] sits behind.  BIG = false: 64 + 8 KB, two workgroups of 512 threads per CU (norb <= 31);
-//   BIG = true: 128 + 16 KB (norb <= 44, or 1024 threads)
-template <bool BIG>
-struct OppLds {
-  static constexpr int COLS = BIG ? 2048 : 1024, ROWS = BIG ? 2048 : 1024;
-  static constexpr int CST0 = 0, CST1 = COLS * 16, WST0 = 2 * COLS * 16, WST1 = WST0 + ROWS * 16;
-  static constexpr int STAGE_BYTES = WST1 + ROWS * 16;
-  static constexpr int JBUF = STAGE_BYTES;
-};
-constexpr uint32_t OPP_DEAD = 0xffffffffu;
+constexpr int OPP_K = 2;      // entries staged per batch (the interleave width of Cst / Wst: one 16-byte gather per operand; 4 measured slower: 219 | 817 | 2319 us per sigma at 1000^2 | 2000^2 | 3000^2 against 195 | 763 | 2209)
+static_assert(OPP_K % 2 == 0, "entries are staged and gathered in pairs");
+constexpr int OPP_SMAX = 12;  // beta links per thread (registers: a packed record + an accumulator each, beside the staged batch)
+constexpr int OPP_SMAX3 = 11; // ... with three staged columns per thread (twelve: two spilled registers in the spin-penalty instantiation)
+constexpr int OPP_RREG = 3;   // staged columns per thread (nb <= 3 * threads: longer rows run k_opp_src, sqd_oppsrc.hip)
+constexpr uint32_t OPP_SIGN = 1u << 28, OPP_LAST = 1u << 29, OPP_LIVE = 1u << 30, OPP_DIR = 1u << 31;  // DIR: low bit of the link's widx
 
 // one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
 // link e - 1); slot < 0: the row has this one item and is written in place, else partial row `slot` (added in slot
@@ -60,26 +49,61 @@ struct OppItem {
   int32_t e0, ne, slot;
 };
 struct OppState {
-  DevBuf tab, cptr, colcut, items, rowinfo, partial, multi;
+  DevBuf link, lcol, back, items, halves, rowinfo, partial, multi;
   std::vector<OppItem> h_items;
   std::vector<int32_t> h_rowinfo;
   std::vector<MultiRow> h_multi;
-  std::vector<uint32_t> h_tab, h_cptr;
-  std::vector<int32_t> h_colcut;
-  std::vector<SRec> h_rec;
-  std::vector<uint32_t> h_row;
-  int H = 1, nsub = 2, jr = 1, T = 512;
-  bool big = false;
-  int64_t n_items = 0, n_slots = 0, n_multi = 0, n_slots_used = 0;
+  std::vector<int64_t> h_halves;  // [H + 1] first link of every column range, then [H + 1] first column
+  int H = 1, S = 0, T = 0;
+  int64_t n_items = 0, n_slots = 0, n_multi = 0;
   size_t shmem = 0;
 };
 
 void opp_release(sqd_ctx* c) {
+  oppsrc_release(c);
   if (!c->opp) return;
   OppState* s = static_cast<OppState*>(c->opp);
-  for (DevBuf* b : {&s->tab, &s->cptr, &s->colcut, &s->items, &s->rowinfo, &s->partial, &s->multi}) b->release();
+  for (DevBuf* b : {&s->link, &s->lcol, &s->back, &s->items, &s->halves, &s->rowinfo, &s->partial, &s->multi}) b->release();
   delete s;
   c->opp = nullptr;
+}
+
+// ---- tables: thread t of column range h owns the links l0[h] + t S .. + S - 1 (consecutive: a run of whole columns and
+// two partial ones); link[h][s][t] packed record, lcol[h][s][t] its target column, back[h][t] = how many preceding
+// threads hold earlier links of the column thread t starts in
+struct OppTabArgs {
+  GPtr<const int64_t> sb_ptr;
+  GPtr<const SRec> sb_rec;
+  GPtr<const uint32_t> sb_row;
+  GPtr<const int64_t> halves;  // [H + 1]
+  GPtr<uint32_t> link, lcol, back;
+  int H, S, T;
+};
+__global__ void __launch_bounds__(256) k_opp_tab(const OppTabArgs g) {
+  const int h = blockIdx.y;
+  const int64_t l0 = g.halves[h], l1 = g.halves[h + 1];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.T) return;
+  const int64_t base = ((int64_t)h * g.S) * g.T;
+  for (int s = 0; s < g.S; ++s) {
+    const int64_t l = l0 + (int64_t)t * g.S + s;
+    uint32_t rec = 0u, col = 0u;
+    if (l < l1) {
+      const SRec r = g.sb_rec[l];
+      col = g.sb_row[l];
+      rec = (r.src & 0xffffu) | ((srec_widx(r.meta) >> 1) << 16) | ((r.meta >> 31) ? OPP_SIGN : 0u) | OPP_LIVE |
+            ((l + 1 == g.sb_ptr[col + 1]) ? OPP_LAST : 0u) | ((srec_widx(r.meta) & 1u) ? OPP_DIR : 0u);
+    }
+    g.link[base + (int64_t)s * g.T + t] = rec;
+    g.lcol[base + (int64_t)s * g.T + t] = col;
+  }
+  uint32_t bk = 0;
+  const int64_t lf = l0 + (int64_t)t * g.S;
+  if (lf < l1) {
+    const int64_t cstart = g.sb_ptr[g.sb_row[lf]];  // first link of the column thread t starts in (>= l0: ranges are cut at columns)
+    bk = (uint32_t)(t - (int)((cstart - l0) / g.S));
+  }
+  g.back[(int64_t)h * g.T + t] = bk;
 }
 
 struct OppArgs {
@@ -88,216 +112,220 @@ struct OppArgs {
   GPtr<const double> hdiag, gdense, ja_row, jbT, eri_pp;
   GPtr<const int64_t> sa_ptr;
   GPtr<const SRec> sa_rec;
-  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | wofs[NSUB][T] | pos[S][T]
-  GPtr<const uint32_t> cptr;   // [H][nb + 1] first position (target order) of every column's links inside the pass
-  GPtr<const int32_t> colcut;  // [H + 1] first source column of every pass
+  GPtr<const uint32_t> link, lcol, back;
   GPtr<const OppItem> items;
-  int64_t nb;
-  int nnorb, T, H;
+  GPtr<const int64_t> colcut;  // [H + 1] first column of every range
+  int64_t na, nb;
+  int nnorb, S, T, H;
   unsigned n_items;
   GPtr<const int> stop, vec_index;
   int64_t c_stride, s_stride;
-  // the linear spin penalty, sigma = (H + shift (S^2 - ss)) c (pyscf's fix_spin_ form for ss < sz(sz+1) + 0.1):
-  // S^2 = sz(sz+1) + sum_p n_pb (1 - n_pa) - sum_{p != q} Ea_qp Eb_pq -- a diagonal term on the own row and -shift on the
-  // weight of the beta links with the alpha link's orbital pair and the opposite direction
-  int spin;
+  // the linear spin penalty, sigma = (H + shift (S^2 - ss)) c (pyscf's fix_spin_ form for ss < sz(sz+1) + 0.1; SPIN
+  // instantiations): S^2 = sz(sz+1) + sum_p n_pb (1 - n_pa) - sum_{p != q} Ea_qp Eb_pq -- a diagonal term on the own row
+  // and -shift on the weight of the ONE beta link with the alpha link's orbital pair and the opposite direction
   double ss, shift, szterm;
   GPtr<const uint64_t> strs_a, strs_b;
 };
 
-// Values every lane of the workgroup agrees on, pinned to scalar registers.  (Loads behind a barrier are vector loads to
-// the compiler -- the fence in __syncthreads() counts as a clobber -- and everything derived from them, row pointers
-// included, would live in vector registers: 64-bit addresses per load instead of a scalar base + 32-bit offset.)
-__device__ inline int opp_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline uint32_t opp_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ inline int64_t opp_uni(int64_t v) {
-  const uint32_t lo = opp_uni((uint32_t)v), hi = opp_uni((uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-template <int NSUB, int JR, int RM, bool BIG>
+template <int RM, bool SPIN>
 __global__ void __launch_bounds__(1024) k_opp_rows(const OppArgs g) {
-  constexpr int S = OPP_SUB * NSUB;
-  using Lds = OppLds<BIG>;
-  HIP_DYNAMIC_SHARED(double, smem)
-  char* const lds = reinterpret_cast<char*>(smem);
+  constexpr int SM = RM >= 3 ? OPP_SMAX3 : OPP_SMAX;  // links per thread
+  static_assert(RM <= OPP_RREG, "rows of more than 3072 columns run k_opp_src (sqd_oppsrc.hip): the 4-8-column instantiations spilled");
+  constexpr int RA = RM;  // accumulators of the alpha single x beta occupation term
+  HIP_DYNAMIC_SHARED(double, smem)  // Cst[nb][2] | Wst[nn][2]; after the last batch outb[nb] | tailb[T] take Cst's place
   if (g.stop && *g.stop) return;
-  const unsigned item_index = blockIdx.x;
+  // workgroup b runs on XCD b mod 8: the H column ranges of one item -- they stage the same source rows and J rows --
+  // take ids 8 apart, i.e. the same XCD at the same time, so that its L2 serves all but the first of them
+  const unsigned xcd = blockIdx.x & 7u, kq = blockIdx.x >> 3;
+  const int h = (int)(kq % (unsigned)g.H);
+  const unsigned item_index = (kq / (unsigned)g.H) * 8u + xcd;
   if (item_index >= g.n_items) return;
   const int T = g.T, tid = threadIdx.x;
-  OppItem it = g.items[item_index];
-  it.A = opp_uni(it.A);
-  it.e0 = opp_uni(it.e0);
-  it.ne = opp_uni(it.ne);
-  it.slot = opp_uni(it.slot);
+  const OppItem it = g.items[item_index];
   const int64_t A = it.A;
   const int64_t nb = g.nb;
-  const int nn = g.nnorb, nw = 2 * g.nnorb;
-  const int64_t vsel = g.vec_index ? (int64_t)opp_uni(*g.vec_index - 1) : 0;
+  const int nn = g.nnorb;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ sig = g.sigma + vsel * g.s_stride;
-  const int64_t k0 = opp_uni(g.sa_ptr[A]);
+  const int64_t nbe = (nb + 1) & ~int64_t(1);
+  double* Cst = smem;
+  double* Wst = Cst + (nbe > (nb + T + 1) / 2 ? nbe : (nb + T + 2) / 2) * OPP_K;  // (room for outb + tailb in Cst's place)
+  double* outb = smem;
+  double* tailb = smem + nbe;
+  const int64_t B0 = g.colcut[h], B1 = g.colcut[h + 1];  // this workgroup writes the columns [B0, B1)
+  // this thread's links: packed records in registers for the whole item
+  uint32_t rec[SM];
+  const uint32_t* __restrict__ lk = g.link + ((int64_t)h * g.S) * T + tid;
+#pragma unroll
+  for (int s = 0; s < SM; ++s) rec[s] = (s < g.S) ? lk[(int64_t)s * T] : 0u;
+  double acc[SM];
+#pragma unroll
+  for (int s = 0; s < SM; ++s) acc[s] = 0.0;
+  double a3[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) a3[r] = 0.0;
+  const int64_t k0 = g.sa_ptr[A];
   const int e_end = it.e0 + it.ne;
-  const bool spin = g.spin != 0;
-  const double pen = -g.shift;
-  double colacc[RM];
+  // Register-staged double buffering: the global loads of batch b + 1 (source rows, J rows, weight rows: everything a
+  // thread stages) are requested right behind the barrier that publishes batch b and land while batch b's links are
+  // gathered from LDS; a workgroup that fills the CU's registers runs alone on it, so nothing else hides that latency.
+  double px[RM][OPP_K], pjb[RM][OPP_K], pw[OPP_K];
+  double psg[OPP_K];
+  bool plnk[OPP_K];
+  uint32_t ppart[OPP_K];  // SPIN: {pair, direction, LIVE} of the beta link an entry's alpha link pairs with in S^2, in the
+                          // bit layout of the link records (0: none -- no live record matches it)
+  const double* pwrow[OPP_K];
+  auto request = [&](int e0) {
+    const double* srow[OPP_K];
+    const double* jrow[OPP_K];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) colacc[r] = 0.0;
-  double* const accb = smem;
-  double* const jbuf = reinterpret_cast<double*>(lds + Lds::JBUF);
-
-  for (int h = 0; h < g.H; ++h) {
-    const int q0 = opp_uni(g.colcut[h]), q1 = opp_uni(g.colcut[h + 1]);
-    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((2 * S + NSUB) * (int64_t)T) + tid;
-    uint32_t rec[S], wofs[NSUB];
+    for (int j = 0; j < OPP_K; ++j) {
+      const int e = e0 + j;
+      const bool valid = e < e_end;
+      plnk[j] = valid && e > 0;
+      SRec r = SRec{(uint32_t)A, 0u};
+      if (plnk[j]) r = g.sa_rec[k0 + e - 1];
+      const int64_t pair = (int64_t)(srec_widx(r.meta) >> 1);
+      if constexpr (SPIN)
+        ppart[j] = plnk[j] ? (((uint32_t)pair << 16) | ((srec_widx(r.meta) & 1u) ? 0u : OPP_DIR) | OPP_LIVE) : 0u;
+      srow[j] = C + (int64_t)r.src * nb;
+      psg[j] = valid ? (plnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
+      pwrow[j] = plnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
+      jrow[j] = g.jbT + pair * nb;
+    }
+    const int iw = tid < nn ? tid : nn - 1;
 #pragma unroll
-    for (int s = 0; s < S; ++s) rec[s] = tab[(int64_t)s * T];
+    for (int j = 0; j < OPP_K; ++j) pw[j] = pwrow[j][iw];
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) wofs[j] = tab[(int64_t)(S + j) * T];
-    double acc[S];
+    for (int r = 0; r < RM; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      const int64_t Bc = B < nb ? B : nb - 1;
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s] = 0.0;
-    double jacc[JR];
-#pragma unroll
-    for (int i = 0; i < JR; ++i) jacc[i] = 0.0;
-
-    // Register-staged prefetch: the global loads of batch b + 1 (the range's share of two source rows and two J rows, two
-    // weight values) are requested right behind the barrier that publishes batch b and land while batch b is gathered.
-    double px[JR][2], pjb[JR][2], pw[2], psg[2];
-    bool plnk[2];
-    int ppart[2];
-    const double* pwrow[2];
-    auto request = [&](int e0) {
-      const double* srow[2];
-      const double* jrow[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = e0 + j;
-        const bool valid = e < e_end;
-        plnk[j] = valid && e > 0;
-        SRec r = SRec{(uint32_t)A, 0u};
-        if (plnk[j]) r = g.sa_rec[k0 + e - 1];
-        r.src = opp_uni(r.src);
-        r.meta = opp_uni(r.meta);
-        const uint32_t widx = srec_widx(r.meta);
-        const int64_t pair = (int64_t)(widx >> 1);
-        ppart[j] = plnk[j] ? (int)(widx ^ 1u) : -1;  // S^2: same orbital pair, opposite direction
-        srow[j] = C + (int64_t)r.src * nb;
-        psg[j] = valid ? (plnk[j] ? srec_sign(r.meta) : 1.0) : 0.0;
-        pwrow[j] = plnk[j] ? g.eri_pp + pair * nn : g.ja_row + A * nn;
-        jrow[j] = g.jbT + pair * nb;
-      }
-      const int iw = (tid < nw ? tid : nw - 1) >> 1;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) pw[j] = pwrow[j][iw];
-#pragma unroll
-      for (int i = 0; i < JR; ++i) {
-        const int B = q0 + tid + i * T;
-        const int Bc = B < q1 ? B : q1 - 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          px[i][j] = srow[j][Bc];
-          pjb[i][j] = jrow[j][Bc];
-        }
-      }
-    };
-    // registers -> LDS buffer BUF (signed source values and weights, interleaved); the alpha single x beta occupation
-    // term of the staged columns on the way
-    auto park = [&](int cst, int wst) {
-      for (int w = tid; w < nw; w += T) {
-        double v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          v[j] = (w == tid) ? pw[j] : pwrow[j][w >> 1];
-          v[j] = psg[j] != 0.0 ? v[j] : 0.0;
-          if (spin && w == ppart[j]) v[j] += pen;
-        }
-        *reinterpret_cast<double2*>(lds + wst + w * 16) = make_double2(v[0], v[1]);
-      }
-#pragma unroll
-      for (int i = 0; i < JR; ++i) {
-        const int Bl = tid + i * T;
-        if (q0 + Bl < q1) {
-          const double x0 = px[i][0] * psg[0], x1 = px[i][1] * psg[1];
-          jacc[i] += plnk[0] ? pjb[i][0] * x0 : 0.0;
-          jacc[i] += plnk[1] ? pjb[i][1] * x1 : 0.0;
-          *reinterpret_cast<double2*>(lds + cst + Bl * 16) = make_double2(x0, x1);
-        }
-      }
-    };
-    // (sub-run j + 1's five reads are issued before sub-run j's eight multiply-adds; the scheduling barriers keep it at two
-    // sub-runs -- 40 registers -- in flight: left alone the compiler hoists all 5 NSUB reads and spills the accumulators)
-    auto gather = [&](int cst, int wst) {
-      double2 w2[2], c2[2][OPP_SUB];
-      auto read = [&](int j) {
-        w2[j & 1] = *reinterpret_cast<const double2*>(lds + wst + wofs[j]);
-#pragma unroll
-        for (int k = 0; k < OPP_SUB; ++k) c2[j & 1][k] = *reinterpret_cast<const double2*>(lds + cst + rec[OPP_SUB * j + k]);
-      };
-      read(0);
-#pragma unroll
-      for (int j = 0; j < NSUB; ++j) {
-        if (j + 1 < NSUB) read(j + 1);
-#pragma unroll
-        for (int k = 0; k < OPP_SUB; ++k) {
-          acc[OPP_SUB * j + k] += w2[j & 1].x * c2[j & 1][k].x;
-          acc[OPP_SUB * j + k] += w2[j & 1].y * c2[j & 1][k].y;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    request(it.e0);
-    for (int e0 = it.e0; e0 < e_end; e0 += 4) {
-      park(Lds::CST0, Lds::WST0);
-      __syncthreads();
-      if (e0 + 2 < e_end) request(e0 + 2);
-      gather(Lds::CST0, Lds::WST0);
-      if (e0 + 2 < e_end) {
-        park(Lds::CST1, Lds::WST1);
-        __syncthreads();
-        if (e0 + 4 < e_end) request(e0 + 4);
-        gather(Lds::CST1, Lds::WST1);
+      for (int j = 0; j < OPP_K; ++j) {
+        px[r][j] = srow[j][Bc];
+        pjb[r][j] = jrow[j][Bc];
       }
     }
-    __syncthreads();  // every gather of the pass is done: the staging buffers become accb
-    // ---- per-link sums -> target columns.  pos = the link's position among the pass's links in target order (sign of
-    // the beta link in bit 31); the owner of a column adds its run in that order, then the staged columns' J term.
-    const uint32_t* __restrict__ ptab = tab + (int64_t)(S + NSUB) * T;
+  };
+  // registers -> LDS (signed source rows and weight rows, interleaved); the alpha single x beta occupation term rides
+  // on the pass over the source rows (own columns)
+  auto park = [&]() {
+    if (tid < nn) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const uint32_t p = ptab[(int64_t)s * T];
-      if (p != OPP_DEAD) accb[p & 0x7fffffffu] = (p >> 31) ? -acc[s] : acc[s];
+      for (int j = 0; j < OPP_K; j += 2)
+        *reinterpret_cast<double2*>(Wst + (int64_t)tid * OPP_K + j) =
+            make_double2(psg[j] != 0.0 ? pw[j] : 0.0, psg[j + 1] != 0.0 ? pw[j + 1] : 0.0);
     }
+    for (int i = tid + T; i < nn; i += T) {  // (more orbital pairs than threads: norb > 44 with 1024 threads)
 #pragma unroll
-    for (int i = 0; i < JR; ++i) jbuf[tid + i * T] = jacc[i];
-    __syncthreads();
-    const uint32_t* __restrict__ cp = g.cptr + (int64_t)h * (nb + 1);
+      for (int j = 0; j < OPP_K; j += 2)
+        *reinterpret_cast<double2*>(Wst + (int64_t)i * OPP_K + j) =
+            make_double2(psg[j] != 0.0 ? pwrow[j][i] : 0.0, psg[j + 1] != 0.0 ? pwrow[j + 1][i] : 0.0);
+    }
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
       const int64_t B = tid + (int64_t)r * T;
       if (B < nb) {
-        const uint32_t c0 = cp[B], c1 = cp[B + 1];
-        double sum = 0.0;
-        for (uint32_t i = c0; i < c1; ++i) sum += accb[i];
-        if (B >= q0 && B < q1) sum += jbuf[B - q0];
-        colacc[r] += sum;
+        double x[OPP_K];
+#pragma unroll
+        for (int j = 0; j < OPP_K; ++j) {
+          x[j] = px[r][j] * psg[j];
+          a3[r] += plnk[j] ? pjb[r][j] * x[j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < OPP_K; j += 2) *reinterpret_cast<double2*>(Cst + B * OPP_K + j) = make_double2(x[j], x[j + 1]);
       }
     }
-    __syncthreads();  // (accb / jbuf are read: the next pass may stage)
+  };
+  request(it.e0);
+  for (int e0 = it.e0; e0 < e_end; e0 += OPP_K) {
+    park();
+    __syncthreads();
+    uint32_t cpart[OPP_K];
+    if constexpr (SPIN) {
+#pragma unroll
+      for (int j = 0; j < OPP_K; ++j) cpart[j] = ppart[j];
+    }
+    if (e0 + OPP_K < e_end) request(e0 + OPP_K);
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+      const uint32_t rc = rec[s];
+      const double* cp = Cst + (rc & 0xffffu) * OPP_K;
+      const double* wp = Wst + ((rc >> 16) & 0xfffu) * OPP_K;
+      double2 cv[OPP_K / 2], wv2[OPP_K / 2];
+#pragma unroll
+      for (int j = 0; j < OPP_K / 2; ++j) {
+        cv[j] = *reinterpret_cast<const double2*>(cp + 2 * j);
+        wv2[j] = *reinterpret_cast<const double2*>(wp + 2 * j);
+      }
+      if constexpr (SPIN) {
+        constexpr uint32_t KEY = OPP_DIR | OPP_LIVE | 0x0fff0000u;  // (a dead slot, rc = 0, matches "none": its sum is never read)
+        const double pen = -g.shift;
+#pragma unroll
+        for (int j = 0; j < OPP_K / 2; ++j) {
+          wv2[j].x += (((rc ^ cpart[2 * j]) & KEY) == 0u) ? pen : 0.0;
+          wv2[j].y += (((rc ^ cpart[2 * j + 1]) & KEY) == 0u) ? pen : 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < OPP_K / 2; ++j) {
+        acc[s] += wv2[j].x * cv[j].x;
+        acc[s] += wv2[j].y * cv[j].y;
+      }
+    }
+    __syncthreads();
   }
+  // ---- per-link sums -> columns, fixed order.  Runs inside the thread; a column that spans threads is finished by the
+  // thread that holds its last link, which adds the open runs of the threads before it, oldest first.
+  for (int64_t B = tid; B < nb; B += T) outb[B] = 0.0;  // (Cst is done with: the loop's last barrier)
+  __syncthreads();
+  const uint32_t* __restrict__ lc = g.lcol + ((int64_t)h * g.S) * T + tid;
+  const uint32_t bk = g.back[(int64_t)h * T + tid];
+  double run = 0.0, firstrun = 0.0;
+  int firstcol = -1;
+  bool first = true, open = false;
+#pragma unroll
+  for (int s = 0; s < SM; ++s) {
+    const uint32_t rc = rec[s];
+    if (rc & OPP_LIVE) {
+      run += (rc & OPP_SIGN) ? -acc[s] : acc[s];
+      open = true;
+      if (rc & OPP_LAST) {
+        const uint32_t col = lc[(int64_t)s * T];
+        if (first && bk > 0) {
+          firstrun = run;
+          firstcol = (int)col;
+        } else {
+          outb[col] = run;
+        }
+        run = 0.0;
+        first = false;
+        open = false;
+      }
+    }
+  }
+  tailb[tid] = open ? run : 0.0;
+  __syncthreads();
+  if (firstcol >= 0) {
+    double sum = 0.0;
+    for (uint32_t j = bk; j >= 1; --j) sum += tailb[tid - (int)j];
+    outb[firstcol] = sum + firstrun;
+  }
+  __syncthreads();
   const bool has0 = it.e0 == 0;  // the piece that holds the row itself also brings the diagonal and the same-spin product
   const double* __restrict__ crow = C + A * nb;
   const double* __restrict__ hd = g.hdiag + A * nb;
   const double* __restrict__ gd = g.gdense + A * nb;
   double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
+  for (int r = 0; r < RA; ++r) {
     const int64_t B = tid + (int64_t)r * T;
-    if (B < nb) {
-      double v = colacc[r];
+    if (B >= B0 && B < B1) {
+      double v = a3[r] + outb[B];
       if (has0) {
         double d = hd[B];
-        if (spin) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
+        if constexpr (SPIN) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
         v += d * crow[B] + gd[B];
       }
       orow[B] = v;
@@ -327,64 +355,64 @@ __global__ void __launch_bounds__(256) k_opp_reduce(const OppReduceArgs g) {
 }
 
 // ---- host side
-static size_t opp_shmem(bool big, int jr, int T) {  // the staging buffers (accb in their place at the end of a pass), then jbuf
-  return (size_t)(big ? OppLds<true>::JBUF : OppLds<false>::JBUF) + (size_t)jr * T * 8;
+static size_t opp_shmem(int64_t nb, int nn, int T) {
+  const int64_t nbe = (nb + 1) & ~int64_t(1);
+  const int64_t crows = nbe > (nb + T + 1) / 2 ? nbe : (nb + T + 2) / 2;  // Cst, or outb + tailb in its place
+  return (size_t)(crows * OPP_K + (int64_t)((nn + 1) & ~1) * OPP_K) * 8;
 }
 
-// phase 2 of set_subspace, behind spmm_select: is the opposite-spin part of this subspace taken by k_opp_rows?
-// (SQD_SIGMA_OPP=0 forbids: the work items then add G as they add the matrix-core product.)
-bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
-  c->sig_opp = false;
-  if (!c->sig_spmm) return false;
-  if (const char* env = std::getenv("SQD_SIGMA_OPP"))
-    if (std::atoi(env) == 0) return false;
+// k_opp_rows on this subspace?  (rows of <= 3 columns per thread, <= 64 column ranges)
+static bool opp_rows_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   const int64_t L = tot[2];  // beta single links
-  if (L < 1 || 2 * c->nnorb > OppLds<true>::ROWS) return false;
+  if (L < 1 || nb > 65535 || c->nnorb > 4095) return false;
   if (!c->opp) c->opp = new OppState();
   OppState* s = static_cast<OppState*>(c->opp);
-  // Geometry.  512 threads with two sub-runs (8 links, 128 registers) and ranges of <= 512 columns: 72 KB of LDS, two
-  // workgroups per CU that cover each other's barriers; rows of more than 4096 columns need 1024 threads for the
-  // thread's <= OPP_RMAX target columns.
-  int T = nb <= (int64_t)OPP_RMAX * 512 ? 512 : 1024;
-  if (const char* env = std::getenv("SQD_OPP_T")) {  // tuning / test hook (small workgroups: many passes on small sets)
+  // threads: 512 for short rows (four workgroups per CU), 1024 beyond (two); column ranges H so that a thread holds at
+  // most OPP_SMAX links
+  int T = (nb <= (int64_t)OPP_RREG * 512 && L <= (int64_t)OPP_SMAX * 512) ? 512 : 1024;
+  if (const char* env = std::getenv("SQD_OPP_T")) {  // tuning / test hook (small workgroups: several column ranges on small sets)
     const int v = std::atoi(env);
     if (v >= 64 && v <= 1024 && v % 64 == 0) T = v;
   }
-  int nsub = 2;
-  if (const char* env = std::getenv("SQD_OPP_S")) {  // tuning / test hook: links per thread (rounded up to whole sub-runs)
-    const int v = (std::atoi(env) + OPP_SUB - 1) / OPP_SUB;
-    if (v >= 1 && v <= OPP_NSUB_MAX) nsub = v;
-  }
-  int jr = 1;
-  if (const char* env = std::getenv("SQD_OPP_JR")) {  // tuning hook: staged columns per thread and pass
+  int smax = OPP_SMAX;
+  if (const char* env = std::getenv("SQD_OPP_S")) {  // test hook: links per thread
     const int v = std::atoi(env);
-    if (v >= 1 && v <= OPP_JR_MAX) jr = v;
+    if (v >= 1 && v <= OPP_SMAX) smax = v;
   }
-  if (nb > (int64_t)OPP_RMAX * T) return false;
-  if (nb > (int64_t)4 * T) jr = 1;  // (two staged columns beside eight target columns per thread do not fit the registers)
-  bool big = 2 * c->nnorb > OppLds<false>::ROWS || jr * T > OppLds<false>::COLS ||
-             (size_t)OPP_SUB * nsub * T * 8 > (size_t)OppLds<false>::STAGE_BYTES;
-  if (const char* env = std::getenv("SQD_OPP_BIG"))
-    if (std::atoi(env) != 0) big = true;
-  if ((size_t)OPP_SUB * nsub * T * 8 > (size_t)(big ? OppLds<true>::STAGE_BYTES : OppLds<false>::STAGE_BYTES)) return false;
-  if (opp_shmem(big, jr, T) + 1024 > (size_t)c->lds_bytes) return false;
-  // a source column's links must fit one pass even if every one of them opens a sub-run of its own
+  if (nb > (int64_t)OPP_RREG * T) return false;  // (longer rows: k_opp_src)
+  if ((nb + T - 1) / T >= 3 && smax > OPP_SMAX3) smax = OPP_SMAX3;
+  if (opp_shmem(nb, c->nnorb, T) + 1024 > (size_t)c->lds_bytes) return false;
+  // cut the link list at column starts, as evenly as the columns allow; one range more while the longest does not fit
   const int64_t* ps = c->h_sptr_b;
-  int64_t longest = 0;
-  for (int64_t B = 0; B < nb; ++B) longest = std::max(longest, ps[B + 1] - ps[B]);
-  if (longest > (int64_t)nsub * T) return false;
-  s->nsub = nsub;
-  s->jr = jr;
-  s->big = big;
+  int H = (int)((L + (int64_t)smax * T - 1) / ((int64_t)smax * T)), S = 0;
+  for (;; ++H) {
+    if (H > 64) return false;
+    s->h_halves.assign((size_t)2 * (H + 1), 0);
+    int64_t B = 0, longest = 0;
+    for (int h = 1; h <= H; ++h) {
+      const int64_t want = (h == H) ? L : (L * h) / H;
+      while (B < nb && ps[B] < want) ++B;
+      if (h == H) B = nb;
+      s->h_halves[h] = ps[B];
+      s->h_halves[(size_t)(H + 1) + h] = B;
+      longest = std::max(longest, s->h_halves[h] - s->h_halves[h - 1]);
+    }
+    S = (int)((longest + T - 1) / T);
+    if (S <= smax) break;
+  }
+  s->H = H;
+  s->S = S < 1 ? 1 : S;
   s->T = T;
-  s->shmem = opp_shmem(big, jr, T);
+  s->shmem = opp_shmem(nb, c->nnorb, T);
   // work items: a row's entries (itself + its alpha single links) in pieces of at most E, so that the rows of the
   // Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain of 90 batches; a row in one
   // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
+  // (measured, HF-centred N x N, us per sigma for E = 4 | 8 | 16 | 32: 1000: 260 | 222 | 202 | 195; 2000: 940 | 828 | 779 |
+  // 763; 3000: 2747 | 2437 | 2278 | 2209 -- profiles/r05/opp_probe.txt)
   int E = 32;
   if (const char* env = std::getenv("SQD_OPP_E")) {  // tuning hook
     const int v = std::atoi(env);
-    if (v >= 2 && v <= 4096) E = v / 2 * 2;
+    if (v >= OPP_K && v <= 4096) E = v / OPP_K * OPP_K;
   }
   const int64_t* pa = c->h_sptr;
   s->h_items.clear();
@@ -410,149 +438,69 @@ bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   s->n_items = (int64_t)s->h_items.size();
   s->n_slots = nslots;
   s->n_multi = (int64_t)s->h_multi.size();
-  c->sig_opp = true;
   return true;
 }
 
-// The pass tables (host): the beta single links come back from the device once per subspace (8 + 4 bytes per link), are
-// cut into source-column ranges of at most `cap` slots and jr * T columns, grouped by widx inside a range and laid
-// out thread by thread.
+// phase 2 of set_subspace, behind spmm_select: is the opposite-spin part of this subspace taken by whole rows -- k_opp_rows
+// (rows of <= 3072 columns) or k_opp_src (sqd_oppsrc.hip: longer rows; SQD_OPP_SRC=1 forces it, =0 forbids it)?
+// (SQD_SIGMA_OPP=0 forbids both: the work items then add G as they add the matrix-core product.)
+bool opp_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
+  c->sig_opp = false;
+  c->opp_src = false;
+  if (!c->sig_spmm) return false;
+  if (const char* env = std::getenv("SQD_SIGMA_OPP"))
+    if (std::atoi(env) == 0) return false;
+  int want_src = -1;
+  if (const char* env = std::getenv("SQD_OPP_SRC")) want_src = std::atoi(env) != 0 ? 1 : 0;
+  if (want_src != 1 && opp_rows_select(c, na, nb, tot)) {
+    c->sig_opp = true;
+    return true;
+  }
+  if (want_src != 0 && oppsrc_select(c, na, nb, tot)) {
+    c->sig_opp = c->opp_src = true;
+    return true;
+  }
+  return false;
+}
+
 int opp_build(sqd_ctx* c) {
+  if (c->opp_src) return oppsrc_build(c);
   OppState* s = static_cast<OppState*>(c->opp);
   const SpinTables& tb = c->sp[1];
-  const int64_t nb = c->nb, L = c->h_sptr_b[nb];
-  const int T = s->T, nsub = s->nsub, S = OPP_SUB * nsub, nw = 2 * c->nnorb;
-  s->h_rec.resize((size_t)L);
-  s->h_row.resize((size_t)L);
-  SQD_HIP_CHECK(hipMemcpyAsync(s->h_rec.data(), tb.s_rec.p, (size_t)L * sizeof(SRec), hipMemcpyDeviceToHost, c->stream));
-  SQD_HIP_CHECK(hipMemcpyAsync(s->h_row.data(), tb.s_row.p, (size_t)L * 4, hipMemcpyDeviceToHost, c->stream));
-  SQD_STREAM_SYNC(c->stream);
-  // links by source column, in link order
-  std::vector<int64_t> sptr((size_t)nb + 1, 0);
-  for (int64_t l = 0; l < L; ++l) ++sptr[s->h_rec[l].src + 1];
-  for (int64_t B = 0; B < nb; ++B) sptr[B + 1] += sptr[B];
-  std::vector<uint32_t> bysrc((size_t)L);
-  {
-    std::vector<int64_t> fill(sptr.begin(), sptr.end() - 1);
-    for (int64_t l = 0; l < L; ++l) bysrc[fill[s->h_rec[l].src]++] = (uint32_t)l;
-  }
-  // ranges: greedy over the source columns; slots of a range = sum over widx of its link count rounded up to sub-runs
-  const int64_t cap_slots = (int64_t)S * T;
-  const int cap_cols = std::min(s->jr * T, s->big ? OppLds<true>::COLS : OppLds<false>::COLS);
-  std::vector<int32_t>& cut = s->h_colcut;
-  cut.assign(1, 0);
-  {
-    std::vector<int32_t> cnt((size_t)nw, 0);
-    std::vector<int32_t> touched;
-    int64_t slots = 0;
-    int width = 0;
-    for (int64_t B = 0; B < nb; ++B) {
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        int64_t add = 0;
-        for (int64_t i = sptr[B]; i < sptr[B + 1]; ++i) {
-          const uint32_t w = srec_widx(s->h_rec[bysrc[i]].meta);
-          if (cnt[w] % OPP_SUB == 0) add += OPP_SUB;
-          if (cnt[w]++ == 0) touched.push_back((int32_t)w);
-        }
-        if (attempt == 1 || (slots + add <= cap_slots && width + 1 <= cap_cols)) {
-          slots += add;
-          ++width;
-          break;
-        }
-        // close the range in front of B and count B again in a fresh one
-        for (int32_t w : touched) cnt[w] = 0;
-        touched.clear();
-        cut.push_back((int32_t)B);
-        slots = 0;
-        width = 0;
-      }
-    }
-    cut.push_back((int32_t)nb);
-  }
-  const int H = (int)cut.size() - 1;
-  s->H = H;
-  // tables per pass: rec[S][T] | wofs[nsub][T] | pos[S][T];  cptr[H][nb + 1]
-  const size_t per_pass = (size_t)(2 * S + nsub) * T;
-  s->h_tab.assign(per_pass * H, 0u);
-  s->h_cptr.assign((size_t)H * (nb + 1), 0u);
-  std::vector<int32_t> range_of((size_t)nb);
-  for (int h = 0; h < H; ++h)
-    for (int32_t B = cut[h]; B < cut[h + 1]; ++B) range_of[B] = h;
-  // position of every link among its pass's links in target order (= link order: the CSR is sorted by target column)
-  std::vector<uint32_t> rank((size_t)L);
-  {
-    std::vector<uint32_t> counter((size_t)H, 0u);
-    const int64_t* ps = c->h_sptr_b;
-    for (int64_t B = 0; B < nb; ++B) {
-      for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + B] = counter[h];
-      for (int64_t l = ps[B]; l < ps[B + 1]; ++l) rank[l] = counter[range_of[s->h_rec[l].src]]++;
-    }
-    for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + nb] = counter[h];
-  }
-  {
-    std::vector<std::vector<uint32_t>> by_w((size_t)nw);
-    std::vector<int32_t> used;
-    for (int h = 0; h < H; ++h) {
-      uint32_t* rec = s->h_tab.data() + per_pass * h;
-      uint32_t* wofs = rec + (size_t)S * T;
-      uint32_t* pos = wofs + (size_t)nsub * T;
-      std::fill(pos, pos + (size_t)S * T, OPP_DEAD);
-      used.clear();
-      for (int32_t B = cut[h]; B < cut[h + 1]; ++B)
-        for (int64_t i = sptr[B]; i < sptr[B + 1]; ++i) {
-          const uint32_t l = bysrc[i], w = srec_widx(s->h_rec[l].meta);
-          if (by_w[w].empty()) used.push_back((int32_t)w);
-          by_w[w].push_back(l);
-        }
-      std::sort(used.begin(), used.end());
-      int64_t u = 0;  // sub-run index: thread u % T, sub-run u / T of that thread
-      for (int32_t w : used) {
-        std::vector<uint32_t>& ls = by_w[w];
-        std::sort(ls.begin(), ls.end());
-        for (size_t i0 = 0; i0 < ls.size(); i0 += OPP_SUB, ++u) {
-          const int t = (int)(u % T), j = (int)(u / T);
-          if (j >= nsub) {
-            set_error("internal: opposite-spin pass tables overflow");
-            return SQD_ERR_STATE;
-          }
-          wofs[(size_t)j * T + t] = (uint32_t)w * 16u;
-          for (int k = 0; k < OPP_SUB && i0 + k < ls.size(); ++k) {
-            const uint32_t l = ls[i0 + k];
-            const size_t at = (size_t)(OPP_SUB * j + k) * T + t;
-            rec[at] = (uint32_t)(s->h_rec[l].src - (uint32_t)cut[h]) * 16u;
-            pos[at] = rank[l] | ((s->h_rec[l].meta >> 31) ? 0x80000000u : 0u);
-          }
-        }
-        ls.clear();
-      }
-    }
-  }
-  SQD_TRY(s->tab.reserve(s->h_tab.size() * 4 + 64));
-  SQD_TRY(s->cptr.reserve(s->h_cptr.size() * 4 + 64));
-  SQD_TRY(s->colcut.reserve(s->h_colcut.size() * 4 + 64));
+  const size_t nrec = (size_t)s->H * s->S * s->T;
+  SQD_TRY(s->link.reserve(nrec * 4 + 64));
+  SQD_TRY(s->lcol.reserve(nrec * 4 + 64));
+  SQD_TRY(s->back.reserve((size_t)s->H * s->T * 4 + 64));
   SQD_TRY(s->items.reserve((size_t)s->n_items * sizeof(OppItem) + 64));
   SQD_TRY(s->rowinfo.reserve((size_t)2 * c->na * 4 + 64));
   SQD_TRY(s->multi.reserve((size_t)s->n_multi * sizeof(MultiRow) + 64));
   SQD_TRY(s->partial.reserve((size_t)s->n_slots * c->nb * 8 + 64));
-  SQD_HIP_CHECK(hipMemcpyAsync(s->tab.p, s->h_tab.data(), s->h_tab.size() * 4, hipMemcpyHostToDevice, c->stream));
-  SQD_HIP_CHECK(hipMemcpyAsync(s->cptr.p, s->h_cptr.data(), s->h_cptr.size() * 4, hipMemcpyHostToDevice, c->stream));
-  SQD_HIP_CHECK(hipMemcpyAsync(s->colcut.p, s->h_colcut.data(), s->h_colcut.size() * 4, hipMemcpyHostToDevice, c->stream));
+  SQD_TRY(s->halves.reserve(s->h_halves.size() * 8));
   SQD_HIP_CHECK(hipMemcpyAsync(s->items.p, s->h_items.data(), (size_t)s->n_items * sizeof(OppItem), hipMemcpyHostToDevice, c->stream));
   SQD_HIP_CHECK(hipMemcpyAsync(s->rowinfo.p, s->h_rowinfo.data(), (size_t)2 * c->na * 4, hipMemcpyHostToDevice, c->stream));
   if (s->n_multi)
     SQD_HIP_CHECK(hipMemcpyAsync(s->multi.p, s->h_multi.data(), (size_t)s->n_multi * sizeof(MultiRow), hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->halves.p, s->h_halves.data(), s->h_halves.size() * 8, hipMemcpyHostToDevice, c->stream));
+  OppTabArgs a;
+  a.sb_ptr = tb.s_ptr.as<int64_t>();
+  a.sb_rec = tb.s_rec.as<SRec>();
+  a.sb_row = tb.s_row.as<uint32_t>();
+  a.halves = s->halves.as<int64_t>();
+  a.link = s->link.as<uint32_t>();
+  a.lcol = s->lcol.as<uint32_t>();
+  a.back = s->back.as<uint32_t>();
+  a.H = s->H;
+  a.S = s->S;
+  a.T = s->T;
+  hipLaunchKernelGGL(k_opp_tab, dim3((unsigned)((s->T + 255) / 256), (unsigned)s->H), dim3(256), 0, c->stream, a);
+  SQD_HIP_CHECK(hipGetLastError());
   return SQD_OK;
-}
-
-// number of source-column passes of the latest build (probes / tests)
-int opp_passes(const sqd_ctx* c) {
-  const OppState* s = static_cast<const OppState*>(c->opp);
-  return (s && c->sig_opp) ? s->H : 0;
 }
 
 // sigma = (hdiag + opposite-spin part) c + G, G = sqd_ctx::gdense as spmm_launch has just formed it for the same vector
 int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride, bool spin, double ss,
                double shift) {
+  if (c->opp_src) return oppsrc_launch(c, d_c, d_sigma, in_stride, out_stride, spin, ss, shift);
   OppState* s = static_cast<OppState*>(c->opp);
   if (!s) {
     set_error("internal: opposite-spin row kernel without its tables");
@@ -570,13 +518,16 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   g.eri_pp = c->eri_pp.as<double>();
   g.sa_ptr = ta.s_ptr.as<int64_t>();
   g.sa_rec = ta.s_rec.as<SRec>();
-  g.tab = s->tab.as<uint32_t>();
-  g.cptr = s->cptr.as<uint32_t>();
-  g.colcut = s->colcut.as<int32_t>();
+  g.link = s->link.as<uint32_t>();
+  g.lcol = s->lcol.as<uint32_t>();
+  g.back = s->back.as<uint32_t>();
   g.items = s->items.as<OppItem>();
   g.partial = s->partial.as<double>();
+  g.colcut = s->halves.as<int64_t>() + (s->H + 1);
+  g.na = c->na;
   g.nb = c->nb;
   g.nnorb = c->nnorb;
+  g.S = s->S;
   g.T = s->T;
   g.H = s->H;
   g.stop = c->sigma_stop;
@@ -584,7 +535,6 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   g.vec_index = indexed ? c->sigma_index : nullptr;
   g.c_stride = in_stride;
   g.s_stride = out_stride;
-  g.spin = spin ? 1 : 0;
   g.ss = ss;
   g.shift = shift;
   {
@@ -593,45 +543,29 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
   }
   g.strs_a = c->sp[0].strs.as<uint64_t>();
   g.strs_b = c->sp[1].strs.as<uint64_t>();
+  if (s->shmem > 64 * 1024) {
+    static std::atomic<size_t> granted[64];
+    const int dev = c->device & 63;
+    if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {
+#define SQD_OPP_F(RM_) reinterpret_cast<const void*>(&k_opp_rows<RM_, false>), reinterpret_cast<const void*>(&k_opp_rows<RM_, true>)
+      for (const void* f : {SQD_OPP_F(1), SQD_OPP_F(2), SQD_OPP_F(3)})
+#undef SQD_OPP_F
+        SQD_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));
+      granted[dev].store(s->shmem, std::memory_order_relaxed);
+    }
+  }
+  const int rm = (int)((c->nb + s->T - 1) / s->T);  // columns per thread in the coalesced passes (<= OPP_RREG: opp_rows_select)
   g.n_items = (unsigned)s->n_items;
-  const int rm = (int)((c->nb + s->T - 1) / s->T);  // target columns per thread (<= OPP_RMAX: opp_select)
-  const dim3 grid((unsigned)s->n_items), block((unsigned)s->T);
-#define SQD_OPP_CASE(NSUB_, JR_, RM_, BIG_)                                                                        \
-  do {                                                                                                             \
-    if (s->shmem > 64 * 1024) {                                                                                    \
-      static std::atomic<size_t> granted[64];                                                                      \
-      const int dev = c->device & 63;                                                                              \
-      if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {                                               \
-        SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_opp_rows<NSUB_, JR_, RM_, BIG_>),       \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));             \
-        granted[dev].store(s->shmem, std::memory_order_relaxed);                                                   \
-      }                                                                                                            \
-    }                                                                                                              \
-    hipLaunchKernelGGL((k_opp_rows<NSUB_, JR_, RM_, BIG_>), grid, block, s->shmem, c->stream, g);                  \
+  const dim3 grid(8u * (unsigned)((s->n_items + 7) / 8) * (unsigned)s->H), block((unsigned)s->T);
+#define SQD_OPP_GO(RM_)                                                                            \
+  do {                                                                                             \
+    if (spin) hipLaunchKernelGGL((k_opp_rows<RM_, true>), grid, block, s->shmem, c->stream, g);    \
+    else hipLaunchKernelGGL((k_opp_rows<RM_, false>), grid, block, s->shmem, c->stream, g);        \
   } while (0)
-#define SQD_OPP_BIG(NSUB_, JR_, RM_)                        \
-  do {                                                      \
-    if (s->big) SQD_OPP_CASE(NSUB_, JR_, RM_, true);        \
-    else SQD_OPP_CASE(NSUB_, JR_, RM_, false);              \
-  } while (0)
-#define SQD_OPP_RM(NSUB_, JR_)                     \
-  do {                                             \
-    if (rm <= 2) SQD_OPP_BIG(NSUB_, JR_, 2);       \
-    else if (rm <= 4) SQD_OPP_BIG(NSUB_, JR_, 4);  \
-    else SQD_OPP_BIG(NSUB_, JR_, 8);               \
-  } while (0)
-#define SQD_OPP_JR(NSUB_)                                 \
-  do {                                                    \
-    if (s->jr == 1) SQD_OPP_RM(NSUB_, 1);                 \
-    else if (rm <= 2) SQD_OPP_BIG(NSUB_, 2, 2);           \
-    else SQD_OPP_BIG(NSUB_, 2, 4); /* (rm <= 4: opp_select) */ \
-  } while (0)
-  if (s->nsub == 1) SQD_OPP_JR(1);
-  else SQD_OPP_JR(2);
-#undef SQD_OPP_JR
-#undef SQD_OPP_RM
-#undef SQD_OPP_BIG
-#undef SQD_OPP_CASE
+  if (rm <= 1) SQD_OPP_GO(1);
+  else if (rm == 2) SQD_OPP_GO(2);
+  else SQD_OPP_GO(3);
+#undef SQD_OPP_GO
   SQD_HIP_CHECK(hipGetLastError());
   // rows in several pieces: inside a Davidson run the first reader of the new vector adds the partial rows (opp_split)
   if (s->n_multi > 0 && !(c->sigma_defer_reduce && indexed)) {
@@ -655,6 +589,7 @@ int opp_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride
 
 // the split-row records of the latest opp_select (for k_dots_eig's deferred sum); false: every row is in one piece
 bool opp_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial) {
+  if (c->opp_src) return c->sig_opp && oppsrc_split(c, rowinfo, partial);
   const OppState* s = static_cast<const OppState*>(c->opp);
   if (!s || !c->sig_opp || s->n_multi == 0) return false;
   *rowinfo = s->rowinfo.as<int32_t>();

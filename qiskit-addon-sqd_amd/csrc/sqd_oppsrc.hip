@@ -1,0 +1,634 @@
+// Opposite-spin part of sigma (and the diagonal) for CONNECTED string sets of 10^3 strings per spin and more, in front of
+// which sqd_spmm.hip has formed the same-spin product G = H_a C + C H_b:
+//   sigma[A,B] = hdiag[A,B] C[A,B] + G[A,B]
+//     + sum_{(A',pq,s) in Sa(A)} s * Jb[B][pq] * C[A',B]            alpha single x beta occupation
+//     + sum_{(B',rs,t) in Sb(B)} t * Ja[A][rs] * C[A,B']            beta single x alpha occupation
+//     + sum_{Sa(A)} sum_{Sb(B)} s t (pq|rs) C[A',B']                single x single
+// -- what pyscf's selected_ci.contract_2e evaluates through SCIcontract_2e_bbaa (reference call sites
+// qiskit_addon_sqd/fermion.py:721-723, :810-818).  The last two terms are one sum over the "entries" of
+// row A -- the row itself (weights Ja[A][:]) and its alpha single links (weights (pq|:)) -- times the beta single links.
+//
+// Round 6: the formulation for rows of more than 3072 columns (k_opp_src).  k_opp_rows (sqd_opp.hip) keeps the beta links
+// by TARGET column range, every range staging whole source rows: its long-row instantiations (4-8 staged columns per
+// thread) spilled 6-40 registers and re-staged every source row once per range (4.7 GB per sigma at 3000 x 3000 already).
+// Measured against it (profiles/r06/opp_src_probe.txt): 5 % slower at 5000 x 5000, 23 % at 3000 x 3000, 47 % at 1000 x
+// 1000 -- the short rows stay with k_opp_rows, whose <= 3-column instantiations do not spill.  ONE workgroup owns a piece of a target row A (<= E = 16 of its entries) and walks the beta
+// link list in PASSES over ranges of the SOURCE column B':
+//   * a pass stages its range [q0, q1) of ALL the piece's source rows at once -- one round trip for the whole pass, every
+//     element of a source row staged once per item, not once per range -- as E / 2 planes of interleaved pairs
+//     Cst[plane][B' - q0][2] (signed); the alpha single x beta occupation term rides on the staging pass;
+//   * inside a range the links are grouped by excitation operator (widx = orbital pair and direction) in sub-runs of four:
+//     a thread holds <= NSUB sub-runs -- per link ONE register, the byte offset of its source column in a plane, and one
+//     accumulator -- and per sub-run its widx: a link costs one 16-byte LDS gather and two multiply-adds per plane, with
+//     the plane as an immediate of the instruction; the weights (pq|rs) / Ja[A][rs] come per sub-run and plane straight
+//     from the integral table (one plane ahead; the table is L2-resident), and the linear spin penalty is one addition to
+//     the weight of the sub-run whose widx is the alpha link's partner;
+//   * no barrier inside the plane loop: three per pass (staged / gathered / folded);
+//   * at the end of a pass the per-link sums go through LDS to the threads that own the target columns (positions in
+//     target order precomputed per range; runs summed in that order), and a thread carries its columns' sums over the
+//     passes in registers: one sigma row per item, written once, same bits on every run.
+// Rows in one piece are written in place; the others as partial rows that the first reader of the vector adds in slot
+// order (k_dots_s inside a Davidson run, k_opp_src_reduce otherwise).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "sqd_common.h"
+
+namespace sqd {
+
+constexpr int OPPS_SUB = 4;       // links per sub-run (one weight pair serves four links)
+constexpr int OPPS_NSUB_MAX = 2;  // sub-runs per thread (8 links: 8 + 16 registers; three sub-runs spill at 128 registers)
+constexpr int OPPS_RMAX = 8;      // target columns per thread (nb <= OPPS_RMAX * threads)
+// LDS plan (bytes; the plane of a batch is an immediate of the gather instruction):
+//   Cst[4][COLS][2] -- the staged range of eight entries (a piece is walked eight entries at a time); accb[links of a pass]
+//   takes its place at the end of a pass; jbuf[T] sits behind.  BIG = false: planes of 512 columns, 32 + 4 KB (512
+//   threads); BIG = true: planes of 1024 columns, 64 + 8 KB (1024 threads: rows of more than 4096 columns)
+template <bool BIG>
+struct OppSrcLds {
+  static constexpr int COLS = BIG ? 1024 : 512, NB = 4;
+  static constexpr int PLANE = COLS * 16;
+  static constexpr int STAGE_BYTES = NB * PLANE;
+  static constexpr int JBUF = STAGE_BYTES;
+};
+constexpr int OPPS_EMAX = 64;  // entries of a piece: one per lane of a wavefront
+constexpr uint32_t OPPS_DEAD = 0xffffffffu;
+
+// one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
+// link e - 1); slot < 0: the row has this one item and is written in place, else partial row `slot` (added in slot
+// order by the first reader of the vector -- k_dots_eig inside a Davidson run, k_opp_src_reduce otherwise)
+struct OppSrcItem {
+  uint32_t A;
+  int32_t e0, ne, slot;
+};
+struct OppSrcState {
+  DevBuf tab, cptr, colcut, items, rowinfo, partial, multi;
+  std::vector<OppSrcItem> h_items;
+  std::vector<int32_t> h_rowinfo;
+  std::vector<MultiRow> h_multi;
+  std::vector<uint32_t> h_tab, h_cptr;
+  std::vector<int32_t> h_colcut;
+  std::vector<SRec> h_rec;
+  std::vector<uint32_t> h_row;
+  int H = 1, nsub = 2, T = 512;
+  bool big = false;
+  int64_t n_items = 0, n_slots = 0, n_multi = 0;
+  size_t shmem = 0;
+};
+
+void oppsrc_release(sqd_ctx* c) {
+  if (!c->oppsrc) return;
+  OppSrcState* s = static_cast<OppSrcState*>(c->oppsrc);
+  for (DevBuf* b : {&s->tab, &s->cptr, &s->colcut, &s->items, &s->rowinfo, &s->partial, &s->multi}) b->release();
+  delete s;
+  c->oppsrc = nullptr;
+}
+
+struct OppSrcArgs {
+  GPtr<const double> c;
+  GPtr<double> sigma, partial;
+  GPtr<const double> hdiag, gdense, ja_row, jbT, eri_pp;
+  GPtr<const int64_t> sa_ptr;
+  GPtr<const SRec> sa_rec;
+  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | widx[NSUB][T] | pos[S][T]
+  GPtr<const uint32_t> cptr;   // [H][nb + 1] first position (target order) of every column's links inside the pass
+  GPtr<const int32_t> colcut;  // [H + 1] first source column of every pass
+  GPtr<const OppSrcItem> items;
+  int64_t nb;
+  int nnorb, T, H;
+  unsigned n_items;
+  GPtr<const int> stop, vec_index;
+  int64_t c_stride, s_stride;
+  // the linear spin penalty, sigma = (H + shift (S^2 - ss)) c (pyscf's fix_spin_ form for ss < sz(sz+1) + 0.1):
+  // S^2 = sz(sz+1) + sum_p n_pb (1 - n_pa) - sum_{p != q} Ea_qp Eb_pq -- a diagonal term on the own row and -shift on the
+  // weight of the beta links with the alpha link's orbital pair and the opposite direction
+  int spin;
+  double ss, shift, szterm;
+  GPtr<const uint64_t> strs_a, strs_b;
+};
+
+// lane e of every wavefront holds entry e of the piece; a field of entry e reaches the scalar registers through
+// v_readlane with e a constant of the unrolled loops -- no table in memory, no load behind a barrier
+__device__ inline uint32_t oppsrc_lane(uint32_t v, int e) { return (uint32_t)__builtin_amdgcn_readlane((int)v, e); }
+// ... and is read again wherever it is used: left alone the compiler hoists all 6 x 16 lane reads out of the pass loop and
+// keeps them in scalar registers it does not have (106 SGPRs, the rest spilled into vector lanes)
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define OPPS_REREAD(v) asm volatile("" : "+v"(v))
+#else
+#define OPPS_REREAD(v) ((void)(v))
+#endif
+
+template <int NSUB, int RM, bool BIG>
+__global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
+  constexpr int S = OPPS_SUB * NSUB;
+  using Lds = OppSrcLds<BIG>;
+  constexpr int NB = Lds::NB, E = 2 * NB;  // planes, entries per round of a pass
+  HIP_DYNAMIC_SHARED(double, smem)
+  char* const lds = reinterpret_cast<char*>(smem);
+  if (g.stop && *g.stop) return;
+  const unsigned item_index = blockIdx.x;
+  if (item_index >= g.n_items) return;
+  const int T = g.T, tid = threadIdx.x, lane = tid & 63;
+  const OppSrcItem it = g.items[item_index];
+  const int64_t A = it.A;
+  const int64_t nb = g.nb;
+  const int nn = g.nnorb;
+  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const double* __restrict__ C = g.c + vsel * g.c_stride;
+  double* __restrict__ sig = g.sigma + vsel * g.s_stride;
+  const int ne = it.ne;
+  const bool spin = g.spin != 0;
+  const double pen = -g.shift;
+  // ---- the piece's entries, one per lane: source row, weight row (as an element offset from eri_pp: the J row of the
+  // own-row entry lies in another array, its distance to eri_pp is added), orbital pair, sign, S^2 partner
+  uint32_t en_src = (uint32_t)A, en_pair = 0u, en_wlo = 0u, en_whi = 0u, en_flags = 0u;  // flags: 1 valid, 2 link, 4 negative
+  uint32_t en_part = 0xffffffffu;
+  {
+    const int e = it.e0 + lane;
+    const bool valid = lane < ne, lnk = valid && e > 0;
+    SRec r = SRec{(uint32_t)A, 0u};
+    if (lnk) r = g.sa_rec[g.sa_ptr[A] + e - 1];
+    const uint32_t widx = srec_widx(r.meta);
+    en_src = r.src;
+    en_pair = widx >> 1;
+    const double* wrow = lnk ? (const double*)g.eri_pp + (int64_t)en_pair * nn : (const double*)g.ja_row + A * nn;
+    const uint64_t wa = (uint64_t)(uintptr_t)wrow;
+    en_wlo = (uint32_t)wa;
+    en_whi = (uint32_t)(wa >> 32);
+    en_flags = (valid ? 1u : 0u) | (lnk ? 2u : 0u) | ((lnk && (r.meta >> 31)) ? 4u : 0u);
+    if (lnk) en_part = widx ^ 1u;  // same orbital pair, opposite direction
+  }
+  double colacc[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) colacc[r] = 0.0;
+  double* const accb = smem;
+  double* const jbuf = reinterpret_cast<double*>(lds + Lds::JBUF);
+
+  for (int h = 0; h < g.H; ++h) {
+    const int q0 = g.colcut[h], q1 = g.colcut[h + 1];
+    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((2 * S + NSUB) * (int64_t)T) + tid;
+    uint32_t rec[S], wpair[NSUB], wwidx[NSUB];
+#pragma unroll
+    for (int s = 0; s < S; ++s) rec[s] = tab[(int64_t)s * T];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+      wwidx[j] = tab[(int64_t)(S + j) * T];
+      wpair[j] = wwidx[j] >> 1;
+    }
+    double acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = 0.0;
+    double jacc = 0.0;
+    const bool mine = q0 + tid < q1;
+    const uint32_t Bc = (uint32_t)(mine ? q0 + tid : q1 - 1);  // (32-bit: scalar row base + vector offset addressing)
+    for (int eb = 0; eb < ne; eb += E) {  // eight entries at a time
+      if (eb > 0) __syncthreads();  // (the planes are gathered: they may be overwritten)
+      // ---- stage the range of eight source rows (signed, pairs interleaved); the alpha single x beta occupation term of
+      // the staged column on the way.  Unconditional loads (a dead entry reads row A / J row 0): all 16 in flight together.
+      {
+        double x[E], jv[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+          const uint32_t src = oppsrc_lane(en_src, eb + i), pair = oppsrc_lane(en_pair, eb + i);
+          const double* __restrict__ srow = C + (int64_t)src * nb;
+          const double* __restrict__ jrow = (const double*)g.jbT + (int64_t)pair * nb;
+          x[i] = srow[Bc];
+          jv[i] = jrow[Bc];
+        }
+#pragma unroll
+        for (int i = 0; i < E; i += 2) {
+          const uint32_t f0 = oppsrc_lane(en_flags, eb + i), f1 = oppsrc_lane(en_flags, eb + i + 1);
+          const double x0 = (f0 & 1u) ? ((f0 & 4u) ? -x[i] : x[i]) : 0.0, x1 = (f1 & 1u) ? ((f1 & 4u) ? -x[i + 1] : x[i + 1]) : 0.0;
+          jacc += (f0 & 2u) ? jv[i] * x0 : 0.0;
+          jacc += (f1 & 2u) ? jv[i + 1] * x1 : 0.0;
+          if (mine) *reinterpret_cast<double2*>(lds + (i >> 1) * Lds::PLANE + tid * 16) = make_double2(x0, x1);
+        }
+      }
+      __syncthreads();
+      // ---- gather: plane b = entries eb + 2b, eb + 2b + 1; the weights of plane b + 1 are requested before plane b's
+      // multiply-adds
+      const int nbat = (ne - eb + 1) >> 1;  // planes that hold an entry
+      double2 w[2][NSUB];
+      auto weights = [&](int b, double2* out) {
+        const int e = eb + 2 * b;
+        const uint64_t r0 = ((uint64_t)oppsrc_lane(en_whi, e) << 32) | oppsrc_lane(en_wlo, e);
+        const uint64_t r1 = ((uint64_t)oppsrc_lane(en_whi, e + 1) << 32) | oppsrc_lane(en_wlo, e + 1);
+        const double* __restrict__ w0 = reinterpret_cast<const double*>((uintptr_t)r0);
+        const double* __restrict__ w1 = reinterpret_cast<const double*>((uintptr_t)r1);
+        const uint32_t p0 = oppsrc_lane(en_part, e), p1 = oppsrc_lane(en_part, e + 1);
+        const bool v1 = (oppsrc_lane(en_flags, e + 1) & 1u) != 0u;
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+          double a = w0[wpair[j]], c1 = w1[wpair[j]];  // (a dead second entry: the lane's default weight row, times a zero plane)
+          c1 = v1 ? c1 : 0.0;
+          if (spin) {
+            a += (wwidx[j] == p0) ? pen : 0.0;
+            c1 += (wwidx[j] == p1) ? pen : 0.0;
+          }
+          out[j] = make_double2(a, c1);
+        }
+      };
+      weights(0, w[0]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (b < nbat) {  // (uniform)
+          if (b + 1 < NB && b + 1 < nbat) weights(b + 1, w[(b + 1) & 1]);
+#pragma unroll
+          for (int j = 0; j < NSUB; ++j) {
+#pragma unroll
+            for (int k = 0; k < OPPS_SUB; ++k) {
+              const double2 c2 = *reinterpret_cast<const double2*>(lds + b * Lds::PLANE + rec[OPPS_SUB * j + k]);
+              acc[OPPS_SUB * j + k] += w[b & 1][j].x * c2.x;
+              acc[OPPS_SUB * j + k] += w[b & 1][j].y * c2.y;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every gather of the pass is done: the planes become accb
+    // ---- per-link sums -> target columns.  pos = the link's position among the pass's links in target order (sign of
+    // the beta link in bit 31); the owner of a column adds its run in that order, then the staged column's J term.
+    const uint32_t* __restrict__ ptab = tab + (int64_t)(S + NSUB) * T;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const uint32_t p = ptab[(int64_t)s * T];
+      if (p != OPPS_DEAD) accb[p & 0x7fffffffu] = (p >> 31) ? -acc[s] : acc[s];
+    }
+    jbuf[tid] = jacc;
+    __syncthreads();
+    const uint32_t* __restrict__ cp = g.cptr + (int64_t)h * (nb + 1);
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int64_t B = tid + (int64_t)r * T;
+      if (B < nb) {
+        const uint32_t c0 = cp[B], c1 = cp[B + 1];
+        double sum = 0.0;
+        for (uint32_t i = c0; i < c1; ++i) sum += accb[i];
+        if (B >= q0 && B < q1) sum += jbuf[B - q0];
+        colacc[r] += sum;
+      }
+    }
+    __syncthreads();  // (accb / jbuf are read: the next pass may stage)
+  }
+  const bool has0 = it.e0 == 0;  // the piece that holds the row itself also brings the diagonal and the same-spin product
+  const double* __restrict__ crow = C + A * nb;
+  const double* __restrict__ hd = g.hdiag + A * nb;
+  const double* __restrict__ gd = g.gdense + A * nb;
+  double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    const int64_t B = tid + (int64_t)r * T;
+    if (B < nb) {
+      double v = colacc[r];
+      if (has0) {
+        double d = hd[B];
+        if (spin) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
+        v += d * crow[B] + gd[B];
+      }
+      orow[B] = v;
+    }
+  }
+}
+
+// sigma[A, :] = sum of the partial rows of A in slot order, for the rows that were cut into several items (outside
+// Davidson runs; inside, k_dots_eig adds them as the first reader of the vector)
+struct OppSrcReduceArgs {
+  GPtr<const MultiRow> rows;
+  GPtr<const double> partial;
+  GPtr<double> sigma;
+  int64_t nb;
+  GPtr<const int> stop, vec_index;
+  int64_t s_stride;
+};
+__global__ void __launch_bounds__(256) k_opp_src_reduce(const OppSrcReduceArgs g) {
+  if (g.stop && *g.stop) return;
+  const MultiRow mr = g.rows[blockIdx.x];
+  double* __restrict__ sig = g.sigma + (g.vec_index ? (int64_t)(*g.vec_index - 1) * g.s_stride : 0) + (int64_t)mr.A * g.nb;
+  for (int64_t B = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; B < g.nb; B += (int64_t)gridDim.y * blockDim.x) {
+    double sacc = 0.0;
+    for (int j = 0; j < mr.nslots; ++j) sacc += g.partial[(int64_t)(mr.slot0 + j) * g.nb + B];
+    sig[B] = sacc;
+  }
+}
+
+// ---- host side
+static size_t oppsrc_shmem(bool big, int T) {  // the planes (accb in their place at the end of a pass), then jbuf
+  return (size_t)(big ? OppSrcLds<true>::JBUF : OppSrcLds<false>::JBUF) + (size_t)T * 8;
+}
+
+// phase 2 of set_subspace, behind spmm_select: is the opposite-spin part of this subspace taken by k_opp_src?
+// (SQD_SIGMA_OPP=0 forbids: the work items then add G as they add the matrix-core product.)
+bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
+  const int64_t L = tot[2];  // beta single links
+  if (L < 1) return false;
+  if (!c->oppsrc) c->oppsrc = new OppSrcState();
+  OppSrcState* s = static_cast<OppSrcState*>(c->oppsrc);
+  // Geometry.  512 threads with two sub-runs (8 links, <= 128 registers), ranges of <= 512 columns, pieces of 16 entries:
+  // 68 KB of LDS, two workgroups per CU that cover each other's staging round trips; rows of more than 4096 columns need
+  // 1024 threads for the thread's <= OPPS_RMAX target columns (ranges of <= 1024 columns, pieces of 8 entries).
+  int T = nb <= (int64_t)OPPS_RMAX * 512 ? 512 : 1024;
+  if (const char* env = std::getenv("SQD_OPPS_T")) {  // tuning / test hook (small workgroups: many passes on small sets)
+    const int v = std::atoi(env);
+    if (v >= 64 && v <= 1024 && v % 64 == 0) T = v;
+  }
+  int nsub = OPPS_NSUB_MAX;
+  if (const char* env = std::getenv("SQD_OPPS_S")) {  // tuning / test hook: links per thread (rounded up to whole sub-runs)
+    const int v = (std::atoi(env) + OPPS_SUB - 1) / OPPS_SUB;
+    if (v >= 1 && v <= OPPS_NSUB_MAX) nsub = v;
+  }
+  if (nb > (int64_t)OPPS_RMAX * T) return false;
+  if (nb > (int64_t)6 * T) nsub = 1;  // (eight target columns per thread beside two sub-runs: 18 spilled registers)
+  bool big = T > OppSrcLds<false>::COLS;
+  if (const char* env = std::getenv("SQD_OPPS_BIG"))  // test hook: the 4-plane layout on small workgroups
+    if (std::atoi(env) != 0) big = true;
+  if ((size_t)OPPS_SUB * nsub * T * 8 > (size_t)(big ? OppSrcLds<true>::STAGE_BYTES : OppSrcLds<false>::STAGE_BYTES)) return false;
+  if (oppsrc_shmem(big, T) + 1024 > (size_t)c->lds_bytes) return false;
+  // a source column's links must fit one pass even if every one of them opens a sub-run of its own
+  const int64_t* ps = c->h_sptr_b;
+  int64_t longest = 0;
+  for (int64_t B = 0; B < nb; ++B) longest = std::max(longest, ps[B + 1] - ps[B]);
+  if (longest > (int64_t)nsub * T) return false;
+  s->nsub = nsub;
+  s->big = big;
+  s->T = T;
+  s->shmem = oppsrc_shmem(big, T);
+  // work items: a row's entries (itself + its alpha single links) in pieces of at most E (<= 64: one entry per lane), so
+  // that the rows of the Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain; a row in one
+  // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
+  int E = 32;
+  if (const char* env = std::getenv("SQD_OPPS_E")) {  // tuning / test hook (short pieces: many partial rows)
+    const int v = std::atoi(env);
+    if (v >= 2 && v <= OPPS_EMAX) E = v / 2 * 2;
+  }
+  const int64_t* pa = c->h_sptr;
+  s->h_items.clear();
+  s->h_multi.clear();
+  s->h_rowinfo.assign((size_t)2 * na, 0);
+  int32_t nslots = 0;
+  for (int64_t A = 0; A < na; ++A) {
+    const int nent = 1 + (int)(pa[A + 1] - pa[A]);
+    const int pieces = (nent + E - 1) / E;
+    if (pieces == 1) {
+      s->h_items.push_back(OppSrcItem{(uint32_t)A, 0, nent, -1});
+    } else {
+      s->h_multi.push_back(MultiRow{(uint32_t)A, nslots, pieces});
+      s->h_rowinfo[2 * A] = nslots;
+      s->h_rowinfo[2 * A + 1] = pieces;
+      for (int p = 0; p < pieces; ++p) {
+        const int e0 = p * E, ne = (nent - e0 < E) ? nent - e0 : E;
+        s->h_items.push_back(OppSrcItem{(uint32_t)A, e0, ne, nslots++});
+      }
+    }
+  }
+  std::stable_sort(s->h_items.begin(), s->h_items.end(), [](const OppSrcItem& a, const OppSrcItem& b) { return a.ne > b.ne; });
+  s->n_items = (int64_t)s->h_items.size();
+  s->n_slots = nslots;
+  s->n_multi = (int64_t)s->h_multi.size();
+  return true;
+}
+
+// The pass tables (host): the beta single links come back from the device once per subspace (8 + 4 bytes per link), are
+// cut into source-column ranges of at most `cap` slots and min(T, plane) columns, grouped by widx inside a range and laid
+// out thread by thread.
+int oppsrc_build(sqd_ctx* c) {
+  OppSrcState* s = static_cast<OppSrcState*>(c->oppsrc);
+  const SpinTables& tb = c->sp[1];
+  const int64_t nb = c->nb, L = c->h_sptr_b[nb];
+  const int T = s->T, nsub = s->nsub, S = OPPS_SUB * nsub, nw = 2 * c->nnorb;
+  s->h_rec.resize((size_t)L);
+  s->h_row.resize((size_t)L);
+  SQD_HIP_CHECK(hipMemcpyAsync(s->h_rec.data(), tb.s_rec.p, (size_t)L * sizeof(SRec), hipMemcpyDeviceToHost, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->h_row.data(), tb.s_row.p, (size_t)L * 4, hipMemcpyDeviceToHost, c->stream));
+  SQD_STREAM_SYNC(c->stream);
+  // links by source column, in link order
+  std::vector<int64_t> sptr((size_t)nb + 1, 0);
+  for (int64_t l = 0; l < L; ++l) ++sptr[s->h_rec[l].src + 1];
+  for (int64_t B = 0; B < nb; ++B) sptr[B + 1] += sptr[B];
+  std::vector<uint32_t> bysrc((size_t)L);
+  {
+    std::vector<int64_t> fill(sptr.begin(), sptr.end() - 1);
+    for (int64_t l = 0; l < L; ++l) bysrc[fill[s->h_rec[l].src]++] = (uint32_t)l;
+  }
+  // ranges: greedy over the source columns; slots of a range = sum over widx of its link count rounded up to sub-runs
+  const int64_t cap_slots = (int64_t)S * T;
+  const int cap_cols = std::min(T, s->big ? OppSrcLds<true>::COLS : OppSrcLds<false>::COLS);
+  std::vector<int32_t>& cut = s->h_colcut;
+  cut.assign(1, 0);
+  {
+    std::vector<int32_t> cnt((size_t)nw, 0);
+    std::vector<int32_t> touched;
+    int64_t slots = 0;
+    int width = 0;
+    for (int64_t B = 0; B < nb; ++B) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        int64_t add = 0;
+        for (int64_t i = sptr[B]; i < sptr[B + 1]; ++i) {
+          const uint32_t w = srec_widx(s->h_rec[bysrc[i]].meta);
+          if (cnt[w] % OPPS_SUB == 0) add += OPPS_SUB;
+          if (cnt[w]++ == 0) touched.push_back((int32_t)w);
+        }
+        if (attempt == 1 || (slots + add <= cap_slots && width + 1 <= cap_cols)) {
+          slots += add;
+          ++width;
+          break;
+        }
+        // close the range in front of B and count B again in a fresh one
+        for (int32_t w : touched) cnt[w] = 0;
+        touched.clear();
+        cut.push_back((int32_t)B);
+        slots = 0;
+        width = 0;
+      }
+    }
+    cut.push_back((int32_t)nb);
+  }
+  const int H = (int)cut.size() - 1;
+  s->H = H;
+  // tables per pass: rec[S][T] | wofs[nsub][T] | pos[S][T];  cptr[H][nb + 1]
+  const size_t per_pass = (size_t)(2 * S + nsub) * T;
+  s->h_tab.assign(per_pass * H, 0u);
+  s->h_cptr.assign((size_t)H * (nb + 1), 0u);
+  std::vector<int32_t> range_of((size_t)nb);
+  for (int h = 0; h < H; ++h)
+    for (int32_t B = cut[h]; B < cut[h + 1]; ++B) range_of[B] = h;
+  // position of every link among its pass's links in target order (= link order: the CSR is sorted by target column)
+  std::vector<uint32_t> rank((size_t)L);
+  {
+    std::vector<uint32_t> counter((size_t)H, 0u);
+    const int64_t* ps = c->h_sptr_b;
+    for (int64_t B = 0; B < nb; ++B) {
+      for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + B] = counter[h];
+      for (int64_t l = ps[B]; l < ps[B + 1]; ++l) rank[l] = counter[range_of[s->h_rec[l].src]]++;
+    }
+    for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + nb] = counter[h];
+  }
+  {
+    std::vector<std::vector<uint32_t>> by_w((size_t)nw);
+    std::vector<int32_t> used;
+    for (int h = 0; h < H; ++h) {
+      uint32_t* rec = s->h_tab.data() + per_pass * h;
+      uint32_t* wofs = rec + (size_t)S * T;
+      uint32_t* pos = wofs + (size_t)nsub * T;
+      std::fill(pos, pos + (size_t)S * T, OPPS_DEAD);
+      used.clear();
+      for (int32_t B = cut[h]; B < cut[h + 1]; ++B)
+        for (int64_t i = sptr[B]; i < sptr[B + 1]; ++i) {
+          const uint32_t l = bysrc[i], w = srec_widx(s->h_rec[l].meta);
+          if (by_w[w].empty()) used.push_back((int32_t)w);
+          by_w[w].push_back(l);
+        }
+      std::sort(used.begin(), used.end());
+      int64_t u = 0;  // sub-run index: thread u % T, sub-run u / T of that thread
+      for (int32_t w : used) {
+        std::vector<uint32_t>& ls = by_w[w];
+        std::sort(ls.begin(), ls.end());
+        for (size_t i0 = 0; i0 < ls.size(); i0 += OPPS_SUB, ++u) {
+          const int t = (int)(u % T), j = (int)(u / T);
+          if (j >= nsub) {
+            set_error("internal: opposite-spin pass tables overflow");
+            return SQD_ERR_STATE;
+          }
+          wofs[(size_t)j * T + t] = (uint32_t)w;
+          for (int k = 0; k < OPPS_SUB && i0 + k < ls.size(); ++k) {
+            const uint32_t l = ls[i0 + k];
+            const size_t at = (size_t)(OPPS_SUB * j + k) * T + t;
+            rec[at] = (uint32_t)(s->h_rec[l].src - (uint32_t)cut[h]) * 16u;
+            pos[at] = rank[l] | ((s->h_rec[l].meta >> 31) ? 0x80000000u : 0u);
+          }
+        }
+        ls.clear();
+      }
+    }
+  }
+  SQD_TRY(s->tab.reserve(s->h_tab.size() * 4 + 64));
+  SQD_TRY(s->cptr.reserve(s->h_cptr.size() * 4 + 64));
+  SQD_TRY(s->colcut.reserve(s->h_colcut.size() * 4 + 64));
+  SQD_TRY(s->items.reserve((size_t)s->n_items * sizeof(OppSrcItem) + 64));
+  SQD_TRY(s->rowinfo.reserve((size_t)2 * c->na * 4 + 64));
+  SQD_TRY(s->multi.reserve((size_t)s->n_multi * sizeof(MultiRow) + 64));
+  SQD_TRY(s->partial.reserve((size_t)s->n_slots * c->nb * 8 + 64));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->tab.p, s->h_tab.data(), s->h_tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->cptr.p, s->h_cptr.data(), s->h_cptr.size() * 4, hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->colcut.p, s->h_colcut.data(), s->h_colcut.size() * 4, hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->items.p, s->h_items.data(), (size_t)s->n_items * sizeof(OppSrcItem), hipMemcpyHostToDevice, c->stream));
+  SQD_HIP_CHECK(hipMemcpyAsync(s->rowinfo.p, s->h_rowinfo.data(), (size_t)2 * c->na * 4, hipMemcpyHostToDevice, c->stream));
+  if (s->n_multi)
+    SQD_HIP_CHECK(hipMemcpyAsync(s->multi.p, s->h_multi.data(), (size_t)s->n_multi * sizeof(MultiRow), hipMemcpyHostToDevice, c->stream));
+  return SQD_OK;
+}
+
+// number of source-column passes of the latest build (probes / tests)
+int oppsrc_passes(const sqd_ctx* c) {
+  const OppSrcState* s = static_cast<const OppSrcState*>(c->oppsrc);
+  return s ? s->H : 0;
+}
+
+// sigma = (hdiag + opposite-spin part) c + G, G = sqd_ctx::gdense as spmm_launch has just formed it for the same vector
+int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_stride, int64_t out_stride, bool spin, double ss,
+               double shift) {
+  OppSrcState* s = static_cast<OppSrcState*>(c->oppsrc);
+  if (!s) {
+    set_error("internal: opposite-spin row kernel without its tables");
+    return SQD_ERR_STATE;
+  }
+  OppSrcArgs g;
+  const SpinTables& ta = c->sp[0];
+  const SpinTables& tb = c->sp[1];
+  g.c = d_c;
+  g.sigma = d_sigma;
+  g.hdiag = c->hdiag.as<double>();
+  g.gdense = c->gdense.as<double>();
+  g.ja_row = ta.jrow.as<double>();
+  g.jbT = tb.jT.as<double>();
+  g.eri_pp = c->eri_pp.as<double>();
+  g.sa_ptr = ta.s_ptr.as<int64_t>();
+  g.sa_rec = ta.s_rec.as<SRec>();
+  g.tab = s->tab.as<uint32_t>();
+  g.cptr = s->cptr.as<uint32_t>();
+  g.colcut = s->colcut.as<int32_t>();
+  g.items = s->items.as<OppSrcItem>();
+  g.partial = s->partial.as<double>();
+  g.nb = c->nb;
+  g.nnorb = c->nnorb;
+  g.T = s->T;
+  g.H = s->H;
+  g.stop = c->sigma_stop;
+  const bool indexed = c->sigma_index && (in_stride || out_stride);
+  g.vec_index = indexed ? c->sigma_index : nullptr;
+  g.c_stride = in_stride;
+  g.s_stride = out_stride;
+  g.spin = spin ? 1 : 0;
+  g.ss = ss;
+  g.shift = shift;
+  {
+    const double sz = 0.5 * (c->nelec[0] - c->nelec[1]);
+    g.szterm = sz * (sz + 1.0);
+  }
+  g.strs_a = c->sp[0].strs.as<uint64_t>();
+  g.strs_b = c->sp[1].strs.as<uint64_t>();
+  g.n_items = (unsigned)s->n_items;
+  const int rm = (int)((c->nb + s->T - 1) / s->T);  // target columns per thread (<= OPPS_RMAX: oppsrc_select)
+  const dim3 grid((unsigned)s->n_items), block((unsigned)s->T);
+#define SQD_OPPS_CASE(NSUB_, RM_, BIG_)                                                                             \
+  do {                                                                                                             \
+    if (s->shmem > 64 * 1024) {                                                                                    \
+      static std::atomic<size_t> granted[64];                                                                      \
+      const int dev = c->device & 63;                                                                              \
+      if (s->shmem > granted[dev].load(std::memory_order_relaxed)) {                                               \
+        SQD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_opp_src<NSUB_, RM_, BIG_>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->shmem));             \
+        granted[dev].store(s->shmem, std::memory_order_relaxed);                                                   \
+      }                                                                                                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL((k_opp_src<NSUB_, RM_, BIG_>), grid, block, s->shmem, c->stream, g);                       \
+  } while (0)
+#define SQD_OPPS_BIG(NSUB_, RM_)                        \
+  do {                                                 \
+    if (s->big) SQD_OPPS_CASE(NSUB_, RM_, true);        \
+    else SQD_OPPS_CASE(NSUB_, RM_, false);              \
+  } while (0)
+  if (s->nsub == 1 || rm > 6) {  // (rows of more than six columns per thread: one sub-run, oppsrc_select)
+    if (rm <= 2) SQD_OPPS_BIG(1, 2);
+    else if (rm <= 4) SQD_OPPS_BIG(1, 4);
+    else if (rm <= 6) SQD_OPPS_BIG(1, 6);
+    else SQD_OPPS_BIG(1, 8);
+  } else {
+    if (rm <= 2) SQD_OPPS_BIG(2, 2);
+    else if (rm <= 4) SQD_OPPS_BIG(2, 4);
+    else SQD_OPPS_BIG(2, 6);
+  }
+#undef SQD_OPPS_BIG
+#undef SQD_OPPS_CASE
+  SQD_HIP_CHECK(hipGetLastError());
+  // rows in several pieces: inside a Davidson run the first reader of the new vector adds the partial rows (oppsrc_split)
+  if (s->n_multi > 0 && !(c->sigma_defer_reduce && indexed)) {
+    OppSrcReduceArgs r;
+    r.rows = s->multi.as<MultiRow>();
+    r.partial = s->partial.as<double>();
+    r.sigma = d_sigma;
+    r.nb = c->nb;
+    r.stop = g.stop;
+    r.vec_index = g.vec_index;
+    r.s_stride = out_stride;
+    hipLaunchKernelGGL(k_opp_src_reduce, dim3((unsigned)s->n_multi, (unsigned)((c->nb + 1023) / 1024)), dim3(256), 0, c->stream, r);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  if (c->ev_after_sigma_kernel) {
+    SQD_HIP_CHECK(hipEventRecord(c->ev_after_sigma_kernel, c->stream));
+    c->ev_after_sigma_kernel = nullptr;
+  }
+  return SQD_OK;
+}
+
+// the split-row records of the latest oppsrc_select (for k_dots_eig's deferred sum); false: every row is in one piece
+bool oppsrc_split(const sqd_ctx* c, const int32_t** rowinfo, const double** partial) {
+  const OppSrcState* s = static_cast<const OppSrcState*>(c->oppsrc);
+  if (!s || s->n_multi == 0) return false;
+  *rowinfo = s->rowinfo.as<int32_t>();
+  *partial = s->partial.as<double>();
+  return true;
+}
+
+}  // namespace sqd

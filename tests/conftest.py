@@ -12,7 +12,7 @@ sys.path.insert(0, str(ROOT))
 EMU_DIR = ROOT / "tests" / "emu"
 EMU_LIB = EMU_DIR / "_build" / "libsqd_emu.so"
 CSRC = ROOT / "qiskit-addon-sqd_amd" / "csrc"
-HIP_SOURCES = ["sqd_tables.hip", "sqd_sigma.hip", "sqd_lists.hip", "sqd_spmm.hip", "sqd_opp.hip", "sqd_davidson.hip", "sqd_rdm.hip", "sqd_pauli.hip", "sqd_recover.hip", "sqd_capi.hip"]
+HIP_SOURCES = ["sqd_tables.hip", "sqd_sigma.hip", "sqd_lists.hip", "sqd_spmm.hip", "sqd_opp.hip", "sqd_oppsrc.hip", "sqd_davidson.hip", "sqd_rdm.hip", "sqd_pauli.hip", "sqd_recover.hip", "sqd_capi.hip"]
 
 
 def pytest_configure(config):

@@ -61,7 +61,7 @@ def test_no_dynamic_stack(records):
 
 
 def test_sigma_kernels_own_no_private_segment(records):
-    pat = re.compile(r"sqd::k_(sigma|sigma_b|opp_rows|spmm_grouped|sigma_lists|alpha_rows|same_spin_mfma)\b")
+    pat = re.compile(r"sqd::k_(sigma|sigma_b|opp_rows|opp_src|spmm_grouped|sigma_lists|alpha_rows|same_spin_mfma)\b")
     allowed = {"sqd::k_sigma_rows<2, true>", "sqd::k_sigma_rows<2, false>"}  # (7-8 spilled registers, no calls; rows kernel of uniform 1000-5000 sets)
     bad = []
     for r in records:

@@ -309,15 +309,30 @@ def test_emu_opp_rows_column_ranges(emu_lib, monkeypatch):
             assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and ctx.link_counts(1)[0] > 64
         run_operator_parity(emu_lib, *case)
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
-    # rows longer than four columns per thread (what more than 4096 strings take with 1024 threads): the J rows ride for
-    # the workgroup's own column range only and the alpha single x beta occupation term is formed from the staged values
-    for s_hook, case in (("2", (11, (2, 5), 6, 230, 29, True)), ("2", (11, (2, 5), 6, 300, 31, True)), ("5", (11, (3, 5), 5, 460, 33, True))):
-        monkeypatch.setenv("SQD_OPP_S", s_hook)
+
+
+@pytest.mark.parametrize("hooks", [{"SQD_OPPS_T": "64", "SQD_OPPS_S": "4"}, {"SQD_OPPS_T": "64", "SQD_OPPS_S": "8", "SQD_OPPS_E": "4"},
+                                   {"SQD_OPPS_T": "128", "SQD_OPPS_BIG": "1", "SQD_OPPS_E": "10"}])
+def test_emu_opp_src_passes(emu_lib, monkeypatch, hooks):
+    # k_opp_src (sqd_oppsrc.hip: what rows of more than 3072 columns take): passes over ranges of the SOURCE column, the
+    # links of a range grouped by excitation operator in sub-runs of four, a piece's entries staged eight at a time, the
+    # per-link sums through LDS to the owners of the target columns.  64-thread workgroups on small sets: many passes,
+    # ragged ranges, pieces of more than eight entries (several staging rounds) and of four (partial rows + the deferred
+    # sum inside the Davidson run), one and two sub-runs per thread, both LDS layouts, rows of 2 .. 8 columns per thread,
+    # the linear spin penalty (run_operator_parity), a whole solve
+    monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
+    monkeypatch.setenv("SQD_OPP_SRC", "1")
+    for k, v in hooks.items():
+        monkeypatch.setenv(k, v)
+    cases = [(7, (3, 3), 20, 20, 7, True), (8, (4, 4), 30, 28, 17, True), (9, (2, 4), 7, 100, 29, True),
+             (11, (2, 5), 6, 230, 29, True), (11, (3, 5), 5, 460, 33, True)]
+    for case in cases:
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and len(sb) > 3 * 64
+            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_src", (case, ctx.sigma_kernel())
         run_operator_parity(emu_lib, *case)
+    run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
 
 
 def test_emu_rdm2_opposite_spin_row_form(emu_lib, monkeypatch):

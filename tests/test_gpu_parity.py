@@ -1044,14 +1044,18 @@ def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
 
 
 
-@pytest.mark.parametrize("na,nb", [(1000, 5003), (901, 3500)])
-def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
-    """Rows of more than 3072 columns in the whole-row opposite-spin kernel (k_opp_rows<RM, true>: 4 ... 8 columns per
-    thread, the J rows held for the workgroup's own column range only): HF-centred 1000 x 5003 and 901 x 3500 by default
-    selection -- sigma on sampled rows and sampled columns against the row-restricted string-space oracle,
-    reproducibility, the work-item formulation on the whole vector, one whole solve (Rayleigh quotient, residual)."""
-    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
+@pytest.mark.parametrize("na,nb,src", [(1000, 5003, None), (901, 3500, None), (700, 7300, None), (901, 2500, "1")])
+def test_connected_long_rows_source_range_kernel(hip_lib, monkeypatch, na, nb, src):
+    """Rows of more than 3072 columns: k_opp_src (sqd_oppsrc.hip: passes over ranges of the source column, round 6; the
+    4-8-columns-per-thread instantiations of k_opp_rows that used to run them spilled 6-40 registers).  HF-centred
+    1000 x 5003, 901 x 3500 and 700 x 7300 (more than six columns per thread: one sub-run) by default selection, 901 x 2500
+    forced (SQD_OPP_SRC=1: 512 threads, the 32 KB layout) -- sigma on sampled rows and sampled columns against the
+    row-restricted string-space oracle, reproducibility, the linear spin penalty and the plain operator against the
+    work-item formulation on the whole vector, one whole solve (Rayleigh quotient, residual)."""
+    for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP", "SQD_OPP_SRC"):
         monkeypatch.delenv(k, raising=False)
+    if src is not None:
+        monkeypatch.setenv("SQD_OPP_SRC", src)
     norb = 30
     h1, eri = O.synthetic_integrals(norb)
     sa, sb = O.hf_centred_strings(norb, 8, na, 31), O.hf_centred_strings(norb, 8, nb, 37)
@@ -1060,18 +1064,18 @@ def test_connected_long_rows_whole_row_kernel(hip_lib, monkeypatch, na, nb):
     hf = int(np.flatnonzero(sa == (1 << 8) - 1)[0])
     rows = np.unique(np.concatenate(([0, hf, na - 1], rng.choice(na, 4, replace=False))))
     hfb = int(np.flatnonzero(sb == (1 << 8) - 1)[0])
-    cols = np.unique(np.concatenate(([0, hfb, nb - 1, 3071, 3072, 3073], rng.choice(nb, 3, replace=False))))
+    cols = np.unique(np.concatenate(([0, hfb, nb - 1, min(3071, nb - 1), min(3072, nb - 1), min(3073, nb - 1)], rng.choice(nb, 3, replace=False))))
     ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
     ref_cols = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), norb, cols)
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
-        assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows"
+        assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_src"
         scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
         sx = ctx.sigma(x)
         assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
         assert np.abs(sx[:, cols].T - ref_cols).max() < 1e-11 * scale
         assert np.array_equal(sx, ctx.sigma(x))
-        sp = ctx.sigma(x, use_spin=1, ss=0.75, shift=0.3)  # (the linear penalty form: the same kernel, SPIN instantiation)
+        sp = ctx.sigma(x, use_spin=1, ss=0.75, shift=0.3)  # (the linear penalty form: the same kernel, one weight per entry shifted)
         amps, st = ctx.davidson()
         e0 = st["e_davidson"]
         hc = ctx.sigma(amps)
