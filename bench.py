@@ -210,11 +210,12 @@ def oracle_energy_check(args, h1, eri, sa, sb, e_gpu):
 def roofline_entry(ctx, t_bracket_ms, t_apply_ms, n_timed, traffic=None, source=None, t_empty_ms=0.0):
     """t_bracket_ms: average HIP-event bracket around the sigma kernel; t_empty_ms: average EMPTY bracket recorded right
     behind it (what event records cost by themselves: ~5 us, more than half of a 9 us bracket at batch size).  A kernel
-    bracket hides part of that cost behind the kernel's own dispatch, so only HALF the empty bracket is subtracted:
-    with that rule the launch duration stays on the conservative side of the rocprofv3 kernel-trace average of the same
-    command and within ~12 % of it on both committed workloads (uniform 317^2: 6.7 vs 5.9 us; HF-centred: 30.5 vs 27.2 us;
-    profiles/r02/final_*_kernel_stats.csv).  Subtracting all of it would claim 4.1 us / frac 0.15 at the headline."""
-    t_kernel_ms = t_bracket_ms - 0.5 * t_empty_ms
+    bracket hides part of that cost behind the kernel's own dispatch, so only a FRACTION of the empty bracket is
+    subtracted: 0.6, calibrated in round 6 against rocprofv3 --kernel-trace of this very command
+    (profiles/r06/roofline_calibration.txt: 200 bracketed launches, bracket 8.97 us, empty 5.28 us -> 5.80 us; the
+    trace's 876 live launches: mean 5.65, median 5.88 us).  Round 2's 0.5 (6.3 us here) sat 7-12 % above the trace;
+    subtracting all of it would claim 3.7 us / frac 0.16 at the headline."""
+    t_kernel_ms = t_bracket_ms - 0.6 * t_empty_ms
     b_alg = ctx.sigma_bytes()
     b_need = ctx.sigma_bytes_needed()
     ach = b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else 0.0
@@ -387,10 +388,22 @@ def main():
     if rank == 0:
         ctx = F._get_context(h1, eri, local_rank)  # the context the timed solves used (cache hit)
         t_sigma_ms = ms_sigma / max(n_timed, 1)
-        # The roofline leg's launch duration: 200 launches of the sigma kernel BEHIND the timed region, every one inside
-        # its own HIP-event bracket with an empty bracket behind it, medians of both (round 5's line carried 5 samples
-        # taken inside the region: 0.060 <-> 0.096 from box to box).  The in-region samples stay as a cross-check.
-        br = ctx.time_sigma_brackets(200, 0 if args.spin_sq is None else 0)
+        # The roofline leg's launch duration: 100 more solves BEHIND the timed region with EVERY sigma launch inside its own
+        # HIP-event bracket and an empty bracket behind it (>= 200 samples under the conditions of the timed solves: new
+        # vectors, the Davidson's own launches around them; round 5's line carried 5 samples taken inside the region and
+        # swung 0.060 <-> 0.096 from box to box).  The in-region samples stay as a cross-check.
+        F.set_profiling(time_sigma_every=1)
+        pr_n = 0
+        pr_k = pr_a = pr_e = 0.0
+        for _ in range(100):
+            F.solve_fermion((sa, sb), h1, eri, spin_sq=args.spin_sq, device=local_rank)
+            stx = F.last_solve_stats()
+            pr_n += stx["n_sigma_timed"]
+            pr_k += stx["ms_sigma_kernel"]
+            pr_a += stx["ms_sigma"]
+            pr_e += stx["ms_event_overhead"]
+        F.set_profiling(0)
+        br = {"kernel_ms": pr_k / max(pr_n, 1), "apply_ms": pr_a / max(pr_n, 1), "empty_ms": pr_e / max(pr_n, 1), "launches": pr_n}
         ns_a, nd_a = ctx.link_counts(0)
         ns_b, nd_b = ctx.link_counts(1)
         traffic, source = pmc_traffic(args)
@@ -430,13 +443,12 @@ def main():
             "tables_ms_per_solve": ms_setup,
             "energy": float(e), "converged": int(st["converged"]), "residual": float(st["residual"]),
             "links": {"alpha_single": ns_a, "alpha_double": nd_a, "beta_single": ns_b, "beta_double": nd_b},
-            "roofline": roofline_entry(ctx, br["kernel_median_ms"], ms_apply / max(n_timed, 1), br["launches"], traffic, source,
-                                       br["empty_median_ms"]),
+            "roofline": roofline_entry(ctx, br["kernel_ms"], br["apply_ms"], br["launches"], traffic, source, br["empty_ms"]),
             "ms_per_step_median": float(np.median(step_ms)),
             "ms_per_step_min": float(np.min(step_ms)),
         }
-        out["roofline"]["bracket_source"] = ("200 launches behind the timed region, one HIP-event bracket each + an empty bracket; "
-                                             "medians (means: %.4f / %.4f ms)" % (br["kernel_mean_ms"], br["empty_mean_ms"]))
+        out["roofline"]["bracket_source"] = ("100 solves behind the timed region, every sigma launch in its own HIP-event bracket + an "
+                                             "empty bracket behind it")
         out["roofline"]["in_region_samples"] = {"launches": n_timed, "event_bracket_ms": t_sigma_ms,
                                                 "empty_bracket_ms": ms_empty / max(n_timed, 1)}
         # SURVEY 8d's second unit: one Davidson ITERATION, B_iter = B_sigma + 8 D (4 m + 6) at basis size m (the mean

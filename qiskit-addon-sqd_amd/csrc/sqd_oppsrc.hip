@@ -42,16 +42,19 @@ namespace sqd {
 constexpr int OPPS_SUB = 4;       // links per sub-run (one weight pair serves four links)
 constexpr int OPPS_NSUB_MAX = 2;  // sub-runs per thread (8 links: 8 + 16 registers; three sub-runs spill at 128 registers)
 constexpr int OPPS_RMAX = 8;      // target columns per thread (nb <= OPPS_RMAX * threads)
+constexpr int OPPS_RL = 3;        // ... of which, beside two sub-runs and six columns, this many are carried in LDS
 // LDS plan (bytes; the plane of a batch is an immediate of the gather instruction):
 //   Cst[4][COLS][2] -- the staged range of eight entries (a piece is walked eight entries at a time); accb[links of a pass]
-//   takes its place at the end of a pass; jbuf[T] sits behind.  BIG = false: planes of 512 columns, 32 + 4 KB (512
-//   threads); BIG = true: planes of 1024 columns, 64 + 8 KB (1024 threads: rows of more than 4096 columns)
+//   takes its place at the end of a pass; Wst[nnorb][8] -- the eight entries' weight rows -- and jbuf[T] sit behind.
+//   BIG = false: planes of 512 columns, 32 + 32 + 4 KB (512 threads, two workgroups per CU, norb <= 31); BIG = true:
+//   planes of 1024 columns, 64 + 64 + 8 KB (1024 threads: rows of more than 4096 columns; or norb <= 44)
 template <bool BIG>
 struct OppSrcLds {
   static constexpr int COLS = BIG ? 1024 : 512, NB = 4;
   static constexpr int PLANE = COLS * 16;
   static constexpr int STAGE_BYTES = NB * PLANE;
-  static constexpr int JBUF = STAGE_BYTES;
+  static constexpr int WROWS = BIG ? 1024 : 512;     // orbital pairs (nnorb): norb <= 44 / 31
+  static constexpr int WST = STAGE_BYTES;            // Wst[pair][8 entries]: the round's weights, 64 bytes per pair
 };
 constexpr int OPPS_EMAX = 64;  // entries of a piece: one per lane of a wavefront
 constexpr uint32_t OPPS_DEAD = 0xffffffffu;
@@ -64,11 +67,11 @@ struct OppSrcItem {
   int32_t e0, ne, slot;
 };
 struct OppSrcState {
-  DevBuf tab, cptr, colcut, items, rowinfo, partial, multi;
+  DevBuf tab, colcut, items, rowinfo, partial, multi;
   std::vector<OppSrcItem> h_items;
   std::vector<int32_t> h_rowinfo;
   std::vector<MultiRow> h_multi;
-  std::vector<uint32_t> h_tab, h_cptr;
+  std::vector<uint32_t> h_tab;
   std::vector<int32_t> h_colcut;
   std::vector<SRec> h_rec;
   std::vector<uint32_t> h_row;
@@ -81,7 +84,7 @@ struct OppSrcState {
 void oppsrc_release(sqd_ctx* c) {
   if (!c->oppsrc) return;
   OppSrcState* s = static_cast<OppSrcState*>(c->oppsrc);
-  for (DevBuf* b : {&s->tab, &s->cptr, &s->colcut, &s->items, &s->rowinfo, &s->partial, &s->multi}) b->release();
+  for (DevBuf* b : {&s->tab, &s->colcut, &s->items, &s->rowinfo, &s->partial, &s->multi}) b->release();
   delete s;
   c->oppsrc = nullptr;
 }
@@ -92,12 +95,12 @@ struct OppSrcArgs {
   GPtr<const double> hdiag, gdense, ja_row, jbT, eri_pp;
   GPtr<const int64_t> sa_ptr;
   GPtr<const SRec> sa_rec;
-  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | widx[NSUB][T] | pos[S][T]
-  GPtr<const uint32_t> cptr;   // [H][nb + 1] first position (target order) of every column's links inside the pass
+  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | widx[NSUB][T] | pos[S][T] | colq[OPPS_RMAX][T]; colq = first position
+                               // (target order) of column t + r T's links inside the pass | their number << 16
   GPtr<const int32_t> colcut;  // [H + 1] first source column of every pass
   GPtr<const OppSrcItem> items;
   int64_t nb;
-  int nnorb, T, H;
+  int nnorb, T, H, jbuf_off;
   unsigned n_items;
   GPtr<const int> stop, vec_index;
   int64_t c_stride, s_stride;
@@ -112,12 +115,36 @@ struct OppSrcArgs {
 // lane e of every wavefront holds entry e of the piece; a field of entry e reaches the scalar registers through
 // v_readlane with e a constant of the unrolled loops -- no table in memory, no load behind a barrier
 __device__ inline uint32_t oppsrc_lane(uint32_t v, int e) { return (uint32_t)__builtin_amdgcn_readlane((int)v, e); }
+// element at a 32-bit BYTE offset of a row whose address is wave-uniform: scalar base + 32-bit vector offset -- one
+// offset register for all the loads of a round instead of a 64-bit address pair per load
+// ... the uniform base pinned to scalar registers behind an opaque lane read: left visible, the compiler folds the
+// uniform row offset into the vector index and builds a 64-bit address pair per load after all
+__device__ inline const double* oppsrc_pin(const double* p) {
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return reinterpret_cast<const double*>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+__device__ inline double oppsrc_ldu(const double* base, uint32_t byte_off) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 // ... and is read again wherever it is used: left alone the compiler hoists all 6 x 16 lane reads out of the pass loop and
 // keeps them in scalar registers it does not have (106 SGPRs, the rest spilled into vector lanes)
 #if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
 #define OPPS_REREAD(v) asm volatile("" : "+v"(v))
 #else
 #define OPPS_REREAD(v) ((void)(v))
+#endif
+
+// ---- phase clocks (probe builds only: -DSQD_PHASE_CLOCK; profiles/probes/_oppsrc_clock.py): thread 0 of every workgroup adds
+// the 100 MHz wall-clock deltas of its phases into ITS OWN row of a device array; the host sums the rows
+#ifdef SQD_PHASE_CLOCK
+constexpr int OCLK_ROWS = 65536, OCLK_COLS = 8;
+__device__ unsigned long long sqd_clk_oppsrc[OCLK_ROWS * OCLK_COLS];
+#define OCLK(var) const unsigned long long var = wall_clock64()
+#define OCLK_ADD(slot, d) do { if (threadIdx.x == 0) sqd_clk_oppsrc[(blockIdx.x % OCLK_ROWS) * OCLK_COLS + (slot)] += (unsigned long long)(d); } while (0)
+#else
+#define OCLK(var)
+#define OCLK_ADD(slot, d)
 #endif
 
 template <int NSUB, int RM, bool BIG>
@@ -130,12 +157,17 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
   if (g.stop && *g.stop) return;
   const unsigned item_index = blockIdx.x;
   if (item_index >= g.n_items) return;
+  OCLK(k_item0);
   const int T = g.T, tid = threadIdx.x, lane = tid & 63;
-  const OppSrcItem it = g.items[item_index];
+  OppSrcItem it = g.items[item_index];
+  it.A = (uint32_t)__builtin_amdgcn_readfirstlane((int)it.A);  // (uniform: scalar registers, not a vector register each)
+  it.e0 = __builtin_amdgcn_readfirstlane(it.e0);
+  it.ne = __builtin_amdgcn_readfirstlane(it.ne);
+  it.slot = __builtin_amdgcn_readfirstlane(it.slot);
   const int64_t A = it.A;
   const int64_t nb = g.nb;
   const int nn = g.nnorb;
-  const int64_t vsel = g.vec_index ? (int64_t)(*g.vec_index - 1) : 0;
+  const int64_t vsel = g.vec_index ? (int64_t)__builtin_amdgcn_readfirstlane(*g.vec_index - 1) : 0;
   const double* __restrict__ C = g.c + vsel * g.c_stride;
   double* __restrict__ sig = g.sigma + vsel * g.s_stride;
   const int ne = it.ne;
@@ -160,31 +192,38 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
     en_flags = (valid ? 1u : 0u) | (lnk ? 2u : 0u) | ((lnk && (r.meta >> 31)) ? 4u : 0u);
     if (lnk) en_part = widx ^ 1u;  // same orbital pair, opposite direction
   }
-  double colacc[RM];
+  // a thread's target columns' sums, carried over the passes: in registers, but for the last RL of six beside two
+  // sub-runs (the allocator spilled them anyway: 28-44 bytes of scratch) -- those sit in LDS behind jbuf
+  constexpr int RL = (NSUB == 2 && RM == 6) ? OPPS_RL : 0, RR = RM - RL;
+  double colacc[RR];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) colacc[r] = 0.0;
+  for (int r = 0; r < RR; ++r) colacc[r] = 0.0;
   double* const accb = smem;
-  double* const jbuf = reinterpret_cast<double*>(lds + Lds::JBUF);
+  double* const jbuf = reinterpret_cast<double*>(lds + g.jbuf_off);  // behind the nnorb pairs of Wst that are in use
+  double* const cbuf = jbuf + T;  // [RL][T]
+#pragma unroll
+  for (int r = 0; r < RL; ++r) cbuf[r * T + tid] = 0.0;
 
   for (int h = 0; h < g.H; ++h) {
     const int q0 = g.colcut[h], q1 = g.colcut[h + 1];
-    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((2 * S + NSUB) * (int64_t)T) + tid;
-    uint32_t rec[S], wpair[NSUB], wwidx[NSUB];
+    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((2 * S + NSUB + OPPS_RMAX) * (int64_t)T) + tid;
+    uint32_t rec[S], wq[NSUB];  // wq: byte offset of the sub-run's orbital pair in Wst | direction bit
 #pragma unroll
     for (int s = 0; s < S; ++s) rec[s] = tab[(int64_t)s * T];
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
-      wwidx[j] = tab[(int64_t)(S + j) * T];
-      wpair[j] = wwidx[j] >> 1;
+      const uint32_t widx = tab[(int64_t)(S + j) * T];
+      wq[j] = (widx >> 1) * 64u | (widx & 1u);
     }
     double acc[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) acc[s] = 0.0;
     double jacc = 0.0;
     const bool mine = q0 + tid < q1;
-    const uint32_t Bc = (uint32_t)(mine ? q0 + tid : q1 - 1);  // (32-bit: scalar row base + vector offset addressing)
+    const uint32_t Bc8 = (uint32_t)(mine ? q0 + tid : q1 - 1) * 8u;  // byte offset of the staged column in a row
     for (int eb = 0; eb < ne; eb += E) {  // eight entries at a time
       if (eb > 0) __syncthreads();  // (the planes are gathered: they may be overwritten)
+      OCLK(k_r0);
       // ---- stage the range of eight source rows (signed, pairs interleaved); the alpha single x beta occupation term of
       // the staged column on the way.  Unconditional loads (a dead entry reads row A / J row 0): all 16 in flight together.
       {
@@ -192,10 +231,10 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
 #pragma unroll
         for (int i = 0; i < E; ++i) {
           const uint32_t src = oppsrc_lane(en_src, eb + i), pair = oppsrc_lane(en_pair, eb + i);
-          const double* __restrict__ srow = C + (int64_t)src * nb;
-          const double* __restrict__ jrow = (const double*)g.jbT + (int64_t)pair * nb;
-          x[i] = srow[Bc];
-          jv[i] = jrow[Bc];
+          const double* __restrict__ srow = oppsrc_pin(C + (int64_t)src * nb);
+          const double* __restrict__ jrow = oppsrc_pin((const double*)g.jbT + (int64_t)pair * nb);
+          x[i] = oppsrc_ldu(srow, Bc8);
+          jv[i] = oppsrc_ldu(jrow, Bc8);
         }
 #pragma unroll
         for (int i = 0; i < E; i += 2) {
@@ -206,47 +245,60 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
           if (mine) *reinterpret_cast<double2*>(lds + (i >> 1) * Lds::PLANE + tid * 16) = make_double2(x0, x1);
         }
       }
-      __syncthreads();
-      // ---- gather: plane b = entries eb + 2b, eb + 2b + 1; the weights of plane b + 1 are requested before plane b's
-      // multiply-adds
-      const int nbat = (ne - eb + 1) >> 1;  // planes that hold an entry
-      double2 w[2][NSUB];
-      auto weights = [&](int b, double2* out) {
-        const int e = eb + 2 * b;
-        const uint64_t r0 = ((uint64_t)oppsrc_lane(en_whi, e) << 32) | oppsrc_lane(en_wlo, e);
-        const uint64_t r1 = ((uint64_t)oppsrc_lane(en_whi, e + 1) << 32) | oppsrc_lane(en_wlo, e + 1);
-        const double* __restrict__ w0 = reinterpret_cast<const double*>((uintptr_t)r0);
-        const double* __restrict__ w1 = reinterpret_cast<const double*>((uintptr_t)r1);
-        const uint32_t p0 = oppsrc_lane(en_part, e), p1 = oppsrc_lane(en_part, e + 1);
-        const bool v1 = (oppsrc_lane(en_flags, e + 1) & 1u) != 0u;
+      // ... and the eight entries' weight rows, Wst[pair][entry]: (pq_e | pair) for a link entry, Ja[A][pair] for the row
+      // itself -- straight from the integral table (L2-resident), requested with the rows above
+      const double* wrow[E];  // (read from the lanes by every thread: wave-uniform, and the emulator's lane exchange
+                              //  needs the whole wavefront -- not inside the loop over pairs, which tid >= nnorb skip)
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-          double a = w0[wpair[j]], c1 = w1[wpair[j]];  // (a dead second entry: the lane's default weight row, times a zero plane)
-          c1 = v1 ? c1 : 0.0;
-          if (spin) {
-            a += (wwidx[j] == p0) ? pen : 0.0;
-            c1 += (wwidx[j] == p1) ? pen : 0.0;
-          }
-          out[j] = make_double2(a, c1);
+      for (int i = 0; i < E; ++i)
+        wrow[i] = reinterpret_cast<const double*>((uintptr_t)(((uint64_t)oppsrc_lane(en_whi, eb + i) << 32) | oppsrc_lane(en_wlo, eb + i)));
+      for (int p = tid; p < nn; p += T) {
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += 4) {  // (four at a time: eight more registers beside the sixteen rows in flight)
+          double wv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wv[i] = oppsrc_ldu(wrow[i0 + i], (uint32_t)p * 8u);  // (a dead entry: the lane's default row, times a zero plane)
+          *reinterpret_cast<double2*>(lds + Lds::WST + p * 64 + i0 * 8) = make_double2(wv[0], wv[1]);
+          *reinterpret_cast<double2*>(lds + Lds::WST + p * 64 + i0 * 8 + 16) = make_double2(wv[2], wv[3]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      };
-      weights(0, w[0]);
+      }
+      __syncthreads();
+      OCLK(k_r1);
+      OCLK_ADD(1, k_r1 - k_r0);
+      // ---- gather: plane b = entries eb + 2b, eb + 2b + 1; per sub-run one more 16-byte read, its weight pair
+      const int nbat = (ne - eb + 1) >> 1;  // planes that hold an entry
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         if (b < nbat) {  // (uniform)
-          if (b + 1 < NB && b + 1 < nbat) weights(b + 1, w[(b + 1) & 1]);
+          uint32_t p0 = 0xffffffffu, p1 = 0xffffffffu;
+          if (spin) {  // (the partner widx in wq's encoding; 0xffffffff -- no partner -- stays out of reach)
+            p0 = oppsrc_lane(en_part, eb + 2 * b);
+            p1 = oppsrc_lane(en_part, eb + 2 * b + 1);
+            p0 = p0 == 0xffffffffu ? p0 : ((p0 >> 1) * 64u | (p0 & 1u));
+            p1 = p1 == 0xffffffffu ? p1 : ((p1 >> 1) * 64u | (p1 & 1u));
+          }
 #pragma unroll
           for (int j = 0; j < NSUB; ++j) {
+            double2 w2 = *reinterpret_cast<const double2*>(lds + Lds::WST + b * 16 + (wq[j] & ~1u));
+            if (spin) {
+              w2.x += (wq[j] == p0) ? pen : 0.0;
+              w2.y += (wq[j] == p1) ? pen : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < OPPS_SUB; ++k) {
               const double2 c2 = *reinterpret_cast<const double2*>(lds + b * Lds::PLANE + rec[OPPS_SUB * j + k]);
-              acc[OPPS_SUB * j + k] += w[b & 1][j].x * c2.x;
-              acc[OPPS_SUB * j + k] += w[b & 1][j].y * c2.y;
+              acc[OPPS_SUB * j + k] += w2.x * c2.x;
+              acc[OPPS_SUB * j + k] += w2.y * c2.y;
             }
           }
         }
       }
+#ifdef SQD_PHASE_CLOCK
+      { OCLK(k_r2); __builtin_amdgcn_s_waitcnt(0); OCLK(k_r3); OCLK_ADD(2, k_r3 - k_r1); OCLK_ADD(7, 1); (void)k_r2; }
+#endif
     }
+    OCLK(k_f0);
     __syncthreads();  // every gather of the pass is done: the planes become accb
     // ---- per-link sums -> target columns.  pos = the link's position among the pass's links in target order (sign of
     // the beta link in bit 31); the owner of a column adds its run in that order, then the staged column's J term.
@@ -258,19 +310,31 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
     }
     jbuf[tid] = jacc;
     __syncthreads();
-    const uint32_t* __restrict__ cp = g.cptr + (int64_t)h * (nb + 1);
+    OCLK(k_f1);
+    OCLK_ADD(3, k_f1 - k_f0);
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
       const int64_t B = tid + (int64_t)r * T;
       if (B < nb) {
-        const uint32_t c0 = cp[B], c1 = cp[B + 1];
+        const uint32_t cq = ptab[(int64_t)(S + r) * T];
+        const uint32_t c0 = cq & 0xffffu, n = cq >> 16;
         double sum = 0.0;
-        for (uint32_t i = c0; i < c1; ++i) sum += accb[i];
+        for (uint32_t i0 = 0; i0 < n; i0 += 4) {  // four reads in flight, added in order
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = (i0 + u < n) ? accb[c0 + i0 + u] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sum += v[u];
+        }
         if (B >= q0 && B < q1) sum += jbuf[B - q0];
-        colacc[r] += sum;
+        if (r < RR) colacc[r < RR ? r : 0] += sum;
+        else cbuf[(r - RR) * T + tid] += sum;
       }
     }
     __syncthreads();  // (accb / jbuf are read: the next pass may stage)
+    OCLK(k_f2);
+    OCLK_ADD(4, k_f2 - k_f1);
+    OCLK_ADD(0, 1);
   }
   const bool has0 = it.e0 == 0;  // the piece that holds the row itself also brings the diagonal and the same-spin product
   const double* __restrict__ crow = C + A * nb;
@@ -281,7 +345,7 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
   for (int r = 0; r < RM; ++r) {
     const int64_t B = tid + (int64_t)r * T;
     if (B < nb) {
-      double v = colacc[r];
+      double v = r < RR ? colacc[r < RR ? r : 0] : cbuf[(r - RR) * T + tid];
       if (has0) {
         double d = hd[B];
         if (spin) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
@@ -290,6 +354,9 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
       orow[B] = v;
     }
   }
+  OCLK(k_item1);
+  OCLK_ADD(5, k_item1 - k_item0);
+  OCLK_ADD(6, 1);
 }
 
 // sigma[A, :] = sum of the partial rows of A in slot order, for the rows that were cut into several items (outside
@@ -314,12 +381,12 @@ __global__ void __launch_bounds__(256) k_opp_src_reduce(const OppSrcReduceArgs g
 }
 
 // ---- host side
-static size_t oppsrc_shmem(bool big, int T) {  // the planes (accb in their place at the end of a pass), then jbuf
-  return (size_t)(big ? OppSrcLds<true>::JBUF : OppSrcLds<false>::JBUF) + (size_t)T * 8;
+static int oppsrc_jbuf(bool big, int nnorb) { return (big ? OppSrcLds<true>::WST : OppSrcLds<false>::WST) + ((nnorb + 1) & ~1) * 64; }
+static size_t oppsrc_shmem(bool big, int nnorb, int T) {  // planes (accb in their place at the end of a pass) | Wst | jbuf[T] | cbuf[RL][T]
+  return (size_t)oppsrc_jbuf(big, nnorb) + (size_t)T * 8 * (1 + OPPS_RL);
 }
 
-// phase 2 of set_subspace, behind spmm_select: is the opposite-spin part of this subspace taken by k_opp_src?
-// (SQD_SIGMA_OPP=0 forbids: the work items then add G as they add the matrix-core product.)
+// phase 2 of set_subspace (behind opp_select): can k_opp_src take the opposite-spin part of this subspace?
 bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   const int64_t L = tot[2];  // beta single links
   if (L < 1) return false;
@@ -340,11 +407,12 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   }
   if (nb > (int64_t)OPPS_RMAX * T) return false;
   if (nb > (int64_t)6 * T) nsub = 1;  // (eight target columns per thread beside two sub-runs: 18 spilled registers)
-  bool big = T > OppSrcLds<false>::COLS;
+  if (c->nnorb > OppSrcLds<true>::WROWS) return false;
+  bool big = T > OppSrcLds<false>::COLS || c->nnorb > OppSrcLds<false>::WROWS;
   if (const char* env = std::getenv("SQD_OPPS_BIG"))  // test hook: the 4-plane layout on small workgroups
     if (std::atoi(env) != 0) big = true;
   if ((size_t)OPPS_SUB * nsub * T * 8 > (size_t)(big ? OppSrcLds<true>::STAGE_BYTES : OppSrcLds<false>::STAGE_BYTES)) return false;
-  if (oppsrc_shmem(big, T) + 1024 > (size_t)c->lds_bytes) return false;
+  if (oppsrc_shmem(big, c->nnorb, T) + 1024 > (size_t)c->lds_bytes) return false;
   // a source column's links must fit one pass even if every one of them opens a sub-run of its own
   const int64_t* ps = c->h_sptr_b;
   int64_t longest = 0;
@@ -353,7 +421,7 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   s->nsub = nsub;
   s->big = big;
   s->T = T;
-  s->shmem = oppsrc_shmem(big, T);
+  s->shmem = oppsrc_shmem(big, c->nnorb, T);
   // work items: a row's entries (itself + its alpha single links) in pieces of at most E (<= 64: one entry per lane), so
   // that the rows of the Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain; a row in one
   // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
@@ -446,23 +514,30 @@ int oppsrc_build(sqd_ctx* c) {
   }
   const int H = (int)cut.size() - 1;
   s->H = H;
-  // tables per pass: rec[S][T] | wofs[nsub][T] | pos[S][T];  cptr[H][nb + 1]
-  const size_t per_pass = (size_t)(2 * S + nsub) * T;
+  // tables per pass: rec[S][T] | widx[nsub][T] | pos[S][T] | colq[OPPS_RMAX][T]
+  const size_t per_pass = (size_t)(2 * S + nsub + OPPS_RMAX) * T;
   s->h_tab.assign(per_pass * H, 0u);
-  s->h_cptr.assign((size_t)H * (nb + 1), 0u);
   std::vector<int32_t> range_of((size_t)nb);
   for (int h = 0; h < H; ++h)
     for (int32_t B = cut[h]; B < cut[h + 1]; ++B) range_of[B] = h;
-  // position of every link among its pass's links in target order (= link order: the CSR is sorted by target column)
+  // position of every link among its pass's links in target order (= link order: the CSR is sorted by target column),
+  // and per pass and column the first position | the number of its links << 16
   std::vector<uint32_t> rank((size_t)L);
   {
-    std::vector<uint32_t> counter((size_t)H, 0u);
+    std::vector<uint32_t> counter((size_t)H, 0u), first((size_t)H, 0u);
     const int64_t* ps = c->h_sptr_b;
     for (int64_t B = 0; B < nb; ++B) {
-      for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + B] = counter[h];
+      first = counter;
       for (int64_t l = ps[B]; l < ps[B + 1]; ++l) rank[l] = counter[range_of[s->h_rec[l].src]]++;
+      for (int h = 0; h < H; ++h) {
+        const uint32_t n = counter[h] - first[h];
+        if (n > 0xffffu || first[h] > 0xffffu) {
+          set_error("internal: opposite-spin pass tables: column run out of range");
+          return SQD_ERR_STATE;
+        }
+        s->h_tab[per_pass * h + (size_t)(2 * S + nsub + B / T) * T + (size_t)(B % T)] = first[h] | (n << 16);
+      }
     }
-    for (int h = 0; h < H; ++h) s->h_cptr[(size_t)h * (nb + 1) + nb] = counter[h];
   }
   {
     std::vector<std::vector<uint32_t>> by_w((size_t)nw);
@@ -503,14 +578,12 @@ int oppsrc_build(sqd_ctx* c) {
     }
   }
   SQD_TRY(s->tab.reserve(s->h_tab.size() * 4 + 64));
-  SQD_TRY(s->cptr.reserve(s->h_cptr.size() * 4 + 64));
   SQD_TRY(s->colcut.reserve(s->h_colcut.size() * 4 + 64));
   SQD_TRY(s->items.reserve((size_t)s->n_items * sizeof(OppSrcItem) + 64));
   SQD_TRY(s->rowinfo.reserve((size_t)2 * c->na * 4 + 64));
   SQD_TRY(s->multi.reserve((size_t)s->n_multi * sizeof(MultiRow) + 64));
   SQD_TRY(s->partial.reserve((size_t)s->n_slots * c->nb * 8 + 64));
   SQD_HIP_CHECK(hipMemcpyAsync(s->tab.p, s->h_tab.data(), s->h_tab.size() * 4, hipMemcpyHostToDevice, c->stream));
-  SQD_HIP_CHECK(hipMemcpyAsync(s->cptr.p, s->h_cptr.data(), s->h_cptr.size() * 4, hipMemcpyHostToDevice, c->stream));
   SQD_HIP_CHECK(hipMemcpyAsync(s->colcut.p, s->h_colcut.data(), s->h_colcut.size() * 4, hipMemcpyHostToDevice, c->stream));
   SQD_HIP_CHECK(hipMemcpyAsync(s->items.p, s->h_items.data(), (size_t)s->n_items * sizeof(OppSrcItem), hipMemcpyHostToDevice, c->stream));
   SQD_HIP_CHECK(hipMemcpyAsync(s->rowinfo.p, s->h_rowinfo.data(), (size_t)2 * c->na * 4, hipMemcpyHostToDevice, c->stream));
@@ -546,7 +619,6 @@ int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_str
   g.sa_ptr = ta.s_ptr.as<int64_t>();
   g.sa_rec = ta.s_rec.as<SRec>();
   g.tab = s->tab.as<uint32_t>();
-  g.cptr = s->cptr.as<uint32_t>();
   g.colcut = s->colcut.as<int32_t>();
   g.items = s->items.as<OppSrcItem>();
   g.partial = s->partial.as<double>();
@@ -554,6 +626,7 @@ int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_str
   g.nnorb = c->nnorb;
   g.T = s->T;
   g.H = s->H;
+  g.jbuf_off = oppsrc_jbuf(s->big, c->nnorb);
   g.stop = c->sigma_stop;
   const bool indexed = c->sigma_index && (in_stride || out_stride);
   g.vec_index = indexed ? c->sigma_index : nullptr;
@@ -632,3 +705,21 @@ bool oppsrc_split(const sqd_ctx* c, const int32_t** rowinfo, const double** part
 }
 
 }  // namespace sqd
+
+#ifdef SQD_PHASE_CLOCK
+// out[8]: column sums over the workgroups' rows {passes, stage, gather, fold 1, fold 2, whole item, items, rounds} (10 ns ticks)
+extern "C" __attribute__((visibility("default"))) int sqd_probe_clk_oppsrc(unsigned long long* out, int reset) {
+  static std::vector<unsigned long long> h((size_t)sqd::OCLK_ROWS * sqd::OCLK_COLS);
+  if (out) {
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(sqd::sqd_clk_oppsrc), h.size() * 8) != hipSuccess) return -1;
+    for (int k = 0; k < sqd::OCLK_COLS; ++k) out[k] = 0;
+    for (size_t r = 0; r < (size_t)sqd::OCLK_ROWS; ++r)
+      for (int k = 0; k < sqd::OCLK_COLS; ++k) out[k] += h[r * sqd::OCLK_COLS + k];
+  }
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(sqd::sqd_clk_oppsrc), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

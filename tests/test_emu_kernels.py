@@ -256,33 +256,33 @@ def test_emu_lists_kernel(emu_lib, monkeypatch):
     assert not ok
 
 
-@pytest.mark.parametrize("xcd,J,tiled,opp", [("1", "1", "g", "1"), ("0", "1", "g", "0"), ("0", "2", "0", "1"), ("1", "4", "0", "0"),
-                                             ("1", "1", "1", "1")])
-def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, tiled, opp):
+@pytest.mark.parametrize("xcd,J,form,opp", [("1", "1", "g", "1"), ("0", "1", "g", "0"), ("0", "2", "r", "1"), ("1", "4", "r", "0"),
+                                            ("1", "2", "g", "1")])
+def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, form, opp):
     # SQD_SIGMA_SPMM=1 forces the sparse-product same-spin path (sqd_spmm.hip: C -> C^T, the product on C and C^T, G +=
     # G2T^T) that connected sets from ~900 strings per spin take by default.
-    #  tiled = g: the DEFAULT product (k_spmm_grouped: 8 adjacent rows share the sorted union of their source lists, a dense
-    #             8-vector of coefficients per source); 0: k_spmm_rows on the merged lists; 1: k_spmm_tiled (LDS tiles)
-    #  opp = 1:   the opposite-spin part and the diagonal by whole rows (sqd_opp.hip: beta links in registers, entries
-    #             staged interleaved, per-link sums folded to columns, long rows in pieces with partial rows) for the plain
-    #             operator -- the default; the S^2 / penalty forms of the same tests still run the work items.  opp = 0:
-    #             work items throughout (they add ONE partial product).
-    # Both task mappings (XCD split on / off), every panel width, ragged panels / tiles / groups, nalpha != nbeta, rows
-    # without links, all operator forms, a Davidson solve and the observables.
+    #  form = g: the DEFAULT product (k_spmm_grouped: 8 adjacent rows share the sorted union of their source lists, a dense
+    #            8-vector of coefficients per source; one and two columns per lane); r: k_spmm_rows on the merged lists
+    #            (what more than 32 768 strings per spin take)
+    #  opp = 1:  the opposite-spin part and the diagonal by whole rows (sqd_opp.hip: beta links in registers, entries
+    #            staged interleaved, per-link sums folded to columns, long rows in pieces with partial rows) for the plain
+    #            operator and the linear spin penalty -- the default.  opp = 0: work items throughout (they add ONE partial
+    #            product).
+    # Both task mappings (XCD split on / off), every panel width, ragged panels / groups, nalpha != nbeta, rows without
+    # links, all operator forms, a Davidson solve and the observables.
     monkeypatch.setenv("SQD_SIGMA_SPMM", "1")
     monkeypatch.setenv("SQD_SIGMA_OPP", opp)
     monkeypatch.setenv("SQD_SPMM_XCD", xcd)
     monkeypatch.setenv("SQD_SPMM_J", J)
-    monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if tiled == "g" else "0")
-    monkeypatch.setenv("SQD_SPMM_TILED", "1" if tiled == "1" else "0")
+    monkeypatch.setenv("SQD_SPMM_GJ", J if J in ("1", "2") else "1")
+    monkeypatch.setenv("SQD_SPMM_GROUPED", "1" if form == "g" else "0")
     monkeypatch.setenv("SQD_OPP_E", "4")  # (pieces of 4 entries: rows in several pieces, partial rows, the deferred sum)
-    # the group records through the scalar cache (k_spmm_grouped, the default) or through LDS (k_spmm_grouped_lds)
-    monkeypatch.setenv("SQD_SPMM_LDS", "1" if xcd == "1" else "0")
+    tiled = form
     default = (tiled, opp) == ("g", "1")
     cases = [(7, (3, 3), 20, 20, 7, True), (6, (2, 3), 9, 14, 5, False), (5, (1, 4), 5, 4, 9, False)]
     if default:
         cases += [(8, (4, 4), 30, 28, 17, True), (9, (2, 4), 7, 100, 29, True), (16, (4, 4), 66, 70, 23, True)]
-    if tiled != "0":  # more than one source chunk / target block (TS = TB = 128), more than one panel, a ragged last group
+    if form == "g":  # more than one panel, a ragged last group
         cases += [(12, (3, 3), 140, 24, 31, True), (12, (3, 3), 18, 150, 33, True)]
     for case in cases:
         h1, eri, sa, sb = make_problem(*case)
