@@ -39,7 +39,7 @@ sys.path.insert(0, str(ROOT))
 
 F64_MFMA_PEAK_TFLOPS = 78.6  # dense f64 matrix peak of the MI355X (public spec)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def parse_args():
@@ -92,7 +92,7 @@ def pmc_traffic(args):
     bench.py cannot collect counters itself.  (None, source) when no matching profile is committed."""
     if (args.norb, args.nelec, args.na, args.nb) != (30, 8, 317, 317):
         return None, None
-    for rnd in (PROFILE_ROUND, "r03", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r03", "r01"):
         f = ROOT / "profiles" / rnd / "pmc" / f"final_{args.strings}317_pmc_summary.json"
         try:
             d = json.loads(f.read_text())["HBM_BYTES"]

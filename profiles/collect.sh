@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash profiles/collect.sh r04'
 # Everything lands under gpurun_out/<round>/; profiles/summarize.py then writes the tracked summaries.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -33,12 +33,13 @@ SIZES="10000 6000 4000" bash profiles/probes/_lists_passes.sh 2>&1 | eval $F > $
 # phase clocks of the Davidson BLAS-1 kernels (probe build of the library: hipcc ... -DSQD_PHASE_CLOCK, see the probe's header)
 [ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_phase_clock.py 2>&1 | eval $F > $OUT/phase_clock_probe.txt
 [ -f profiles/probes/_build/libsqd_hip_clk.so ] && python profiles/probes/_sigma_clock.py 2>&1 | eval $F > $OUT/sigma_clock_probe.txt
+[ -f profiles/probes/_build/libsqd_hip_clk.so ] && (for cfg in "N=5000" "N=3000 SQD_OPP_SRC=1"; do echo "--- $cfg"; env $cfg python profiles/probes/_oppsrc_clock.py 2>&1 | eval $F; done) > $OUT/oppsrc_clock_probe.txt
 [ -x profiles/probes/anyorder/anyorder_probe ] && ./profiles/probes/anyorder/anyorder_probe > $OUT/anyorder_probe.txt 2>&1
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 # CONNECTED subspaces at D = 1e6 .. 9e6 (round 5): every same-spin formulation, kernel traces of the default one
-TAG=$R/conn SIZES="700 1000 2000 3000" MODES="default dense1 dense0" TRACE_SIZES="1000 3000" bash profiles/probes/_connected.sh > /dev/null 2>&1
+TAG=$R/conn SIZES="700 1000 2000 3000 5000" MODES="default dense1 dense0" TRACE_SIZES="1000 3000 5000" bash profiles/probes/_connected.sh > /dev/null 2>&1
 cp $OUT/conn/connected_probe.txt $OUT/connected_probe.txt; cp $OUT/conn/connected_kernel_stats.txt $OUT/connected_kernel_stats_probe.txt
-for n in 1000 3000; do mkdir -p $OUT/prof_hf$n; cp -r $OUT/conn/prof_hf$n/* $OUT/prof_hf$n/ 2>/dev/null; done
+for n in 1000 3000 5000; do mkdir -p $OUT/prof_hf$n; cp -r $OUT/conn/prof_hf$n/* $OUT/prof_hf$n/ 2>/dev/null; done
 cd /tmp && export TMPDIR=/tmp
 # kernel traces of the SAME commands as the bench lines, and of the batched solves
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_uniform317 -o p -- python $ROOT/bench.py --skip-cpu --skip-secondary > /dev/null 2>&1
@@ -61,7 +62,7 @@ done
 # matrix-core utilisation of the dense same-spin product: busy cycles of the MFMA pipe against the kernel's cycles
 CASE=hf16 REPS=3 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_batch_hf16 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
 CASE=hf16 REPS=3 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_mfma2_batch_hf16 -o p -- python $ROOT/profiles/probes/_batch_trace.py > /dev/null 2>&1
-for n in 1000 3000; do
+for n in 1000 3000 5000; do
   SIZES=$n MODES=default CHECK=0 DAV=0 REPS=4 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_hf$n -o p -- python $ROOT/profiles/probes/_connected_probe.py > /dev/null 2>&1
   SIZES=$n MODES=default CHECK=0 DAV=0 REPS=4 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_hf$n -o p -- python $ROOT/profiles/probes/_connected_probe.py > /dev/null 2>&1
 done

@@ -1,5 +1,5 @@
 """GPU probe (not a test): where a workgroup of k_opp_src spends its time.  Needs the probe build of the library
-(profiles/probes/build_variant.sh oclk "-DSQD_PHASE_CLOCK" sqd_oppsrc.hip -> profiles/probes/_build/libsqd_hip_oclk.so).
+(profiles/probes/build_variant.sh oclk "-DSQD_PHASE_CLOCK" sqd_oppsrc.hip -> profiles/probes/_build/libsqd_hip_clk.so).
 env N (strings per spin), plus the kernel's hooks (SQD_OPP_SRC=1 forces it below 3073 columns)."""
 import ctypes as C, os, sys
 from pathlib import Path
@@ -7,7 +7,7 @@ ROOT = Path(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 sys.path.insert(0, str(ROOT))
 import numpy as np
 from qiskit_addon_sqd_amd import _capi
-_capi.LIB_PATH = ROOT / 'profiles' / 'probes' / '_build' / 'libsqd_hip_oclk.so'
+_capi.LIB_PATH = ROOT / "profiles" / "probes" / "_build" / "libsqd_hip_clk.so"
 from qiskit_addon_sqd_amd import synthetic as S
 
 lib = _capi.load_library()

@@ -5,7 +5,7 @@ profiles/<round>/: bench JSON lines, kernel-stat tables, and per-kernel HBM traf
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", rnd), os.path.join(root, "profiles", rnd)
 os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
@@ -51,7 +51,7 @@ for d in glob.glob(os.path.join(src, "prof_*")):
             json.dump(out, open(os.path.join(dst, "final_" + os.path.basename(d)[5:] + "_sigma_launches.json"), "w"), indent=1)
 
 
-for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16", "hf1000", "hf3000"):
+for wl in ("uniform317", "hf317", "big", "batch_uniform8", "batch_hf16", "hf1000", "hf3000", "hf5000"):
     out = {}
     for counter, sub in (("FETCH_SIZE", "pmc_fetch_"), ("WRITE_SIZE", "pmc_write_")):
         acc = defaultdict(list)

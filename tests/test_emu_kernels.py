@@ -324,8 +324,11 @@ def test_emu_opp_src_passes(emu_lib, monkeypatch, hooks):
     monkeypatch.setenv("SQD_OPP_SRC", "1")
     for k, v in hooks.items():
         monkeypatch.setenv(k, v)
-    cases = [(7, (3, 3), 20, 20, 7, True), (8, (4, 4), 30, 28, 17, True), (9, (2, 4), 7, 100, 29, True),
-             (11, (2, 5), 6, 230, 29, True), (11, (3, 5), 5, 460, 33, True)]
+    cases = [(7, (3, 3), 20, 20, 7, True), (9, (2, 4), 7, 100, 29, True)]
+    if "SQD_OPPS_BIG" in hooks:
+        cases += [(8, (4, 4), 30, 28, 17, True)]
+    else:
+        cases += [(11, (2, 5), 6, 230, 29, True)] if hooks["SQD_OPPS_S"] == "8" else [(11, (3, 5), 5, 460, 33, True)]
     for case in cases:
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:

@@ -6,11 +6,16 @@ Tolerances: CI-string addressing (targets, sources, orbitals, pair indices, sign
 sigma / hdiag <= 1e-11 * |H|max * sqrt(D) absolute; energies <= 1e-8 Ha against dense ``eigh``
 (north_star bar: 1e-6 Ha); RDMs 1e-12.
 """
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 
 from oracle import sqd_oracle as O
 from qiskit_addon_sqd_amd import _capi
+
+ROOT = Path(__file__).resolve().parents[1]
 
 from _parity import check_link_tables, check_operators, make_problem, run_full_parity
 
@@ -1014,10 +1019,11 @@ def test_rdm2_row_form_on_a_connected_set(hip_lib, monkeypatch):
 @pytest.mark.parametrize("na,nb", [(900, 8193), (1000, 10000)])
 def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
     """HF-centred sets with more than 8192 beta strings (nine and more columns per thread in the work-item kernel, which
-    runs behind the sparse product there: the whole-row kernel does not take such rows).  The single-pass instantiation
-    k_sigma<16, ., true, false> did not return on the MI355X at nb = 8193 (profiles/r05/long_rows_hang_probe.txt); such rows
-    go through the multi-pass instantiation.  Sigma on sampled rows against the row-restricted string-space oracle, the
-    work items alone on the whole vector, and it comes back."""
+    runs behind the sparse product there: the whole-row kernels do not take such rows).  Round 5's single-pass
+    instantiation k_sigma<16, ., true, false> did not return on the MI355X at nb = 8193: its body was an out-of-line
+    function whose long branches overwrote the return address (profiles/r06/hang_root_cause.txt; fixed by inlining,
+    pinned by tests/test_codeobj_audit.py and test_single_pass_r16_instantiation_returns below).  Sigma on sampled rows
+    against the row-restricted string-space oracle, the work items alone on the whole vector, and it comes back."""
     for k in ("SQD_SIGMA_DENSE", "SQD_SIGMA_SPMM", "SQD_SIGMA_OPP"):
         monkeypatch.delenv(k, raising=False)
     norb = 30
@@ -1042,6 +1048,37 @@ def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
         assert ctx.sigma_kernel() == "k_sigma"
         assert np.abs(ctx.sigma(x) - sx).max() < 1e-11 * scale
 
+
+
+def test_single_pass_r16_instantiation_returns(hip_lib, tmp_path):
+    """The launch that never returned in round 5, k_sigma<16, false, true, false> (rows of nine and more columns per thread
+    whose beta lists fit one pass), forced back on in a child process (SQD_SIGMA_R16_SINGLE=1 is read once per process)
+    under a timeout: it returns, and with the bits of the default routing (the multi-pass instantiation with zero extra
+    passes evaluates the same sums in the same order)."""
+    import subprocess
+    import sys as _sys
+
+    script = tmp_path / "r16.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from oracle import sqd_oracle as O\n"
+        "from qiskit_addon_sqd_amd import _capi\n"
+        "h1, eri = O.synthetic_integrals(30)\n"
+        "sa, sb = O.hf_centred_strings(30, 8, 300, 31), O.hf_centred_strings(30, 8, 8193, 37)\n"
+        "x = np.random.default_rng(43).standard_normal((300, 8193), dtype=np.float32).astype(np.float64)\n"
+        "with _capi.Context(h1, eri) as ctx:\n"
+        "    ctx.set_subspace(sa, sb)\n"
+        "    np.save(sys.argv[1], ctx.sigma(x))\n"
+    )
+    outs = []
+    for tag, hook in (("multi", "0"), ("single", "1")):
+        env = dict(os.environ, SQD_SIGMA_R16_SINGLE=hook, SQD_SIGMA_OPP="0", SQD_SIGMA_SPMM="0", SQD_SIGMA_DENSE="0")
+        out = tmp_path / f"{tag}.npy"
+        subprocess.run([_sys.executable, str(script), str(out)], env=env, check=True, timeout=180)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0.0
 
 
 @pytest.mark.parametrize("na,nb,src", [(1000, 5003, None), (901, 3500, None), (700, 7300, None), (901, 2500, "1")])
