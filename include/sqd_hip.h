@@ -228,6 +228,9 @@ int sqd_shard_dav_sigma_part(sqd_ctx* ctx, const double* d_c_full, int part);
 int sqd_shard_dav_dots(sqd_ctx* ctx, double** d_totals, int* count);
 int sqd_shard_dav_residual(sqd_ctx* ctx, double** d_totals, int* count);
 int sqd_shard_dav_orth(sqd_ctx* ctx, long long* ticket);
+/* ... and pick + sigma + dots + eigen step + residual + orth as ONE call, for a context that holds all rows (a group of one
+ * rank: every collective between the stages is the identity); SQD_ERR_STATE on a true shard.  Same bits as the stages. */
+int sqd_shard_dav_iteration(sqd_ctx* ctx, long long* ticket);
 int sqd_shard_dav_wait(sqd_ctx* ctx, long long ticket, int* stopped, double* e, double* rnorm2, int* basis_size);
 int sqd_shard_dav_end(sqd_ctx* ctx, double** d_solution_rows, sqd_davidson_stats* stats);
 

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "sqd_shard_dav_dots",
     "sqd_shard_dav_residual",
     "sqd_shard_dav_orth",
+    "sqd_shard_dav_iteration",
     "sqd_shard_dav_wait",
     "sqd_shard_dav_end",
     "sqd_solution_device_ptr",
@@ -160,6 +161,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.sqd_shard_dav_dots.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.sqd_shard_dav_residual.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     lib.sqd_shard_dav_orth.argtypes = [_ctxp, C.POINTER(C.c_longlong)]
+    lib.sqd_shard_dav_iteration.argtypes = [_ctxp, C.POINTER(C.c_longlong)]
     lib.sqd_shard_dav_wait.argtypes = [_ctxp, C.c_longlong, C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_int)]
     lib.sqd_shard_dav_end.argtypes = [_ctxp, C.POINTER(C.c_void_p), C.POINTER(DavidsonStats)]
     lib.sqd_solution_device_ptr.argtypes = [_ctxp, C.POINTER(C.c_void_p)]
@@ -587,6 +589,22 @@ class Context:
             return t.value
 
         return pick, sigma, dots, residual, orth
+
+    def shard_dav_iteration_call(self):
+        """``iteration() -> ticket``: the five stages as ONE native call (a group of one rank, where no collective sits
+        between them), arguments built once."""
+        lib, h, check = self._lib, self._h, self._check
+        t = C.c_longlong()
+        r_t = C.byref(t)
+        f = lib.sqd_shard_dav_iteration
+
+        def iteration():
+            rc = f(h, r_t)
+            if rc:
+                check(rc)
+            return t.value
+
+        return iteration
 
     def shard_dav_end(self):
         out = C.c_void_p()

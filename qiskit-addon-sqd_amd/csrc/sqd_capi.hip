@@ -397,6 +397,11 @@ SQD_API int sqd_shard_dav_residual(sqd_ctx* c, double** d_totals, int* count) {
   if (!d_totals || !count) return SQD_ERR_INVALID;
   return shard_dav_residual(c, d_totals, count);
 }
+SQD_API int sqd_shard_dav_iteration(sqd_ctx* c, long long* ticket) {
+  CTX_ENTER(c);
+  if (!ticket) return SQD_ERR_INVALID;
+  return shard_dav_iteration(c, ticket);
+}
 SQD_API int sqd_shard_dav_orth(sqd_ctx* c, long long* ticket) {
   CTX_ENTER(c);
   return shard_dav_orth(c, ticket);

@@ -415,7 +415,8 @@ int shard_dav_begin(sqd_ctx* c, const sqd_davidson_opts* o, double** d_x0);
 int shard_dav_pick(sqd_ctx* c, double** d_send);
 int shard_dav_sigma(sqd_ctx* c, const double* d_full, int part = 0);
 int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count);
-int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count);
+int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count, bool eig_done = false);
+int shard_dav_iteration(sqd_ctx* c, long long* seq_out);
 int shard_dav_orth(sqd_ctx* c, long long* seq_out);
 int shard_dav_wait(sqd_ctx* c, long long seq, int* stopped, double* e, double* rnorm2, int* m_cur);
 int shard_dav_end(sqd_ctx* c, double** d_solution_rows, sqd_davidson_stats* st);

@@ -1812,7 +1812,7 @@ int shard_dav_dots(sqd_ctx* c, double** d_tot, int* count) {
   *count = MAXB + 1;
   return SQD_OK;
 }
-int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count) {
+int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count, bool eig_done) {
   SQD_TRY(shard_check(c));
   const int64_t Dl = c->shard_Dl;
   const unsigned gb = red_blocks(Dl);
@@ -1834,12 +1834,12 @@ int shard_dav_residual(sqd_ctx* c, double** d_tot2, int* count) {
     pd.nb = c->nb;
   }
   if (c->shard_max_space <= 12) {
-    hipLaunchKernelGGL((k_shard_eig<13>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
+    if (!eig_done) hipLaunchKernelGGL((k_shard_eig<13>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
     hipLaunchKernelGGL((k_shard_residual<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
                        (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
                        part_res, width, counter_ptr(c), tot2);
   } else {
-    hipLaunchKernelGGL((k_shard_eig<MAXB>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
+    if (!eig_done) hipLaunchKernelGGL((k_shard_eig<MAXB>), dim3(1), dim3(64), 0, c->stream, dst, (const double*)tot, prm);
     hipLaunchKernelGGL((k_shard_residual<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, c->X.as<double>(),
                        (const double*)c->AX.as<double>(), Dl, (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd,
                        part_res, width, counter_ptr(c), tot2);
@@ -1868,6 +1868,44 @@ int shard_dav_orth(sqd_ctx* c, long long* seq_out) {
   c->shard_send_fresh = true;  // (the orth stage left the next vector in the send buffer)
   if (seq_out) *seq_out = seq;
   return SQD_OK;
+}
+// A whole iteration in ONE call for a group of one rank (every collective is the identity: nothing has to happen between
+// the stages): pick -> sigma on the send buffer (= the whole vector) -> the single solver's fused dots + eigen kernel (no
+// totals to all-reduce, so the workgroup that arrives last goes on to the projected problem: one launch less) -> residual ->
+// orth.  Same stages, same bits as the five calls.
+int shard_dav_iteration(sqd_ctx* c, long long* seq_out) {
+  SQD_TRY(shard_check(c));
+  if (c->row0 != 0 || c->row1 != c->na) {
+    set_error("shard_dav_iteration: the context holds a true row shard (the stages need their collectives)");
+    return SQD_ERR_STATE;
+  }
+  double* send = nullptr;
+  SQD_TRY(shard_dav_pick(c, &send));
+  SQD_TRY(shard_dav_sigma(c, send, 0));
+  {
+    const int64_t Dl = c->shard_Dl;
+    const unsigned gb = red_blocks(Dl);
+    const int width = SQD_MAX_SPACE + 4;
+    SplitRows split{nullptr, nullptr, c->nb};
+    const int32_t* ri = nullptr;
+    const double* pp = nullptr;
+    if (shard_split_rows(c, &ri, &pp)) {
+      split.rowinfo = ri;
+      split.partial = pp;
+    }
+    const DavParams prm = shard_params(c);
+    if (c->shard_max_space <= 12)
+      hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
+                         c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c), state_ptr_dev(c), prm, split);
+    else
+      hipLaunchKernelGGL((k_dots_eig<MAXB>), dim3(gb), dim3(RED_T), 0, c->stream, Dl, (const double*)c->X.as<double>(),
+                         c->AX.as<double>(), Dl, c->partial.as<double>(), width, counter_ptr(c), state_ptr_dev(c), prm, split);
+    SQD_HIP_CHECK(hipGetLastError());
+  }
+  double* tot2 = nullptr;
+  int n2 = 0;
+  SQD_TRY(shard_dav_residual(c, &tot2, &n2, /*eig_done=*/true));
+  return shard_dav_orth(c, seq_out);
 }
 // the progress record of the iteration whose orth stage returned `seq` (or of a later one: the stop flag only rises)
 int shard_dav_wait(sqd_ctx* c, long long seq, int* stopped, double* e, double* rnorm2, int* m_cur) {

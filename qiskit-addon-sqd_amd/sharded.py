@@ -141,7 +141,8 @@ class ShardedSubspace:
         # cost when there is nothing to exchange
         import os
 
-        self._force = bool(os.environ.get("SQD_SHARD_FORCE_COLLECTIVES")) and self.on_gpu
+        # (=2: on the CPU test backend as well -- the staged calls of a real group against the one-call iteration of a group of one)
+        self._force = os.environ.get("SQD_SHARD_FORCE_COLLECTIVES") == "2" or (bool(os.environ.get("SQD_SHARD_FORCE_COLLECTIVES")) and self.on_gpu)
         if not self.on_gpu:
             self._sync()  # (GPU: library kernels, torch operations and collectives share ONE stream -- order without waits)
 
@@ -377,14 +378,13 @@ def solve_sci_sharded(
             alone = sub.world == 1 and not sub._force  # a group of one: every collective is the identity
             overlap = _os.environ.get("SQD_SHARD_OVERLAP", "1") != "0"  # (probe switch)
 
+            st_iteration = sub.ctx.shard_dav_iteration_call() if alone else None
+
             def enqueue_iteration() -> int:
-                p = st_pick()
                 if alone:
                     sub.n_allgather += 1  # (counted as the collective it stands for)
-                    st_sigma(p)
-                    st_dots()
-                    st_residual()
-                    return st_orth()
+                    return st_iteration()  # the five stages as one native call (fused dots + eigen kernel)
+                p = st_pick()
                 # the all-gather of the newest vector is started, the part of the sigma build that reads only this rank's
                 # rows (own-row work items: diagonal, beta links) runs while it is in flight, the rest behind it
                 finish = sub.gather_rows_async(view(p, (sub.nrows, sub.nb)))

@@ -23,13 +23,13 @@ def test_shard_indices():
     assert sorted(sum((shard_indices(11, r, 4) for r in range(4)), [])) == list(range(11))
 
 
-def _run_two_ranks(worker: str, **extra_env):
+def _run_two_ranks(worker: str, world: int = 2, **extra_env):
     from conftest import EMU_LIB
 
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SQD_EMU_LIB=str(EMU_LIB), OMP_NUM_THREADS="1", **extra_env)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -61,3 +61,11 @@ def test_two_rank_gloo_row_sharded_sigma_and_solve(emu_lib, kernel_env):
     bit-identical to the single-rank sigma, and the collective Davidson against dense diagonalisation; with each of
     the three sigma kernels on the row range."""
     _run_two_ranks("_dist_shard_worker.py", **kernel_env)
+
+
+def test_one_rank_group_single_call_iteration(emu_lib):
+    """A group of ONE rank (what a 1-GPU run of a multi-GPU script is): the row-sharded solver's iteration as one native
+    call with the fused dots / eigen kernel, against the staged calls of a real group -- bit for bit -- and against
+    dense diagonalisation; with and without the linear spin penalty."""
+    _run_two_ranks("_dist_alone_worker.py", world=1)
+

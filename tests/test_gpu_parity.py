@@ -656,9 +656,14 @@ def test_row_sharded_sigma_on_gpu(hip_lib, monkeypatch):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        res = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+        res = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)  # a group of one: ONE native call per iteration
+        monkeypatch.setenv("SQD_SHARD_FORCE_COLLECTIVES", "1")    # ... against the staged calls around the collectives
+        staged = solve_sci_sharded((sa, sb), h1, eri, norb, nelec)
+        monkeypatch.delenv("SQD_SHARD_FORCE_COLLECTIVES")
     finally:
         dist.destroy_process_group()
+    assert staged._sharded_stats["converged"] and staged.energy == res.energy
+    assert np.array_equal(staged.sci_state.amplitudes, res.sci_state.amplitudes)
     assert res._sharded_stats["converged"]
     assert abs(res.energy - ref.energy) < 1e-8
     assert abs(abs(np.vdot(res.sci_state.amplitudes, ref.sci_state.amplitudes)) - 1.0) < 1e-8
