@@ -253,15 +253,11 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
       for (int i = 0; i < E; ++i)
         wrow[i] = reinterpret_cast<const double*>((uintptr_t)(((uint64_t)oppsrc_lane(en_whi, eb + i) << 32) | oppsrc_lane(en_wlo, eb + i)));
       for (int p = tid; p < nn; p += T) {
+        double wv[E];
 #pragma unroll
-        for (int i0 = 0; i0 < E; i0 += 4) {  // (four at a time: eight more registers beside the sixteen rows in flight)
-          double wv[4];
+        for (int i = 0; i < E; ++i) wv[i] = oppsrc_ldu(wrow[i], (uint32_t)p * 8u);  // (a dead entry: the lane's default row, times a zero plane)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wv[i] = oppsrc_ldu(wrow[i0 + i], (uint32_t)p * 8u);  // (a dead entry: the lane's default row, times a zero plane)
-          *reinterpret_cast<double2*>(lds + Lds::WST + p * 64 + i0 * 8) = make_double2(wv[0], wv[1]);
-          *reinterpret_cast<double2*>(lds + Lds::WST + p * 64 + i0 * 8 + 16) = make_double2(wv[2], wv[3]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int i = 0; i < E; i += 2) *reinterpret_cast<double2*>(lds + Lds::WST + p * 64 + i * 8) = make_double2(wv[i], wv[i + 1]);
       }
       __syncthreads();
       OCLK(k_r1);
@@ -303,6 +299,9 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
     // ---- per-link sums -> target columns.  pos = the link's position among the pass's links in target order (sign of
     // the beta link in bit 31); the owner of a column adds its run in that order, then the staged column's J term.
     const uint32_t* __restrict__ ptab = tab + (int64_t)(S + NSUB) * T;
+    uint32_t colq[RM];  // (requested with the positions: ONE table round trip per fold, not one per barrier)
+#pragma unroll
+    for (int r = 0; r < RM; ++r) colq[r] = ptab[(int64_t)(S + r) * T];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const uint32_t p = ptab[(int64_t)s * T];
@@ -316,8 +315,7 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
     for (int r = 0; r < RM; ++r) {
       const int64_t B = tid + (int64_t)r * T;
       if (B < nb) {
-        const uint32_t cq = ptab[(int64_t)(S + r) * T];
-        const uint32_t c0 = cq & 0xffffu, n = cq >> 16;
+        const uint32_t c0 = colq[r] & 0xffffu, n = colq[r] >> 16;
         double sum = 0.0;
         for (uint32_t i0 = 0; i0 < n; i0 += 4) {  // four reads in flight, added in order
           double v[4];
