@@ -42,7 +42,7 @@ namespace sqd {
 constexpr int OPPS_SUB = 4;       // links per sub-run (one weight pair serves four links)
 constexpr int OPPS_NSUB_MAX = 2;  // sub-runs per thread (8 links: 8 + 16 registers; three sub-runs spill at 128 registers)
 constexpr int OPPS_RMAX = 8;      // target columns per thread (nb <= OPPS_RMAX * threads)
-constexpr int OPPS_RL = 3;        // ... of which, beside two sub-runs and six columns, this many are carried in LDS
+constexpr int OPPS_RL = 6;        // ... of which, beside two sub-runs, at most this many are carried in LDS (2 of 5, 4 of 6, 6 of 8)
 // LDS plan (bytes; the plane of a batch is an immediate of the gather instruction):
 //   Cst[4][COLS][2] -- the staged range of eight entries (a piece is walked eight entries at a time); accb[links of a pass]
 //   takes its place at the end of a pass; Wst[nnorb][8] -- the eight entries' weight rows -- and jbuf[T] sit behind.
@@ -57,7 +57,9 @@ struct OppSrcLds {
   static constexpr int WST = STAGE_BYTES;            // Wst[pair][8 entries]: the round's weights, 64 bytes per pair
 };
 constexpr int OPPS_EMAX = 64;  // entries of a piece: one per lane of a wavefront
-constexpr uint32_t OPPS_DEAD = 0xffffffffu;
+// a link's table word: byte offset of its source column in a plane (bits 0-13) | its position among the pass's links in
+// target order (bits 14-26) | sign of the beta link (27) | live (28); 0 = padding of a sub-run
+constexpr uint32_t OPPS_ADDR = 0x3fffu, OPPS_POS_SHIFT = 14, OPPS_POS = 0x1fffu, OPPS_NEG = 1u << 27, OPPS_LIVE = 1u << 28;
 
 // one workgroup's share of a row: entries [e0, e0 + ne) of row A (entry 0 = the row itself, entry e > 0 = its alpha single
 // link e - 1); slot < 0: the row has this one item and is written in place, else partial row `slot` (added in slot
@@ -95,8 +97,8 @@ struct OppSrcArgs {
   GPtr<const double> hdiag, gdense, ja_row, jbT, eri_pp;
   GPtr<const int64_t> sa_ptr;
   GPtr<const SRec> sa_rec;
-  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | widx[NSUB][T] | pos[S][T] | colq[OPPS_RMAX][T]; colq = first position
-                               // (target order) of column t + r T's links inside the pass | their number << 16
+  GPtr<const uint32_t> tab;    // per pass: rec[S][T] | widx[NSUB][T] | colq[OPPS_RMAX][T]; colq = first position (target
+                               // order) of column t + r T's links inside the pass | their number << 16
   GPtr<const int32_t> colcut;  // [H + 1] first source column of every pass
   GPtr<const OppSrcItem> items;
   int64_t nb;
@@ -194,8 +196,9 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
   }
   // a thread's target columns' sums, carried over the passes: in registers, but for the last RL of six beside two
   // sub-runs (the allocator spilled them anyway: 28-44 bytes of scratch) -- those sit in LDS behind jbuf
-  constexpr int RL = (NSUB == 2 && RM == 6) ? OPPS_RL : 0, RR = RM - RL;
-  double colacc[RR];
+  constexpr int RL = (NSUB == 2 && RM >= 5) ? (RM == 5 ? 2 : RM - 2) : 0, RR = RM - RL;  // (2 of 5, 4 of 6, 6 of 8)
+  static_assert(RL <= OPPS_RL, "cbuf holds OPPS_RL columns per thread");
+  double colacc[RR > 0 ? RR : 1];
 #pragma unroll
   for (int r = 0; r < RR; ++r) colacc[r] = 0.0;
   double* const accb = smem;
@@ -204,10 +207,14 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
 #pragma unroll
   for (int r = 0; r < RL; ++r) cbuf[r * T + tid] = 0.0;
 
-  for (int h = 0; h < g.H; ++h) {
-    const int q0 = g.colcut[h], q1 = g.colcut[h + 1];
-    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((2 * S + NSUB + OPPS_RMAX) * (int64_t)T) + tid;
-    uint32_t rec[S], wq[NSUB];  // wq: byte offset of the sub-run's orbital pair in Wst | direction bit
+  // a pass's tables: requested during the fold of the pass before (the first: here), so that no pass starts -- and no fold
+  // runs -- behind a table round trip
+  // (six columns beside two sub-runs: the column table would be six registers too many through the gather -- requested
+  // with the scatter instead)
+  constexpr bool CQ_EARLY = !(NSUB == 2 && RM >= 5);
+  uint32_t rec[S], wq[NSUB], colq[RM];  // wq: byte offset of the sub-run's orbital pair in Wst | direction bit
+  auto load_tables = [&](int h) {
+    const uint32_t* __restrict__ tab = g.tab + (int64_t)h * ((S + NSUB + OPPS_RMAX) * (int64_t)T) + tid;
 #pragma unroll
     for (int s = 0; s < S; ++s) rec[s] = tab[(int64_t)s * T];
 #pragma unroll
@@ -215,6 +222,15 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
       const uint32_t widx = tab[(int64_t)(S + j) * T];
       wq[j] = (widx >> 1) * 64u | (widx & 1u);
     }
+    if constexpr (CQ_EARLY) {
+#pragma unroll
+      for (int r = 0; r < RM; ++r) colq[r] = tab[(int64_t)(S + NSUB + r) * T];
+    }
+  };
+  if (CQ_EARLY) load_tables(0);
+  for (int h = 0; h < g.H; ++h) {
+    const int q0 = g.colcut[h], q1 = g.colcut[h + 1];
+    if (!CQ_EARLY) load_tables(h);
     double acc[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) acc[s] = 0.0;
@@ -283,7 +299,7 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
             }
 #pragma unroll
             for (int k = 0; k < OPPS_SUB; ++k) {
-              const double2 c2 = *reinterpret_cast<const double2*>(lds + b * Lds::PLANE + rec[OPPS_SUB * j + k]);
+              const double2 c2 = *reinterpret_cast<const double2*>(lds + b * Lds::PLANE + (rec[OPPS_SUB * j + k] & OPPS_ADDR));
               acc[OPPS_SUB * j + k] += w2.x * c2.x;
               acc[OPPS_SUB * j + k] += w2.y * c2.y;
             }
@@ -296,38 +312,47 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
     }
     OCLK(k_f0);
     __syncthreads();  // every gather of the pass is done: the planes become accb
-    // ---- per-link sums -> target columns.  pos = the link's position among the pass's links in target order (sign of
-    // the beta link in bit 31); the owner of a column adds its run in that order, then the staged column's J term.
-    const uint32_t* __restrict__ ptab = tab + (int64_t)(S + NSUB) * T;
-    uint32_t colq[RM];  // (requested with the positions: ONE table round trip per fold, not one per barrier)
-#pragma unroll
-    for (int r = 0; r < RM; ++r) colq[r] = ptab[(int64_t)(S + r) * T];
+    // ---- per-link sums -> target columns: every live link's sum to its position in target order (signed); the owner of
+    // a column adds its run in that order, then the staged column's J term.
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      const uint32_t p = ptab[(int64_t)s * T];
-      if (p != OPPS_DEAD) accb[p & 0x7fffffffu] = (p >> 31) ? -acc[s] : acc[s];
+      const uint32_t p = rec[s];
+      if (p & OPPS_LIVE) accb[(p >> OPPS_POS_SHIFT) & OPPS_POS] = (p & OPPS_NEG) ? -acc[s] : acc[s];
     }
+    uint32_t cq[CQ_EARLY ? RM : 1];
+    if constexpr (CQ_EARLY) {
+#pragma unroll
+      for (int r = 0; r < RM; ++r) cq[r] = colq[r];
+    }
+    const uint32_t* __restrict__ cqtab = g.tab + (int64_t)h * ((S + NSUB + OPPS_RMAX) * (int64_t)T) + (int64_t)(S + NSUB) * T + tid;
+    if (CQ_EARLY && h + 1 < g.H) load_tables(h + 1);  // (lands while the columns are summed)
     jbuf[tid] = jacc;
     __syncthreads();
     OCLK(k_f1);
     OCLK_ADD(3, k_f1 - k_f0);
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
+    auto column_sum = [&](int r) -> double {  // the run of column tid + r T in accb, in order, + the staged column's J term
       const int64_t B = tid + (int64_t)r * T;
-      if (B < nb) {
-        const uint32_t c0 = colq[r] & 0xffffu, n = colq[r] >> 16;
-        double sum = 0.0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 4) {  // four reads in flight, added in order
-          double v[4];
+      const uint32_t cqv = (CQ_EARLY && r < RR) ? cq[(CQ_EARLY && r < RR) ? r : 0] : cqtab[(int64_t)r * T];
+      const uint32_t c0 = cqv & 0xffffu, n = cqv >> 16;
+      double sum = 0.0;
+      for (uint32_t i0 = 0; i0 < n; i0 += 4) {  // four reads in flight, added in order
+        double v[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = (i0 + u < n) ? accb[c0 + i0 + u] : 0.0;
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u < n) ? accb[c0 + i0 + u] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) sum += v[u];
-        }
-        if (B >= q0 && B < q1) sum += jbuf[B - q0];
-        if (r < RR) colacc[r < RR ? r : 0] += sum;
-        else cbuf[(r - RR) * T + tid] += sum;
+        for (int u = 0; u < 4; ++u) sum += v[u];
       }
+      if (B >= q0 && B < q1) sum += jbuf[B - q0];
+      return sum;
+    };
+#pragma unroll
+    for (int r = 0; r < RR; ++r)  // the columns carried in registers
+      if (tid + (int64_t)r * T < nb) colacc[r] += column_sum(r);
+    if constexpr (RL > 0) {       // ... and in LDS (eight columns: two at a time -- fully unrolled they spilled)
+      constexpr int UNR = 2;
+#pragma unroll UNR
+      for (int r = RR; r < RM; ++r)
+        if (tid + (int64_t)r * T < nb) cbuf[(r - RR) * T + tid] += column_sum(r);
     }
     __syncthreads();  // (accb / jbuf are read: the next pass may stage)
     OCLK(k_f2);
@@ -339,11 +364,9 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
   const double* __restrict__ hd = g.hdiag + A * nb;
   const double* __restrict__ gd = g.gdense + A * nb;
   double* __restrict__ orow = it.slot < 0 ? sig + A * nb : g.partial + (int64_t)it.slot * nb;
-#pragma unroll
-  for (int r = 0; r < RM; ++r) {
+  auto finish = [&](int r, double v) {
     const int64_t B = tid + (int64_t)r * T;
     if (B < nb) {
-      double v = r < RR ? colacc[r < RR ? r : 0] : cbuf[(r - RR) * T + tid];
       if (has0) {
         double d = hd[B];
         if (spin) d += g.shift * (g.szterm + (double)__popcll(g.strs_b[B] & ~g.strs_a[A]) - g.ss);
@@ -351,6 +374,12 @@ __global__ void __launch_bounds__(1024) k_opp_src(const OppSrcArgs g) {
       }
       orow[B] = v;
     }
+  };
+#pragma unroll
+  for (int r = 0; r < RR; ++r) finish(r, colacc[r]);
+  if constexpr (RL > 0) {
+#pragma unroll 1
+    for (int r = RR; r < RM; ++r) finish(r, cbuf[(r - RR) * T + tid]);
   }
   OCLK(k_item1);
   OCLK_ADD(5, k_item1 - k_item0);
@@ -380,8 +409,10 @@ __global__ void __launch_bounds__(256) k_opp_src_reduce(const OppSrcReduceArgs g
 
 // ---- host side
 static int oppsrc_jbuf(bool big, int nnorb) { return (big ? OppSrcLds<true>::WST : OppSrcLds<false>::WST) + ((nnorb + 1) & ~1) * 64; }
-static size_t oppsrc_shmem(bool big, int nnorb, int T) {  // planes (accb in their place at the end of a pass) | Wst | jbuf[T] | cbuf[RL][T]
-  return (size_t)oppsrc_jbuf(big, nnorb) + (size_t)T * 8 * (1 + OPPS_RL);
+static size_t oppsrc_shmem(bool big, int nnorb, int T, int nsub, int64_t nb) {  // planes (accb in their place at the end of a pass) | Wst | jbuf[T] | cbuf[RL][T]
+  const int rm = (int)((nb + T - 1) / T);
+  const int rl = (nsub == 2 && rm >= 5) ? (rm == 5 ? 2 : (rm == 6 ? 4 : 6)) : 0;  // (the kernel's RL; RM = 8 for rm = 7)
+  return (size_t)oppsrc_jbuf(big, nnorb) + (size_t)T * 8 * (1 + rl);
 }
 
 // phase 2 of set_subspace (behind opp_select): can k_opp_src take the opposite-spin part of this subspace?
@@ -393,7 +424,8 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   // Geometry.  512 threads with two sub-runs (8 links, <= 128 registers), ranges of <= 512 columns, pieces of 16 entries:
   // 68 KB of LDS, two workgroups per CU that cover each other's staging round trips; rows of more than 4096 columns need
   // 1024 threads for the thread's <= OPPS_RMAX target columns (ranges of <= 1024 columns, pieces of 8 entries).
-  int T = nb <= (int64_t)OPPS_RMAX * 512 ? 512 : 1024;
+  // (3073-4096 columns with 512 threads would be seven or eight columns per thread, i.e. one sub-run: 5.4 against 3.8 ms at 4000^2)
+  int T = nb <= (int64_t)5 * 512 ? 512 : 1024;  // (six columns per thread at 512 threads: 82 KB of LDS, one workgroup per CU)
   if (const char* env = std::getenv("SQD_OPPS_T")) {  // tuning / test hook (small workgroups: many passes on small sets)
     const int v = std::atoi(env);
     if (v >= 64 && v <= 1024 && v % 64 == 0) T = v;
@@ -404,13 +436,15 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
     if (v >= 1 && v <= OPPS_NSUB_MAX) nsub = v;
   }
   if (nb > (int64_t)OPPS_RMAX * T) return false;
-  if (nb > (int64_t)6 * T) nsub = 1;  // (eight target columns per thread beside two sub-runs: 18 spilled registers)
   if (c->nnorb > OppSrcLds<true>::WROWS) return false;
   bool big = T > OppSrcLds<false>::COLS || c->nnorb > OppSrcLds<false>::WROWS;
   if (const char* env = std::getenv("SQD_OPPS_BIG"))  // test hook: the 4-plane layout on small workgroups
     if (std::atoi(env) != 0) big = true;
+  // (seven or eight target columns per thread beside two sub-runs: 18 spilled registers -- unless six of them live in LDS,
+  // which the 1024-thread layout has room for)
+  if (nb > (int64_t)6 * T && !big) nsub = 1;
   if ((size_t)OPPS_SUB * nsub * T * 8 > (size_t)(big ? OppSrcLds<true>::STAGE_BYTES : OppSrcLds<false>::STAGE_BYTES)) return false;
-  if (oppsrc_shmem(big, c->nnorb, T) + 1024 > (size_t)c->lds_bytes) return false;
+  if (oppsrc_shmem(big, c->nnorb, T, nsub, nb) + 1024 > (size_t)c->lds_bytes) return false;
   // a source column's links must fit one pass even if every one of them opens a sub-run of its own
   const int64_t* ps = c->h_sptr_b;
   int64_t longest = 0;
@@ -419,7 +453,7 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   s->nsub = nsub;
   s->big = big;
   s->T = T;
-  s->shmem = oppsrc_shmem(big, c->nnorb, T);
+  s->shmem = oppsrc_shmem(big, c->nnorb, T, nsub, nb);
   // work items: a row's entries (itself + its alpha single links) in pieces of at most E (<= 64: one entry per lane), so
   // that the rows of the Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain; a row in one
   // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
@@ -512,8 +546,8 @@ int oppsrc_build(sqd_ctx* c) {
   }
   const int H = (int)cut.size() - 1;
   s->H = H;
-  // tables per pass: rec[S][T] | widx[nsub][T] | pos[S][T] | colq[OPPS_RMAX][T]
-  const size_t per_pass = (size_t)(2 * S + nsub + OPPS_RMAX) * T;
+  // tables per pass: rec[S][T] | widx[nsub][T] | colq[OPPS_RMAX][T]
+  const size_t per_pass = (size_t)(S + nsub + OPPS_RMAX) * T;
   s->h_tab.assign(per_pass * H, 0u);
   std::vector<int32_t> range_of((size_t)nb);
   for (int h = 0; h < H; ++h)
@@ -529,11 +563,11 @@ int oppsrc_build(sqd_ctx* c) {
       for (int64_t l = ps[B]; l < ps[B + 1]; ++l) rank[l] = counter[range_of[s->h_rec[l].src]]++;
       for (int h = 0; h < H; ++h) {
         const uint32_t n = counter[h] - first[h];
-        if (n > 0xffffu || first[h] > 0xffffu) {
+        if (n > 0xffffu || first[h] > OPPS_POS) {
           set_error("internal: opposite-spin pass tables: column run out of range");
           return SQD_ERR_STATE;
         }
-        s->h_tab[per_pass * h + (size_t)(2 * S + nsub + B / T) * T + (size_t)(B % T)] = first[h] | (n << 16);
+        s->h_tab[per_pass * h + (size_t)(S + nsub + B / T) * T + (size_t)(B % T)] = first[h] | (n << 16);
       }
     }
   }
@@ -543,8 +577,6 @@ int oppsrc_build(sqd_ctx* c) {
     for (int h = 0; h < H; ++h) {
       uint32_t* rec = s->h_tab.data() + per_pass * h;
       uint32_t* wofs = rec + (size_t)S * T;
-      uint32_t* pos = wofs + (size_t)nsub * T;
-      std::fill(pos, pos + (size_t)S * T, OPPS_DEAD);
       used.clear();
       for (int32_t B = cut[h]; B < cut[h + 1]; ++B)
         for (int64_t i = sptr[B]; i < sptr[B + 1]; ++i) {
@@ -567,8 +599,8 @@ int oppsrc_build(sqd_ctx* c) {
           for (int k = 0; k < OPPS_SUB && i0 + k < ls.size(); ++k) {
             const uint32_t l = ls[i0 + k];
             const size_t at = (size_t)(OPPS_SUB * j + k) * T + t;
-            rec[at] = (uint32_t)(s->h_rec[l].src - (uint32_t)cut[h]) * 16u;
-            pos[at] = rank[l] | ((s->h_rec[l].meta >> 31) ? 0x80000000u : 0u);
+            rec[at] = ((uint32_t)(s->h_rec[l].src - (uint32_t)cut[h]) * 16u) | (rank[l] << OPPS_POS_SHIFT) |
+                      ((s->h_rec[l].meta >> 31) ? OPPS_NEG : 0u) | OPPS_LIVE;
           }
         }
         ls.clear();
@@ -660,7 +692,9 @@ int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_str
     if (s->big) SQD_OPPS_CASE(NSUB_, RM_, true);        \
     else SQD_OPPS_CASE(NSUB_, RM_, false);              \
   } while (0)
-  if (s->nsub == 1 || rm > 6) {  // (rows of more than six columns per thread: one sub-run, oppsrc_select)
+  if (s->nsub == 2 && rm > 6) {  // (1024 threads only: oppsrc_select)
+    SQD_OPPS_CASE(2, 8, true);
+  } else if (s->nsub == 1 || rm > 6) {  // (512 threads, rows of more than six columns per thread: one sub-run, oppsrc_select)
     if (rm <= 2) SQD_OPPS_BIG(1, 2);
     else if (rm <= 4) SQD_OPPS_BIG(1, 4);
     else if (rm <= 6) SQD_OPPS_BIG(1, 6);
@@ -668,6 +702,7 @@ int oppsrc_launch(sqd_ctx* c, const double* d_c, double* d_sigma, int64_t in_str
   } else {
     if (rm <= 2) SQD_OPPS_BIG(2, 2);
     else if (rm <= 4) SQD_OPPS_BIG(2, 4);
+    else if (rm == 5) SQD_OPPS_BIG(2, 5);
     else SQD_OPPS_BIG(2, 6);
   }
 #undef SQD_OPPS_BIG
