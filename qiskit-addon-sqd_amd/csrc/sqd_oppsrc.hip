@@ -457,7 +457,7 @@ bool oppsrc_select(sqd_ctx* c, int64_t na, int64_t nb, const int64_t* tot) {
   // work items: a row's entries (itself + its alpha single links) in pieces of at most E (<= 64: one entry per lane), so
   // that the rows of the Hartree-Fock neighbourhood (up to 177 entries) do not run as one workgroup's chain; a row in one
   // piece is written in place, the others as partial rows added in slot order.  Longest pieces first.
-  int E = 32;
+  int E = OPPS_EMAX;  // (64 against 32: 1-3 % -- fewer folds and partial rows per multiply-add)
   if (const char* env = std::getenv("SQD_OPPS_E")) {  // tuning / test hook (short pieces: many partial rows)
     const int v = std::atoi(env);
     if (v >= 2 && v <= OPPS_EMAX) E = v / 2 * 2;
