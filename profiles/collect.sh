@@ -37,7 +37,7 @@ SIZES="10000 6000 4000" bash profiles/probes/_lists_passes.sh 2>&1 | eval $F > $
 [ -x profiles/probes/anyorder/anyorder_probe ] && ./profiles/probes/anyorder/anyorder_probe > $OUT/anyorder_probe.txt 2>&1
 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1
 # CONNECTED subspaces at D = 1e6 .. 9e6 (round 5): every same-spin formulation, kernel traces of the default one
-TAG=$R/conn SIZES="700 1000 2000 3000 5000" MODES="default dense1 dense0" TRACE_SIZES="1000 3000 5000" bash profiles/probes/_connected.sh > /dev/null 2>&1
+TAG=$R/conn SIZES="700 1000 2000 3000 4000 5000 7000" MODES="default dense1 dense0" TRACE_SIZES="1000 3000 5000" bash profiles/probes/_connected.sh > /dev/null 2>&1
 cp $OUT/conn/connected_probe.txt $OUT/connected_probe.txt; cp $OUT/conn/connected_kernel_stats.txt $OUT/connected_kernel_stats_probe.txt
 for n in 1000 3000 5000; do mkdir -p $OUT/prof_hf$n; cp -r $OUT/conn/prof_hf$n/* $OUT/prof_hf$n/ 2>/dev/null; done
 cd /tmp && export TMPDIR=/tmp
