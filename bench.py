@@ -639,10 +639,11 @@ def secondary_entries(args, h1, eri, device):
             entry = {"D": n * n, "links": [ctx.link_counts(0), ctx.link_counts(1)],
                      "roofline": roofline_entry(ctx, t_sig, t_sig, 5)}
             entry["roofline"]["note_kernels"] = (
-                "one sigma = the same-spin product (sqd::k_spmm_grouped between two k_spmm_transpose launches) + sqd::k_opp_rows "
-                "(opposite-spin part + diagonal by whole rows, the beta link list in registers; rows of more than 3072 columns "
-                "in its 4-8-columns-per-thread form); avg_launch_ms is the whole application (HIP events around 5 of them); "
-                "per-kernel times: profiles/r05/final_hf1000_kernel_stats.csv, final_hf3000_kernel_stats.csv")
+                "one sigma = the same-spin product (sqd::k_spmm_grouped between two k_spmm_transpose launches) + the "
+                "opposite-spin part and the diagonal by whole rows, the beta link list in registers (sqd::k_opp_rows up to "
+                "3072 columns; sqd::k_opp_src, passes over ranges of the source column, beyond); avg_launch_ms is the whole "
+                "application (HIP events around 5 of them); per-kernel times: profiles/r06/final_hf1000_kernel_stats.csv, "
+                "final_hf3000_kernel_stats.csv, final_hf5000_kernel_stats.csv")
             ctx.davidson(fetch=False)  # (first call at this size grows the arenas: not timed)
             ctx.sync()
             t0 = time.perf_counter()

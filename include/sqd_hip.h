@@ -319,7 +319,8 @@ int sqd_sigma_bytes_needed(sqd_ctx* ctx, double* bytes);
  * 4 = list passes for large sets with short lists (k_sigma_lists: link lists in registers, rows of C and C^T through LDS),
  * 5 = sparse same-spin product (k_spmm_*) + work items, 6 = sparse product + whole-row opposite-spin kernel (k_opp_rows,
  * rows of <= 3072 columns), 7 = sparse product + the source-range form of it (k_opp_src, longer rows);
- * rows_per_workgroup is set for kind 2, else 0. */
+ * rows_per_workgroup: kind 2 -> rows of C per workgroup; kinds 5-7 -> rows per group of the sparse product (8 =
+ * k_spmm_grouped, 1 = k_spmm_rows); else 0. */
 int sqd_sigma_kernel(sqd_ctx* ctx, int* kind, int* rows_per_workgroup);
 
 /* ---- qubit / Pauli path (reference qiskit_addon_sqd/qubit.py) -----------------

@@ -956,12 +956,14 @@ class Context:
         (element gather), ``k_sigma_rows<R>`` (R whole rows of C per workgroup in LDS), ``k_same_spin_mfma+k_sigma``
         (dense same-spin blocks on the f64 matrix cores + work items for the opposite-spin terms), ``k_sigma_lists``
         (large sets with short lists: link lists in registers, one pass over C and one over its transpose) or
-        ``k_spmm_rows+k_sigma`` / ``k_spmm_rows+k_opp_rows`` (connected sets from ~10^3 strings per spin: the same-spin
-        part as a sparse product in row-AXPY form on C and C^T; the opposite-spin terms by work items, or -- the default
+        ``k_spmm_grouped+k_sigma`` / ``k_spmm_grouped+k_opp_rows`` (connected sets from ~10^3 strings per spin: the
+        same-spin part as a sparse product in row-AXPY form on C and C^T, on groups of 8 rows -- ``k_spmm_rows``, one row
+        per wavefront, beyond 32768 strings per spin; the opposite-spin terms by work items, or -- the default
         for the plain operator -- by whole rows with the beta link list in registers: ``k_opp_rows`` up to 3072 columns,
         ``k_opp_src``, passes over ranges of the source column, beyond)."""
         kind, rows = C.c_int(), C.c_int()
         self._check(self._lib.sqd_sigma_kernel(self._h, C.byref(kind), C.byref(rows)))
+        spmm = "k_spmm_grouped" if rows.value > 1 else "k_spmm_rows"
         return ("k_sigma", "k_sigma_direct", f"k_sigma_rows<{rows.value}>", "k_same_spin_mfma+k_sigma",
-                "k_sigma_lists", "k_spmm_rows+k_sigma", "k_spmm_rows+k_opp_rows", "k_spmm_rows+k_opp_src")[kind.value]
+                "k_sigma_lists", f"{spmm}+k_sigma", f"{spmm}+k_opp_rows", f"{spmm}+k_opp_src")[kind.value]
 

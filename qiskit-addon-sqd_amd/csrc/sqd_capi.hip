@@ -1207,7 +1207,7 @@ SQD_API int sqd_sigma_kernel(sqd_ctx* c, int* kind, int* rows_per_workgroup) {
   CTX_ENTER(c);
   NEED_SUBSPACE(c);
   if (kind) *kind = c->sig_lists ? 4 : c->sig_rows > 0 ? 2 : (c->sig_direct ? 1 : (c->sig_opp ? (c->opp_src ? 7 : 6) : (c->sig_spmm ? 5 : (c->sig_dense ? 3 : 0))));
-  if (rows_per_workgroup) *rows_per_workgroup = c->sig_rows;
+  if (rows_per_workgroup) *rows_per_workgroup = c->sig_spmm ? spmm_rows_per_group(c) : c->sig_rows;
   return SQD_OK;
 }
 

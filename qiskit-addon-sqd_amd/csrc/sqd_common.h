@@ -365,6 +365,7 @@ bool spmm_select(sqd_ctx* c, int64_t na, int64_t nb, int64_t row0, int64_t row1,
 int spmm_build(sqd_ctx* c);
 int spmm_launch(sqd_ctx* c, const double* d_c, int64_t in_stride);
 void spmm_release(sqd_ctx* c);
+int spmm_rows_per_group(const sqd_ctx* c);  // 8: the row-grouped product (k_spmm_grouped); 1: one row per wavefront (k_spmm_rows)
 // opposite-spin part + diagonal by whole rows for the subspaces of the sparse-product path (sqd_opp.hip).  opp_select:
 // phase 2 of set_subspace, behind spmm_select (sets sqd_ctx::sig_opp); opp_build: device tables, behind launch C;
 // opp_launch: sigma = (hdiag + opposite-spin part) c + gdense, behind spmm_launch of the same vector

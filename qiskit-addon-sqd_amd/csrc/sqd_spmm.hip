@@ -55,6 +55,12 @@ struct SpmmState {
   DevBuf ct, g2t;  // C^T (nb x na) and H_b C^T (nb x na)
 };
 
+#ifndef SQD_SPMM_GR
+#define SQD_SPMM_GR 8  // (probe builds: 4 / 16 -- profiles/r05/spmm_group_size_probe.txt)
+#endif
+int spmm_rows_per_group(const sqd_ctx* c) {
+  return c->spmm && static_cast<const SpmmState*>(c->spmm)->grouped ? SQD_SPMM_GR : 1;
+}
 void spmm_release(sqd_ctx* c) {
   if (!c->spmm) return;
   SpmmState* s = static_cast<SpmmState*>(c->spmm);
@@ -270,9 +276,6 @@ __global__ void __launch_bounds__(256) k_spmm_rows(const SpmmArgs g) {
 // bytes through the vector L1 per useful multiply-add drop to 0.42 / 0.52 of k_spmm_rows'; the extra multiply-adds by
 // zero are free (the vector units have an 8-fold margin over the L1 here).  Records travel through the scalar cache:
 // per round of GU sources one s_load of their addresses and GU x 8 coefficients, which enter v_fmac_f64 as scalar operands.
-#ifndef SQD_SPMM_GR
-#define SQD_SPMM_GR 8  // (probe builds: 4 / 16 -- profiles/r05/spmm_group_size_probe.txt)
-#endif
 constexpr int GR = SQD_SPMM_GR, GPAD = 16;
 struct GroupBuildArgs {
   int64_t n[2];
@@ -552,10 +555,8 @@ int spmm_build(sqd_ctx* c) {
   hipLaunchKernelGGL(k_spmm_merge, dim3((unsigned)((maxn + 1 + 3) / 4), 2), dim3(256), 0, c->stream, ma);
   SQD_HIP_CHECK(hipGetLastError());
   // the row-grouped form (default; SQD_SPMM_GROUPED=0 forbids): up to 32 768 strings per spin (the build kernel's bitmap)
-  static const bool grouped_env = [] {
-    const char* env = std::getenv("SQD_SPMM_GROUPED");
-    return !env || std::atoi(env) != 0;
-  }();
+  const char* genv = std::getenv("SQD_SPMM_GROUPED");  // (read per build: the tests switch it inside one process)
+  const bool grouped_env = !genv || std::atoi(genv) != 0;
   s->grouped = grouped_env && maxn <= 32768;
   if (s->grouped) {
     GroupBuildArgs gb;

@@ -288,7 +288,8 @@ def test_emu_spmm_same_spin(emu_lib, monkeypatch, xcd, J, form, opp):
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == ("k_spmm_rows+k_opp_rows" if opp == "1" else "k_spmm_rows+k_sigma"), case
+            spmm = "k_spmm_grouped" if form == "g" else "k_spmm_rows"
+            assert ctx.sigma_kernel() == (f"{spmm}+k_opp_rows" if opp == "1" else f"{spmm}+k_sigma"), case
     run_full_parity(emu_lib, *cases[0], variants=False)
     for case in cases[1:]:
         run_operator_parity(emu_lib, *case)
@@ -306,7 +307,7 @@ def test_emu_opp_rows_column_ranges(emu_lib, monkeypatch):
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_rows" and ctx.link_counts(1)[0] > 64
+            assert ctx.sigma_kernel() == "k_spmm_grouped+k_opp_rows" and ctx.link_counts(1)[0] > 64
         run_operator_parity(emu_lib, *case)
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
 
@@ -333,7 +334,7 @@ def test_emu_opp_src_passes(emu_lib, monkeypatch, hooks):
         h1, eri, sa, sb = make_problem(*case)
         with _capi.Context(h1, eri, lib=emu_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_src", (case, ctx.sigma_kernel())
+            assert ctx.sigma_kernel() == "k_spmm_grouped+k_opp_src", (case, ctx.sigma_kernel())
         run_operator_parity(emu_lib, *case)
     run_full_parity(emu_lib, 7, (3, 3), 20, 20, 7, True, variants=False)
 

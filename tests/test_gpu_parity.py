@@ -866,8 +866,8 @@ import functools  # noqa: E402
 _CONNECTED_MODES = {
     "mfma": ({"SQD_SIGMA_DENSE": "1"}, "k_same_spin_mfma+k_sigma"),
     "sparse": ({"SQD_SIGMA_DENSE": "0"}, "k_sigma"),
-    "spmm": ({"SQD_SIGMA_SPMM": "1"}, "k_spmm_rows+k_opp_rows"),
-    "spmm_items": ({"SQD_SIGMA_SPMM": "1", "SQD_SIGMA_OPP": "0"}, "k_spmm_rows+k_sigma"),
+    "spmm": ({"SQD_SIGMA_SPMM": "1"}, "k_spmm_grouped+k_opp_rows"),
+    "spmm_items": ({"SQD_SIGMA_SPMM": "1", "SQD_SIGMA_OPP": "0"}, "k_spmm_grouped+k_sigma"),
 }
 
 
@@ -1040,7 +1040,7 @@ def test_connected_more_than_8192_beta_strings(hip_lib, monkeypatch, na, nb):
     ref_rows = O.sigma_rows_string_space(h1, eri, sa, sb, x, norb, rows)
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
-        assert ctx.sigma_kernel() == "k_spmm_rows+k_sigma"
+        assert ctx.sigma_kernel() == "k_spmm_grouped+k_sigma"
         scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
         sx = ctx.sigma(x)
         assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
@@ -1111,7 +1111,7 @@ def test_connected_long_rows_source_range_kernel(hip_lib, monkeypatch, na, nb, s
     ref_cols = O.sigma_rows_string_space(h1, eri, sb, sa, np.ascontiguousarray(x.T), norb, cols)
     with _capi.Context(h1, eri, lib=hip_lib) as ctx:
         ctx.set_subspace(sa, sb)
-        assert ctx.sigma_kernel() == "k_spmm_rows+k_opp_src"
+        assert ctx.sigma_kernel() == "k_spmm_grouped+k_opp_src"
         scale = np.abs(ctx.hdiag()).max() * max(1.0, np.abs(x).max())
         sx = ctx.sigma(x)
         assert np.abs(sx[rows] - ref_rows).max() < 1e-11 * scale
@@ -1154,7 +1154,7 @@ def test_connected_ragged_fes_sized_sparse_product_path(hip_lib, monkeypatch):
             monkeypatch.setenv("SQD_SIGMA_SPMM", "0")
         with _capi.Context(h1, eri, lib=hip_lib) as ctx:
             ctx.set_subspace(sa, sb)
-            assert ctx.sigma_kernel() == ("k_spmm_rows+k_opp_rows" if forced == "default" else "k_sigma"), ctx.sigma_kernel()
+            assert ctx.sigma_kernel() == ("k_spmm_grouped+k_opp_rows" if forced == "default" else "k_sigma"), ctx.sigma_kernel()
             ops = (ctx.sigma(x), ctx.sigma(x, 1, 0.75, 0.3), ctx.contract_ss(x))
             assert np.array_equal(ops[0], ctx.sigma(x))
             _, st = ctx.davidson(fetch=False)
