@@ -6,6 +6,11 @@ import numpy as np
 from qiskit_addon_sqd_amd import synthetic as S
 from qiskit_addon_sqd_amd import fermion as F
 
+if os.environ.get("SQD_LIB"):  # A/B against another build of the library (profiles/probes/build_variant.sh)
+    from pathlib import Path
+    from qiskit_addon_sqd_amd import _capi
+    _capi.LIB_PATH = Path(os.environ.get("GRAFT_REPO_ROOT", "/root/repo")) / os.environ["SQD_LIB"]
+
 h1, eri = F.freeze_integrals(*S.synthetic_integrals(30))
 for name, gen, nb in (('uniform', S.uniform_strings, 8), ('uniform', S.uniform_strings, 16), ('hf', S.hf_centred_strings, 8),
                       ('hf', S.hf_centred_strings, 16)):

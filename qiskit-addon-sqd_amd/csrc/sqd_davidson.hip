@@ -1148,8 +1148,13 @@ __global__ void __launch_bounds__(RED_T) k_eig_b(const DavBatchArgs* __restrict_
   if (threadIdx.x >= 64) return;
   wave_eig_step<MV>(st, s_head, s_heff, tot, a.prm, sA, sM, sv_eig);
 }
+// (four workgroups per CU: the 128-VGPR cap costs the <13> instantiation 4 spilled registers, 20 bytes of scratch, and is
+// still 2-5 % faster per batched solve than three workgroups without a spill -- profiles/r06/resid_b_waves_probe.txt)
+#ifndef SQD_RESID_B_WAVES
+#define SQD_RESID_B_WAVES 4
+#endif
 template <int MV>
-__global__ void __launch_bounds__(RED_T, 4) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
+__global__ void __launch_bounds__(RED_T, SQD_RESID_B_WAVES) k_residual_precond_b(const DavBatchArgs* __restrict__ as) {
   const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
   if (blockIdx.x >= a.gb) return;
   residual_precond_body<MV>(a.n, a.X, a.AX, a.n, a.st, a.hdiag, a.pd, a.part_res, a.width, blockIdx.x, a.gb);
