@@ -26,6 +26,7 @@
 #include "sqd_common.h"
 #include "sqd_device.h"
 #include "sqd_davstate.h"
+#include "sqd_direct.h"
 
 namespace sqd {
 
@@ -728,6 +729,62 @@ __global__ void __launch_bounds__(RED_T) k_dots_eig(int64_t n, const double* __r
   dots_eig_body<MV, true>(n, X, AX, stride, partial, width, counter, st, prm, split, blockIdx.x, gridDim.x);
 }
 
+// ---- The sigma build AND the fused reduction behind it in ONE launch, for the element-gather formulation (round 6).  That
+// sigma kernel is a thread per output element with no exchange between threads, and the dot products need sigma[i] only
+// where they need X_v[i]: the thread that gathers element i multiplies it into its partial sums while the value is in a
+// register.  One kernel boundary less per iteration on a chain whose kernels run 5-8 us and whose boundaries cost 4-5 (a
+// pass that wrote a vector has to drain the L2s before the next kernel starts): uniform 317 x 317, 2-3 iterations per
+// solve.  Geometry, loop order and reductions are k_dots_eig's, the element is k_sigma_direct's (direct_element): the
+// same bits as the two launches, which the batched solves and the timing hooks keep (tests compare them).
+template <int MV, int K, bool SPIN>
+__device__ inline void dots_loop_direct(int64_t n, const double* __restrict__ X, double* __restrict__ y, int64_t stride, int nvec,
+                                        const DirectArgs& dg, unsigned bx, unsigned nbx, double (&acc)[MV + 1]) {
+  static_assert(K <= MV, "slot bound");
+  const double* __restrict__ Cn = X + (int64_t)(nvec - 1) * stride;  // the newest basis vector: sigma's operand
+  const double pen = -dg.shift;
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
+    double xv[K];
+    load_vectors<K>(X, stride, nvec, i, xv);
+    const double yv = direct_element<SPIN>(dg, Cn, i, pen);
+    y[i] = yv;
+#pragma unroll
+    for (int v = 0; v < K; ++v) {
+      acc[1 + v] += (v < nvec) ? xv[v] * yv : 0.0;
+      acc[0] += (v == nvec - 1) ? xv[v] * xv[v] : 0.0;
+    }
+  }
+}
+template <int MV, bool SPIN>
+__global__ void __launch_bounds__(RED_T) k_sigma_dots_eig(int64_t n, const double* __restrict__ X, double* __restrict__ AX,
+                                                           int64_t stride, double* __restrict__ partial, int width,
+                                                           unsigned* counter, DavState* st, const DavParams prm,
+                                                           const DirectArgs dg) {
+  __shared__ double red[16 * (MV + 1)];
+  __shared__ double tot[MV + 1];
+  __shared__ double sA[MV * MV], sM[MV * MV], sv_eig[MV + 1];
+  __shared__ unsigned long long s_head[DAV_HEAD_WORDS];
+  __shared__ double s_heff[MV * MV];
+  if (st->stop) return;
+  const unsigned bx = blockIdx.x, nbx = gridDim.x;
+  const int nvec = st->m_next;
+  dav_state_prefetch<MV>(st, s_head, s_heff);
+  double* __restrict__ y = AX + (int64_t)(nvec - 1) * stride;
+  double acc[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+  if (nvec <= 2) dots_loop_direct<MV, (2 < MV ? 2 : MV), SPIN>(n, X, y, stride, nvec, dg, bx, nbx, acc);
+  else if (nvec <= 4) dots_loop_direct<MV, (4 < MV ? 4 : MV), SPIN>(n, X, y, stride, nvec, dg, bx, nbx, acc);
+  else if (nvec <= 8) dots_loop_direct<MV, (8 < MV ? 8 : MV), SPIN>(n, X, y, stride, nvec, dg, bx, nbx, acc);
+  else dots_loop_direct<MV, MV, SPIN>(n, X, y, stride, nvec, dg, bx, nbx, acc);
+  block_sum_multi<MV + 1>(acc, nvec + 1, red);
+  if ((int)threadIdx.x < nvec + 1)
+    coherent_store(&partial[(int64_t)bx * width + threadIdx.x], block_sum_multi_get<MV + 1>(red, threadIdx.x));
+  if (!arrive_last(counter, bx, nbx)) return;
+  fold_partials<true>(partial, (int)nbx, width, nvec + 1, tot);
+  if (threadIdx.x >= 64) return;
+  wave_eig_step<MV>(st, s_head, s_heff, tot, prm, sA, sM, sv_eig);
+}
+
 // Single solves of large subspaces (D >= DOTS_SPLIT_D): dots and eigen step as two launches, as the batched solves run
 // them -- the eigen step's code holds the fused kernel at 232 VGPRs, i.e. ONE 512-thread workgroup per CU, and from
 // D ~ 5e5 on the launch is 512 workgroups of bandwidth-bound work (HF-centred 1000^2: 44 us of a 290 us iteration);
@@ -1392,7 +1449,34 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
                    std::sqrt(h_prog[MAIL_PAYLOAD + 4]));
     return SQD_OK;
   };
+  static const int64_t dots_split_d = [] {  // tuning hook: subspace dimension from which dots and eigen step are two launches
+    const char* env = std::getenv("SQD_DOTS_SPLIT_D");
+    return env ? (int64_t)std::atoll(env) : (int64_t)200000;  // (profiles/r05/dots_split_probe.txt)
+  }();
+  const bool split_dots = D >= dots_split_d;
+  // element-gather sigma, fused reduction (not from D = dots_split_d on, not the squared penalty form): the sigma build and
+  // the reduction behind it are ONE launch, k_sigma_dots_eig -- except a sigma launch that is being timed, which goes out as
+  // the sigma kernel alone between its events and the reduction behind them (the same bits either way)
+  bool fuse_direct = c->sig_direct && c->sig_rows == 0 && !split_dots && form_sel != 2 && max_space <= 12 && !c->sharded();
+  if (fuse_direct)
+    if (const char* env = std::getenv("SQD_DAV_FUSE_DIRECT")) fuse_direct = std::atoi(env) != 0;  // test / probe hook
+  DirectArgs dg;
+  if (fuse_direct) fill_direct_args(c, X, AX, 0, form_sel == 1, o->ss, o->shift, D, D, &dg);
+  bool fused_of[4] = {false, false, false, false};  // was round r's sigma build the fused launch? (ring, like seq_of)
   auto part_a = [&](int round) -> int {  // the sigma build of a round (reads "which vector" from the state block)
+    fused_of[round & 3] = false;
+    if (fuse_direct && !(ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0))) {
+      fused_of[round & 3] = true;
+      ++c->sigma_launches;
+      if (form_sel == 1)
+        hipLaunchKernelGGL((k_sigma_dots_eig<13, true>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                           c->partial.as<double>(), width, counter, dst, prm, dg);
+      else
+        hipLaunchKernelGGL((k_sigma_dots_eig<13, false>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
+                           c->partial.as<double>(), width, counter, dst, prm, dg);
+      SQD_HIP_CHECK(hipGetLastError());
+      return SQD_OK;
+    }
     const bool timed = ev_every && nev < max_ev && (c->sigma_launches % ev_every == 0);
     ++c->sigma_launches;
     if (timed) {
@@ -1411,11 +1495,6 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     }
     return SQD_OK;
   };
-  static const int64_t dots_split_d = [] {  // tuning hook: subspace dimension from which dots and eigen step are two launches
-    const char* env = std::getenv("SQD_DOTS_SPLIT_D");
-    return env ? (int64_t)std::atoll(env) : (int64_t)200000;  // (profiles/r05/dots_split_probe.txt)
-  }();
-  const bool split_dots = D >= dots_split_d;
   auto part_b = [&](int round) -> int {
     const long long seq = ++c->mail_seq;
     seq_of[round & 3] = seq;
@@ -1425,7 +1504,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
                            c->partial.as<double>(), width, counter, dst, prm, split);
         hipLaunchKernelGGL((k_eig_s<13>), dim3(1), dim3(RED_T), 0, s, (const double*)c->partial.as<double>(), (int)gb, width, dst,
                            prm);
-      } else {
+      } else if (!fused_of[round & 3]) {  // (fused: part A has done it)
         hipLaunchKernelGGL((k_dots_eig<13>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
                            c->partial.as<double>(), width, counter, dst, prm, split);
       }
@@ -1445,8 +1524,11 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
     // In the first rounds -- where the solves of uniform-random sets stop -- the solution kernel is queued right behind
     // the round, conditional on the stop flag: a solve that stops there has its solution formed without waiting for
     // the host to see the record and come back with the launch (13 us of idle stream at the headline); a round that
-    // does not stop pays one early-exit dispatch.
-    if (!lockstep && round < full_from) {
+    // does not stop pays one early-exit dispatch -- 4.7 us on the stream, not the 1-2 of an empty kernel: a kernel boundary
+    // behind a pass that wrote a vector waits for that pass's lines to leave the L2s (final_uniform317 trace, round 6).
+    // Round 0 stops a solve only when the start vector is already the answer (one-determinant subspaces): it goes
+    // without, and such a solve gets its solution launch from the host.
+    if (!lockstep && round >= 1 && round < full_from) {
       hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
                          c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 1);
       SQD_HIP_CHECK(hipGetLastError());

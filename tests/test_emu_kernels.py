@@ -52,6 +52,33 @@ def test_emu_direct_and_work_item_sigma(emu_lib, monkeypatch, direct):
     run_operator_parity(emu_lib, 7, (3, 3), 20, 20, 7, True)
 
 
+def test_emu_fused_direct_sigma_and_reduction(emu_lib, monkeypatch):
+    # element-gather formulation inside a Davidson run: the sigma build and the fused dot products / eigen step are ONE
+    # launch (k_sigma_dots_eig, round 6) -- against the two launches (SQD_DAV_FUSE_DIRECT=0; what batched solves and timed
+    # runs keep) bit for bit: plain operator and the linear spin penalty, bases of more than 8 vectors, restarts
+    # (max_space 4), a start vector from the caller
+    monkeypatch.setenv("SQD_SIGMA_DIRECT", "1")
+    h1, eri, sa, sb = make_problem(8, (4, 3), 40, 30, 13)
+    ci0 = np.random.default_rng(5).standard_normal((len(sa), len(sb)))
+    runs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SQD_DAV_FUSE_DIRECT", fused)
+        with _capi.Context(h1, eri, lib=emu_lib) as ctx:
+            ctx.set_subspace(sa, sb)
+            assert ctx.sigma_kernel() == "k_sigma_direct"
+            out = []
+            # (time_sigma_every=2: every other sigma launch goes out alone between its events, the rest fused)
+            for kw in ({}, {"spin_sq": 0.75, "shift": 0.3}, {"max_space": 4}, {"ci0": ci0, "tol": 1e-11},
+                       {"time_sigma_every": 2}):
+                c, st = ctx.davidson(**kw)
+                assert st["converged"], kw
+                out.append((c.copy(), st["e_davidson"], st["n_sigma"], st["iterations"]))
+            runs[fused] = out
+    for a, b in zip(runs["1"], runs["0"]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    assert max(r[2] for r in runs["1"]) > 9  # (the thirteen-slot loop ran)
+
+
 @pytest.mark.parametrize("rows", ["1", "2", "3", "8"])
 def test_emu_rows_kernel(emu_lib, monkeypatch, rows):
     # SQD_SIGMA_ROWS=R forces k_sigma_rows (R whole rows of C per workgroup in LDS, beta doubles in per-slice
