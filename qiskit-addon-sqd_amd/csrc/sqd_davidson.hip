@@ -907,7 +907,8 @@ __global__ void __launch_bounds__(RED_T, SQD_RESID_WAVES) k_residual_precond(int
 }
 
 // progress record of one iteration in host-visible memory: {sequence word | it, stop, e, de, |r|^2, m}
-__device__ inline void post_progress(double* mail, long long seq, const DavState* st, int stop, double rr) {
+__device__ inline void post_progress(double* mail, long long seq, const DavState* st, int stop, double rr, int sol_done = 0) {
+  mail_store(&mail[MAIL_PAYLOAD + 6], (double)sol_done);
   mail_store(&mail[MAIL_PAYLOAD + 0], (double)st->it);
   mail_store(&mail[MAIL_PAYLOAD + 1], (double)stop);
   mail_store(&mail[MAIL_PAYLOAD + 2], st->e);
@@ -953,7 +954,11 @@ template <int MV>
 __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                                      const DavParams& prm, const double* __restrict__ partial, int nblocks, int width,
                                      double* mail, long long seq, unsigned bx, unsigned nbx,
-                                     const double* __restrict__ tot_in = nullptr, double* __restrict__ send = nullptr) {
+                                     const double* __restrict__ tot_in = nullptr, double* __restrict__ send = nullptr,
+                                     double* __restrict__ sol_out = nullptr, double* res_out = nullptr) {
+  // sol_out != nullptr (single solves): the launch that stops the solve forms the solution in the same pass -- the Ritz
+  // vector of the projected problem this iteration solved -- and leaves the run's outcome in res_out, as k_solution would
+  // one dispatch later (a kernel boundary costs 4-5 us on this chain; a solve of the headline is 2-3 iterations long)
   // send != nullptr (row-sharded solves): the new vector is also written to the buffer the next iteration's all-gather
   // reads -- the k_shard_pick launch that copied it there is needed for the start vector only
   // tot_in != nullptr (row-sharded solves): the totals {|r|^2, |t|^2, X_v . t} are already folded AND all-reduced
@@ -967,10 +972,16 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   // (workgroup 0 raises st->stop further down while other workgroups may still be starting: the flag is
   // sampled once per workgroup so that all its threads take the same path)
   CLK(o0);
-  if (threadIdx.x == 0) s_was_stopped = st->stop;
+  const int my_mark = (int)(seq & 0x3fffffff) + 2;  // (>= 2: DavState::stop)
+  if (threadIdx.x == 0) {
+    // (a flag raised by THIS launch carries its mark: this workgroup then goes on, reaches the same stop decision from the
+    // same totals and forms its share of the solution)
+    const int up = st->stop;
+    s_was_stopped = (up != 0 && up != my_mark) ? 1 : 0;
+  }
   __syncthreads();
   if (s_was_stopped) {
-    if (bx == 0 && threadIdx.x == 0) post_progress(mail, seq, st, 1, st->rnorm2);
+    if (bx == 0 && threadIdx.x == 0) post_progress(mail, seq, st, 1, st->rnorm2, (sol_out && st->stop >= 2) ? 1 : 0);
     return;
   }
   const int nvec = st->m_cur;
@@ -1006,7 +1017,7 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
         st->rnorm2 = rr;
         if (s_stop) {
           st->conv = (rr < prm.tol2) ? 1 : 0;
-          st->stop = 1;
+          st->stop = my_mark;
         } else if (restart) {
           // from here on the solution is X0 alone (the collapse below), should the run end before the next
           // projected problem is solved
@@ -1019,8 +1030,38 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
   __syncthreads();
   CLK(o2);
   // the iteration's progress record for the host: by the LAST wavefront of workgroup 0, beside the others' main loop
-  if (bx == 0 && threadIdx.x == blockDim.x - 64) post_progress(mail, seq, st, s_stop, rr);
-  if (s_stop) return;  // the correction is not needed (and may be 0/0)
+  if (bx == 0 && threadIdx.x == blockDim.x - 64) post_progress(mail, seq, st, s_stop, rr, (s_stop && sol_out) ? 1 : 0);
+  if (s_stop) {  // the correction is not needed (and may be 0/0)
+    if (sol_out) {
+      // (workgroup 0's thread 0 has just written conv / stop: it is the thread that writes the outcome record)
+      if (bx == 0 && threadIdx.x == 0) {
+        mail_store(&res_out[0], (double)((rr < prm.tol2) ? 1 : 0));
+        mail_store(&res_out[1], (double)st->it);
+        mail_store(&res_out[2], (double)st->nsig);
+        mail_store(&res_out[3], st->e);
+        mail_store(&res_out[4], rr);
+        mail_store(&res_out[5], (double)st->err);
+        mail_store(&res_out[6], 1.0);
+        mail_store(&res_out[7], (double)st->n_rqi);
+        mail_store(&res_out[8], (double)st->n_jacobi);
+      }
+      // sum_{v < sol_m} sol_coef[v] X_v, as solution_body forms it (sol_m = nvec: this iteration's projected problem)
+      if ((int)threadIdx.x < MV + 2) g[threadIdx.x] = ((int)threadIdx.x < nvec) ? st->sol_coef[threadIdx.x] : 0.0;
+      __syncthreads();
+      for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < n; i += (int64_t)nbx * blockDim.x) {
+        double sacc = 0.0;
+        for (int v0 = 0; v0 < nvec; v0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = X[(int64_t)(v0 + u < nvec ? v0 + u : v0) * stride + i];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sacc += (v0 + u < nvec) ? g[v0 + u < nvec ? v0 + u : v0] * x[u] : 0.0;
+        }
+        sol_out[i] = sacc;
+      }
+    }
+    return;
+  }
   const double scale = s_scale;
   double* __restrict__ t = X + (int64_t)nvec * stride;
   if (!restart) {
@@ -1072,8 +1113,9 @@ __device__ inline void orth_dev_body(int64_t n, double* __restrict__ X, double* 
 template <int MV>
 __global__ void __launch_bounds__(RED_T) k_orth_dev(int64_t n, double* __restrict__ X, double* __restrict__ AX, int64_t stride, DavState* st,
                            const DavParams prm, const double* __restrict__ partial, int nblocks, int width,
-                           double* mail, long long seq) {
-  orth_dev_body<MV>(n, X, AX, stride, st, prm, partial, nblocks, width, mail, seq, blockIdx.x, gridDim.x);
+                           double* mail, long long seq, double* __restrict__ sol_out, double* res_out) {
+  orth_dev_body<MV>(n, X, AX, stride, st, prm, partial, nblocks, width, mail, seq, blockIdx.x, gridDim.x, nullptr, nullptr,
+                    sol_out, res_out);
 }
 
 // the solution: sum_{v < sol_m} sol_coef[v] X_v (unit norm: orthonormal basis, unit Ritz coefficients), and the
@@ -1091,7 +1133,7 @@ __device__ inline void solution_body(int64_t n, const double* __restrict__ X, in
     mail_store(&res[3], st->e);
     mail_store(&res[4], st->rnorm2);
     mail_store(&res[5], (double)st->err);
-    mail_store(&res[6], (double)st->stop);
+    mail_store(&res[6], (double)(st->stop != 0));
     mail_store(&res[7], (double)st->n_rqi);
     mail_store(&res[8], (double)st->n_jacobi);
   }
@@ -1439,7 +1481,6 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   const int full_from = 3;
   long long seq_of[4] = {0, 0, 0, 0};  // sequence numbers of the latest rounds enqueued (ring)
   bool stopped = false;
-  int spec_round = -1;  // the latest round with a conditional solution launch queued behind it
   auto settle = [&](int j) -> int {  // wait for round j's progress record
     SQD_TRY(wait_mail(c, 1, seq_of[j & 3]));
     if (h_prog[MAIL_PAYLOAD + 1] != 0.0) stopped = true;
@@ -1511,29 +1552,18 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
       hipLaunchKernelGGL((k_residual_precond<13>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
                          (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
       hipLaunchKernelGGL((k_orth_dev<13>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,
-                         (int)gb, width, mail_prog, seq);
+                         (int)gb, width, mail_prog, seq, c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
     } else {
       hipLaunchKernelGGL((k_dots_eig<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, AX, D,
                          c->partial.as<double>(), width, counter, dst, prm, split);
       hipLaunchKernelGGL((k_residual_precond<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, (const double*)AX, D,
                          (const DavState*)dst, (const double*)c->hdiag.as<double>(), pd, part_res, width);
       hipLaunchKernelGGL((k_orth_dev<MAXB>), dim3(gb), dim3(RED_T), 0, s, D, X, AX, D, dst, prm, (const double*)part_res,
-                         (int)gb, width, mail_prog, seq);
+                         (int)gb, width, mail_prog, seq, c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD);
     }
     SQD_HIP_CHECK(hipGetLastError());
-    // In the first rounds -- where the solves of uniform-random sets stop -- the solution kernel is queued right behind
-    // the round, conditional on the stop flag: a solve that stops there has its solution formed without waiting for
-    // the host to see the record and come back with the launch (13 us of idle stream at the headline); a round that
-    // does not stop pays one early-exit dispatch -- 4.7 us on the stream, not the 1-2 of an empty kernel: a kernel boundary
-    // behind a pass that wrote a vector waits for that pass's lines to leave the L2s (final_uniform317 trace, round 6).
-    // Round 0 stops a solve only when the start vector is already the answer (one-determinant subspaces): it goes
-    // without, and such a solve gets its solution launch from the host.
-    if (!lockstep && round >= 1 && round < full_from) {
-      hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
-                         c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 1);
-      SQD_HIP_CHECK(hipGetLastError());
-      spec_round = round;
-    }
+    // (The launch that stops the solve forms the solution itself -- k_orth_dev, sol_out: rounds 2-5 queued a conditional
+    // k_solution behind each of the first rounds instead, and every round that did not stop paid 4.7 us for its early exit.)
     return SQD_OK;
   };
   int last_settled = -1;
@@ -1561,9 +1591,11 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
   // conditional launch behind the stopping round has formed it already
   // (WHICH round stopped the solve is read from the record itself -- its iteration counter freezes at the stop --: with
   // rounds queued ahead, the record the host finds may already be a later round's)
-  const int stop_round = stopped ? (int)h_prog[MAIL_PAYLOAD + 0] - 1 : -1;
   (void)last_settled;
-  if (!(stopped && stop_round >= 0 && stop_round <= spec_round)) {
+  // ... unless the launch that stopped the run has formed it (record word 6; a later round's record, found when rounds
+  // were queued ahead, repeats it from the state block).  Not formed: the cycle limit, a stop taken inside the eigen step
+  // (linear dependence, a zero start vector)
+  if (!(stopped && h_prog[MAIL_PAYLOAD + 6] != 0.0)) {
     hipLaunchKernelGGL(k_solution, dim3(gb), dim3(RED_T), 0, s, D, (const double*)X, D, (const DavState*)dst,
                        c->sol.as<double>(), c->d_mail + 2 * MAIL_SLOT + MAIL_PAYLOAD, 0);
     SQD_HIP_CHECK(hipGetLastError());

@@ -14,7 +14,10 @@ struct DavState {
   int m_cur;     // size of the basis of the CURRENT projected problem (written by k_dots_eig; read by residual / orth)
   int it;        // projected problems solved so far
   int nsig;      // sigma builds that entered the projected matrix
-  int stop;      // the solve is over: every kernel enqueued behind this returns at once
+  int stop;      // != 0: the solve is over, every kernel enqueued behind this returns at once.  1: raised by the eigen step;
+                 // >= 2: by a k_orth_dev launch, the value is that launch's mark (its sequence number folded to an int) -- a
+                 // workgroup of THAT launch which starts late and finds the flag up still has its share of the solution to
+                 // form (single solves: sol_out); ONE word, so no ordering between a flag and a mark is needed
   int conv;      // ... and converged
   int first;     // no projected problem solved yet (dE of the first one is the eigenvalue itself)
   int m_eig;     // size of the last projected problem solved (-1: none, e.g. right after a restart)

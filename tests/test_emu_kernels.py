@@ -72,6 +72,9 @@ def test_emu_fused_direct_sigma_and_reduction(emu_lib, monkeypatch):
                        {"time_sigma_every": 2}):
                 c, st = ctx.davidson(**kw)
                 assert st["converged"], kw
+                # (two workgroups per BLAS-1 launch at D = 1200: the solution is formed by the launch that stops the solve,
+                # and the workgroup that starts behind the one raising the flag has to do its share)
+                assert abs(np.linalg.norm(c) - 1.0) < 1e-12, kw
                 out.append((c.copy(), st["e_davidson"], st["n_sigma"], st["iterations"]))
             runs[fused] = out
     for a, b in zip(runs["1"], runs["0"]):
