@@ -219,7 +219,14 @@ def roofline_entry(ctx, t_bracket_ms, t_apply_ms, n_timed, traffic=None, source=
     b_alg = ctx.sigma_bytes()
     b_need = ctx.sigma_bytes_needed()
     ach = b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else 0.0
+    fused = {}
+    if ctx.sigma_kernel() == "k_sigma_direct":
+        fused = {"fused_in_run": "inside a Davidson run of fewer than 2e5 determinants the sigma builds that are not being timed "
+                                 "go out as sqd::k_sigma_dots_eig -- this kernel's per-element code in the geometry of the "
+                                 "dot-product / eigen-step kernel behind it, ONE launch, the same bits; a bracketed launch is the "
+                                 "stand-alone sqd::k_sigma_direct, which is what avg_launch_ms, frac and traffic describe"}
     return {
+        **fused,
         "bound": "hbm", "kernel": "sqd::" + ctx.sigma_kernel(), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
         "bytes_per_launch": b_alg, "bytes_needed": b_need,
