@@ -5,6 +5,8 @@ The marks wait for outstanding stores (s_waitcnt) where the product kernels do n
 import ctypes as C, os, sys, time
 from pathlib import Path
 ROOT = Path(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+# (the clocks sit in k_dots_eig: the element-gather path is measured in its two-launch form)
+os.environ.setdefault('SQD_DAV_FUSE_DIRECT', '0')
 sys.path.insert(0, str(ROOT))
 import numpy as np
 from qiskit_addon_sqd_amd import _capi

@@ -18,6 +18,12 @@
 // keeps one iteration enqueued ahead of the one it has seen finish (a small progress record in host-
 // visible memory) and no launch ever waits for the host.  Reductions are fixed-order => bitwise
 // reproducible run to run.
+//
+// Round 6: on this chip a kernel boundary behind a pass that wrote a vector costs 4-5 us (the lines leave the L2s before
+// the next kernel starts), as much as the kernels of a batch-size solve themselves.  Two boundaries went: for the
+// element-gather formulation the sigma build and k_dots_eig are ONE launch (k_sigma_dots_eig: three launches per
+// iteration), and the k_orth_dev launch that stops a solve forms the solution in the same pass (k_solution only runs
+// when the stop came from the eigen step or the cycle limit).
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
