@@ -781,6 +781,9 @@ SQD_API int sqd_solve(sqd_ctx* c, const sqd_davidson_opts* opts, const double* c
   // sqd_ctx_set_async_state: the state follows the results (k_state_copy on the copy stream); the call returns with the
   // results and a ticket, sqd_ctx_state_wait(ticket) says when the caller's buffer is complete
   SQD_TRY(dev_observables_enqueue(c, c->sol.as<double>(), /*with_h=*/false, /*with_s2=*/need_s2, twin, late));
+  // (the copy's start event sits BEHIND the observables' kernel on purpose: enqueued in front of it -- 19 us of posted PCIe
+  // writes beside the kernel's 15 instead of after them -- a headline call takes 0.154 ms instead of 0.132, measured in
+  // round 6, profiles/r06/kernel_boundaries_probe.txt)
   long long ticket = 0;
   if (late) {
     SQD_TRY(state_copy_enqueue(c, twin, &ticket));
