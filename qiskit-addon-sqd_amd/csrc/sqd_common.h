@@ -401,7 +401,8 @@ size_t sigma_batch_bytes(size_t nsub);
 // stride_scale != 0: inside a Davidson run (vector chosen on the device, strides = each subspace's D)
 int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const double*>& d_c,
                      const std::vector<double*>& d_sigma, int mode, bool spin, double ss, double shift,
-                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan);
+                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan,
+                     bool skip_direct = false);  // skip_direct: the caller launches the element-gather class itself
 int sigma_batch_launch(sqd_ctx* parent, const SigmaBatchPlan& plan);
 // blas-1 (sqd_davidson.hip)
 int dev_dot(sqd_ctx* c, const double* x, const double* y, double* out);
@@ -428,6 +429,11 @@ struct DavBatchPlan {
   int n = 0, max_space = 12, max_cycle = 100;
   unsigned gb = 1;
   SigmaBatchPlan sigma;
+  // subspaces of the element-gather class: sigma build and dot products in ONE launch (k_sigma_dots_b), as the single solve
+  const char* fused_args = nullptr;  // device array of their DirectArgs
+  const char* fused_map = nullptr;   // ... and of their indices into `args`
+  int n_fused = 0;
+  bool fused_spin = false;
 };
 size_t davidson_batch_bytes(size_t nsub);
 int davidson_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const sqd_davidson_opts* o, char* h,

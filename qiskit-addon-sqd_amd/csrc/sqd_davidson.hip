@@ -1230,12 +1230,38 @@ struct DavBatchArgs {
   GPtr<double> mail;  // progress records (host-visible)
   GPtr<double> sol;
   GPtr<double> res;  // the run's outcome (host-visible)
+  int dots_fused;    // k_sigma_dots_b has left this subspace's partials: k_dots_b returns at once
 };
 template <int MV>
 __global__ void __launch_bounds__(RED_T, 4) k_dots_b(const DavBatchArgs* __restrict__ as) {
   const DavBatchArgs a = as[blockIdx.z];  // (a by-value copy: the record in SGPRs, as a kernel argument would be)
-  if (blockIdx.x >= a.gb) return;
+  if (blockIdx.x >= a.gb || a.dots_fused) return;
   dots_eig_body<MV, false>(a.n, a.X, a.AX, a.n, a.partial, a.width, a.counter, a.st, a.prm, a.split, blockIdx.x, a.gb);
+}
+// the element-gather class of a batch: sigma build + dot products of every such subspace in ONE launch (k_sigma_dots_eig
+// without the eigen step, which k_eig_b does for all subspaces): blockIdx.z = member of the class, sub_of[z] = its record
+template <int MV, bool SPIN>
+__global__ void __launch_bounds__(RED_T, 4) k_sigma_dots_b(const DavBatchArgs* __restrict__ as, const DirectArgs* __restrict__ ds,
+                                                            const int* __restrict__ sub_of) {
+  __shared__ double red[16 * (MV + 1)];
+  const DavBatchArgs a = as[sub_of[blockIdx.z]];
+  const unsigned bx = blockIdx.x, nbx = a.gb;
+  if (bx >= nbx) return;
+  const DavState* st = a.st;
+  if (st->stop) return;
+  const DirectArgs dg = ds[blockIdx.z];
+  const int nvec = st->m_next;
+  const double* __restrict__ X = a.X;
+  double* __restrict__ y = a.AX + (int64_t)(nvec - 1) * a.n;
+  double acc[MV + 1];
+#pragma unroll
+  for (int v = 0; v < MV + 1; ++v) acc[v] = 0.0;
+  if (nvec <= 2) dots_loop_direct<MV, (2 < MV ? 2 : MV), SPIN>(a.n, X, y, a.n, nvec, dg, bx, nbx, acc);
+  else if (nvec <= 4) dots_loop_direct<MV, (4 < MV ? 4 : MV), SPIN>(a.n, X, y, a.n, nvec, dg, bx, nbx, acc);
+  else if (nvec <= 8) dots_loop_direct<MV, (8 < MV ? 8 : MV), SPIN>(a.n, X, y, a.n, nvec, dg, bx, nbx, acc);
+  else dots_loop_direct<MV, MV, SPIN>(a.n, X, y, a.n, nvec, dg, bx, nbx, acc);
+  block_sum_multi<MV + 1>(acc, nvec + 1, red);
+  if ((int)threadIdx.x < nvec + 1) a.partial[(int64_t)bx * a.width + threadIdx.x] = block_sum_multi_get<MV + 1>(red, threadIdx.x);
 }
 // the eigen step of every subspace of the batch: one workgroup each (fold of the partials k_dots_b left, then one wavefront)
 template <int MV>
@@ -1619,7 +1645,7 @@ int run_davidson(sqd_ctx* c, const sqd_davidson_opts* o, const double* ci0_host,
 // ---- batched Davidson (sqd_solve_batch): the same four launches per round advance EVERY subspace of the batch.  Each
 // subspace has its own state block, arrival counters, partial arrays and mailbox (its sub-context's), stops itself, and
 // from then on its workgroups return at once; the host keeps rounds coming until every subspace has stopped.
-size_t davidson_batch_bytes(size_t nsub) { return nsub * (sizeof(DavBatchArgs) + 64) + sigma_batch_bytes(nsub) + 256; }
+size_t davidson_batch_bytes(size_t nsub) { return nsub * (sizeof(DavBatchArgs) + 64 + sizeof(int)) + sigma_batch_bytes(nsub) + 512; }
 
 static long long common_seq(const std::vector<sqd_ctx*>& subs) {
   // one sequence number for the same mailbox word of every subspace: above everything any of them has used
@@ -1718,7 +1744,37 @@ int davidson_batch_prepare(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, c
     c->dav_ev_iter.clear();
     c->have_solution = true;
   }
-  const int rc = sigma_batch_plan(subs, xin, axout, 0, form == 1, o->ss, o->shift, 1, h, d, &off, &plan->sigma);
+  // the element-gather class: sigma build and dot products in one launch, as the single solve has them (k_sigma_dots_eig)
+  plan->n_fused = 0;
+  bool fuse = max_space <= 12;
+  if (fuse)
+    if (const char* env = std::getenv("SQD_DAV_FUSE_DIRECT")) fuse = std::atoi(env) != 0;  // test / probe hook
+  for (int p = 0; p < n; ++p) ha[p].dots_fused = 0;
+  if (fuse) {
+    std::vector<int> fidx;
+    for (int p = 0; p < n; ++p)
+      if (subs[p]->sig_direct && subs[p]->sig_rows == 0) fidx.push_back(p);
+    if (!fidx.empty()) {
+      off = (off + 63) & ~size_t(63);
+      DirectArgs* hd = reinterpret_cast<DirectArgs*>(h + off);
+      plan->fused_args = d + off;
+      off += fidx.size() * sizeof(DirectArgs);
+      off = (off + 63) & ~size_t(63);
+      int* hm = reinterpret_cast<int*>(h + off);
+      plan->fused_map = d + off;
+      off += fidx.size() * sizeof(int);
+      for (size_t k = 0; k < fidx.size(); ++k) {
+        sqd_ctx* c = subs[fidx[k]];
+        fill_direct_args(c, xin[fidx[k]], axout[fidx[k]], 0, form == 1, o->ss, o->shift, c->D, c->D, &hd[k]);
+        hm[k] = fidx[k];
+        ha[fidx[k]].dots_fused = 1;
+      }
+      plan->n_fused = (int)fidx.size();
+      plan->fused_spin = (form == 1);
+    }
+  }
+  const int rc = sigma_batch_plan(subs, xin, axout, 0, form == 1, o->ss, o->shift, 1, h, d, &off, &plan->sigma,
+                                  /*skip_direct=*/plan->n_fused > 0);
   for (sqd_ctx* c : subs) {
     c->sigma_stop = nullptr;
     c->sigma_index = nullptr;
@@ -1745,7 +1801,17 @@ int davidson_batch_run(sqd_ctx* parent, const std::vector<sqd_ctx*>& subs, const
     stopped = all;
     return SQD_OK;
   };
-  auto part_a = [&]() -> int { return sigma_batch_launch(parent, plan.sigma); };
+  auto part_a = [&]() -> int {
+    if (plan.n_fused > 0) {
+      const dim3 fg(plan.gb, 1, (unsigned)plan.n_fused);
+      const DirectArgs* ds = reinterpret_cast<const DirectArgs*>(plan.fused_args);
+      const int* sub_of = reinterpret_cast<const int*>(plan.fused_map);
+      if (plan.fused_spin) hipLaunchKernelGGL((k_sigma_dots_b<13, true>), fg, dim3(RED_T), 0, s, args, ds, sub_of);
+      else hipLaunchKernelGGL((k_sigma_dots_b<13, false>), fg, dim3(RED_T), 0, s, args, ds, sub_of);
+      SQD_HIP_CHECK(hipGetLastError());
+    }
+    return sigma_batch_launch(parent, plan.sigma);
+  };
   auto part_b = [&](int round) -> int {
     const long long seq = common_seq(subs);
     seq_of[round & 3] = seq;

@@ -1391,7 +1391,7 @@ size_t sigma_batch_bytes(size_t nsub) {
 }
 int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const double*>& d_c,
                      const std::vector<double*>& d_sigma, int mode, bool spin, double ss, double shift,
-                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan) {
+                     int64_t stride_scale, char* h, char* d, size_t* off_io, SigmaBatchPlan* plan, bool skip_direct) {
   plan->launches.clear();
   const bool sp = (mode == 1 || spin);
   size_t off = *off_io;
@@ -1407,7 +1407,7 @@ int sigma_batch_plan(const std::vector<sqd_ctx*>& subs, const std::vector<const 
     std::vector<int> idx;
     for (int p = 0; p < n; ++p)
       if (subs[p]->sig_direct && subs[p]->sig_rows == 0) idx.push_back(p);
-    if (!idx.empty()) {
+    if (!idx.empty() && !skip_direct) {
       const size_t at = take(idx.size() * sizeof(DirectArgs));
       SigmaBatchPlan::Launch L;
       L.kind = 1;
