@@ -59,9 +59,12 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     p.add_argument("--cpu-threads", type=int, default=0)
     p.add_argument("--extra", action="store_true", help="also measure a D ladder")
-    p.add_argument("--time-sigma-every", type=int, default=8,
-                   help="bracket every k-th sigma launch of the timed region with HIP events (roofline leg); an "
-                        "event pair costs ~10 us of stream time, hence sampling")
+    p.add_argument("--time-sigma-every", type=int, default=0,
+                   help="bracket every k-th sigma launch of the TIMED REGION with HIP events (a cross-check of the roofline "
+                        "leg, `in_region_samples`); default 0 = none: a bracket and the empty bracket behind it cost 10-20 us "
+                        "of stream time on a 130 us step -- with every 8th launch bracketed a third of the steps carried "
+                        "one and the mean of the steps sat 6 % above their median (round 6).  The roofline leg's duration "
+                        "comes from 100 solves right behind the region with EVERY launch bracketed, either way")
     return p.parse_args()
 
 
@@ -400,6 +403,8 @@ def main():
         # vectors, the Davidson's own launches around them; round 5's line carried 5 samples taken inside the region and
         # swung 0.060 <-> 0.096 from box to box).  The in-region samples stay as a cross-check.
         F.set_profiling(time_sigma_every=1)
+        for _ in range(5):  # (not counted: the first bracketed launches of a process pay for the events' own set-up)
+            F.solve_fermion((sa, sb), h1, eri, spin_sq=args.spin_sq, device=local_rank)
         pr_n = 0
         pr_k = pr_a = pr_e = 0.0
         for _ in range(100):
